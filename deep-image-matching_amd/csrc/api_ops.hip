@@ -1,0 +1,47 @@
+// C-ABI: error reporting + operator-level entry points (thin wrappers over the
+// internal launchers so each kernel can be parity-tested on its own).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/dim_hip.h"
+#include "dim_kernels.h"
+
+static thread_local char g_err[1024] = "";
+
+void dim_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+const char* dim_last_error(void) { return g_err; }
+
+int dim_abi_version(void) { return DIM_HIP_ABI_VERSION; }
+
+int dim_op_gemm_f32(const float* A, int lda, const float* B, int ldb, int b_is_nk, const float* bias,
+                    const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int relu, void* stream) {
+  GemmArgs g;
+  g.A0 = A; g.lda0 = lda; g.B = B; g.ldb = ldb; g.bt = b_is_nk; g.bias = bias;
+  g.R = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = relu;
+  return launch_gemm(g, 1, (hipStream_t)stream);
+}
+
+int dim_op_conv3x3_nhwc_f32(const float* in, const float* w_tap_cin_cout, const float* bias, float* out, int batch,
+                            int H, int W, int cin, int cout, int pool2x2, int relu, void* stream) {
+  return launch_conv3x3(in, w_tap_cin_cout, bias, out, batch, H, W, cin, cout, pool2x2, relu, (hipStream_t)stream);
+}
+
+int dim_op_conv1a_f32(const float* in, const float* w_tap_cout, const float* bias, float* out, int batch, int H,
+                      int W, void* stream) {
+  return launch_conv1a(in, w_tap_cout, bias, out, batch, H, W, (hipStream_t)stream);
+}
+
+int dim_device_synchronize(void) {
+  DIM_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+}  // extern "C"

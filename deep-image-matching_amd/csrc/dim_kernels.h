@@ -1,0 +1,40 @@
+// Internal launcher interface shared by the SuperPoint and LightGlue pipelines.
+// Everything here runs on a caller-provided HIP stream and never synchronises.
+#pragma once
+#include "dim_common.h"
+
+// ---------------------------------------------------------------------------
+// Batched, ragged fp32 GEMM on v_mfma_f32_32x32x2_f32:
+//   C[z][m][n] = act( sum_k A[z][m][k] * B[k][n] + bias[n] ) (+ R[z][m][n])
+// A may be split along K between two sources (A0 for k < ksplit, A1 after) so
+// that LightGlue's ffn(cat[x, message]) never materialises the concatenation
+// (reference LGN:159,209).  bt != 0 means B is given as [n][k] row-major (the
+// "NT" product used for sim = mdesc0 * mdesc1^T, LGN:271).
+// Raggedness: rows of item z = rows[z*rows_mul + rows_off] (device array) when
+// rows != nullptr, else M; same for cols (bt mode only).  flag gating: the item
+// is skipped unless flag[z >> flag_shift] == flag_eq (flag == nullptr: always run).
+struct GemmArgs {
+  const float* A0 = nullptr; const float* A1 = nullptr;
+  int lda0 = 0, lda1 = 0, ksplit = 0;
+  long long strideA0 = 0, strideA1 = 0;
+  const float* B = nullptr; int ldb = 0; long long strideB = 0; int bt = 0;
+  const float* bias = nullptr;
+  const float* R = nullptr; int ldr = 0; long long strideR = 0;
+  float* C = nullptr; int ldc = 0; long long strideC = 0;
+  int M = 0, N = 0, K = 0;
+  const int* rows = nullptr; int rows_mul = 1, rows_off = 0;
+  const int* cols = nullptr; int cols_mul = 1, cols_off = 0;
+  const int* flag = nullptr; int flag_shift = 0, flag_eq = 0;
+  int relu = 0;
+};
+int launch_gemm(const GemmArgs& a, int batch, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution over NHWC fp32 images as an implicit GEMM
+// on MFMA, bias + ReLU fused, optional fused 2x2/2 max-pool (floor semantics,
+// SPN:163-171).  in: [B][H][W][cin], w: [9][cin][cout], out: [B][H'][W'][cout].
+int launch_conv3x3(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W,
+                   int cin, int cout, int pool, int relu, hipStream_t s);
+// conv1a: 1 -> 64 channels, direct (VALU) convolution; in: [B][H][W], w: [9][64].
+int launch_conv1a(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W,
+                  hipStream_t s);

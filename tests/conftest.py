@@ -1,0 +1,35 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """The HIP sources compiled against tests/hipemu (CPU fibers). Test-only."""
+    import importlib
+
+    build = importlib.import_module("deep-image-matching_amd.build")
+    import ctypes
+
+    lib = ctypes.CDLL(str(build.build_emu()))
+    lib.dim_last_error.restype = ctypes.c_char_p
+    return lib
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The real gfx950 library through the package loader (fails loudly without a GPU)."""
+    import importlib
+
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    return capi.load()

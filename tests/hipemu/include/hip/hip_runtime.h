@@ -1,0 +1,234 @@
+// hipemu — TEST-ONLY stand-in for <hip/hip_runtime.h>.
+//
+// This header is NOT part of the product.  It exists so that the very same
+// .hip kernel sources that hipcc compiles for gfx950 can also be compiled
+// with the host clang and stepped through on a CPU-only machine, one fiber
+// per GPU thread, to check indexing / fragment-layout / barrier logic before
+// spending GPU minutes.  The product library (libdim_hip.so) is built by
+// hipcc against the real ROCm header and never sees this file; the emulated
+// library is only ever loaded by tests under tests/ (never by the package,
+// bench.py or smoke()).
+//
+// Semantics that are emulated faithfully:
+//   * wave = 64 lanes, workgroup barriers, wave-level cross-lane ops
+//     (shfl / ballot) with lock-step exchange between the lanes of a wave,
+//   * v_mfma_f32_32x32x2_f32 and v_mfma_f32_16x16x4_f32 with the gfx950
+//     A/B/C/D lane->element maps (cdna_hip_programming.md §3), k-ordered fmaf
+//     chain, so a wrong fragment layout fails here exactly as on hardware,
+//   * __shared__ (one copy per workgroup; workgroups run one after another).
+// Not emulated: timing, caches, memory model (fibers of a block run in a
+// fixed or reversed order between sync points: HIPEMU_ORDER=reverse flips the
+// order so a missing barrier shows up as a result change).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <algorithm>
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3 { unsigned x, y, z; };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipErrorInvalidValue 1
+#define hipErrorOutOfMemory 2
+typedef struct hipemu_stream* hipStream_t;
+typedef struct hipemu_event* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+namespace hipemu {
+struct Fiber;
+struct Fiber {
+  void* sp;
+  uint3 tid;
+  unsigned flat;     // flat thread id in block
+  unsigned lane;     // flat & 63
+  unsigned wave;     // flat >> 6
+  int state;         // 0 runnable, 1 at barrier, 2 done
+  unsigned opcount;  // wave-op sequence number
+};
+extern Fiber* cur;
+extern uint3 g_block, g_bdim, g_gdim;
+void barrier();
+// Lock-step exchange between the live lanes of the calling lane's wave.
+// Deposits `bytes` from `in`; returns a pointer to a [64][stride] byte table of
+// every lane's deposit (valid until this lane's next-but-one wave op) and the
+// mask of lanes that took part.
+const unsigned char* wave_exchange(const void* in, unsigned bytes, unsigned* stride, unsigned long long* present);
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur->tid)
+#define blockIdx (hipemu::g_block)
+#define blockDim (hipemu::g_bdim)
+#define gridDim (hipemu::g_gdim)
+#define warpSize 64
+
+static inline void __syncthreads() { hipemu::barrier(); }
+static inline void __builtin_amdgcn_s_barrier() { hipemu::barrier(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+template <typename T>
+static inline T hipemu_shfl_from(T v, int src_lane_for_me) {
+  unsigned stride; unsigned long long present;
+  const unsigned char* tab = hipemu::wave_exchange(&v, sizeof(T), &stride, &present);
+  T out;
+  int s = src_lane_for_me & 63;
+  if (!((present >> s) & 1ull)) return v;  // inactive source: undefined on HW; keep own value
+  memcpy(&out, tab + (size_t)s * stride, sizeof(T));
+  return out;
+}
+template <typename T> static inline T __shfl(T v, int lane, int width = 64) {
+  int me = hipemu::cur->lane;
+  int base = me & ~(width - 1);
+  return hipemu_shfl_from(v, base + (lane & (width - 1)));
+}
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+  int me = hipemu::cur->lane;
+  int base = me & ~(width - 1);
+  return hipemu_shfl_from(v, base + (((me & (width - 1)) ^ mask) & (width - 1)));
+}
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+  int me = hipemu::cur->lane;
+  int in = me & (width - 1);
+  int src = (in + (int)d < width) ? me + (int)d : me;
+  return hipemu_shfl_from(v, src);
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+  int me = hipemu::cur->lane;
+  int in = me & (width - 1);
+  int src = (in - (int)d >= 0) ? me - (int)d : me;
+  return hipemu_shfl_from(v, src);
+}
+static inline unsigned long long __ballot(int pred) {
+  unsigned stride; unsigned long long present;
+  int p = pred ? 1 : 0;
+  const unsigned char* tab = hipemu::wave_exchange(&p, sizeof(int), &stride, &present);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if ((present >> l) & 1ull) { int q; memcpy(&q, tab + (size_t)l * stride, 4); if (q) m |= 1ull << l; }
+  return m;
+}
+static inline int __any(int p) { return __ballot(p) != 0ull; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+// D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5); k-ordered fmaf chain.
+static inline hipemu_f32x16 hipemu_mfma_32x32x2(float a, float b, hipemu_f32x16 c) {
+  float ab[2] = {a, b};
+  unsigned stride; unsigned long long present;
+  const unsigned char* tab = hipemu::wave_exchange(ab, sizeof(ab), &stride, &present);
+  if (present != ~0ull) { fprintf(stderr, "hipemu: MFMA issued with a partial wave (exec mask %016llx)\n", present); abort(); }
+  int l = hipemu::cur->lane;
+  int col = l & 31;
+  hipemu_f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) {
+      float av, bv;
+      memcpy(&av, tab + (size_t)(row + 32 * k) * stride, 4);
+      memcpy(&bv, tab + (size_t)(col + 32 * k) * stride + 4, 4);
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+// D: col=l&15, row=(l>>4)*4+r.
+static inline hipemu_f32x4 hipemu_mfma_16x16x4(float a, float b, hipemu_f32x4 c) {
+  float ab[2] = {a, b};
+  unsigned stride; unsigned long long present;
+  const unsigned char* tab = hipemu::wave_exchange(ab, sizeof(ab), &stride, &present);
+  if (present != ~0ull) { fprintf(stderr, "hipemu: MFMA issued with a partial wave\n"); abort(); }
+  int l = hipemu::cur->lane;
+  int col = l & 15;
+  hipemu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      float av, bv;
+      memcpy(&av, tab + (size_t)(row + 16 * k) * stride, 4);
+      memcpy(&bv, tab + (size_t)(col + 16 * k) * stride + 4, 4);
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4((a), (b), (c))
+
+// atomics: one fiber runs at a time, so plain read-modify-write is atomic.
+template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; *p = o > v ? o : v; return o; }
+template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; *p = o < v ? o : v; return o; }
+template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
+static inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
+static inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
+
+// ---- host runtime subset -------------------------------------------------
+extern "C" {
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipFree(void* p);
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
+hipError_t hipMemset(void* d, int v, size_t n);
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
+hipError_t hipStreamSynchronize(hipStream_t st);
+hipError_t hipDeviceSynchronize();
+hipError_t hipGetLastError();
+hipError_t hipPeekAtLastError();
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipGetDevice(int* d);
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDeviceCount(int* n);
+}
+template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
