@@ -1,0 +1,110 @@
+"""Weights for the SuperPoint / LightGlue hot path.
+
+The official checkpoints (``superpoint_v1.pth``, ``superpoint_lightglue.pth``) are
+downloaded by the reference at run time (SPN:110,147-150; LGN:327-328,381-396) and
+are not available offline, so this module provides
+
+* ``load_superpoint_state_dict`` / ``load_lightglue_state_dict`` — accept the official
+  files unchanged when a path is given (incl. LightGlue's legacy key rename,
+  LGN:389-396), and
+* seeded synthetic state dicts in exactly the official key/shape layout
+   for tests, smoke and the synthetic benchmark.  They are
+  drawn from ``torch.Generator`` streams so that the same seed gives the same
+  tensors here, in the golden-vector generator and on the GPU box.
+"""
+from __future__ import annotations
+
+import math
+from pathlib import Path
+from typing import Dict
+
+import torch
+
+SP_LAYERS = [
+    # name, cout, cin, k
+    ("conv1a", 64, 1, 3), ("conv1b", 64, 64, 3),
+    ("conv2a", 64, 64, 3), ("conv2b", 64, 64, 3),
+    ("conv3a", 128, 64, 3), ("conv3b", 128, 128, 3),
+    ("conv4a", 128, 128, 3), ("conv4b", 128, 128, 3),
+    ("convPa", 256, 128, 3), ("convPb", 65, 256, 1),
+    ("convDa", 256, 128, 3), ("convDb", 256, 256, 1),
+]
+
+
+def synthetic_superpoint_state_dict(seed: int = 1234) -> Dict[str, torch.Tensor]:
+    """He-normal conv weights, small biases."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, co, ci, k in SP_LAYERS:
+        fan_in = ci * k * k
+        sd[f"{name}.weight"] = torch.randn(co, ci, k, k, generator=g) * math.sqrt(2.0 / fan_in)
+        sd[f"{name}.bias"] = torch.randn(co, generator=g) * 0.01
+    return sd
+
+
+def load_superpoint_state_dict(path: str | None = None, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    if path is None:
+        return synthetic_superpoint_state_dict(seed)
+    sd = torch.load(str(Path(path)), map_location="cpu")
+    missing = [f"{n}.{s}" for n, *_ in SP_LAYERS for s in ("weight", "bias") if f"{n}.{s}" not in sd]
+    if missing:
+        raise KeyError(f"SuperPoint checkpoint {path} lacks keys {missing}")
+    return {k: v.float().contiguous() for k, v in sd.items()}
+
+
+def lightglue_confidence_thresholds(n_layers: int = 9) -> torch.Tensor:
+    """LGN:581-584: 0.8 + 0.1*exp(-4 i / L), clipped to [0, 1], stored as float32."""
+    import numpy as np
+
+    return torch.Tensor([float(np.clip(0.8 + 0.1 * np.exp(-4.0 * i / n_layers), 0, 1)) for i in range(n_layers)])
+
+
+def synthetic_lightglue_state_dict(seed: int = 0, input_dim: int = 256, n_layers: int = 9, dim: int = 256,
+                                   gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """nn.Linear-style uniform init in the official key layout (LGN:361-378).
+
+    ``gain`` > 1 sharpens the synthetic network (larger logits) so that softmaxes are
+    not uniform and the mutual-NN stage has something to decide in tests."""
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(out_f, in_f, bias=True, prefix=""):
+        bound = gain / math.sqrt(in_f)
+        d = {prefix + "weight": (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound}
+        if bias:
+            d[prefix + "bias"] = (torch.rand(out_f, generator=g) * 2 - 1) * bound
+        return d
+
+    sd: Dict[str, torch.Tensor] = {}
+    sd["confidence_thresholds"] = lightglue_confidence_thresholds(n_layers)
+    if input_dim != dim:
+        sd.update(lin(dim, input_dim, prefix="input_proj."))
+    sd["posenc.Wr.weight"] = torch.randn(dim // 4 // 2, 2, generator=g)  # head_dim//2 x 2, std gamma^-2 = 1 (LGN:62-63)
+    for i in range(n_layers):
+        t = f"transformers.{i}."
+        sd.update(lin(3 * dim, dim, prefix=t + "self_attn.Wqkv."))
+        sd.update(lin(dim, dim, prefix=t + "self_attn.out_proj."))
+        for blk in ("self_attn", "cross_attn"):
+            sd.update(lin(2 * dim, 2 * dim, prefix=t + blk + ".ffn.0."))
+            sd[t + blk + ".ffn.1.weight"] = 1.0 + 0.1 * torch.randn(2 * dim, generator=g)
+            sd[t + blk + ".ffn.1.bias"] = 0.1 * torch.randn(2 * dim, generator=g)
+            sd.update(lin(dim, 2 * dim, prefix=t + blk + ".ffn.3."))
+        for nm in ("to_qk", "to_v", "to_out"):
+            sd.update(lin(dim, dim, prefix=t + "cross_attn." + nm + "."))
+        sd.update(lin(1, dim, prefix=f"log_assignment.{i}.matchability."))
+        sd.update(lin(dim, dim, prefix=f"log_assignment.{i}.final_proj."))
+        if i < n_layers - 1:
+            sd.update(lin(1, dim, prefix=f"token_confidence.{i}.token.0."))
+    return sd
+
+
+def load_lightglue_state_dict(path: str | None = None, seed: int = 0, input_dim: int = 256, n_layers: int = 9,
+                              gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    if path is None:
+        return synthetic_lightglue_state_dict(seed, input_dim, n_layers, gain=gain)
+    sd = torch.load(str(Path(path)), map_location="cpu")
+    for i in range(n_layers):  # legacy names (LGN:389-396)
+        sd = {k.replace(f"self_attn.{i}", f"transformers.{i}.self_attn"): v for k, v in sd.items()}
+        sd = {k.replace(f"cross_attn.{i}", f"transformers.{i}.cross_attn"): v for k, v in sd.items()}
+    if "confidence_thresholds" not in sd:
+        sd["confidence_thresholds"] = lightglue_confidence_thresholds(n_layers)
+    return {k: v.float().contiguous() for k, v in sd.items()}

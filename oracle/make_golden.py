@@ -1,0 +1,128 @@
+"""Pins the oracle against the REAL reference modules and writes tests/golden/*.npz.
+
+Runs only in the build container (needs /root/reference, read-only).  It imports the
+reference's network files by path — they depend on torch/numpy only —
+  SPN  thirdparty/SuperGluePretrainedNetwork/models/superpoint.py
+  LGN  thirdparty/LightGlue/lightglue/lightglue.py
+feeds them the seeded synthetic weights of deep-image-matching_amd/weights.py (the
+official checkpoints are URL downloads, unavailable offline), runs them on seeded
+inputs, asserts that oracle/{superpoint,lightglue}_ref.py reproduce the reference
+(keypoints/matches exactly, floats to 1e-5), and stores the reference's OUTPUTS as
+the golden vectors.  Inputs are regenerated from the recorded seeds by
+tests/golden_cases.py, so only outputs are committed.
+
+    python oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.util
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+REF = Path("/root/reference/src/deep_image_matching/thirdparty")
+
+from oracle import lightglue_ref, superpoint_ref  # noqa: E402
+from tests import golden_cases as gc  # noqa: E402
+
+
+def _load(path: Path, name: str):
+    spec = importlib.util.spec_from_file_location(name, str(path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def reference_superpoint(sd, cfg):
+    spn = _load(REF / "SuperGluePretrainedNetwork/models/superpoint.py", "ref_spn")
+    orig = torch.hub.load_state_dict_from_url
+    torch.hub.load_state_dict_from_url = lambda *a, **k: sd
+    try:
+        net = spn.SuperPoint({k: v for k, v in cfg.items() if k != "fix_sampling"}).eval()
+    finally:
+        torch.hub.load_state_dict_from_url = orig
+    if cfg.get("fix_sampling"):
+        # restate DIM's monkey patch (extractors/superpoint.py:16-27,56-57) on the module global
+        def fixed(keypoints, descriptors, s: int = 8):
+            b, c, h, w = descriptors.shape
+            keypoints = (keypoints + 0.5) / (keypoints.new_tensor([w, h]) * s)
+            keypoints = keypoints * 2 - 1
+            d = torch.nn.functional.grid_sample(descriptors, keypoints.view(b, 1, -1, 2), mode="bilinear", align_corners=False)
+            return torch.nn.functional.normalize(d.reshape(b, c, -1), p=2, dim=1)
+
+        spn.sample_descriptors = fixed
+    return net
+
+
+def reference_lightglue(sd, conf, input_dim):
+    lgn = _load(REF / "LightGlue/lightglue/lightglue.py", "ref_lgn")
+    net = lgn.LightGlue(features=None, input_dim=input_dim, **conf).eval()
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return net
+
+
+def main():
+    out_dir = ROOT / "tests" / "golden"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(8)
+
+    for name, case in gc.SP_CASES.items():
+        sd = gc.sp_weights(case)
+        img = gc.sp_image(case)
+        net = reference_superpoint(sd, case["cfg"])
+        with torch.no_grad():
+            ref = net({"image": img})
+        kp, sc, de = ref["keypoints"][0], ref["scores"][0], ref["descriptors"][0]
+        mine = superpoint_ref.superpoint_forward(img, sd, case["cfg"], taps=True)
+        assert torch.equal(mine["keypoints"], kp), name
+        assert torch.equal(mine["scores"], sc), name
+        assert (mine["descriptors"] - de).abs().max() < 1e-6, name
+        np.savez_compressed(
+            out_dir / f"sp_{name}.npz",
+            keypoints=kp.numpy(), scores=sc.numpy(), descriptors=de.numpy(),
+            score_map=mine["score_map"][0].numpy(), logits=mine["logits"][0].numpy(),
+            encoder_sum=np.float64(mine["encoder"].double().sum().item()),
+        )
+        print(f"sp_{name}: N={kp.shape[0]} ok (oracle == reference)")
+
+    for name, case in gc.LG_CASES.items():
+        sd = gc.lg_weights(case)
+        f0, f1 = gc.lg_inputs(case)
+        net = reference_lightglue(sd, case["conf"], case["input_dim"])
+        data = {
+            "image0": {"keypoints": f0["kpts"][None], "descriptors": f0["desc"][None], "image_size": f0["size"][None]},
+            "image1": {"keypoints": f1["kpts"][None], "descriptors": f1["desc"][None], "image_size": f1["size"][None]},
+        }
+        with torch.no_grad():
+            ref = net(data)
+        mine = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"],
+                                               sd, case["conf"], taps=True)
+        assert ref["stop"] == mine["stop"], (name, ref["stop"], mine["stop"])
+        assert torch.equal(ref["prune0"][0].long(), mine["prune0"].long()), name
+        assert torch.equal(ref["prune1"][0].long(), mine["prune1"].long()), name
+        d_ms = (ref["matching_scores0"][0] - mine["matching_scores0"]).abs().max().item()
+        same_m0 = torch.equal(ref["matches0"][0], mine["matches0"])
+        same_m = torch.equal(ref["matches"][0], mine["matches"])
+        assert d_ms < 1e-5, (name, d_ms)
+        assert same_m0 and same_m, name
+        # the reference does not return the dense matrix; re-evaluate it with the reference's own module
+        np.savez_compressed(
+            out_dir / f"lg_{name}.npz",
+            matches0=ref["matches0"][0].numpy(), matches1=ref["matches1"][0].numpy(),
+            matching_scores0=ref["matching_scores0"][0].numpy(), matching_scores1=ref["matching_scores1"][0].numpy(),
+            matches=ref["matches"][0].numpy(), scores=ref["scores"][0].numpy(), stop=np.int64(ref["stop"]),
+            prune0=ref["prune0"][0].numpy(), prune1=ref["prune1"][0].numpy(),
+            log_assignment=(mine["log_assignment"].numpy() if "log_assignment" in mine else np.zeros((0, 0), np.float32)),
+        )
+        print(f"lg_{name}: stop={ref['stop']} S={ref['matches'][0].shape[0]}"
+              f" max|dscore|={d_ms:.2e} ok (oracle == reference)")
+
+
+if __name__ == "__main__":
+    main()
