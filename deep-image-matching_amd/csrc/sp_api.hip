@@ -1,0 +1,179 @@
+// dim_sp_* : resident SuperPoint extractor (C ABI in include/dim_hip.h).
+// Replaces SuperPoint.__init__/forward (SPN:101-227) as driven by
+// SuperPointExtractor._extract (extractors/superpoint.py:107-132).
+//
+// HBM layout: every activation is NHWC fp32 ([batch][H][W][C]); 1x1 convolutions
+// are therefore plain GEMMs over pixels; the descriptor head's output stays
+// un-normalised in HBM and is normalised only at the <= 4 cells each keypoint
+// touches (sample_desc_kernel), which is algebraically the reference's
+// normalise-then-sample (SPN:215,218-221).
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/dim_hip.h"
+#include "sp_kernels.h"
+
+struct dim_sp {
+  dim_sp_config cfg;
+  int max_batch, max_h, max_w, capacity;
+  // weights (device)
+  float* w1a; float* wk[12]; float* bias[12];
+  // activations
+  float *a1, *b1, *a2, *b2, *a3, *b3, *a4, *x, *pa, *logits, *da, *dd, *smap, *nms, *cand_score;
+  int *cand_idx, *rowcount, *rowoff, *ncand;
+  int last_h, last_w, last_batch;
+  std::vector<void*> allocs;
+};
+
+namespace {
+const int kCin[12] = {1, 64, 64, 64, 64, 128, 128, 128, 128, 256, 128, 256};
+const int kCout[12] = {64, 64, 64, 64, 128, 128, 128, 128, 256, 65, 256, 256};
+const int kK[12] = {3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 3, 1};
+
+template <typename T>
+int dev_alloc(dim_sp* h, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+  if (e != hipSuccess) {
+    dim_set_error("hipMalloc of %zu bytes failed: out of memory (%s)", count * sizeof(T), hipGetErrorString(e));
+    return -1;
+  }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+void dim_sp_destroy(dim_sp* h) {
+  if (!h) return;
+  for (void* p : h->allocs) hipFree(p);
+  delete h;
+}
+
+int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_batch, int max_h, int max_w, int capacity,
+                  dim_sp** out) {
+  DIM_REQUIRE(w && cfg && out, "dim_sp_create: null argument");
+  DIM_REQUIRE(max_batch > 0 && max_h >= 8 && max_w >= 8, "dim_sp_create: bad sizes");
+  DIM_REQUIRE(cfg->max_keypoints != 0 && cfg->max_keypoints >= -1, "\"max_keypoints\" must be positive or \"-1\"");  // SPN:152-154
+  DIM_REQUIRE(capacity > 0 && capacity >= cfg->max_keypoints, "dim_sp_create: capacity %d < max_keypoints %d", capacity, cfg->max_keypoints);
+  DIM_REQUIRE(cfg->nms_radius >= 0, "nms_radius must be >= 0");  // SPN:49
+  dim_sp* h = new dim_sp();
+  memset((void*)&h->cfg, 0, sizeof(h->cfg));
+  h->cfg = *cfg;
+  h->max_batch = max_batch; h->max_h = max_h; h->max_w = max_w; h->capacity = capacity;
+  h->last_h = h->last_w = h->last_batch = 0;
+#define SP_TRY(x) do { if ((x) != 0) { dim_sp_destroy(h); return -1; } } while (0)
+  // ---- weights: OIHW (SPN:128-143) -> [tap][cin][cout] / [cin][cout_padded4] ----
+  for (int l = 0; l < 12; ++l) {
+    const int ci = kCin[l], co = kCout[l], k = kK[l];
+    const int co_pad = (co + 3) & ~3;
+    std::vector<float> host((size_t)k * k * ci * co_pad, 0.0f);
+    for (int o = 0; o < co; ++o)
+      for (int i = 0; i < ci; ++i)
+        for (int t = 0; t < k * k; ++t) host[((size_t)t * ci + i) * co_pad + o] = w->conv_w[l][((size_t)o * ci + i) * k * k + t];
+    SP_TRY(dev_alloc(h, &h->wk[l], host.size()));
+    if (hipMemcpy(h->wk[l], host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
+    std::vector<float> hb(co_pad, 0.0f);
+    memcpy(hb.data(), w->conv_b[l], co * sizeof(float));
+    SP_TRY(dev_alloc(h, &h->bias[l], hb.size()));
+    if (hipMemcpy(h->bias[l], hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("bias upload failed"); dim_sp_destroy(h); return -1; }
+  }
+  // ---- activations ----
+  const size_t B = max_batch, H = max_h, W = max_w;
+  const size_t H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, hh = H4 / 2, ww = W4 / 2;
+  SP_TRY(dev_alloc(h, &h->a1, B * H * W * 64));
+  SP_TRY(dev_alloc(h, &h->b1, B * H2 * W2 * 64));
+  SP_TRY(dev_alloc(h, &h->a2, B * H2 * W2 * 64));
+  SP_TRY(dev_alloc(h, &h->b2, B * H4 * W4 * 64));
+  SP_TRY(dev_alloc(h, &h->a3, B * H4 * W4 * 128));
+  SP_TRY(dev_alloc(h, &h->b3, B * hh * ww * 128));
+  SP_TRY(dev_alloc(h, &h->a4, B * hh * ww * 128));
+  SP_TRY(dev_alloc(h, &h->x, B * hh * ww * 128));
+  SP_TRY(dev_alloc(h, &h->pa, B * hh * ww * 256));
+  SP_TRY(dev_alloc(h, &h->logits, B * hh * ww * 65));
+  SP_TRY(dev_alloc(h, &h->da, B * hh * ww * 256));
+  SP_TRY(dev_alloc(h, &h->dd, B * hh * ww * 256));
+  SP_TRY(dev_alloc(h, &h->smap, B * hh * ww * 64));
+  SP_TRY(dev_alloc(h, &h->nms, B * hh * ww * 64));
+  SP_TRY(dev_alloc(h, &h->cand_score, B * hh * ww * 64));
+  SP_TRY(dev_alloc(h, &h->cand_idx, B * hh * ww * 64));
+  SP_TRY(dev_alloc(h, &h->rowcount, B * hh * 8));
+  SP_TRY(dev_alloc(h, &h->rowoff, B * hh * 8));
+  SP_TRY(dev_alloc(h, &h->ncand, B));
+#undef SP_TRY
+  *out = h;
+  return 0;
+}
+
+int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, float* kpts_xy_dev, float* scores_dev,
+                   float* desc_dev, int32_t* n_kpts_dev, void* stream) {
+  DIM_REQUIRE(h && images_dev && kpts_xy_dev && scores_dev && desc_dev && n_kpts_dev, "dim_sp_extract: null argument");
+  DIM_REQUIRE(batch >= 1 && batch <= h->max_batch, "dim_sp_extract: batch %d outside [1,%d]", batch, h->max_batch);
+  DIM_REQUIRE(H >= 8 && W >= 8 && H <= h->max_h && W <= h->max_w && (size_t)H * W <= (size_t)h->max_h * h->max_w,
+              "dim_sp_extract: image %dx%d outside the handle's %dx%d", H, W, h->max_h, h->max_w);
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, hh = H4 / 2, ww = W4 / 2;  // floor at every pool (Q12)
+  const int H8 = hh * 8, W8 = ww * 8;
+#define SP_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
+  // encoder (SPN:161-171)
+  SP_RUN(launch_conv1a(images_dev, h->wk[0], h->bias[0], h->a1, batch, H, W, s));
+  SP_RUN(launch_conv3x3(h->a1, h->wk[1], h->bias[1], h->b1, batch, H, W, 64, 64, 1, 1, s));
+  SP_RUN(launch_conv3x3(h->b1, h->wk[2], h->bias[2], h->a2, batch, H2, W2, 64, 64, 0, 1, s));
+  SP_RUN(launch_conv3x3(h->a2, h->wk[3], h->bias[3], h->b2, batch, H2, W2, 64, 64, 1, 1, s));
+  SP_RUN(launch_conv3x3(h->b2, h->wk[4], h->bias[4], h->a3, batch, H4, W4, 64, 128, 0, 1, s));
+  SP_RUN(launch_conv3x3(h->a3, h->wk[5], h->bias[5], h->b3, batch, H4, W4, 128, 128, 1, 1, s));
+  SP_RUN(launch_conv3x3(h->b3, h->wk[6], h->bias[6], h->a4, batch, hh, ww, 128, 128, 0, 1, s));
+  SP_RUN(launch_conv3x3(h->a4, h->wk[7], h->bias[7], h->x, batch, hh, ww, 128, 128, 0, 1, s));
+  // detector head (SPN:174-180)
+  SP_RUN(launch_conv3x3(h->x, h->wk[8], h->bias[8], h->pa, batch, hh, ww, 128, 256, 0, 1, s));
+  {
+    GemmArgs g;
+    g.A0 = h->pa; g.lda0 = 256; g.B = h->wk[9]; g.ldb = 68; g.bias = h->bias[9];
+    g.C = h->logits; g.ldc = 65; g.M = batch * hh * ww; g.N = 65; g.K = 256;
+    SP_RUN(launch_gemm(g, 1, s));
+  }
+  SP_RUN(launch_softmax_d2s(h->logits, h->smap, batch, hh, ww, s));
+  SP_RUN(launch_nms(h->smap, h->nms, batch, H8, W8, h->cfg.nms_radius, s));
+  // selection (SPN:183-210)
+  SP_RUN(launch_select(h->nms, batch, H8, W8, h->cfg.keypoint_threshold, h->cfg.remove_borders, h->rowcount, h->rowoff,
+                       h->ncand, h->cand_score, h->cand_idx, s));
+  SP_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H8, W8, h->cfg.max_keypoints, h->capacity, kpts_xy_dev,
+                     scores_dev, n_kpts_dev, s));
+  // descriptor head (SPN:213-221)
+  SP_RUN(launch_conv3x3(h->x, h->wk[10], h->bias[10], h->da, batch, hh, ww, 128, 256, 0, 1, s));
+  {
+    GemmArgs g;
+    g.A0 = h->da; g.lda0 = 256; g.B = h->wk[11]; g.ldb = 256; g.bias = h->bias[11];
+    g.C = h->dd; g.ldc = 256; g.M = batch * hh * ww; g.N = 256; g.K = 256;
+    SP_RUN(launch_gemm(g, 1, s));
+  }
+  SP_RUN(launch_sample_desc(h->dd, kpts_xy_dev, n_kpts_dev, desc_dev, batch, hh, ww, h->capacity, h->cfg.fix_sampling, s));
+#undef SP_RUN
+  h->last_h = hh; h->last_w = ww; h->last_batch = batch;
+  return 0;
+}
+
+int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits, const float** score_map,
+                         const float** nms_map, const float** dense_desc, int* h8, int* w8) {
+  DIM_REQUIRE(h, "dim_sp_debug_buffers: null handle");
+  if (encoder) *encoder = h->x;
+  if (logits) *logits = h->logits;
+  if (score_map) *score_map = h->smap;
+  if (nms_map) *nms_map = h->nms;
+  if (dense_desc) *dense_desc = h->dd;
+  if (h8) *h8 = h->last_h * 8;
+  if (w8) *w8 = h->last_w * 8;
+  return 0;
+}
+
+int dim_sp_candidate_counts(dim_sp* h, const int32_t** ncand_dev) {
+  DIM_REQUIRE(h && ncand_dev, "dim_sp_candidate_counts: null argument");
+  *ncand_dev = h->ncand;
+  return 0;
+}
+
+}  // extern "C"

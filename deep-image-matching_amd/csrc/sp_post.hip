@@ -1,0 +1,383 @@
+// SuperPoint detector/descriptor post-processing for gfx950 — the HBM-bound,
+// compare/integer half of the extractor (reference SPN:47-98,176-221).
+//
+//   softmax_d2s   : 65-way softmax per 8x8 cell, drop dustbin, depth-to-space (SPN:176-179)
+//   nms           : simple_nms fused into ONE pass per 32x32 tile with a 5r halo
+//                   staged in LDS (the reference runs 5 full-res max-pools, SPN:47-63)
+//   count/scan/emit: row-major ordered compaction of (s > thr) & border (SPN:183-196)
+//   topk          : radix-select + LDS bitonic sort, score-descending (SPN:74-78,199-207)
+//   sample        : bilinear sampling of the dense descriptor map at the keypoints with
+//                   both L2 normalisations, touching only the <=4 cells per keypoint
+//                   (SPN:81-98,215; DIM's fix_sampling variant SPX:16-27)
+#include <math.h>
+
+#include "sp_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// one wave per cell: lane c holds logit c; lane-uniform dustbin.
+__global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* __restrict__ logits, float* __restrict__ smap,
+                                                          int n_cells_total, int h, int w) {
+  const int lane = threadIdx.x & 63;
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= n_cells_total) return;
+  const float* p = logits + (size_t)cell * 65;
+  const float v = p[lane];
+  const float dust = p[64];
+  const float m = fmaxf(wave_max(v), dust);
+  const float e = expf(v - m);
+  const float s = wave_sum(e) + expf(dust - m);
+  const int b = cell / (h * w);
+  const int rem = cell - b * h * w;
+  const int cy = rem / w, cx = rem - cy * w;
+  const int W8 = w * 8;
+  smap[((size_t)b * h * 8 + cy * 8 + (lane >> 3)) * W8 + cx * 8 + (lane & 7)] = e / s;
+}
+
+// ---------------------------------------------------------------------------
+// simple_nms on a TILE x TILE output tile; T = TILE + 10 r.  LDS: s (scores, -inf
+// outside the image), tmp (row-pass scratch), msk (bit0 keep, bit1 near-kept),
+// orr (row-pass scratch of the dilation).
+template <int TILE, int TMAX>
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ smap, float* __restrict__ out, int H8, int W8,
+                                                  int r, int tiles_x) {
+  __shared__ float s[TMAX * TMAX];
+  __shared__ float tmp[TMAX * TMAX];
+  __shared__ unsigned char msk[TMAX * TMAX];
+  __shared__ unsigned char orr[TMAX * TMAX];
+  const int halo = 5 * r, T = TILE + 2 * halo, TT = T * T;
+  const int t = threadIdx.x;
+  const int b = blockIdx.z;
+  const int ty0 = (blockIdx.x / tiles_x) * TILE - halo, tx0 = (blockIdx.x % tiles_x) * TILE - halo;
+  const float* src = smap + (size_t)b * H8 * W8;
+  const float NEG = -INFINITY;
+
+  for (int i = t; i < TT; i += 256) {
+    const int y = i / T, x = i - y * T, gy = ty0 + y, gx = tx0 + x;
+    s[i] = (gy >= 0 && gy < H8 && gx >= 0 && gx < W8) ? src[(size_t)gy * W8 + gx] : NEG;
+    msk[i] = 0;
+  }
+  __syncthreads();
+
+  // round 0 builds keep = (s == P(s)); rounds 1,2 do suppress-and-recover.
+  for (int round = 0; round < 3; ++round) {
+    if (round > 0) {
+      // near = dilate(keep, r): separable OR
+      for (int i = t; i < TT; i += 256) {
+        const int y = i / T, x = i - y * T;
+        const int x0 = max(x - r, 0), x1 = min(x + r, T - 1);
+        unsigned char o = 0;
+        for (int xx = x0; xx <= x1; ++xx) o |= msk[y * T + xx] & 1;
+        orr[i] = o;
+      }
+      __syncthreads();
+      for (int i = t; i < TT; i += 256) {
+        const int y = i / T, x = i - y * T;
+        const int y0 = max(y - r, 0), y1 = min(y + r, T - 1);
+        unsigned char o = 0;
+        for (int yy = y0; yy <= y1; ++yy) o |= orr[yy * T + x];
+        msk[i] = (msk[i] & 1) | (o << 1);
+      }
+      __syncthreads();
+    }
+    // row max of rest = near ? 0 : s   (round 0: near == 0 everywhere)
+    for (int i = t; i < TT; i += 256) {
+      const int y = i / T, x = i - y * T;
+      const int x0 = max(x - r, 0), x1 = min(x + r, T - 1);
+      float m = NEG;
+      for (int xx = x0; xx <= x1; ++xx) {
+        const int j = y * T + xx;
+        const float v = (msk[j] & 2) ? ((s[j] == NEG) ? NEG : 0.0f) : s[j];
+        m = fmaxf(m, v);
+      }
+      tmp[i] = m;
+    }
+    __syncthreads();
+    for (int i = t; i < TT; i += 256) {
+      const int y = i / T, x = i - y * T;
+      const int y0 = max(y - r, 0), y1 = min(y + r, T - 1);
+      float m = NEG;
+      for (int yy = y0; yy <= y1; ++yy) m = fmaxf(m, tmp[yy * T + x]);
+      const unsigned char k = msk[i];
+      const float sv = s[i];
+      const float rest = (k & 2) ? 0.0f : sv;
+      const bool inside = sv != NEG;  // scores are softmax outputs: finite inside the image
+      const bool newkeep = inside && !(k & 2) && (rest == m);
+      orr[i] = newkeep ? 1 : 0;  // staged: msk is still being read by nobody, but keep phases separate
+    }
+    __syncthreads();
+    for (int i = t; i < TT; i += 256) msk[i] |= orr[i];
+    __syncthreads();
+  }
+
+  float* dst = out + (size_t)b * H8 * W8;
+  for (int i = t; i < TILE * TILE; i += 256) {
+    const int y = i / TILE, x = i - y * TILE;
+    const int gy = ty0 + halo + y, gx = tx0 + halo + x;
+    if (gy < H8 && gx < W8) {
+      const int j = (y + halo) * T + x + halo;
+      dst[(size_t)gy * W8 + gx] = (msk[j] & 1) ? s[j] : 0.0f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool sp_is_candidate(float v, int y, int x, int H8, int W8, float thr, int border) {
+  return v > thr && y >= border && y < H8 - border && x >= border && x < W8 - border;
+}
+
+// one wave per score-map row: count candidates
+__global__ __launch_bounds__(256) void count_rows_kernel(const float* __restrict__ nms, int* __restrict__ rowcount, int H8,
+                                                         int W8, float thr, int border) {
+  const int lane = threadIdx.x & 63;
+  const int y = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (y >= H8) return;
+  const float* row = nms + ((size_t)b * H8 + y) * W8;
+  int c = 0;
+  for (int x = lane; x < W8; x += 64) c += sp_is_candidate(row[x], y, x, H8, W8, thr, border) ? 1 : 0;
+  c = wave_sum_i(c);
+  if (lane == 0) rowcount[(size_t)b * H8 + y] = c;
+}
+
+// one block per image: exclusive scan over rows
+__global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__ rowcount, int* __restrict__ rowoff,
+                                                         int* __restrict__ ncand, int H8) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int per = (H8 + 1023) / 1024;
+  const int y0 = t * per, y1 = min(y0 + per, H8);
+  int sum = 0;
+  for (int y = y0; y < y1; ++y) sum += rowcount[(size_t)b * H8 + y];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  for (int y = y0; y < y1; ++y) {
+    rowoff[(size_t)b * H8 + y] = run;
+    run += rowcount[(size_t)b * H8 + y];
+  }
+  if (t == 1023) ncand[b] = part[1023];
+}
+
+// one wave per row: ordered emission (row-major == torch.nonzero order, SPN:183-186)
+__global__ __launch_bounds__(256) void emit_rows_kernel(const float* __restrict__ nms, const int* __restrict__ rowoff,
+                                                        float* __restrict__ cand_score, int* __restrict__ cand_idx, int H8,
+                                                        int W8, float thr, int border) {
+  const int lane = threadIdx.x & 63;
+  const int y = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (y >= H8) return;
+  const float* row = nms + ((size_t)b * H8 + y) * W8;
+  const size_t base_img = (size_t)b * H8 * W8;
+  int base = rowoff[(size_t)b * H8 + y];
+  for (int x0 = 0; x0 < W8; x0 += 64) {
+    const int x = x0 + lane;
+    const float v = (x < W8) ? row[x] : 0.0f;
+    const bool c = (x < W8) && sp_is_candidate(v, y, x, H8, W8, thr, border);
+    const unsigned long long m = __ballot(c);
+    if (c) {
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      cand_score[base_img + pos] = v;
+      cand_idx[base_img + pos] = y * W8 + x;
+    }
+    base += __popcll(m);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// one block per image.  key = score bits (positive floats order like uints) << 32 |
+// (~idx): descending key order = descending score, ascending index among ties.
+constexpr int TOPK_MAX = 4096;
+__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ cand_score, const int* __restrict__ cand_idx,
+                                                    const int* __restrict__ ncand, int H8, int W8, int k, int capacity,
+                                                    float* __restrict__ kpts, float* __restrict__ scores,
+                                                    int* __restrict__ n_out) {
+  __shared__ unsigned long long keys[TOPK_MAX];
+  __shared__ int hist[256];
+  __shared__ unsigned long long sh_prefix;
+  __shared__ int sh_krem, sh_cnt;
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int n = ncand[b];
+  const float* cs = cand_score + (size_t)b * H8 * W8;
+  const int* ci = cand_idx + (size_t)b * H8 * W8;
+  float* kp = kpts + (size_t)b * capacity * 2;
+  float* sc = scores + (size_t)b * capacity;
+
+  if (k < 0 || n <= k) {  // keep all, row-major order (SPN:75-76)
+    const int m = min(n, capacity);
+    for (int i = t; i < m; i += 1024) {
+      const int idx = ci[i];
+      kp[2 * i] = (float)(idx % W8);
+      kp[2 * i + 1] = (float)(idx / W8);
+      sc[i] = cs[i];
+    }
+    if (t == 0) n_out[b] = m;
+    return;
+  }
+
+  // ---- radix select of the k-th largest key, one byte per pass from the top ----
+  if (t == 0) { sh_prefix = 0ull; sh_krem = k; }
+  __syncthreads();
+  for (int byte = 7; byte >= 0; --byte) {
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const unsigned long long prefix = sh_prefix;
+    const unsigned long long himask = (byte == 7) ? 0ull : (~0ull << (8 * (byte + 1)));
+    for (int i = t; i < n; i += 1024) {
+      const unsigned long long key = ((unsigned long long)__float_as_uint(cs[i]) << 32) | (unsigned)(~ci[i]);
+      if ((key & himask) == prefix) atomicAdd(&hist[(int)((key >> (8 * byte)) & 0xffull)], 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+      int krem = sh_krem, d = 255;
+      for (; d > 0; --d) {
+        if (hist[d] >= krem) break;
+        krem -= hist[d];
+      }
+      sh_krem = krem;
+      sh_prefix = prefix | ((unsigned long long)d << (8 * byte));
+    }
+    __syncthreads();
+  }
+  const unsigned long long kth = sh_prefix;
+
+  // ---- gather the k keys >= kth, pad to a power of two, bitonic sort descending ----
+  int P = 1;
+  while (P < k) P <<= 1;
+  for (int i = t; i < P; i += 1024) keys[i] = 0ull;
+  if (t == 0) sh_cnt = 0;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(cs[i]) << 32) | (unsigned)(~ci[i]);
+    if (key >= kth) {
+      const int pos = atomicAdd(&sh_cnt, 1);
+      if (pos < P) keys[pos] = key;
+    }
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < (P >> 1); i += 1024) {
+        const int lo = 2 * i - (i & (stride - 1));  // index with bit `stride` clear
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = keys[lo], c = keys[hi];
+        if (desc ? (a < c) : (a > c)) { keys[lo] = c; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = t; i < k; i += 1024) {
+    const unsigned long long key = keys[i];
+    const int idx = (int)(~(unsigned)(key & 0xffffffffull));
+    kp[2 * i] = (float)(idx % W8);
+    kp[2 * i + 1] = (float)(idx / W8);
+    sc[i] = __uint_as_float((unsigned)(key >> 32));
+  }
+  if (t == 0) n_out[b] = k;
+}
+
+// ---------------------------------------------------------------------------
+// one wave per keypoint; lane owns channels 4*lane .. 4*lane+3 of the 256.
+__global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restrict__ dense, const float* __restrict__ kpts,
+                                                          const int* __restrict__ n_kpts, float* __restrict__ desc, int h,
+                                                          int w, int capacity, int fix_sampling) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (i >= n_kpts[b]) return;
+  const float kx = kpts[((size_t)b * capacity + i) * 2], ky = kpts[((size_t)b * capacity + i) * 2 + 1];
+  float ix, iy;
+  if (fix_sampling) {  // SPX:16-27: (k + 0.5) / (w*8), align_corners=False
+    float gx = (kx + 0.5f) / ((float)w * 8.0f), gy = (ky + 0.5f) / ((float)h * 8.0f);
+    gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f;
+    ix = ((gx + 1.0f) * (float)w - 1.0f) / 2.0f;
+    iy = ((gy + 1.0f) * (float)h - 1.0f) / 2.0f;
+  } else {  // SPN:84-94: (k - 4 + 0.5) / (w*8 - 4 - 0.5), align_corners=True
+    float gx = (kx - 4.0f + 0.5f) / ((float)(w * 8) - 4.0f - 0.5f), gy = (ky - 4.0f + 0.5f) / ((float)(h * 8) - 4.0f - 0.5f);
+    gx = gx * 2.0f - 1.0f; gy = gy * 2.0f - 1.0f;
+    ix = ((gx + 1.0f) / 2.0f) * (float)(w - 1);
+    iy = ((gy + 1.0f) / 2.0f) * (float)(h - 1);
+  }
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  // bilinear weights exactly as ATen's grid_sampler: nw, ne, sw, se
+  const float wnw = (fx + 1.0f - ix) * (fy + 1.0f - iy), wne = (ix - fx) * (fy + 1.0f - iy);
+  const float wsw = (fx + 1.0f - ix) * (iy - fy), wse = (ix - fx) * (iy - fy);
+  const float* base = dense + (size_t)b * h * w * 256;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int cxs[4] = {x0, x0 + 1, x0, x0 + 1};
+  const int cys[4] = {y0, y0, y0 + 1, y0 + 1};
+  const float wts[4] = {wnw, wne, wsw, wse};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool in = cxs[c] >= 0 && cxs[c] < w && cys[c] >= 0 && cys[c] < h;  // wave-uniform
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) v = *(const float4*)(base + ((size_t)cys[c] * w + cxs[c]) * 256 + lane * 4);
+    float ss = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+    const float den = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize of the dense map (SPN:215)
+    if (in) {
+      acc[0] += (v.x / den) * wts[c]; acc[1] += (v.y / den) * wts[c];
+      acc[2] += (v.z / den) * wts[c]; acc[3] += (v.w / den) * wts[c];
+    }
+  }
+  const float ss = wave_sum(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2] + acc[3] * acc[3]);
+  const float den = fmaxf(sqrtf(ss), 1e-12f);  // SPN:95-97
+  *(float4*)(desc + ((size_t)b * capacity + i) * 256 + lane * 4) =
+      make_float4(acc[0] / den, acc[1] / den, acc[2] / den, acc[3] / den);
+}
+
+}  // namespace
+
+int launch_softmax_d2s(const float* logits, float* smap, int batch, int h, int w, hipStream_t s) {
+  const int n = batch * h * w;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(softmax_d2s_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, logits, smap, n, h, w);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_nms(const float* smap, float* out, int batch, int H8, int W8, int radius, hipStream_t s) {
+  DIM_REQUIRE(radius >= 0 && radius <= 6, "nms: radius %d unsupported (0..6)", radius);
+  if (batch <= 0 || H8 <= 0 || W8 <= 0) return 0;
+  if (radius <= 4) {
+    const int tx = cdiv(W8, 32), ty = cdiv(H8, 32);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_kernel<32, 72>), dim3(tx * ty, 1, batch), dim3(256), 0, s, smap, out, H8, W8, radius, tx);
+  } else {
+    const int tx = cdiv(W8, 16), ty = cdiv(H8, 16);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_kernel<16, 76>), dim3(tx * ty, 1, batch), dim3(256), 0, s, smap, out, H8, W8, radius, tx);
+  }
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_select(const float* nms, int batch, int H8, int W8, float thr, int border, int* rowcount, int* rowoff,
+                  int* ncand, float* cand_score, int* cand_idx, hipStream_t s) {
+  if (batch <= 0 || H8 <= 0 || W8 <= 0) return 0;
+  hipLaunchKernelGGL(count_rows_kernel, dim3(cdiv(H8, 4), batch), dim3(256), 0, s, nms, rowcount, H8, W8, thr, border);
+  hipLaunchKernelGGL(scan_rows_kernel, dim3(batch), dim3(1024), 0, s, (const int*)rowcount, rowoff, ncand, H8);
+  hipLaunchKernelGGL(emit_rows_kernel, dim3(cdiv(H8, 4), batch), dim3(256), 0, s, nms, (const int*)rowoff, cand_score, cand_idx, H8, W8, thr, border);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_topk(const float* cand_score, const int* cand_idx, const int* ncand, int batch, int H8, int W8, int k,
+                int capacity, float* kpts, float* scores, int* n_out, hipStream_t s) {
+  DIM_REQUIRE(k <= TOPK_MAX, "topk: max_keypoints %d > %d unsupported", k, TOPK_MAX);
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(1024), 0, s, cand_score, cand_idx, ncand, H8, W8, k, capacity, kpts, scores, n_out);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sample_desc(const float* dense, const float* kpts, const int* n_kpts, float* desc, int batch, int h, int w,
+                       int capacity, int fix_sampling, hipStream_t s) {
+  if (batch <= 0 || capacity <= 0) return 0;
+  hipLaunchKernelGGL(sample_desc_kernel, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, dense, kpts, n_kpts, desc, h, w, capacity, fix_sampling);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}

@@ -86,6 +86,10 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
 int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits, const float** score_map,
                          const float** nms_map, const float** dense_desc, int* h8, int* w8);
 
+/* Number of NMS survivors above threshold/border per image of the last call
+ * (before top-k), device int32 [batch] owned by the handle. */
+int dim_sp_candidate_counts(dim_sp* h, const int32_t** ncand_dev);
+
 /* ------------------------------------------------------------------------ */
 /* operator-level entry points (each is one kernel launch; used by the      */
 /* parity tests and available to integrators)                               */

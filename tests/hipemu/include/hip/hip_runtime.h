@@ -41,6 +41,8 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
+using std::max;
+using std::min;
 #define __global__
 #define __device__
 #define __host__

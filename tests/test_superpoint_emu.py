@@ -1,0 +1,42 @@
+"""CPU: the HIP SuperPoint sources, compiled against the test-only emulator, vs the
+oracle and the reference's golden vectors on the small golden cases."""
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import superpoint_ref
+from tests import golden_cases as gc
+from tests.parity import compare_superpoint, order_is_reference_like
+
+sp_mod = importlib.import_module("deep-image-matching_amd.superpoint_hip")
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.mark.parametrize("name", list(gc.SP_CASES))
+def test_superpoint_emulated_vs_golden_and_oracle(emu_lib, name):
+    case = gc.SP_CASES[name]
+    sd, img = gc.sp_weights(case), gc.sp_image(case)
+    net = sp_mod.SuperPointHIP(sd, case["cfg"], max_batch=1, max_hw=(case["H"], case["W"]), capacity=512, device="cpu", lib=emu_lib)
+    out = net(img)
+    taps = net.debug_taps()
+    ref = superpoint_ref.superpoint_forward(img, sd, case["cfg"], taps=True)
+    # dense stages
+    np.testing.assert_allclose(taps["encoder"][0].permute(2, 0, 1).numpy(), ref["encoder"][0].numpy(), atol=2e-4, rtol=1e-4)
+    h, w = ref["logits"].shape[-2:]
+    np.testing.assert_allclose(taps["logits"][0].reshape(h, w, 65).permute(2, 0, 1).numpy(), ref["logits"][0].numpy(), atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(taps["score_map"][0].numpy(), ref["score_map"][0].numpy(), atol=2e-6, rtol=1e-4)
+    # selection stage must be bit-exact GIVEN the same score map: run the oracle's NMS on OUR map
+    nms_on_ours = superpoint_ref.simple_nms(taps["score_map"], case["cfg"]["nms_radius"])
+    assert torch.equal(nms_on_ours[0], taps["nms_map"][0])
+    yx, sc = superpoint_ref.select_keypoints(taps["nms_map"][0], case["cfg"]["keypoint_threshold"], case["cfg"]["remove_borders"],
+                                              case["cfg"]["max_keypoints"])
+    assert set(map(tuple, torch.flip(yx, [1]).tolist())) == set(map(tuple, out["keypoints"].long().tolist()))
+    # end to end vs the reference's golden outputs
+    g = np.load(GOLD / f"sp_{name}.npz")
+    gold = {"keypoints": torch.from_numpy(g["keypoints"]), "scores": torch.from_numpy(g["scores"]), "descriptors": torch.from_numpy(g["descriptors"])}
+    res = compare_superpoint({k: v.cpu() for k, v in out.items()}, gold)
+    k = case["cfg"]["max_keypoints"]
+    order_is_reference_like(out, k_limited=(k >= 0 and res["n_out"] == k))
