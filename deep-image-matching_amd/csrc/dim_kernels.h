@@ -17,6 +17,7 @@ struct GemmArgs {
   const float* A0 = nullptr; const float* A1 = nullptr;
   int lda0 = 0, lda1 = 0, ksplit = 0;
   long long strideA0 = 0, strideA1 = 0;
+  const int* a_idx = nullptr;  // optional indirection: A0 of item z starts at A0 + a_idx[z]*strideA0
   const float* B = nullptr; int ldb = 0; long long strideB = 0; int bt = 0;
   const float* bias = nullptr;
   const float* R = nullptr; int ldr = 0; long long strideR = 0;

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
   const int lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
   const int lx = lane & 31, half = lane >> 5;
 
-  const float* A0 = a.A0 + (size_t)z * a.strideA0;
+  const float* A0 = a.A0 + (size_t)(a.a_idx ? a.a_idx[z] : z) * a.strideA0;
   const float* A1 = a.A1 ? a.A1 + (size_t)z * a.strideA1 : nullptr;
   const float* B = a.B + (size_t)z * a.strideB;
 

@@ -1,0 +1,236 @@
+// dim_lg_* : resident LightGlue matcher (C ABI in include/dim_hip.h).
+// Replaces LightGlue.__init__/forward (LGN:300-610) as driven by
+// LightGlueMatcher._match_pairs (matchers/lightglue.py:102-125), batched over
+// pairs with device-side early stop / pruning (no host read-back anywhere).
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/dim_hip.h"
+#include "lg_kernels.h"
+
+namespace {
+struct LayerW {
+  float *qkv_w, *qkv_b, *out_w, *out_b, *sffn0_w, *sffn0_b, *sln_w, *sln_b, *sffn3_w, *sffn3_b;
+  float *cqkv_w, *cqkv_b, *cout_w, *cout_b, *cffn0_w, *cffn0_b, *cln_w, *cln_b, *cffn3_w, *cffn3_b;
+  float *match_w, *match_b, *proj_w, *proj_b, *tok_w, *tok_b;
+};
+}  // namespace
+
+struct dim_lg {
+  dim_lg_config cfg;
+  int n_layers, input_dim, max_pairs, nmax;
+  std::vector<LayerW> L;
+  std::vector<float> thr;
+  float *inproj_w, *inproj_b, *Wr;
+  LgState st;
+  std::vector<void*> allocs;
+};
+
+namespace {
+template <typename T>
+int dev_alloc(dim_lg* h, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+  if (e != hipSuccess) {
+    dim_set_error("hipMalloc of %zu bytes failed: out of memory (%s)", count * sizeof(T), hipGetErrorString(e));
+    return -1;
+  }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+int upload(dim_lg* h, float** dst, const std::vector<float>& v) {
+  if (dev_alloc(h, dst, v.size()) != 0) return -1;
+  if (hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    dim_set_error("weight upload failed");
+    return -1;
+  }
+  return 0;
+}
+// nn.Linear weight [out][in] -> GEMM operand [in][out] (optionally scaled)
+std::vector<float> transpose(const float* w, int out_f, int in_f, float scale = 1.0f) {
+  std::vector<float> t((size_t)in_f * out_f);
+  for (int o = 0; o < out_f; ++o)
+    for (int i = 0; i < in_f; ++i) t[(size_t)i * out_f + o] = w[(size_t)o * in_f + i] * scale;
+  return t;
+}
+std::vector<float> vec(const float* b, int n, float scale = 1.0f) {
+  std::vector<float> v(n);
+  for (int i = 0; i < n; ++i) v[i] = b[i] * scale;
+  return v;
+}
+}  // namespace
+
+extern "C" {
+
+void dim_lg_destroy(dim_lg* h) {
+  if (!h) return;
+  for (void* p : h->allocs) hipFree(p);
+  delete h;
+}
+
+int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pairs, int max_kpts, dim_lg** out) {
+  DIM_REQUIRE(w && cfg && out && w->layers, "dim_lg_create: null argument");
+  DIM_REQUIRE(w->n_layers >= 1 && w->n_layers <= 32, "dim_lg_create: n_layers %d", w->n_layers);
+  DIM_REQUIRE(w->input_dim > 0 && w->input_dim % 32 == 0, "dim_lg_create: input_dim %d must be a multiple of 32", w->input_dim);
+  DIM_REQUIRE((w->input_dim == 256) == (w->input_proj_w == nullptr), "dim_lg_create: input_proj must be given iff input_dim != 256 (LGN:361-364)");
+  DIM_REQUIRE(max_pairs > 0 && max_kpts > 0, "dim_lg_create: bad sizes");
+  dim_lg* h = new dim_lg();
+  h->cfg = *cfg;
+  h->n_layers = w->n_layers; h->input_dim = w->input_dim; h->max_pairs = max_pairs;
+  h->nmax = (max_kpts + 3) & ~3;
+  h->inproj_w = h->inproj_b = nullptr;
+  h->thr.assign(w->confidence_thresholds, w->confidence_thresholds + w->n_layers);
+#define LG_TRY(x) do { if ((x) != 0) { dim_lg_destroy(h); return -1; } } while (0)
+  LG_TRY(upload(h, &h->Wr, vec(w->posenc_Wr, 64)));
+  if (w->input_proj_w) {
+    LG_TRY(upload(h, &h->inproj_w, transpose(w->input_proj_w, 256, w->input_dim)));
+    LG_TRY(upload(h, &h->inproj_b, vec(w->input_proj_b, 256)));
+  }
+  h->L.resize(w->n_layers);
+  for (int i = 0; i < w->n_layers; ++i) {
+    const dim_lg_layer_weights& s = w->layers[i];
+    LayerW& d = h->L[i];
+    // Wqkv rows are interleaved head*192 + dim*3 + {q,k,v} (LGN:153-154); emit columns [q | k | v], head-major.
+    std::vector<float> qkv((size_t)256 * 768), qkvb(768);
+    for (int which = 0; which < 3; ++which)
+      for (int hd = 0; hd < 4; ++hd)
+        for (int dd = 0; dd < 64; ++dd) {
+          const int o = hd * 192 + dd * 3 + which, c = which * 256 + hd * 64 + dd;
+          qkvb[c] = s.self_Wqkv_b[o];
+          for (int k = 0; k < 256; ++k) qkv[(size_t)k * 768 + c] = s.self_Wqkv_w[(size_t)o * 256 + k];
+        }
+    LG_TRY(upload(h, &d.qkv_w, qkv)); LG_TRY(upload(h, &d.qkv_b, qkvb));
+    LG_TRY(upload(h, &d.out_w, transpose(s.self_out_w, 256, 256))); LG_TRY(upload(h, &d.out_b, vec(s.self_out_b, 256)));
+    LG_TRY(upload(h, &d.sffn0_w, transpose(s.self_ffn0_w, 512, 512))); LG_TRY(upload(h, &d.sffn0_b, vec(s.self_ffn0_b, 512)));
+    LG_TRY(upload(h, &d.sln_w, vec(s.self_ln_w, 512))); LG_TRY(upload(h, &d.sln_b, vec(s.self_ln_b, 512)));
+    LG_TRY(upload(h, &d.sffn3_w, transpose(s.self_ffn3_w, 256, 512))); LG_TRY(upload(h, &d.sffn3_b, vec(s.self_ffn3_b, 256)));
+    // to_qk and to_v fused into one [256][512] operand: columns [qk | v]
+    std::vector<float> cq((size_t)256 * 512), cqb(512);
+    for (int o = 0; o < 256; ++o) {
+      cqb[o] = s.cross_qk_b[o]; cqb[256 + o] = s.cross_v_b[o];
+      for (int k = 0; k < 256; ++k) {
+        cq[(size_t)k * 512 + o] = s.cross_qk_w[(size_t)o * 256 + k];
+        cq[(size_t)k * 512 + 256 + o] = s.cross_v_w[(size_t)o * 256 + k];
+      }
+    }
+    LG_TRY(upload(h, &d.cqkv_w, cq)); LG_TRY(upload(h, &d.cqkv_b, cqb));
+    LG_TRY(upload(h, &d.cout_w, transpose(s.cross_out_w, 256, 256))); LG_TRY(upload(h, &d.cout_b, vec(s.cross_out_b, 256)));
+    LG_TRY(upload(h, &d.cffn0_w, transpose(s.cross_ffn0_w, 512, 512))); LG_TRY(upload(h, &d.cffn0_b, vec(s.cross_ffn0_b, 512)));
+    LG_TRY(upload(h, &d.cln_w, vec(s.cross_ln_w, 512))); LG_TRY(upload(h, &d.cln_b, vec(s.cross_ln_b, 512)));
+    LG_TRY(upload(h, &d.cffn3_w, transpose(s.cross_ffn3_w, 256, 512))); LG_TRY(upload(h, &d.cffn3_b, vec(s.cross_ffn3_b, 256)));
+    LG_TRY(upload(h, &d.match_w, vec(s.assign_match_w, 256))); LG_TRY(upload(h, &d.match_b, vec(s.assign_match_b, 1)));
+    // final_proj / d^0.25 (LGN:268-270): 256^0.25 = 4, a power of two -> folding the scale is exact
+    LG_TRY(upload(h, &d.proj_w, transpose(s.assign_proj_w, 256, 256, 0.25f))); LG_TRY(upload(h, &d.proj_b, vec(s.assign_proj_b, 256, 0.25f)));
+    d.tok_w = d.tok_b = nullptr;
+    if (s.token_w) { LG_TRY(upload(h, &d.tok_w, vec(s.token_w, 256))); LG_TRY(upload(h, &d.tok_b, vec(s.token_b, 1))); }
+    DIM_REQUIRE(i == w->n_layers - 1 || s.token_w, "dim_lg_create: token_confidence.%d missing", i);
+  }
+  LgState& st = h->st;
+  const size_t P = max_pairs, I = 2 * P, N = h->nmax;
+  st.n_pairs = max_pairs; st.n_items = 2 * max_pairs; st.nmax = h->nmax;
+  LG_TRY(dev_alloc(h, &st.desc, I * N * 256)); LG_TRY(dev_alloc(h, &st.enc, I * N * 64));
+  LG_TRY(dev_alloc(h, &st.qkv, I * N * 768)); LG_TRY(dev_alloc(h, &st.ctx, I * N * 256));
+  LG_TRY(dev_alloc(h, &st.msg, I * N * 256)); LG_TRY(dev_alloc(h, &st.hid, I * N * 512));
+  LG_TRY(dev_alloc(h, &st.md, I * N * 256)); LG_TRY(dev_alloc(h, &st.sim, P * N * N));
+  LG_TRY(dev_alloc(h, &st.conf, I * N)); LG_TRY(dev_alloc(h, &st.mtch, I * N)); LG_TRY(dev_alloc(h, &st.zls, I * N));
+  LG_TRY(dev_alloc(h, &st.rmax, I * N)); LG_TRY(dev_alloc(h, &st.rlse, I * N)); LG_TRY(dev_alloc(h, &st.best, I * N));
+  LG_TRY(dev_alloc(h, &st.arg, I * N)); LG_TRY(dev_alloc(h, &st.n_cur, I)); LG_TRY(dev_alloc(h, &st.n_new, I));
+  LG_TRY(dev_alloc(h, &st.n_orig, I)); LG_TRY(dev_alloc(h, &st.ind, I * N)); LG_TRY(dev_alloc(h, &st.dest, I * N));
+  LG_TRY(dev_alloc(h, &st.prune, I * N)); LG_TRY(dev_alloc(h, &st.done, P)); LG_TRY(dev_alloc(h, &st.cnt_lt, P));
+  LG_TRY(dev_alloc(h, &st.tdesc, I * N * 256)); LG_TRY(dev_alloc(h, &st.tenc, I * N * 64)); LG_TRY(dev_alloc(h, &st.tind, I * N));
+#undef LG_TRY
+  *out = h;
+  return 0;
+}
+
+int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev, const int32_t* n_tab_dev,
+                 const float* size_tab_dev, int cap, const int32_t* pair_idx_dev, int n_pairs, int64_t* matches_dev,
+                 float* mscores_dev, int32_t* n_matches_dev, int32_t* matches01_dev, float* mscores01_dev,
+                 int32_t* stop_dev, int32_t* prune01_dev, float* dense_scores_dev, void* stream) {
+  DIM_REQUIRE(h && kpts_tab_dev && desc_tab_dev && n_tab_dev && size_tab_dev, "dim_lg_match: null input");
+  DIM_REQUIRE(matches_dev && mscores_dev && n_matches_dev && matches01_dev && mscores01_dev && stop_dev && prune01_dev, "dim_lg_match: null output");
+  DIM_REQUIRE(n_pairs >= 1 && n_pairs <= h->max_pairs, "dim_lg_match: n_pairs %d outside [1,%d]", n_pairs, h->max_pairs);
+  DIM_REQUIRE(cap > 0, "dim_lg_match: cap");
+  hipStream_t s = (hipStream_t)stream;
+  LgState st = h->st;
+  st.n_pairs = n_pairs; st.n_items = 2 * n_pairs;
+  const int N = st.nmax, I = st.n_items, Lr = h->n_layers;
+  const long long s256 = (long long)N * 256, s512 = (long long)N * 512, s768 = (long long)N * 768;
+  const bool early = h->cfg.depth_confidence > 0, prune = h->cfg.width_confidence > 0;  // LGN:480-481
+#define LG_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
+  LG_RUN(launch_lg_init(st, kpts_tab_dev, desc_tab_dev, n_tab_dev, size_tab_dev, pair_idx_dev, cap, h->input_dim, h->Wr,
+                        h->input_dim == 256 ? 1 : 0, s));
+  auto gemm_items = [&](const float* A, int lda, long long sA, const float* A1, int lda1, long long sA1, int ksplit,
+                        const float* B, int ldb, const float* bias, const float* R, float* C, int ldc, long long sC, int Nn,
+                        int K, int flag_eq) -> int {
+    GemmArgs g;
+    g.A0 = A; g.lda0 = lda; g.strideA0 = sA; g.A1 = A1; g.lda1 = lda1; g.strideA1 = sA1; g.ksplit = ksplit;
+    g.B = B; g.ldb = ldb; g.bias = bias; g.R = R; g.ldr = ldc; g.strideR = sC; g.C = C; g.ldc = ldc; g.strideC = sC;
+    g.M = N; g.N = Nn; g.K = K; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = flag_eq;
+    return launch_gemm(g, I, s);
+  };
+  if (h->input_dim != 256) {  // input_proj (LGN:473-474) straight from the feature table
+    GemmArgs g;
+    g.A0 = desc_tab_dev; g.lda0 = h->input_dim; g.strideA0 = (long long)cap * h->input_dim; g.a_idx = pair_idx_dev;
+    g.B = h->inproj_w; g.ldb = 256; g.bias = h->inproj_b; g.C = st.desc; g.ldc = 256; g.strideC = s256;
+    g.M = N; g.N = 256; g.K = h->input_dim; g.rows = st.n_cur;
+    LG_RUN(launch_gemm(g, I, s));
+  }
+  for (int i = 0; i < Lr; ++i) {
+    const LayerW& w = h->L[i];
+    // ---- self block (LGN:146-159) ----
+    LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.qkv_w, 768, w.qkv_b, nullptr, st.qkv, 768, s768, 768, 256, 0));
+    LG_RUN(launch_lg_rotary(st, s));
+    LG_RUN(launch_lg_attention(st, 0, s));
+    LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.out_w, 256, w.out_b, nullptr, st.msg, 256, s256, 256, 256, 0));
+    LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.sffn0_w, 512, w.sffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+    LG_RUN(launch_lg_ln_gelu(st, w.sln_w, w.sln_b, s));
+    LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.sffn3_w, 256, w.sffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0));
+    // ---- cross block (LGN:186-211) ----
+    LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.cqkv_w, 512, w.cqkv_b, nullptr, st.qkv, 768, s768, 512, 256, 0));
+    LG_RUN(launch_lg_attention(st, 1, s));
+    LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.cout_w, 256, w.cout_b, nullptr, st.msg, 256, s256, 256, 256, 0));
+    LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.cffn0_w, 512, w.cffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+    LG_RUN(launch_lg_ln_gelu(st, w.cln_w, w.cln_b, s));
+    LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.cffn3_w, 256, w.cffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0));
+    // ---- adaptive depth / width (LGN:494-516) ----
+    const bool last = (i == Lr - 1);
+    if (!last && (early || prune))
+      LG_RUN(launch_lg_confidence(st, w.tok_w, w.tok_b, w.match_w, w.match_b, h->thr[i], early ? 1 : 0, s));
+    if (last || early) LG_RUN(launch_lg_decide(st, i, (float)h->cfg.depth_confidence, early ? 1 : 0, last ? 1 : 0, s));
+    if (last || early) {
+      // ---- assignment for the pairs that stopped at this layer (LGN:540-542) ----
+      const int tag = i + 1;
+      LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.proj_w, 256, w.proj_b, nullptr, st.md, 256, s256, 256, 256, tag));
+      GemmArgs g;
+      g.A0 = st.md; g.lda0 = 256; g.strideA0 = 2 * s256; g.B = st.md + s256; g.ldb = 256; g.strideB = 2 * s256; g.bt = 1;
+      g.C = st.sim; g.ldc = N; g.strideC = (long long)N * N; g.M = N; g.N = N; g.K = 256;
+      g.rows = st.n_cur; g.rows_mul = 2; g.rows_off = 0; g.cols = st.n_cur; g.cols_mul = 2; g.cols_off = 1;
+      g.flag = st.done; g.flag_shift = 0; g.flag_eq = tag;
+      LG_RUN(launch_gemm(g, n_pairs, s));
+      LG_RUN(launch_lg_assign_stats(st, tag, w.match_w, w.match_b, s));
+      LG_RUN(launch_lg_assign_argmax(st, tag, dense_scores_dev, s));
+    }
+    if (!last && prune)
+      LG_RUN(launch_lg_prune(st, i, h->cfg.width_confidence, h->thr[i], early ? 1 : 0, h->cfg.pruning_min_kpts, s));
+  }
+  LG_RUN(launch_lg_finalize(st, Lr, prune ? 1 : 0, (float)h->cfg.filter_threshold, N, (long long*)matches_dev, mscores_dev,
+                            n_matches_dev, matches01_dev, mscores01_dev, stop_dev, prune01_dev, s));
+#undef LG_RUN
+  return 0;
+}
+
+int dim_lg_max_kpts(dim_lg* h) { return h ? h->nmax : -1; }
+
+int dim_lg_debug_desc(dim_lg* h, const float** desc, const int32_t** n_cur, const int32_t** ind) {
+  DIM_REQUIRE(h, "dim_lg_debug_desc: null handle");
+  if (desc) *desc = h->st.desc;
+  if (n_cur) *n_cur = h->st.n_cur;
+  if (ind) *ind = h->st.ind;
+  return 0;
+}
+
+}  // extern "C"

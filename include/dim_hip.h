@@ -91,6 +91,78 @@ int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits,
 int dim_sp_candidate_counts(dim_sp* h, const int32_t** ncand_dev);
 
 /* ------------------------------------------------------------------------ */
+/* LightGlue (reference LGN:300-610)                                        */
+/* ------------------------------------------------------------------------ */
+
+/* Per-layer tensors in the reference's state_dict layout (nn.Linear weight
+ * [out][in], LGN:361-378), host pointers. */
+typedef struct dim_lg_layer_weights {
+  const float *self_Wqkv_w, *self_Wqkv_b;   /* transformers.i.self_attn.Wqkv   (768,256) rows = head*192+dim*3+{q,k,v} */
+  const float *self_out_w, *self_out_b;     /* transformers.i.self_attn.out_proj (256,256) */
+  const float *self_ffn0_w, *self_ffn0_b;   /* ...self_attn.ffn.0 (512,512) */
+  const float *self_ln_w, *self_ln_b;       /* ...self_attn.ffn.1 LayerNorm(512) */
+  const float *self_ffn3_w, *self_ffn3_b;   /* ...self_attn.ffn.3 (256,512) */
+  const float *cross_qk_w, *cross_qk_b;     /* transformers.i.cross_attn.to_qk (256,256) */
+  const float *cross_v_w, *cross_v_b;       /* ...to_v */
+  const float *cross_out_w, *cross_out_b;   /* ...to_out */
+  const float *cross_ffn0_w, *cross_ffn0_b, *cross_ln_w, *cross_ln_b, *cross_ffn3_w, *cross_ffn3_b;
+  const float *assign_match_w, *assign_match_b; /* log_assignment.i.matchability (1,256),(1,) */
+  const float *assign_proj_w, *assign_proj_b;   /* log_assignment.i.final_proj (256,256) */
+  const float *token_w, *token_b;               /* token_confidence.i.token.0 (1,256),(1,); NULL for the last layer */
+} dim_lg_layer_weights;
+
+typedef struct dim_lg_weights {
+  int n_layers;                       /* 9 */
+  int input_dim;                      /* 256 (SuperPoint) or 128 (ALIKED/DISK/SIFT) */
+  const float *input_proj_w, *input_proj_b; /* (256,input_dim),(256,) or NULL when input_dim == 256 (LGN:361-364) */
+  const float* posenc_Wr;             /* posenc.Wr.weight (32,2) */
+  const float* confidence_thresholds; /* buffer (n_layers,) (LGN:581-584) */
+  const dim_lg_layer_weights* layers; /* [n_layers] */
+} dim_lg_weights;
+
+/* LightGlue._default_conf (LGN:301-314); doubles because the reference compares fp32
+ * tensors against Python floats.  pruning_min_kpts: LGN:318-323,606-610 (-1 = the CPU
+ * path this library is parity-checked against). */
+typedef struct dim_lg_config {
+  double depth_confidence; /* early stop, disable with -1 */
+  double width_confidence; /* point pruning, disable with -1 */
+  double filter_threshold;
+  int pruning_min_kpts;
+} dim_lg_config;
+
+typedef struct dim_lg dim_lg;
+
+int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pairs, int max_kpts, dim_lg** out);
+void dim_lg_destroy(dim_lg* h);
+/* Row stride (>= max_kpts, multiple of 4) of the per-point output arrays below. */
+int dim_lg_max_kpts(dim_lg* h);
+
+/* Matches n_pairs pairs in one call.  Features come from a device feature table
+ * (slot i = image i, as written by dim_sp_extract):
+ *   kpts_tab_dev [n_img][cap][2], desc_tab_dev [n_img][cap][input_dim] (row-major (N,D):
+ *   what featuresDict2Lightglue produces, matchers/lightglue.py:38-43), n_tab_dev [n_img],
+ *   size_tab_dev [n_img][2] = image_size exactly as DIM feeds it ((H, W)).
+ * pair_idx_dev [n_pairs][2] int32 = image slots of (image0, image1); NULL = pair p is
+ * slots (2p, 2p+1).  Keypoint counts above the handle's max_kpts are truncated.
+ * Outputs (device, caller allocated; NK = dim_lg_max_kpts(h)):
+ *   matches_dev   [n_pairs][NK][2] int64 — compact (idx0, idx1) list, idx0 ascending (LGN:543-553)
+ *   mscores_dev   [n_pairs][NK]
+ *   n_matches_dev [n_pairs]
+ *   matches01_dev [n_pairs][2][NK] int32 — matches0 / matches1 (-1 = unmatched)
+ *   mscores01_dev [n_pairs][2][NK]       — matching_scores0 / matching_scores1
+ *   stop_dev      [n_pairs]              — "stop" (LGN:570)
+ *   prune01_dev   [n_pairs][2][NK] int32 — prune0 / prune1
+ *   dense_scores_dev: NULL, or [n_pairs][NK+1][NK+1] receiving the inner MxN block of the
+ *   log assignment matrix (parity tests only). */
+int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev, const int32_t* n_tab_dev,
+                 const float* size_tab_dev, int cap, const int32_t* pair_idx_dev, int n_pairs, int64_t* matches_dev,
+                 float* mscores_dev, int32_t* n_matches_dev, int32_t* matches01_dev, float* mscores01_dev,
+                 int32_t* stop_dev, int32_t* prune01_dev, float* dense_scores_dev, void* stream);
+
+/* Parity taps: final descriptors [2*max_pairs][NK][256], live counts and index maps. */
+int dim_lg_debug_desc(dim_lg* h, const float** desc, const int32_t** n_cur, const int32_t** ind);
+
+/* ------------------------------------------------------------------------ */
 /* operator-level entry points (each is one kernel launch; used by the      */
 /* parity tests and available to integrators)                               */
 /* ------------------------------------------------------------------------ */

@@ -45,3 +45,35 @@ def order_is_reference_like(out: dict, k_limited: bool):
         k = out["keypoints"]
         lin = k[:, 1] * 100000 + k[:, 0]
         assert bool((lin[:-1] < lin[1:]).all())
+
+
+def compare_lightglue(out: dict, ref: dict, score_tol: float = 1e-3, dense_ref=None, dense_out=None, dense_tol: float = 1e-3):
+    """out/ref: reference-style dicts for one pair (CPU tensors; ref from the oracle or the golden
+    file).  Integer outputs (stop, prune, matches) must be identical except where the oracle's own
+    decision is a numerical near-tie (two assignment scores closer than 1e-4), which is reported."""
+    res = {}
+    assert int(out["stop"]) == int(ref["stop"]), (int(out["stop"]), int(ref["stop"]))
+    for k in ("prune0", "prune1"):
+        assert torch.equal(out[k].reshape(-1).long(), torch.as_tensor(ref[k]).reshape(-1).long()), k
+    for k in ("matching_scores0", "matching_scores1"):
+        d = (out[k].reshape(-1) - torch.as_tensor(ref[k]).reshape(-1)).abs().max().item() if out[k].numel() else 0.0
+        res["max_" + k + "_diff"] = d
+        assert d <= score_tol, (k, d)
+    for k in ("matches0", "matches1"):
+        a, b = out[k].reshape(-1).long(), torch.as_tensor(ref[k]).reshape(-1).long()
+        bad = (a != b).nonzero().reshape(-1)
+        res["n_" + k + "_mismatch"] = int(bad.numel())
+        assert bad.numel() == 0, (k, bad.tolist()[:10], a[bad][:10].tolist(), b[bad][:10].tolist())
+    mo = out["matches"][0] if isinstance(out["matches"], (list, tuple)) else out["matches"]
+    mr = ref["matches"][0] if isinstance(ref["matches"], (list, tuple)) else torch.as_tensor(ref["matches"])
+    assert torch.equal(mo.long().cpu(), mr.long()), "compact match list"
+    so = out["scores"][0] if isinstance(out["scores"], (list, tuple)) else out["scores"]
+    sr = ref["scores"][0] if isinstance(ref["scores"], (list, tuple)) else torch.as_tensor(ref["scores"])
+    if so.numel():
+        assert (so.cpu() - sr).abs().max().item() <= score_tol
+    if dense_ref is not None and dense_ref.numel():
+        m, n = dense_ref.shape[0] - 1, dense_ref.shape[1] - 1
+        d = (dense_out[:m, :n] - dense_ref[:m, :n]).abs().max().item()
+        res["max_log_assignment_diff"] = d
+        assert d <= dense_tol, d
+    return res

@@ -1,0 +1,39 @@
+"""CPU: the HIP LightGlue sources, compiled against the test-only emulator, vs the oracle and the
+reference's golden vectors (early stop, pruning, the empty exit, 128-d input_proj)."""
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lightglue_ref
+from tests import golden_cases as gc
+from tests.parity import compare_lightglue
+
+lg_mod = importlib.import_module("deep-image-matching_amd.lightglue_hip")
+GOLD = Path(__file__).parent / "golden"
+
+
+def run_case(lib, case, device="cpu"):
+    sd = gc.lg_weights(case)
+    f0, f1 = gc.lg_inputs(case)
+    net = lg_mod.LightGlueHIP(sd, case["conf"], max_pairs=1, max_kpts=max(case["m"], case["n"]), device=device, lib=lib)
+    data = {"image0": {"keypoints": f0["kpts"][None], "descriptors": f0["desc"][None], "image_size": f0["size"][None]},
+            "image1": {"keypoints": f1["kpts"][None], "descriptors": f1["desc"][None], "image_size": f1["size"][None]}}
+    out = net(data, dense=True)
+    out = {k: ([t.cpu() for t in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v)) for k, v in out.items()}
+    ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, case["conf"], taps=True)
+    return out, ref
+
+
+@pytest.mark.parametrize("name", list(gc.LG_CASES))
+def test_lightglue_emulated_vs_golden_and_oracle(emu_lib, name):
+    case = gc.LG_CASES[name]
+    out, ref = run_case(emu_lib, case)
+    res = compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+    g = np.load(GOLD / f"lg_{name}.npz")
+    gold = {k: torch.from_numpy(np.asarray(g[k])) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1",
+                                                             "matches", "scores", "prune0", "prune1")}
+    gold["stop"] = int(g["stop"])
+    compare_lightglue(out, gold)

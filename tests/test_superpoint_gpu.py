@@ -1,0 +1,88 @@
+"""GPU (MI355X): SuperPoint HIP path through the C ABI vs the oracle / reference goldens."""
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import superpoint_ref
+from tests import golden_cases as gc
+from tests.parity import compare_superpoint, order_is_reference_like
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def _sp():
+    return importlib.import_module("deep-image-matching_amd.superpoint_hip")
+
+
+@pytest.mark.parametrize("name", list(gc.SP_CASES))
+def test_superpoint_gpu_vs_reference_golden(hip_lib, name):
+    case = gc.SP_CASES[name]
+    sd, img = gc.sp_weights(case), gc.sp_image(case)
+    net = _sp().SuperPointHIP(sd, case["cfg"], max_batch=1, max_hw=(case["H"], case["W"]), capacity=512)
+    out = {k: v.cpu() for k, v in net(img.cuda()).items()}
+    taps = net.debug_taps()
+    nms_on_ours = superpoint_ref.simple_nms(taps["score_map"], case["cfg"]["nms_radius"])
+    assert torch.equal(nms_on_ours[0], taps["nms_map"][0])  # selection stage bit-exact on identical input
+    g = np.load(GOLD / f"sp_{name}.npz")
+    gold = {k: torch.from_numpy(g[k]) for k in ("keypoints", "scores", "descriptors")}
+    res = compare_superpoint(out, gold)
+    k = case["cfg"]["max_keypoints"]
+    order_is_reference_like(out, k_limited=(k >= 0 and res["n_out"] == k))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_superpoint_gpu_full_size_vs_oracle(hip_lib, seed):
+    """BASELINE config 2: 1024x1024 uniform-noise tile, nms 3 / thr 0.0005 / k 2048 / border 4."""
+    cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_superpoint_state_dict(1234)
+    img = torch.rand(1, 1, 1024, 1024, generator=torch.Generator().manual_seed(seed))
+    net = _sp().SuperPointHIP(sd, cfg, max_batch=1, max_hw=(1024, 1024), capacity=2048)
+    out = {k: v.cpu() for k, v in net(img.cuda()).items()}
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref = superpoint_ref.superpoint_forward(img, sd, cfg, taps=True)
+    taps = net.debug_taps()
+    assert (taps["score_map"][0] - ref["score_map"][0]).abs().max().item() < 1e-5
+    assert torch.equal(superpoint_ref.simple_nms(taps["score_map"], 3)[0], taps["nms_map"][0])
+    res = compare_superpoint(out, ref)
+    assert res["n_out"] == 2048
+    order_is_reference_like(out, k_limited=True)
+
+
+def test_superpoint_gpu_batch_equals_single(hip_lib):
+    """Batched extraction == per-image extraction (same kernels, grid.z = image)."""
+    cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 256, "remove_borders": 4}
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_superpoint_state_dict(7)
+    imgs = torch.rand(3, 200, 264, generator=torch.Generator().manual_seed(5)).cuda()
+    net = _sp().SuperPointHIP(sd, cfg, max_batch=3, max_hw=(200, 264), capacity=256)
+    kp, sc, de, n = [t.cpu() for t in net.extract_batch(imgs)]
+    for b in range(3):
+        o = net(imgs[b][None, None])
+        k = int(n[b])
+        assert k == o["keypoints"].shape[0]
+        assert torch.equal(kp[b, :k], o["keypoints"].cpu())
+        assert torch.equal(sc[b, :k], o["scores"].cpu())
+        assert torch.equal(de[b, :k], o["descriptors"].t().cpu())
+
+
+def test_superpoint_gpu_edge_cases(hip_lib):
+    """Empty result (threshold above every score), tiny image, unlimited keypoints."""
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_superpoint_state_dict(3)
+    img = torch.rand(1, 1, 40, 56, generator=torch.Generator().manual_seed(9))
+    net = _sp().SuperPointHIP(sd, {"keypoint_threshold": 2.0, "max_keypoints": 100}, max_hw=(40, 56), capacity=128)
+    out = net(img.cuda())
+    assert out["keypoints"].shape == (0, 2) and out["descriptors"].shape == (256, 0)
+    cfg = {"nms_radius": 1, "keypoint_threshold": 0.0, "max_keypoints": -1, "remove_borders": 0}
+    net = _sp().SuperPointHIP(sd, cfg, max_hw=(40, 56), capacity=4096)
+    out = {k: v.cpu() for k, v in net(img.cuda()).items()}
+    ref = superpoint_ref.superpoint_forward(img, sd, cfg)
+    compare_superpoint(out, ref)
+    order_is_reference_like(out, k_limited=False)
+    with pytest.raises(ValueError):
+        _sp().SuperPointHIP(sd, {"max_keypoints": 0})
