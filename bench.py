@@ -1,0 +1,214 @@
+"""Headline benchmark: image-pairs/s, SuperPoint+LightGlue, synthetic 1024x1024 pairs @2048 kpts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of `--pairs` synthetic pairs that are
+already resident in HBM: SuperPoint extraction of both images of every pair (2*pairs images,
+1024x1024, nms 3 / thr 0.0005 / top-2048) followed by LightGlue matching of every pair in
+fixed-work mode (9 layers, 2048 x 2048, early stop and pruning off — BASELINE config 3's
+roofline denominator).  Nothing is cached between steps and nothing is skipped.  Pairs are
+sharded across ranks (weak scaling: every rank runs K steps of `--pairs` pairs) with no
+data-path collective; after the last step the per-rank match tables are exchanged with ONE
+RCCL all-gather (inside the timed region), as north_star asks.
+
+Rank 0 prints one JSON line carrying the contract fields plus
+  roofline     — the dominant kernel (conv3x3_mfma_kernel<64,1>: conv1b+conv2b, 54 % of SuperPoint's
+                 FLOPs) timed live with HIP events on the launch stream over the timed region,
+                 against the fp32-MFMA peak;
+  cpu_baseline — the oracle (CPU restatement of the reference path) timed on this box's host
+                 cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+PKG = "deep-image-matching_amd"
+
+SP_GFLOP_PER_IMAGE = 177.85       # SURVEY.md §8(d), torch flop counter on the reference module
+LG_GFLOP_PER_PAIR = 229.8         # 2048 x 2048, 9 layers, fixed work
+CONV1B_GFLOP_PER_IMAGE = 2 * 38.655  # Appendix B: 3x3, 64->64 @1024^2 (+ReLU+pool)
+CONV2B_GFLOP_PER_IMAGE = 2 * 9.664   # Appendix B: 3x3, 64->64 @512^2  (+ReLU+pool) — same kernel instance
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=8, help="pairs per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(n_pairs: int):
+    """Oracle (kind 'port') on the host cores: same synthetic inputs, same configuration."""
+    from oracle import lightglue_ref, superpoint_ref
+
+    weights = importlib.import_module(PKG + ".weights")
+    cores = torch.get_num_threads()
+    sp_sd = weights.synthetic_superpoint_state_dict(1234)
+    lg_sd = weights.synthetic_lightglue_state_dict(0, 256)
+    cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
+    conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
+    size = torch.tensor([1024.0, 1024.0])
+
+    def one_pair(seed):
+        f = []
+        for s in (2 * seed, 2 * seed + 1):
+            img = torch.rand(1, 1, 1024, 1024, generator=torch.Generator().manual_seed(s))
+            f.append(superpoint_ref.superpoint_forward(img, sp_sd, cfg))
+        lightglue_ref.lightglue_forward(f[0]["keypoints"], f[0]["descriptors"].t().contiguous(), size,
+                                        f[1]["keypoints"], f[1]["descriptors"].t().contiguous(), size, lg_sd, conf)
+
+    one_pair(1000)  # warm-up
+    t0 = time.perf_counter()
+    for i in range(n_pairs):
+        one_pair(i)
+    dt = time.perf_counter() - t0
+    return {"value": n_pairs / dt, "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n_pairs} pairs (= {2 * n_pairs} SuperPoint 1024x1024 forwards + {n_pairs} LightGlue 2048x2048 "
+                      f"9-layer forwards) after 1 warm-up pair, oracle/*.py on torch CPU, {cores} threads"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    sp = importlib.import_module(PKG + ".superpoint_hip")
+    lg = importlib.import_module(PKG + ".lightglue_hip")
+    weights = importlib.import_module(PKG + ".weights")
+    capi = importlib.import_module(PKG + ".capi")
+    lib = capi.load()
+
+    P, K, W = a.pairs, a.steps, a.warmup
+    cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
+    conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
+    ext = sp.SuperPointHIP(weights.synthetic_superpoint_state_dict(1234), cfg, max_batch=2 * P, max_hw=(1024, 1024),
+                           capacity=2048, device=dev)
+    mat = lg.LightGlueHIP(weights.synthetic_lightglue_state_dict(0, 256), conf, max_pairs=P, max_kpts=2048, device=dev)
+    NK = mat.nk
+
+    # synthetic pairs resident in HBM before the timed region: a pool of distinct batches
+    n_pool = min(K + W, 4)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    pool = [torch.rand(2 * P, 1024, 1024, generator=g).to(dev) for _ in range(n_pool)]
+    size_tab = torch.full((2 * P, 2), 1024.0, device=dev)
+    # per-rank match tables of the whole job (filled step by step, exchanged once at the end)
+    T = K
+    tab = {
+        "matches": torch.zeros(T, P, NK, 2, dtype=torch.int64, device=dev),
+        "scores": torch.zeros(T, P, NK, dtype=torch.float32, device=dev),
+        "n_matches": torch.zeros(T, P, dtype=torch.int32, device=dev),
+        "matches01": torch.zeros(T, P, 2, NK, dtype=torch.int32, device=dev),
+        "mscores01": torch.zeros(T, P, 2, NK, dtype=torch.float32, device=dev),
+        "stop": torch.zeros(T, P, dtype=torch.int32, device=dev),
+        "prune01": torch.zeros(T, P, 2, NK, dtype=torch.int32, device=dev),
+    }
+
+    def step(i, slot):
+        kp, sc, de, n = ext.extract_batch(pool[i % n_pool])
+        out = {k: v[slot] for k, v in tab.items()}
+        mat.match_batch(kp, de, n, size_tab, n_pairs=P, out=out)
+        return n
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        step(i, 0)
+    barrier()
+    # time every launch of conv3x3_mfma_kernel<64,1> (sites conv1b and conv2b) with HIP events on the launch stream
+    capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong((1 << 1) | (1 << 3))))  # DIM_PROF_SP_CONV1B | DIM_PROF_SP_CONV2B
+    t0 = time.perf_counter()
+    for i in range(K):
+        n_last = step(W + i, i)
+    if dist is not None:  # one collective for the whole job: per-rank match tables -> every rank
+        cnt_all = torch.empty(world * T * P, dtype=torch.int32, device=dev)
+        m_all = torch.empty(world * T * P * NK * 2, dtype=torch.int64, device=dev)
+        s_all = torch.empty(world * T * P * NK, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(cnt_all, tab["n_matches"].reshape(-1))
+        dist.all_gather_into_tensor(m_all, tab["matches"].reshape(-1))
+        dist.all_gather_into_tensor(s_all, tab["scores"].reshape(-1))
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_ms, launches = ctypes.c_double(), ctypes.c_int()
+    capi.check(lib, lib.dim_profile_stop(ctypes.byref(tot_ms), ctypes.byref(launches)))
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    n_kpts_ok = bool((n_last == 2048).all().item())
+
+    if rank == 0:
+        pairs_total = world * K * P
+        value = pairs_total / dt
+        conv_ms = tot_ms.value / max(1, launches.value)
+        gflop_per_launch = (CONV1B_GFLOP_PER_IMAGE + CONV2B_GFLOP_PER_IMAGE) / 2 * 2 * P  # mean over its two launch sites
+        conv_tflops = gflop_per_launch / conv_ms  # GFLOP / ms == TFLOP/s
+        traffic = None
+        pmc = ROOT / "profiles" / "conv1b_hbm_bytes.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "image-pairs/s (SuperPoint+LightGlue, 1024^2, 2048 kpts)",
+            "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: SuperPoint+LightGlue, synthetic 1024x1024 grayscale pairs @2048 kpts, "
+                                   "2 extractions + 1 match per pair, LightGlue fixed-work (9 layers, no early stop/pruning), "
+                                   "seeded synthetic weights", "pairs_per_step_per_gpu": P, "image": "1024x1024",
+                       "keypoints": 2048, "all_2048_kpts": n_kpts_ok, "gflop_per_pair": 2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR,
+                       "sharding": f"pairs sharded over {world} rank(s), one RCCL all-gather of match tables at the end"},
+            "end_to_end_tflops_per_gpu": (2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR) * value / world / 1e3,
+            "roofline": {"kernel": "conv3x3_mfma_kernel<64,1> (3x3 conv 64->64 + bias + ReLU + 2x2 max-pool; launch sites conv1b @1024^2 and conv2b @512^2)", "bound": "mfma",
+                         "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": conv_ms, "launches": launches.value,
+                         "algorithmic_gflop_per_launch": gflop_per_launch},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.cpu_sample_pairs)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,51 @@ void dim_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+#include <vector>
+namespace {
+unsigned long long g_prof_mask = 0ull;
+std::vector<hipEvent_t> g_prof_ev;  // begin/end pairs
+size_t g_prof_used = 0;
+}  // namespace
+
+void dim_prof_begin(int site, hipStream_t s) {
+  if (!((g_prof_mask >> site) & 1ull)) return;
+  if (g_prof_used + 2 > g_prof_ev.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    g_prof_ev.push_back(a); g_prof_ev.push_back(b);
+  }
+  hipEventRecord(g_prof_ev[g_prof_used], s);
+}
+void dim_prof_end(int site, hipStream_t s) {
+  if (!((g_prof_mask >> site) & 1ull) || g_prof_used + 2 > g_prof_ev.size()) return;
+  hipEventRecord(g_prof_ev[g_prof_used + 1], s);
+  g_prof_used += 2;
+}
+
 extern "C" {
+
+int dim_profile_start(unsigned long long site_mask) {
+  g_prof_mask = site_mask;
+  g_prof_used = 0;
+  return 0;
+}
+
+int dim_profile_stop(double* total_ms, int* launches) {
+  DIM_REQUIRE(total_ms && launches, "dim_profile_stop: null argument");
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
+    DIM_HIP(hipEventSynchronize(g_prof_ev[i + 1]));
+    float ms = 0.f;
+    DIM_HIP(hipEventElapsedTime(&ms, g_prof_ev[i], g_prof_ev[i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int)(g_prof_used / 2);
+  g_prof_mask = 0ull;
+  g_prof_used = 0;
+  return 0;
+}
 
 const char* dim_last_error(void) { return g_err; }
 

@@ -39,3 +39,10 @@ int launch_conv3x3(const float* in, const float* w, const float* bias, float* ou
 // conv1a: 1 -> 64 channels, direct (VALU) convolution; in: [B][H][W], w: [9][64].
 int launch_conv1a(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W,
                   hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Optional per-launch-site timing with HIP events on the launch stream (used by
+// bench.py for the roofline figure; zero cost when disabled).  Site ids are the
+// DIM_PROF_* constants of include/dim_hip.h.
+void dim_prof_begin(int site, hipStream_t s);
+void dim_prof_end(int site, hipStream_t s);

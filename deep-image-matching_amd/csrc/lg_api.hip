@@ -184,14 +184,18 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     // ---- self block (LGN:146-159) ----
     LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.qkv_w, 768, w.qkv_b, nullptr, st.qkv, 768, s768, 768, 256, 0));
     LG_RUN(launch_lg_rotary(st, s));
+    dim_prof_begin(DIM_PROF_LG_SELF_ATTN, s);
     LG_RUN(launch_lg_attention(st, 0, s));
+    dim_prof_end(DIM_PROF_LG_SELF_ATTN, s);
     LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.out_w, 256, w.out_b, nullptr, st.msg, 256, s256, 256, 256, 0));
     LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.sffn0_w, 512, w.sffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
     LG_RUN(launch_lg_ln_gelu(st, w.sln_w, w.sln_b, s));
     LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.sffn3_w, 256, w.sffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0));
     // ---- cross block (LGN:186-211) ----
     LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.cqkv_w, 512, w.cqkv_b, nullptr, st.qkv, 768, s768, 512, 256, 0));
+    dim_prof_begin(DIM_PROF_LG_CROSS_ATTN, s);
     LG_RUN(launch_lg_attention(st, 1, s));
+    dim_prof_end(DIM_PROF_LG_CROSS_ATTN, s);
     LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.cout_w, 256, w.cout_b, nullptr, st.msg, 256, s256, 256, 256, 0));
     LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.cffn0_w, 512, w.cffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
     LG_RUN(launch_lg_ln_gelu(st, w.cln_w, w.cln_b, s));

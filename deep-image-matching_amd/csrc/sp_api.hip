@@ -119,17 +119,18 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, hh = H4 / 2, ww = W4 / 2;  // floor at every pool (Q12)
   const int H8 = hh * 8, W8 = ww * 8;
 #define SP_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
+#define SP_SITE(id, x) do { dim_prof_begin(id, s); SP_RUN(x); dim_prof_end(id, s); } while (0)
   // encoder (SPN:161-171)
-  SP_RUN(launch_conv1a(images_dev, h->wk[0], h->bias[0], h->a1, batch, H, W, s));
-  SP_RUN(launch_conv3x3(h->a1, h->wk[1], h->bias[1], h->b1, batch, H, W, 64, 64, 1, 1, s));
-  SP_RUN(launch_conv3x3(h->b1, h->wk[2], h->bias[2], h->a2, batch, H2, W2, 64, 64, 0, 1, s));
-  SP_RUN(launch_conv3x3(h->a2, h->wk[3], h->bias[3], h->b2, batch, H2, W2, 64, 64, 1, 1, s));
-  SP_RUN(launch_conv3x3(h->b2, h->wk[4], h->bias[4], h->a3, batch, H4, W4, 64, 128, 0, 1, s));
-  SP_RUN(launch_conv3x3(h->a3, h->wk[5], h->bias[5], h->b3, batch, H4, W4, 128, 128, 1, 1, s));
-  SP_RUN(launch_conv3x3(h->b3, h->wk[6], h->bias[6], h->a4, batch, hh, ww, 128, 128, 0, 1, s));
-  SP_RUN(launch_conv3x3(h->a4, h->wk[7], h->bias[7], h->x, batch, hh, ww, 128, 128, 0, 1, s));
+  SP_SITE(DIM_PROF_SP_CONV1A, launch_conv1a(images_dev, h->wk[0], h->bias[0], h->a1, batch, H, W, s));
+  SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3(h->a1, h->wk[1], h->bias[1], h->b1, batch, H, W, 64, 64, 1, 1, s));
+  SP_SITE(DIM_PROF_SP_CONV2A, launch_conv3x3(h->b1, h->wk[2], h->bias[2], h->a2, batch, H2, W2, 64, 64, 0, 1, s));
+  SP_SITE(DIM_PROF_SP_CONV2B, launch_conv3x3(h->a2, h->wk[3], h->bias[3], h->b2, batch, H2, W2, 64, 64, 1, 1, s));
+  SP_SITE(DIM_PROF_SP_CONV3A, launch_conv3x3(h->b2, h->wk[4], h->bias[4], h->a3, batch, H4, W4, 64, 128, 0, 1, s));
+  SP_SITE(DIM_PROF_SP_CONV3B, launch_conv3x3(h->a3, h->wk[5], h->bias[5], h->b3, batch, H4, W4, 128, 128, 1, 1, s));
+  SP_SITE(DIM_PROF_SP_CONV4A, launch_conv3x3(h->b3, h->wk[6], h->bias[6], h->a4, batch, hh, ww, 128, 128, 0, 1, s));
+  SP_SITE(DIM_PROF_SP_CONV4B, launch_conv3x3(h->a4, h->wk[7], h->bias[7], h->x, batch, hh, ww, 128, 128, 0, 1, s));
   // detector head (SPN:174-180)
-  SP_RUN(launch_conv3x3(h->x, h->wk[8], h->bias[8], h->pa, batch, hh, ww, 128, 256, 0, 1, s));
+  SP_SITE(DIM_PROF_SP_CONVPA, launch_conv3x3(h->x, h->wk[8], h->bias[8], h->pa, batch, hh, ww, 128, 256, 0, 1, s));
   {
     GemmArgs g;
     g.A0 = h->pa; g.lda0 = 256; g.B = h->wk[9]; g.ldb = 68; g.bias = h->bias[9];
@@ -144,7 +145,7 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   SP_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H8, W8, h->cfg.max_keypoints, h->capacity, kpts_xy_dev,
                      scores_dev, n_kpts_dev, s));
   // descriptor head (SPN:213-221)
-  SP_RUN(launch_conv3x3(h->x, h->wk[10], h->bias[10], h->da, batch, hh, ww, 128, 256, 0, 1, s));
+  SP_SITE(DIM_PROF_SP_CONVDA, launch_conv3x3(h->x, h->wk[10], h->bias[10], h->da, batch, hh, ww, 128, 256, 0, 1, s));
   {
     GemmArgs g;
     g.A0 = h->da; g.lda0 = 256; g.B = h->wk[11]; g.ldb = 256; g.bias = h->bias[11];
@@ -152,6 +153,7 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
     SP_RUN(launch_gemm(g, 1, s));
   }
   SP_RUN(launch_sample_desc(h->dd, kpts_xy_dev, n_kpts_dev, desc_dev, batch, hh, ww, h->capacity, h->cfg.fix_sampling, s));
+#undef SP_SITE
 #undef SP_RUN
   h->last_h = hh; h->last_w = ww; h->last_batch = batch;
   return 0;

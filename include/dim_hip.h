@@ -36,6 +36,19 @@ const char* dim_last_error(void);
 int dim_abi_version(void);
 int dim_device_synchronize(void);
 
+/* Per-launch-site timing with HIP events recorded on the launch stream (bench.py's
+ * roofline figure).  dim_profile_start(mask) arms the sites whose bits (1 << DIM_PROF_*) are set;
+ * dim_profile_stop() waits for the recorded events and returns the summed kernel time and the
+ * number of launches. */
+enum {
+  DIM_PROF_SP_CONV1A = 0, DIM_PROF_SP_CONV1B, DIM_PROF_SP_CONV2A, DIM_PROF_SP_CONV2B, DIM_PROF_SP_CONV3A,
+  DIM_PROF_SP_CONV3B, DIM_PROF_SP_CONV4A, DIM_PROF_SP_CONV4B, DIM_PROF_SP_CONVPA, DIM_PROF_SP_CONVPB,
+  DIM_PROF_SP_CONVDA, DIM_PROF_SP_CONVDB, DIM_PROF_SP_POST, DIM_PROF_LG_SELF_ATTN, DIM_PROF_LG_CROSS_ATTN,
+  DIM_PROF_LG_GEMMS, DIM_PROF_LG_ASSIGN
+};
+int dim_profile_start(unsigned long long site_mask);
+int dim_profile_stop(double* total_ms, int* launches);
+
 /* ------------------------------------------------------------------------ */
 /* SuperPoint (reference SPN:101-227)                                       */
 /* ------------------------------------------------------------------------ */

@@ -1,0 +1,94 @@
+"""GPU (MI355X): LightGlue HIP path through the C ABI vs the oracle / reference goldens."""
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lightglue_ref
+from tests import golden_cases as gc
+from tests.parity import compare_lightglue
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def _lg():
+    return importlib.import_module("deep-image-matching_amd.lightglue_hip")
+
+
+def _cpu(out):
+    return {k: ([t.cpu() for t in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v)) for k, v in out.items()}
+
+
+def _data(f0, f1):
+    return {"image0": {"keypoints": f0["kpts"][None], "descriptors": f0["desc"][None], "image_size": f0["size"][None]},
+            "image1": {"keypoints": f1["kpts"][None], "descriptors": f1["desc"][None], "image_size": f1["size"][None]}}
+
+
+@pytest.mark.parametrize("name", list(gc.LG_CASES))
+def test_lightglue_gpu_vs_reference_golden(hip_lib, name):
+    case = gc.LG_CASES[name]
+    sd = gc.lg_weights(case)
+    f0, f1 = gc.lg_inputs(case)
+    net = _lg().LightGlueHIP(sd, case["conf"], max_pairs=1, max_kpts=max(case["m"], case["n"]))
+    out = _cpu(net(_data(f0, f1), dense=True))
+    ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, case["conf"], taps=True)
+    compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+    g = np.load(GOLD / f"lg_{name}.npz")
+    gold = {k: torch.from_numpy(np.asarray(g[k])) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1",
+                                                             "matches", "scores", "prune0", "prune1")}
+    gold["stop"] = int(g["stop"])
+    compare_lightglue(out, gold)
+
+
+def _full_inputs(seed, m, n):
+    case = {"seed": seed, "m": m, "n": n, "input_dim": 256, "size0": (1024.0, 1024.0), "size1": (1024.0, 1024.0)}
+    return gc.lg_inputs(case)
+
+
+@pytest.mark.parametrize("mode", ["fixed", "default"])
+def test_lightglue_gpu_full_size_vs_oracle(hip_lib, mode):
+    """BASELINE config 3: 2048 x 2048 keypoints, 9 layers; fixed-work and reference-default modes."""
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_lightglue_state_dict(0, 256, gain=2.0)
+    conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0} if mode == "fixed" else \
+           {"depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.0}
+    f0, f1 = _full_inputs(21, 2048, 2048)
+    net = _lg().LightGlueHIP(sd, conf, max_pairs=1, max_kpts=2048)
+    out = _cpu(net(_data(f0, f1), dense=True))
+    ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, conf, taps=True)
+    res = compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+    print(mode, res, "stop", out["stop"], "S", out["matches"][0].shape[0])
+
+
+def test_lightglue_gpu_batch_equals_single_and_pair_index(hip_lib):
+    """A batch of ragged pairs through pair_idx == the same pairs one by one."""
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_lightglue_state_dict(5, 256, gain=2.0)
+    conf = {"depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.0}
+    lg = _lg()
+    g = torch.Generator().manual_seed(3)
+    n_img, cap = 4, 300
+    counts = [300, 0, 123, 257]  # includes an image with no keypoints
+    kt = torch.rand(n_img, cap, 2, generator=g) * 640
+    dt = torch.nn.functional.normalize(torch.randn(n_img, cap, 256, generator=g), dim=-1)
+    nt = torch.tensor(counts, dtype=torch.int32)
+    st = torch.tensor([[480.0, 640.0]] * n_img)
+    pairs = torch.tensor([[0, 2], [2, 3], [0, 1], [3, 0]], dtype=torch.int32)
+    net = lg.LightGlueHIP(sd, conf, max_pairs=4, max_kpts=cap)
+    o = net.match_batch(kt.cuda(), dt.cuda(), nt.cuda(), st.cuda(), pair_idx=pairs.cuda())
+    o = {k: v.cpu() for k, v in o.items()}
+    single = lg.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=cap)
+    for p, (a, b) in enumerate(pairs.tolist()):
+        data = {"image0": {"keypoints": kt[a, :counts[a]][None], "descriptors": dt[a, :counts[a]][None], "image_size": st[a][None]},
+                "image1": {"keypoints": kt[b, :counts[b]][None], "descriptors": dt[b, :counts[b]][None], "image_size": st[b][None]}}
+        r = _cpu(single(data))
+        S = int(o["n_matches"][p])
+        assert int(o["stop"][p]) == r["stop"]
+        assert torch.equal(o["matches"][p, :S], r["matches"][0])
+        assert torch.equal(o["scores"][p, :S], r["scores"][0])
+        assert torch.equal(o["matches01"][p, 0, :counts[a]].long(), r["matches0"][0])
+        if counts[a] == 0 or counts[b] == 0:
+            assert S == 0 and r["stop"] == 1
