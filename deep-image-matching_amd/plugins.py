@@ -1,0 +1,219 @@
+"""Drop-in plugins for deep-image-matching's extractor / matcher plugin surface.
+
+``SuperPointExtractor`` mirrors extractors/superpoint.py:64-146 and ``LightGlueMatcher``
+mirrors matchers/lightglue.py:77-125: same class attributes (``_default_conf``,
+``required_inputs``, ``grayscale``, ``descriptor_size`` …), same constructor arguments, same
+``_extract(image) -> dict`` / ``_match_pairs(feats0, feats1) -> np.ndarray`` contracts and
+error behaviour, with the network replaced by the gfx950 library.  When the real
+``deep_image_matching`` package is importable the classes subclass its ``ExtractorBase`` /
+``MatcherBase`` (so ``extractor_loader`` / ``matcher_loader`` discover them, extractor_base.py:29-52,
+matcher_base.py:36-60); otherwise a minimal stand-in base with the same constructor contract
+(extractor_base.py:119-160) is used so the hooks can be driven and tested on their own.
+See INTEGRATION.md for the module files a maintainer adds to the reference tree.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import weights as _weights
+from .lightglue_hip import LightGlueHIP
+from .superpoint_hip import SuperPointHIP
+
+logger = logging.getLogger("dim")
+
+try:  # pragma: no cover - the reference package is not importable in the build container
+    from deep_image_matching.extractors.extractor_base import ExtractorBase as _ExtractorBase
+    from deep_image_matching.matchers.matcher_base import MatcherBase as _MatcherBase
+
+    HAVE_DIM = True
+except Exception:  # noqa: BLE001
+    HAVE_DIM = False
+
+    class _StandInBase:
+        """Constructor contract of ExtractorBase/MatcherBase (extractor_base.py:119-160,
+        matcher_base.py:95-140): config exposes .general/.extractor/.matcher (or is a dict with
+        those keys); self.config = {"general", "extractor"|"matcher"}; device honours force_cpu."""
+
+        _role = "extractor"
+        _default_conf: dict = {}
+
+        def __init__(self, config):
+            get = (lambda k: config.get(k, {})) if isinstance(config, dict) else (lambda k: getattr(config, k, {}) or {})
+            if not isinstance(config, dict) and not all(hasattr(config, a) for a in ("general",)):
+                raise TypeError("`config` must be a Config object (or a dict with 'general' / '%s')" % self._role)
+            general = dict(get("general"))
+            self.config = {"general": general, self._role: {**self._default_conf, **dict(get(self._role))}}
+            self._device = "cuda" if torch.cuda.is_available() and not general.get("force_cpu", False) else "cpu"
+
+    class _ExtractorBase(_StandInBase):
+        _role = "extractor"
+
+    class _MatcherBase(_StandInBase):
+        _role = "matcher"
+
+
+def _require_gpu(device: str, what: str):
+    if str(device) != "cuda" and not str(device).startswith("cuda"):
+        raise RuntimeError(f"{what}: the MI355X plugin has no CPU path (device={device!r}); "
+                           "use the reference's own plugin when general.force_cpu is set")
+
+
+class SuperPointExtractor(_ExtractorBase):
+    """extractors/superpoint.py:64 — SuperPoint on the gfx950 library."""
+
+    _default_conf = {
+        "name": "superpoint",
+        "nms_radius": 4,
+        "keypoint_threshold": 0.005,
+        "max_keypoints": -1,
+        "remove_borders": 4,
+        "fix_sampling": False,
+    }
+    required_inputs = ["image"]
+    grayscale = True
+    as_float = True
+    descriptor_size = 256
+    features_as_half = True
+    detection_noise = 2.0
+
+    def __init__(self, config, _lib=None, _device=None):
+        super().__init__(config)
+        self._lib = _lib
+        if _device is not None:
+            self._device = _device
+        if _lib is None:
+            _require_gpu(self._device, "SuperPointExtractor")
+        cfg = self.config.get("extractor")
+        path = cfg.get("weights_path") or os.environ.get("DIM_SUPERPOINT_WEIGHTS")
+        if path is None:
+            logger.warning("SuperPoint: no weights_path / DIM_SUPERPOINT_WEIGHTS given - using seeded SYNTHETIC weights "
+                           "(the official superpoint_v1.pth is a download, SPN:110)")
+        self._sd = _weights.load_superpoint_state_dict(path)
+        self._net_cfg = {k: cfg[k] for k in ("nms_radius", "keypoint_threshold", "max_keypoints", "remove_borders", "fix_sampling")}
+        self._net: Optional[SuperPointHIP] = None
+        self._net_hw = (0, 0)
+
+    def _ensure(self, H: int, W: int):
+        if self._net is None or H > self._net_hw[0] or W > self._net_hw[1]:
+            hw = (max(H, self._net_hw[0]), max(W, self._net_hw[1]))
+            mk = self._net_cfg["max_keypoints"]
+            cap = mk if mk > 0 else min(4096 * 4, max(1024, (H // 8) * (W // 8) * 4))
+            self._net = SuperPointHIP(self._sd, self._net_cfg, max_batch=1, max_hw=hw, capacity=cap,
+                                      device=self._device, lib=self._lib)
+            self._net_hw = hw
+
+    @torch.no_grad()
+    def _extract(self, image: np.ndarray) -> dict:
+        """image: float32 HxW, values 0..255 (extractor_base.py:197-202).  Returns numpy
+        keypoints (N,2) float32 (x,y), scores (N,), descriptors (256,N) (SPX:126-130)."""
+        image_ = self._frame2tensor(image, self._device)
+        if image_.shape[1] != 1:
+            raise ValueError("SuperPoint expects a single-channel image")
+        self._ensure(image_.shape[-2], image_.shape[-1])
+        feats = self._net(image_)
+        return {k: v.cpu().numpy() for k, v in feats.items()}
+
+    def _frame2tensor(self, image: np.ndarray, device: str = "cuda"):
+        """SPX:134-146."""
+        if len(image.shape) == 2:
+            image = image[None][None]
+        elif len(image.shape) == 3:
+            image = image.transpose(2, 0, 1)[None]
+        return torch.tensor(image / 255.0, dtype=torch.float).to(device)
+
+
+def featuresDict2Lightglue(feats: dict) -> dict:
+    """matchers/lightglue.py:8-66 up to (not including) the tensor conversion: unwrap, fix the
+    descriptor layout by the keypoint count ((D,N) -> (N,D)), drop path keys."""
+    feats = {k: v[0] if isinstance(v, (list, tuple)) else v for k, v in feats.items()}
+    if "keypoints" not in feats or "descriptors" not in feats:
+        raise KeyError("features must contain 'keypoints' and 'descriptors'")
+    kpts, desc = np.asarray(feats["keypoints"]), np.asarray(feats["descriptors"])
+    if kpts.ndim != 2 or kpts.shape[1] != 2:
+        raise ValueError(f"Invalid keypoints shape: {kpts.shape}")
+    N = kpts.shape[0]
+    if desc.ndim != 2:
+        raise ValueError(f"Invalid descriptors shape: {desc.shape}")
+    if desc.shape[1] == N and desc.shape[0] != N:
+        desc = desc.T
+    elif desc.shape[0] == N:
+        pass
+    else:
+        raise ValueError(f"Descriptor / keypoint mismatch: descriptors={desc.shape}, keypoints={kpts.shape}")
+    out = dict(feats)
+    out["keypoints"], out["descriptors"] = kpts, desc
+    out.pop("feature_path", None)
+    out.pop("im_path", None)
+    return out
+
+
+class LightGlueMatcher(_MatcherBase):
+    """matchers/lightglue.py:77 — LightGlue on the gfx950 library."""
+
+    _default_conf = {
+        "flash": True,   # accepted for compatibility; attention here is always the fp32 MFMA kernel
+        "mp": False,
+        "depth_confidence": 0.95,
+        "width_confidence": 0.99,
+        "filter_threshold": 0.1,
+        "weights": None,
+    }
+    required_inputs = []
+    min_matches = 20
+    max_feat_no_tiling = 200000
+    _input_dims = {"superpoint": 256, "disk": 128, "aliked": 128, "sift": 128}  # LGN:331-349
+
+    def __init__(self, config, local_features="superpoint", _lib=None, _device=None) -> None:
+        self._localfeatures = local_features
+        super().__init__(config)
+        self._lib = _lib
+        if _device is not None:
+            self._device = _device
+        if _lib is None:
+            _require_gpu(getattr(self._device, "type", self._device), "LightGlueMatcher")
+        cfg = {**self._default_conf, **self.config.get("matcher", {})}
+        if cfg.get("mp"):
+            logger.warning("LightGlue: mixed precision ('mp') is not implemented on the MI355X path; running fp32")
+        self._conf = {k: cfg[k] for k in ("depth_confidence", "width_confidence", "filter_threshold")}
+        self._conf["n_layers"] = int(cfg.get("n_layers", 9))
+        path = cfg.get("weights_path") or os.environ.get("DIM_LIGHTGLUE_WEIGHTS")
+        in_dim = self._input_dims.get(local_features, 256)
+        if path is None:
+            logger.warning("LightGlue: no weights_path / DIM_LIGHTGLUE_WEIGHTS given - using seeded SYNTHETIC weights "
+                           "(the official %s_lightglue.pth is a download, LGN:327-328)", local_features)
+        self._sd = _weights.load_lightglue_state_dict(path, input_dim=in_dim, n_layers=self._conf["n_layers"])
+        self._net: Optional[LightGlueHIP] = None
+        self._net_n = 0
+        if self._localfeatures == "disk":
+            self.max_feat_no_tiling = 50000
+
+    def _ensure(self, n: int):
+        if self._net is None or n > self._net_n:
+            self._net_n = max(256, 1 << (max(n, 1) - 1).bit_length())
+            dev = self._device if isinstance(self._device, (str, torch.device)) else "cuda"
+            self._net = LightGlueHIP(self._sd, self._conf, max_pairs=1, max_kpts=self._net_n, device=dev, lib=self._lib)
+
+    @torch.no_grad()
+    def _match_pairs(self, feats0: dict, feats1: dict) -> np.ndarray:
+        """feats: numpy dicts as read from features.h5 (keypoints (N,2), descriptors (D,N) or (N,D),
+        image_size (2,) = (H,W), + ignored keys).  Returns (S,2) int64 index pairs (LGX:102-125)."""
+        f0, f1 = featuresDict2Lightglue(feats0), featuresDict2Lightglue(feats1)
+        self._ensure(max(f0["keypoints"].shape[0], f1["keypoints"].shape[0]))
+
+        def img(f):
+            d = {"keypoints": torch.as_tensor(f["keypoints"], dtype=torch.float32)[None],
+                 "descriptors": torch.as_tensor(f["descriptors"], dtype=torch.float32)[None]}
+            if "image_size" in f:
+                d["image_size"] = torch.as_tensor(np.asarray(f["image_size"]), dtype=torch.float32).reshape(1, 2)
+            else:  # LGN:26-27: size inferred from the keypoint extent
+                k = d["keypoints"][0]
+                d["image_size"] = (1 + k.max(0).values - k.min(0).values).reshape(1, 2) if k.numel() else torch.ones(1, 2)
+            return d
+
+        res = self._net({"image0": img(f0), "image1": img(f1)})
+        return res["matches"][0].cpu().numpy()

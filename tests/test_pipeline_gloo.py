@@ -1,0 +1,81 @@
+"""CPU, world_size 2 over gloo: the N>1 data-parallel path (shard images -> all-gather features ->
+shard pairs -> all-gather match tables) must give every rank exactly the single-process result.
+The device work runs through the emulator-built library on CPU tensors."""
+import importlib
+import os
+import socket
+import sys
+from pathlib import Path
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _build(lib_path, rank, world):
+    import ctypes
+
+    sys.path.insert(0, str(ROOT))
+    sp = importlib.import_module("deep-image-matching_amd.superpoint_hip")
+    lg = importlib.import_module("deep-image-matching_amd.lightglue_hip")
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    pl = importlib.import_module("deep-image-matching_amd.pipeline")
+    lib = ctypes.CDLL(lib_path)
+    lib.dim_last_error.restype = ctypes.c_char_p
+    cfg = {"nms_radius": 2, "keypoint_threshold": 0.001, "max_keypoints": 12, "remove_borders": 2}
+    conf = {"n_layers": 2, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0}
+    ext = sp.SuperPointHIP(weights.synthetic_superpoint_state_dict(5), cfg, max_batch=2, max_hw=(32, 40), capacity=12, device="cpu", lib=lib)
+    mat = lg.LightGlueHIP(weights.synthetic_lightglue_state_dict(2, 256, n_layers=2, gain=2.0), conf, max_pairs=2, max_kpts=12, device="cpu", lib=lib)
+    return pl, pl.PairMatchingPipeline(ext, mat, rank, world)
+
+
+def _run(lib_path, rank, world):
+    pl, pipe = _build(lib_path, rank, world)
+    imgs = torch.rand(5, 32, 40, generator=torch.Generator().manual_seed(11))
+    table = pipe.extract_all(imgs)
+    pairs = pl.exhaustive_pairs(5, limit=7)
+    cnt, mt, ms = pipe.match_all(table, pairs)
+    return table, (cnt, mt, ms)
+
+
+def _worker(rank, world, port, lib_path, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    table, res = _run(lib_path, rank, world)
+    torch.save({"table": [t.clone() for t in table], "res": [t.clone() for t in res]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pipeline_equals_single_process(tmp_path):
+    build = importlib.import_module("deep-image-matching_amd.build")
+    lib_path = str(build.build_emu())
+    table1, res1 = _run(lib_path, 0, 1)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, lib_path, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(tmp_path / f"rank{r}.pt")
+        for a, b in zip(got["table"], table1):
+            assert torch.equal(a, b)
+        for a, b in zip(got["res"], res1):
+            assert torch.equal(a, b)
+    pl = importlib.import_module("deep-image-matching_amd.pipeline")
+    lists = pl.PairMatchingPipeline.to_match_lists(*res1)
+    assert len(lists) == 7 and all(m.shape[1] == 2 for m, _ in lists)
+
+
+def test_sharding_helpers():
+    pl = importlib.import_module("deep-image-matching_amd.pipeline")
+    p = pl.exhaustive_pairs(150, limit=10000)
+    assert p.shape == (10000, 2) and p[0].tolist() == [0, 1] and p[148].tolist() == [0, 149] and p[149].tolist() == [1, 2]
+    cover = torch.cat([pl.shard_indices(10000, r, 8) for r in range(8)]).sort().values
+    assert torch.equal(cover, torch.arange(10000))
+    assert max(len(pl.shard_indices(10000, r, 8)) for r in range(8)) - min(len(pl.shard_indices(10000, r, 8)) for r in range(8)) <= 1
