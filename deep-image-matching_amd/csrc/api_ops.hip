@@ -4,7 +4,7 @@
 #include <stdio.h>
 
 #include "../../include/dim_hip.h"
-#include "dim_kernels.h"
+#include "sp_kernels.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -81,6 +81,10 @@ int dim_op_conv3x3_nhwc_f32(const float* in, const float* w_tap_cin_cout, const 
 int dim_op_conv1a_f32(const float* in, const float* w_tap_cout, const float* bias, float* out, int batch, int H,
                       int W, void* stream) {
   return launch_conv1a(in, w_tap_cout, bias, out, batch, H, W, (hipStream_t)stream);
+}
+
+int dim_op_simple_nms_f32(const float* score_map, float* out, int batch, int H, int W, int radius, void* stream) {
+  return launch_nms(score_map, out, batch, H, W, radius, (hipStream_t)stream);
 }
 
 int dim_device_synchronize(void) {

@@ -248,20 +248,37 @@ __global__ __launch_bounds__(256) void lg_row_stats_kernel(LgState st, int tag, 
   s = wave_sum(s);
   if (lane == 0) { st.rmax[r] = m; st.rlse[r] = logf(s); }
 }
-// side 1 columns: one thread per column, rows walked sequentially (coalesced across threads).
-__global__ __launch_bounds__(256) void lg_col_stats_kernel(LgState st, int tag) {
+// side 1 columns: block = 64 columns x 16 row groups (1024 threads); each thread walks every 16th
+// row of its column (coalesced across the 64 lanes of a wave), partials merged through LDS.
+__global__ __launch_bounds__(1024) void lg_col_stats_kernel(LgState st, int tag) {
+  __shared__ float red[16][64];
   const int p = blockIdx.y;
   if (st.done[p] != tag) return;
-  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
-  if (col >= ncol) return;
+  if (blockIdx.x * 64 >= ncol) return;
+  const bool ok = col < ncol;
   const float* sp = st.sim + (size_t)p * st.nmax * st.nmax + col;
   float m = -INFINITY;
-  for (int i = 0; i < nrow; ++i) m = fmaxf(m, sp[(size_t)i * st.nmax]);
+  if (ok) for (int i = ty; i < nrow; i += 16) m = fmaxf(m, sp[(size_t)i * st.nmax]);
+  red[ty][tx] = m;
+  __syncthreads();
+  m = red[0][tx];
+#pragma unroll
+  for (int g = 1; g < 16; ++g) m = fmaxf(m, red[g][tx]);
+  __syncthreads();
   float s = 0.f;
-  for (int i = 0; i < nrow; ++i) s += expf(sp[(size_t)i * st.nmax] - m);
-  const size_t r = (size_t)(2 * p + 1) * st.nmax + col;
-  st.rmax[r] = m; st.rlse[r] = logf(s);
+  if (ok) for (int i = ty; i < nrow; i += 16) s += expf(sp[(size_t)i * st.nmax] - m);
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && ok) {
+    s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][tx];
+    const size_t r = (size_t)(2 * p + 1) * st.nmax + col;
+    st.rmax[r] = m; st.rlse[r] = logf(s);
+  }
 }
 
 __device__ __forceinline__ float lg_score(float sim, float rm, float rl, float cm, float cl, float z0, float z1) {
@@ -293,22 +310,37 @@ __global__ __launch_bounds__(256) void lg_row_argmax_kernel(LgState st, int tag,
   }
   if (lane == 0) { st.best[r0] = best; st.arg[r0] = bi; }
 }
-__global__ __launch_bounds__(256) void lg_col_argmax_kernel(LgState st, int tag) {
+__global__ __launch_bounds__(1024) void lg_col_argmax_kernel(LgState st, int tag) {
+  __shared__ float redv[16][64];
+  __shared__ int redi[16][64];
   const int p = blockIdx.y;
   if (st.done[p] != tag) return;
-  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
-  if (col >= ncol) return;
-  const size_t r0 = (size_t)(2 * p) * st.nmax, c = (size_t)(2 * p + 1) * st.nmax + col;
+  if (blockIdx.x * 64 >= ncol) return;
+  const bool ok = col < ncol;
+  const size_t r0 = (size_t)(2 * p) * st.nmax, c = (size_t)(2 * p + 1) * st.nmax + (ok ? col : 0);
   const float cm = st.rmax[c], cl = st.rlse[c], z1 = st.zls[c];
   const float* sp = st.sim + (size_t)p * st.nmax * st.nmax + col;
   float best = -INFINITY;
-  int bi = 0;
-  for (int i = 0; i < nrow; ++i) {
-    const float v = lg_score(sp[(size_t)i * st.nmax], st.rmax[r0 + i], st.rlse[r0 + i], cm, cl, st.zls[r0 + i], z1);
-    if (v > best) { best = v; bi = i; }
+  int bi = 0x7fffffff;
+  if (ok)
+    for (int i = ty; i < nrow; i += 16) {
+      const float v = lg_score(sp[(size_t)i * st.nmax], st.rmax[r0 + i], st.rlse[r0 + i], cm, cl, st.zls[r0 + i], z1);
+      if (v > best) { best = v; bi = i; }
+    }
+  redv[ty][tx] = best; redi[ty][tx] = bi;
+  __syncthreads();
+  if (ty == 0 && ok) {
+#pragma unroll
+    for (int g = 1; g < 16; ++g) {  // first maximal row index wins ties (Tensor.max on CPU)
+      const float ov = redv[g][tx];
+      const int oi = redi[g][tx];
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    st.best[c] = best; st.arg[c] = bi;
   }
-  st.best[c] = best; st.arg[c] = bi;
 }
 
 // ---------------------------------------------------------------------------
@@ -431,13 +463,13 @@ int launch_lg_prune(const LgState& st, int layer, double width_conf, float thr, 
 }
 int launch_lg_assign_stats(const LgState& st, int tag, const float* w_match, const float* b_match, hipStream_t s) {
   hipLaunchKernelGGL(lg_row_stats_kernel, dim3(cdiv(st.nmax, 4), st.n_items), dim3(256), 0, s, st, tag, w_match, b_match);
-  hipLaunchKernelGGL(lg_col_stats_kernel, dim3(cdiv(st.nmax, 256), st.n_pairs), dim3(256), 0, s, st, tag);
+  hipLaunchKernelGGL(lg_col_stats_kernel, dim3(cdiv(st.nmax, 64), st.n_pairs), dim3(1024), 0, s, st, tag);
   DIM_LAUNCH_CHECK();
   return 0;
 }
 int launch_lg_assign_argmax(const LgState& st, int tag, float* dense_scores, hipStream_t s) {
   hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(cdiv(st.nmax, 4), st.n_pairs), dim3(256), 0, s, st, tag, dense_scores);
-  hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(cdiv(st.nmax, 256), st.n_pairs), dim3(256), 0, s, st, tag);
+  hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(cdiv(st.nmax, 64), st.n_pairs), dim3(1024), 0, s, st, tag);
   DIM_LAUNCH_CHECK();
   return 0;
 }

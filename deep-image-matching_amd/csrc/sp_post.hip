@@ -36,88 +36,90 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------
-// simple_nms on a TILE x TILE output tile; T = TILE + 10 r.  LDS: s (scores, -inf
-// outside the image), tmp (row-pass scratch), msk (bit0 keep, bit1 near-kept),
-// orr (row-pass scratch of the dilation).
-template <int TILE, int TMAX>
+// simple_nms (SPN:47-63) fused into ONE pass per TILE x TILE output tile with a 5R halo
+// (dependency radius R -> 2R -> ... -> 5R) staged in LDS; T = TILE + 10R,
+// row stride TS = T|1 (odd).  Every (2R+1)^2 max-pool is separable; a line filter gives each
+// thread one 16-long segment of one line, loads 16+2R values into registers once and emits 16
+// window maxima (1 LDS read + 1 write per element instead of 2R+1 reads).  Lane -> line
+// mapping keeps both passes bank-conflict free: the row pass strides lanes over y (odd TS),
+// the column pass over x.  Arrays: s (scores, -inf outside the image), t (row-pass scratch),
+// rest (suppressed scores; sign bit marks "near a kept maximum"), kp / t8 (keep mask, bytes).
+template <int R, typename T, bool ROW, typename Emit>
+__device__ __forceinline__ void nms_line_max(const T* src, int Tn, int TS, T lowest, Emit emit) {
+  constexpr int SEG = 16;
+  const int nseg = (Tn + SEG - 1) / SEG;
+  for (int item = threadIdx.x; item < Tn * nseg; item += 256) {
+    const int line = item % Tn, seg = item / Tn;
+    const int base = seg * SEG - R;
+    const int stride = ROW ? 1 : TS;
+    const int off = ROW ? line * TS : line;
+    T v[SEG + 2 * R];
+#pragma unroll
+    for (int k = 0; k < SEG + 2 * R; ++k) {
+      const int q = base + k;
+      v[k] = (q >= 0 && q < Tn) ? src[off + q * stride] : lowest;
+    }
+#pragma unroll
+    for (int o = 0; o < SEG; ++o) {
+      T m = v[o];
+#pragma unroll
+      for (int k = 1; k <= 2 * R; ++k) m = v[o + k] > m ? v[o + k] : m;
+      const int q = seg * SEG + o;
+      if (q < Tn) emit(off + q * stride, m);
+    }
+  }
+}
+
+template <int R, int TILE>
 __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ smap, float* __restrict__ out, int H8, int W8,
-                                                  int r, int tiles_x) {
-  __shared__ float s[TMAX * TMAX];
-  __shared__ float tmp[TMAX * TMAX];
-  __shared__ unsigned char msk[TMAX * TMAX];
-  __shared__ unsigned char orr[TMAX * TMAX];
-  const int halo = 5 * r, T = TILE + 2 * halo, TT = T * T;
-  const int t = threadIdx.x;
-  const int b = blockIdx.z;
-  const int ty0 = (blockIdx.x / tiles_x) * TILE - halo, tx0 = (blockIdx.x % tiles_x) * TILE - halo;
+                                                  int tiles_x) {
+  constexpr int HALO = 5 * R, T = TILE + 2 * HALO, TS = T | 1, TT = T * TS;
+  __shared__ float s[TT];
+  __shared__ float t[TT];
+  __shared__ float rest[TT];
+  __shared__ unsigned char kp[TT];
+  __shared__ unsigned char t8[TT];
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int ty0 = (blockIdx.x / tiles_x) * TILE - HALO, tx0 = (blockIdx.x % tiles_x) * TILE - HALO;
   const float* src = smap + (size_t)b * H8 * W8;
   const float NEG = -INFINITY;
 
-  for (int i = t; i < TT; i += 256) {
+  for (int i = tid; i < T * T; i += 256) {
     const int y = i / T, x = i - y * T, gy = ty0 + y, gx = tx0 + x;
-    s[i] = (gy >= 0 && gy < H8 && gx >= 0 && gx < W8) ? src[(size_t)gy * W8 + gx] : NEG;
-    msk[i] = 0;
+    s[y * TS + x] = (gy >= 0 && gy < H8 && gx >= 0 && gx < W8) ? src[(size_t)gy * W8 + gx] : NEG;
   }
   __syncthreads();
-
-  // round 0 builds keep = (s == P(s)); rounds 1,2 do suppress-and-recover.
-  for (int round = 0; round < 3; ++round) {
-    if (round > 0) {
-      // near = dilate(keep, r): separable OR
-      for (int i = t; i < TT; i += 256) {
-        const int y = i / T, x = i - y * T;
-        const int x0 = max(x - r, 0), x1 = min(x + r, T - 1);
-        unsigned char o = 0;
-        for (int xx = x0; xx <= x1; ++xx) o |= msk[y * T + xx] & 1;
-        orr[i] = o;
-      }
-      __syncthreads();
-      for (int i = t; i < TT; i += 256) {
-        const int y = i / T, x = i - y * T;
-        const int y0 = max(y - r, 0), y1 = min(y + r, T - 1);
-        unsigned char o = 0;
-        for (int yy = y0; yy <= y1; ++yy) o |= orr[yy * T + x];
-        msk[i] = (msk[i] & 1) | (o << 1);
-      }
-      __syncthreads();
-    }
-    // row max of rest = near ? 0 : s   (round 0: near == 0 everywhere)
-    for (int i = t; i < TT; i += 256) {
-      const int y = i / T, x = i - y * T;
-      const int x0 = max(x - r, 0), x1 = min(x + r, T - 1);
-      float m = NEG;
-      for (int xx = x0; xx <= x1; ++xx) {
-        const int j = y * T + xx;
-        const float v = (msk[j] & 2) ? ((s[j] == NEG) ? NEG : 0.0f) : s[j];
-        m = fmaxf(m, v);
-      }
-      tmp[i] = m;
-    }
+  // round 0: keep = (s == P(s)); the column pass compares in its epilogue
+  nms_line_max<R, float, true>(s, T, TS, NEG, [&](int j, float m) { t[j] = m; });
+  __syncthreads();
+  nms_line_max<R, float, false>(t, T, TS, NEG, [&](int j, float m) { kp[j] = (s[j] != NEG && s[j] == m) ? 1 : 0; });
+  __syncthreads();
+  // two rounds of suppress-and-recover
+  for (int round = 0; round < 2; ++round) {
+    nms_line_max<R, unsigned char, true>(kp, T, TS, (unsigned char)0, [&](int j, unsigned char m) { t8[j] = m; });
     __syncthreads();
-    for (int i = t; i < TT; i += 256) {
-      const int y = i / T, x = i - y * T;
-      const int y0 = max(y - r, 0), y1 = min(y + r, T - 1);
-      float m = NEG;
-      for (int yy = y0; yy <= y1; ++yy) m = fmaxf(m, tmp[yy * T + x]);
-      const unsigned char k = msk[i];
-      const float sv = s[i];
-      const float rest = (k & 2) ? 0.0f : sv;
-      const bool inside = sv != NEG;  // scores are softmax outputs: finite inside the image
-      const bool newkeep = inside && !(k & 2) && (rest == m);
-      orr[i] = newkeep ? 1 : 0;  // staged: msk is still being read by nobody, but keep phases separate
-    }
+    // near = dilate(keep); rest = near ? 0 : s, the sign bit of the 0 remembers "near"
+    nms_line_max<R, unsigned char, false>(t8, T, TS, (unsigned char)0, [&](int j, unsigned char m) {
+      const float sv = s[j];
+      rest[j] = (sv == NEG) ? NEG : (m ? -0.0f : sv);
+    });
     __syncthreads();
-    for (int i = t; i < TT; i += 256) msk[i] |= orr[i];
+    nms_line_max<R, float, true>(rest, T, TS, NEG, [&](int j, float m) { t[j] = m; });
+    __syncthreads();
+    nms_line_max<R, float, false>(t, T, TS, NEG, [&](int j, float m) {
+      const float rv = rest[j];
+      const bool near = __float_as_uint(rv) == 0x80000000u;
+      if (rv != NEG && !near && rv == m) kp[j] = 1;
+    });
     __syncthreads();
   }
-
   float* dst = out + (size_t)b * H8 * W8;
-  for (int i = t; i < TILE * TILE; i += 256) {
+  for (int i = tid; i < TILE * TILE; i += 256) {
     const int y = i / TILE, x = i - y * TILE;
-    const int gy = ty0 + halo + y, gx = tx0 + halo + x;
+    const int gy = ty0 + HALO + y, gx = tx0 + HALO + x;
     if (gy < H8 && gx < W8) {
-      const int j = (y + halo) * T + x + halo;
-      dst[(size_t)gy * W8 + gx] = (msk[j] & 1) ? s[j] : 0.0f;
+      const int j = (y + HALO) * TS + x + HALO;
+      dst[(size_t)gy * W8 + gx] = kp[j] ? s[j] : 0.0f;
     }
   }
 }
@@ -344,13 +346,21 @@ int launch_softmax_d2s(const float* logits, float* smap, int batch, int h, int w
 int launch_nms(const float* smap, float* out, int batch, int H8, int W8, int radius, hipStream_t s) {
   DIM_REQUIRE(radius >= 0 && radius <= 6, "nms: radius %d unsupported (0..6)", radius);
   if (batch <= 0 || H8 <= 0 || W8 <= 0) return 0;
-  if (radius <= 4) {
-    const int tx = cdiv(W8, 32), ty = cdiv(H8, 32);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_kernel<32, 72>), dim3(tx * ty, 1, batch), dim3(256), 0, s, smap, out, H8, W8, radius, tx);
-  } else {
-    const int tx = cdiv(W8, 16), ty = cdiv(H8, 16);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_kernel<16, 76>), dim3(tx * ty, 1, batch), dim3(256), 0, s, smap, out, H8, W8, radius, tx);
+#define DIM_NMS(RR, TL)                                                                                              \
+  {                                                                                                                  \
+    const int tx = cdiv(W8, TL), ty = cdiv(H8, TL);                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_kernel<RR, TL>), dim3(tx * ty, 1, batch), dim3(256), 0, s, smap, out, H8, W8, tx); \
   }
+  switch (radius) {
+    case 0: DIM_NMS(0, 32) break;
+    case 1: DIM_NMS(1, 32) break;
+    case 2: DIM_NMS(2, 32) break;
+    case 3: DIM_NMS(3, 32) break;
+    case 4: DIM_NMS(4, 32) break;
+    case 5: DIM_NMS(5, 16) break;
+    default: DIM_NMS(6, 16) break;
+  }
+#undef DIM_NMS
   DIM_LAUNCH_CHECK();
   return 0;
 }

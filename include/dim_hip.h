@@ -190,6 +190,9 @@ int dim_op_gemm_f32(const float* A, int lda, const float* B, int ldb, int b_is_n
 int dim_op_conv3x3_nhwc_f32(const float* in, const float* w_tap_cin_cout, const float* bias, float* out, int batch,
                             int H, int W, int cin, int cout, int pool2x2, int relu, void* stream);
 
+/* simple_nms (SPN:47-63) on [batch][H][W] score maps, radius 0..6; non-maxima -> 0. */
+int dim_op_simple_nms_f32(const float* score_map, float* out, int batch, int H, int W, int radius, void* stream);
+
 /* conv1a: [batch][H][W] -> [batch][H][W][64], weights [9][64], bias, ReLU. */
 int dim_op_conv1a_f32(const float* in, const float* w_tap_cout, const float* bias, float* out, int batch, int H, int W,
                       void* stream);

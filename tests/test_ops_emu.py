@@ -1,0 +1,54 @@
+"""CPU: operator-level kernels on the test emulator vs torch / the oracle (bit-exact where integer)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import superpoint_ref
+
+
+def p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("radius", [0, 1, 2, 3, 4, 5, 6])
+def test_simple_nms_bit_exact_with_ties_and_plateaus(emu_lib, radius):
+    g = torch.Generator().manual_seed(radius)
+    H, W = 45, 70  # not multiples of the tile; includes the image border logic
+    s = torch.rand(2, H, W, generator=g)
+    s[0] = (s[0] * 6).round() / 6 + 0.01  # heavy ties / plateaus (SURVEY App. D KATs)
+    s[1, 10:20, 10:30] = 0.5
+    out = torch.full_like(s, -1.0)
+    assert emu_lib.dim_op_simple_nms_f32(p(s), p(out), 2, H, W, radius, None) == 0, emu_lib.dim_last_error()
+    ref = superpoint_ref.simple_nms(s, radius)
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("M,N,K,bt", [(200, 65, 64, 0), (130, 256, 256, 0), (150, 140, 64, 1), (1, 4, 32, 0)])
+def test_gemm_mfma(emu_lib, M, N, K, bt):
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) if bt else torch.randn(K, ((N + 3) // 4) * 4, generator=g)
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    C = torch.zeros(M, N)
+    assert emu_lib.dim_op_gemm_f32(p(A), K, p(B), B.shape[1], bt, p(bias), p(R), N, p(C), N, M, N, K, 1, None) == 0
+    ref = torch.relu((A @ B.T if bt else A @ B[:, :N]) + bias + R)
+    assert (C - ref).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,H,W,pool", [(64, 64, 20, 37, 1), (64, 128, 9, 33, 0), (128, 128, 16, 34, 1)])
+def test_conv3x3_mfma(emu_lib, cin, cout, H, W, pool):
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(2, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    xin = x.permute(0, 2, 3, 1).contiguous()
+    wk = w.permute(2, 3, 1, 0).contiguous().reshape(9, cin, cout)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.full((2, Ho, Wo, cout), -7.0)
+    assert emu_lib.dim_op_conv3x3_nhwc_f32(p(xin), p(wk), p(b), p(out), 2, H, W, cin, cout, pool, 1, None) == 0
+    ref = torch.relu(F.conv2d(x, w, b, padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    assert (out - ref.permute(0, 2, 3, 1)).abs().max() < 1e-4
