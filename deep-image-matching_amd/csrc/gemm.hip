@@ -46,44 +46,69 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  for (int k0 = 0; k0 < a.K; k0 += KC) {
-    // ---- stage A chunk: 128 rows x 32 k (coalesced 128-B row segments) ----
-    {
-      const float* src; int ld, kk0;
-      if (A1 == nullptr || k0 < a.ksplit) { src = A0; ld = a.lda0; kk0 = k0; }
-      else { src = A1; ld = a.lda1; kk0 = k0 - a.ksplit; }
+  // Software pipeline: the global loads of chunk k+1 are issued before the MFMA loop of chunk k
+  // and only consumed (written to LDS) after it, so HBM/L2 latency hides behind 64 MFMAs/wave.
+  float4 ra[(BM * KC / 4) / 256], rb[(KC * BN / 4) / 256];
+  auto load_chunk = [&](int k0) {
+    const float* src; int ld, kk0;
+    if (A1 == nullptr || k0 < a.ksplit) { src = A0; ld = a.lda0; kk0 = k0; }
+    else { src = A1; ld = a.lda1; kk0 = k0 - a.ksplit; }
 #pragma unroll
-      for (int i = 0; i < (BM * KC / 4) / 256; ++i) {
-        int idx = t + 256 * i;
-        int row = idx >> 3, q = idx & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + row < rows) v = *(const float4*)(src + (size_t)(m0 + row) * ld + kk0 + q * 4);
-        float* d = &As[row * AS + q * 4];
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
+    for (int i = 0; i < (BM * KC / 4) / 256; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx >> 3, q = idx & 7;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + row < rows) ra[i] = *(const float4*)(src + (size_t)(m0 + row) * ld + kk0 + q * 4);
     }
-    // ---- stage B chunk ----
     if (BT) {
 #pragma unroll
       for (int i = 0; i < (BN * KC / 4) / 256; ++i) {
-        int idx = t + 256 * i;
-        int col = idx >> 3, q = idx & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0 + col < cols) v = *(const float4*)(B + (size_t)(n0 + col) * a.ldb + k0 + q * 4);
-        float* d = &Bs[col * AS + q * 4];
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        const int idx = t + 256 * i;
+        const int col = idx >> 3, q = idx & 7;
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + col < cols) rb[i] = *(const float4*)(B + (size_t)(n0 + col) * a.ldb + k0 + q * 4);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < (KC * BN / 4) / 256; ++i) {
-        int idx = t + 256 * i;
-        int kk = idx >> 5, q = idx & 31;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0 + q * 4 < a.ldb) v = *(const float4*)(B + (size_t)(k0 + kk) * a.ldb + n0 + q * 4);
-        *(float4*)&Bs[kk * BN + q * 4] = v;
+        const int idx = t + 256 * i;
+        const int kk = idx >> 5, q = idx & 31;
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + q * 4 < a.ldb) rb[i] = *(const float4*)(B + (size_t)(k0 + kk) * a.ldb + n0 + q * 4);
       }
     }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < (BM * KC / 4) / 256; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx >> 3, q = idx & 7;
+      float* d = &As[row * AS + q * 4];
+      d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+    }
+    if (BT) {
+#pragma unroll
+      for (int i = 0; i < (BN * KC / 4) / 256; ++i) {
+        const int idx = t + 256 * i;
+        const int col = idx >> 3, q = idx & 7;
+        float* d = &Bs[col * AS + q * 4];
+        d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < (KC * BN / 4) / 256; ++i) {
+        const int idx = t + 256 * i;
+        const int kk = idx >> 5, q = idx & 31;
+        *(float4*)&Bs[kk * BN + q * 4] = rb[i];
+      }
+    }
+  };
+
+  load_chunk(0);
+  for (int k0 = 0; k0 < a.K; k0 += KC) {
+    store_chunk();
     __syncthreads();
+    if (k0 + KC < a.K) load_chunk(k0 + KC);
 #pragma unroll 4
     for (int s = 0; s < KC / 2; ++s) {
       const int kk = 2 * s + half;

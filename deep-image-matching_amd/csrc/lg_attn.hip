@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   {
     const float* qp = a.q + (size_t)item * a.sq + (size_t)(qok ? qrow : 0) * a.ldq + head * 64 + half;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) qreg[s] = qok ? qp[2 * s] * a.scale : 0.0f;
+    for (int s = 0; s < 32; ++s) qreg[s] = qok ? qp[2 * s] * (a.scale * 1.44269504088896340736f) : 0.0f;
   }
   f32x16 oacc[2];
 #pragma unroll
@@ -67,22 +67,33 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   const float* kb = a.k + (size_t)kitem * a.sk + head * 64;
   const float* vb = a.v + (size_t)kitem * a.sv + head * 64;
 
-  for (int kt = 0; kt < nk; kt += 32) {
-    __syncthreads();
+  // software pipeline: tile kt+32 is fetched into registers while tile kt is being consumed
+  float4 rk[2], rv[2];
+  auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = t + 256 * i;
       const int key = idx >> 4, q4 = idx & 15;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rv[i] = rk[i];
       if (kt + key < nk) {
-        kv = *(const float4*)(kb + (size_t)(kt + key) * a.ldk + q4 * 4);
-        vv = *(const float4*)(vb + (size_t)(kt + key) * a.ldv + q4 * 4);
+        rk[i] = *(const float4*)(kb + (size_t)(kt + key) * a.ldk + q4 * 4);
+        rv[i] = *(const float4*)(vb + (size_t)(kt + key) * a.ldv + q4 * 4);
       }
+    }
+  };
+  load_tile(0);
+  for (int kt = 0; kt < nk; kt += 32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = t + 256 * i;
+      const int key = idx >> 4, q4 = idx & 15;
       float* d = &Ks[key * 65 + q4 * 4];
-      d[0] = kv.x; d[1] = kv.y; d[2] = kv.z; d[3] = kv.w;
-      *(float4*)&Vs[key * 64 + q4 * 4] = vv;
+      d[0] = rk[i].x; d[1] = rk[i].y; d[2] = rk[i].z; d[3] = rk[i].w;
+      *(float4*)&Vs[key * 64 + q4 * 4] = rv[i];
     }
     __syncthreads();
+    if (kt + 32 < nk) load_tile(kt + 32);
 
     f32x16 sacc;
 #pragma unroll
@@ -91,34 +102,46 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int s = 0; s < 32; ++s) sacc = mfma32(kp[2 * s], qreg[s], sacc);
 
-    float tmax = -INFINITY;
+    // ---- online softmax in the log2 domain (Q was pre-scaled by scale*log2(e)) ----
+    if (kt + 32 > nk) {  // ragged last tile only: mask the missing keys
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (kt + mfma_row(r, half) >= nk) sacc[r] = -INFINITY;
-      tmax = fmaxf(tmax, sacc[r]);
+      for (int r = 0; r < 16; ++r)
+        if (kt + mfma_row(r, half) >= nk) sacc[r] = -INFINITY;
     }
+    float tmax = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[r]), sacc[r + 1]);
+    tmax = fmaxf(tmax, sacc[15]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = expf(m_run - m_new);
+    // Deferred rescale: the running reference m_run is only moved when the tile maximum exceeds it
+    // by more than 2^RESCALE_LOG2 (probabilities then stay <= 2^RESCALE_LOG2, far from fp32
+    // overflow); mathematically identical after the final division by l.
+    constexpr float RESCALE_LOG2 = 8.0f;
+    if (__any(tmax > m_run + RESCALE_LOG2)) {
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+      l_run *= alpha;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
+      m_run = m_new;
+    }
     float p[16];
     float psum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      p[r] = expf(sacc[r] - m_new);
+      p[r] = __builtin_amdgcn_exp2f(sacc[r] - m_run);
       psum += p[r];
     }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
+    l_run += psum;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float* vp = &Vs[mfma_row(r, half) * 64 + lx];
       oacc[0] = mfma32(vp[0], p[r], oacc[0]);
       oacc[1] = mfma32(vp[32], p[r], oacc[1]);
     }
+    __syncthreads();
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);

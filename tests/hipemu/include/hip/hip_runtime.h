@@ -200,6 +200,7 @@ template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; 
 template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 
 #define __expf(x) expf(x)
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 #define __logf(x) logf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
