@@ -87,6 +87,11 @@ int dim_op_simple_nms_f32(const float* score_map, float* out, int batch, int H, 
   return launch_nms(score_map, out, batch, H, W, radius, (hipStream_t)stream);
 }
 
+int dim_tune_set(int key, int value) {
+  if (key == 0) dim_conv_set_variant(value);
+  return 0;
+}
+
 int dim_device_synchronize(void) {
   DIM_HIP(hipDeviceSynchronize());
   return 0;

@@ -18,12 +18,20 @@
 #include "dim_kernels.h"
 
 namespace {
-constexpr int TH = 8, TW = 32, KC = 16, CS = KC + 1, IW = TW + 2, IH = TH + 2;
+constexpr int TH = 8, TW = 32, IW = TW + 2, IH = TH + 2;
 
-template <int CIN, int POOL>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                           int H, int W, int cout, int relu, int tiles_x) {
+// KC   : input channels per LDS chunk (16: 60 KB LDS, 288 MFMAs/wave between barriers;
+//        8: 31 KB LDS, 144 MFMAs).
+// PF   : software pipeline — the next chunk's halo tile and weight slice are fetched into
+//        registers while the MFMAs of the current chunk run (affordable only at KC = 8:
+//        32 staging VGPRs; at KC = 16 the 60 extra VGPRs halve the occupancy).
+// OCC  : __launch_bounds__ minimum waves per SIMD.
+template <int CIN, int POOL, int KC, int PF, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                int H, int W, int cout, int relu, int tiles_x) {
+  constexpr int CS = KC + 1;
+  constexpr int NIN_TOT = IH * IW * (KC / 4), NIN = (NIN_TOT + 255) / 256, NW_TOT = 9 * KC * 16, NW = (NW_TOT + 255) / 256;
   __shared__ float Is[IH * IW * CS];
   __shared__ float Ws[9 * KC * 64];
 
@@ -42,24 +50,48 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  for (int c0 = 0; c0 < CIN; c0 += KC) {
-    for (int i = t; i < IH * IW * (KC / 4); i += 256) {
-      const int p = i >> 2, q = i & 3;
+  float4 rin[NIN], rw[NW];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = t + 256 * i;
+      const int p = idx / (KC / 4), q = idx % (KC / 4);
       const int py = p / IW, px = p - py * IW;
       const int gy = oy + py - 1, gx = ox + px - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *(const float4*)(in_b + ((size_t)gy * W + gx) * CIN + c0 + q * 4);
-      float* d = &Is[p * CS + q * 4];
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      rin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < NIN_TOT && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        rin[i] = *(const float4*)(in_b + ((size_t)gy * W + gx) * CIN + c0 + q * 4);
     }
 #pragma unroll
-    for (int i = 0; i < (9 * KC * 16) / 256; ++i) {
+    for (int i = 0; i < NW; ++i) {
       const int idx = t + 256 * i;
       const int rowi = idx >> 4, q = idx & 15;
       const int tap = rowi / KC, ci = rowi - tap * KC;
-      *(float4*)&Ws[rowi * 64 + q * 4] = *(const float4*)(w + ((size_t)tap * CIN + c0 + ci) * cout + cb * 64 + q * 4);
+      if (NW_TOT % 256 == 0 || idx < NW_TOT) rw[i] = *(const float4*)(w + ((size_t)tap * CIN + c0 + ci) * cout + cb * 64 + q * 4);
     }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < NIN_TOT) {
+        float* d = &Is[(idx / (KC / 4)) * CS + (idx % (KC / 4)) * 4];
+        d[0] = rin[i].x; d[1] = rin[i].y; d[2] = rin[i].z; d[3] = rin[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = t + 256 * i;
+      if (NW_TOT % 256 == 0 || idx < NW_TOT) *(float4*)&Ws[(idx >> 4) * 64 + (idx & 15) * 4] = rw[i];
+    }
+  };
+
+  if (PF) load_chunk(0);
+  for (int c0 = 0; c0 < CIN; c0 += KC) {
+    if (!PF) load_chunk(c0);
+    store_chunk();
     __syncthreads();
+    if (PF && c0 + KC < CIN) load_chunk(c0 + KC);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - 3 * (tap / 3);
@@ -144,6 +176,9 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ i
 }
 }  // namespace
 
+static int g_conv_variant = 3;
+void dim_conv_set_variant(int v) { g_conv_variant = v; }
+
 int launch_conv3x3(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W, int cin,
                    int cout, int pool, int relu, hipStream_t s) {
   DIM_REQUIRE(cout % 64 == 0, "conv3x3: cout=%d must be a multiple of 64", cout);
@@ -151,12 +186,22 @@ int launch_conv3x3(const float* in, const float* w, const float* bias, float* ou
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-#define DIM_CONV(CI, P) \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_mfma_kernel<CI, P>), grid, dim3(256), 0, s, in, w, bias, out, H, W, cout, relu, tiles_x)
-  if (cin == 64 && pool) DIM_CONV(64, 1);
-  else if (cin == 64) DIM_CONV(64, 0);
-  else if (pool) DIM_CONV(128, 1);
-  else DIM_CONV(128, 0);
+#define DIM_CONV(CI, P, KCV, PFV, OC) \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_mfma_kernel<CI, P, KCV, PFV, OC>), grid, dim3(256), 0, s, in, w, bias, out, H, W, cout, relu, tiles_x)
+#define DIM_CONV_V(KCV, PFV, OC)               \
+  {                                            \
+    if (cin == 64 && pool) DIM_CONV(64, 1, KCV, PFV, OC);  \
+    else if (cin == 64) DIM_CONV(64, 0, KCV, PFV, OC);     \
+    else if (pool) DIM_CONV(128, 1, KCV, PFV, OC);         \
+    else DIM_CONV(128, 0, KCV, PFV, OC);                   \
+  }
+  switch (g_conv_variant) {  // measured r01 (TFLOP/s, conv1b / conv4a): v0 117/111, v1 121/116, v2 118/105, v3 122/122
+    case 1: DIM_CONV_V(8, 0, 3) break;
+    case 2: DIM_CONV_V(8, 1, 2) break;
+    case 4: DIM_CONV_V(16, 0, 1) break;
+    default: DIM_CONV_V(8, 1, 3) break;
+  }
+#undef DIM_CONV_V
 #undef DIM_CONV
   DIM_LAUNCH_CHECK();
   return 0;

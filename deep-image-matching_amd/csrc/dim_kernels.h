@@ -36,6 +36,7 @@ int launch_gemm(const GemmArgs& a, int batch, hipStream_t s);
 // SPN:163-171).  in: [B][H][W][cin], w: [9][cin][cout], out: [B][H'][W'][cout].
 int launch_conv3x3(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W,
                    int cin, int cout, int pool, int relu, hipStream_t s);
+void dim_conv_set_variant(int v);  // tuning hook: selects the conv3x3 kernel variant (see conv.hip)
 // conv1a: 1 -> 64 channels, direct (VALU) convolution; in: [B][H][W], w: [9][64].
 int launch_conv1a(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W,
                   hipStream_t s);

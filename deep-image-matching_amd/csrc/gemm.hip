@@ -19,7 +19,7 @@ namespace {
 constexpr int BM = 128, BN = 128, KC = 32, AS = KC + 1;
 
 template <int BT>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, 4) void gemm_mfma_kernel(GemmArgs a) {
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] : a.M;

@@ -37,7 +37,7 @@ struct AttnArgs {
   float scale;
 };
 
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_kernel(AttnArgs a) {
   const int item = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
   if (a.done[item >> 1] != 0) return;
   const int kitem = a.cross ? (item ^ 1) : item;

@@ -35,6 +35,8 @@ extern "C" {
 const char* dim_last_error(void);
 int dim_abi_version(void);
 int dim_device_synchronize(void);
+/* Tuning hook (experiments / A-B benchmarking): key 0 = conv3x3 kernel variant. */
+int dim_tune_set(int key, int value);
 
 /* Per-launch-site timing with HIP events recorded on the launch stream (bench.py's
  * roofline figure).  dim_profile_start(mask) arms the sites whose bits (1 << DIM_PROF_*) are set;
