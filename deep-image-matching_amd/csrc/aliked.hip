@@ -1,0 +1,610 @@
+// ALIKED kernels for gfx950 (reference ALN = thirdparty/LightGlue/lightglue/aliked.py).
+//
+// ALIKED's dense stage is HBM-bound (≈10 kMAC/px against a 512 B/px feature map), its
+// channel counts are small (3..128), and BatchNorm runs in TRAINING mode (Q7: statistics of the
+// current image), so every conv output needs a global per-channel reduction before it can be
+// activated.  Layout NHWC; convolutions are direct VALU kernels whose weights are wave-uniform and
+// therefore come through the scalar cache (s_load + v_fmac with an SGPR operand), inputs through an
+// LDS halo tile with a (C+4)-dword pixel stride (conflict-free ds_read_b128); MFMA is used only for
+// the SDDH GEMMs (gemm.hip).
+#include <math.h>
+
+#include "aliked_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float selu_(float x) {
+  // ATen elu kernel: x <= 0 ? (exp(x) - 1) * (alpha*scale) : x * scale
+  const float scale = 1.0507009873554804934193349852946f, alpha = 1.6732632423543772848170429916717f;
+  return x <= 0.0f ? (expf(x) - 1.0f) * (alpha * scale) : x * scale;
+}
+__device__ __forceinline__ float act_(float v, int act) {
+  if (act == AL_ACT_SELU) return selu_(v);
+  if (act == AL_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// direct 3x3 conv, 16x16 pixel tile per workgroup, one pixel per thread, all COUT per thread;
+// input channels are walked in chunks of CC through an LDS halo tile.
+template <int CC, int COUT>
+__global__ __launch_bounds__(256) void al_conv3x3_kernel(const float* __restrict__ in, int in_c, int cin_pad,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int out_c, int H, int W, int act, int tiles_x,
+                                                         int crop_y, int crop_x, int out_h, int out_w) {
+  constexpr int PS = CC + 4;  // pixel stride in dwords
+  __shared__ float tile[18 * 18 * PS];
+  const int t = threadIdx.x, b = blockIdx.z;
+  const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+  const float* src = in + (size_t)b * H * W * in_c;
+  const int py = t >> 4, px = t & 15;
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  for (int c0 = 0; c0 < cin_pad; c0 += CC) {
+    if (c0 > 0) __syncthreads();
+    if (in_c % 4 == 0) {
+      for (int i = t; i < 18 * 18 * (CC / 4); i += 256) {
+        const int p = i / (CC / 4), q = i % (CC / 4);
+        const int gy = ty0 + p / 18 - 1, gx = tx0 + p % 18 - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *(const float4*)(src + ((size_t)gy * W + gx) * in_c + c0 + q * 4);
+        *(float4*)&tile[p * PS + q * 4] = v;
+      }
+    } else {
+      for (int i = t; i < 18 * 18 * CC; i += 256) {
+        const int p = i / CC, c = i % CC;
+        const int gy = ty0 + p / 18 - 1, gx = tx0 + p % 18 - 1;
+        float v = 0.f;
+        if (c < in_c && gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[((size_t)gy * W + gx) * in_c + c];
+        tile[p * PS + c] = v;
+      }
+    }
+    __syncthreads();
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* tp = &tile[((py + tap / 3) * 18 + px + tap % 3) * PS];
+      const float* wt = w + ((size_t)tap * cin_pad + c0) * COUT;
+#pragma unroll
+      for (int c4 = 0; c4 < CC / 4; ++c4) {
+        const float4 a = *(const float4*)(tp + c4 * 4);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) acc[co] = fmaf(av[j], wt[(c4 * 4 + j) * COUT + co], acc[co]);
+      }
+    }
+  }
+  const int y = ty0 + py - crop_y, x = tx0 + px - crop_x;
+  if (ty0 + py < H && tx0 + px < W && y >= 0 && y < out_h && x >= 0 && x < out_w) {
+    float* dst = out + (((size_t)b * out_h + y) * out_w + x) * out_c;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+      if (co < out_c) dst[co] = act_(acc[co] + (bias ? bias[co] : 0.f), act);
+  }
+}
+
+// 1x1 conv: one pixel per thread, weights [CIN][COUT] through the scalar cache.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void al_conv1x1_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int n, int act) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+  const float* src = in + (size_t)p * CIN;
+#pragma unroll
+  for (int c4 = 0; c4 < CIN / 4; ++c4) {
+    const float4 a = *(const float4*)(src + c4 * 4);
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[co] = fmaf(av[j], w[(c4 * 4 + j) * COUT + co], acc[co]);
+  }
+  float* dst = out + (size_t)p * COUT;
+#pragma unroll
+  for (int co = 0; co < COUT; co += 4)
+    *(float4*)(dst + co) = make_float4(act_(acc[co], act), act_(acc[co + 1], act), act_(acc[co + 2], act), act_(acc[co + 3], act));
+}
+
+// replicate padding to a multiple of 32 (InputPadder, ALN:247-271); gray -> RGB repeat (ALN:679-680)
+__global__ __launch_bounds__(256) void al_pad_kernel(const float* __restrict__ img, float* __restrict__ out, int H, int W, int Hp,
+                                                     int Wp, int pad_t, int pad_l, int in_ch) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= Hp * Wp) return;
+  const int y = i / Wp, x = i - y * Wp;
+  const int sy = min(max(y - pad_t, 0), H - 1), sx = min(max(x - pad_l, 0), W - 1);
+  const float* s = img + (((size_t)b * H + sy) * W + sx) * in_ch;
+  float* d = out + ((size_t)b * Hp * Wp + i) * 3;
+  d[0] = s[0]; d[1] = in_ch == 3 ? s[1] : s[0]; d[2] = in_ch == 3 ? s[2] : s[0];
+}
+
+__global__ __launch_bounds__(256) void al_avgpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C,
+                                                         int k) {
+  const int Ho = H / k, Wo = W / k, C4 = C / 4;
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= Ho * Wo * C4) return;
+  const int c4 = i % C4, p = i / C4, y = p / Wo, x = p - y * Wo;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int dy = 0; dy < k; ++dy)
+    for (int dx = 0; dx < k; ++dx) {
+      const float4 v = *(const float4*)(in + (((size_t)b * H + y * k + dy) * W + x * k + dx) * C + c4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  const float inv = (float)(k * k);
+  *(float4*)(out + (((size_t)b * Ho + y) * Wo + x) * C + c4 * 4) = make_float4(s.x / inv, s.y / inv, s.z / inv, s.w / inv);
+}
+
+// ---------------------------------------------------------------------------
+// BN training-mode statistics: stage 1 = per-block fp64 partial (sum, sumsq) per channel, stage 2 =
+// fixed-order reduction -> alpha = gamma/sqrt(var+eps), beta = bias - mean*alpha (ATen's contiguous
+// CPU path: out = x*alpha + beta).  Deterministic (no atomics).
+constexpr int BN_BLOCKS = 64;
+__global__ __launch_bounds__(256) void al_bn_partial_kernel(const float* __restrict__ x, int n_pixels, int C, double* __restrict__ partial) {
+  __shared__ double red[256][2];
+  const int b = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  const int lanes_per_c = 256 / C;  // C in {16,32,64,128} -> 16,8,4,2 pixel lanes per channel
+  const int c = t % C, pl = t / C;
+  const float* src = x + (size_t)b * n_pixels * C;
+  double s = 0.0, q = 0.0;
+  for (int p = blk * lanes_per_c + pl; p < n_pixels; p += BN_BLOCKS * lanes_per_c) {
+    const double v = (double)src[(size_t)p * C + c];
+    s += v; q += v * v;
+  }
+  red[t][0] = s; red[t][1] = q;
+  __syncthreads();
+  if (t < C) {
+    for (int k = 1; k < lanes_per_c; ++k) { s += red[t + k * C][0]; q += red[t + k * C][1]; }
+    double* d = partial + (((size_t)b * BN_BLOCKS + blk) * C + t) * 2;
+    d[0] = s; d[1] = q;
+  }
+}
+__global__ void al_bn_final_kernel(const double* __restrict__ partial, int n_pixels, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta_w, float* __restrict__ alpha, float* __restrict__ beta) {
+  const int c = threadIdx.x, b = blockIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < BN_BLOCKS; ++k) {
+    const double* d = partial + (((size_t)b * BN_BLOCKS + k) * C + c) * 2;
+    s += d[0]; q += d[1];
+  }
+  const double mean = s / n_pixels;
+  double var = q / n_pixels - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+  const float a = invstd * gamma[c];
+  alpha[b * C + c] = a;
+  beta[b * C + c] = beta_w[c] - (float)mean * a;
+}
+// y = selu(x*alpha + beta (+ residual))
+__global__ __launch_bounds__(256) void al_bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                          const float* __restrict__ beta, const float* __restrict__ res,
+                                                          float* __restrict__ out, int n_pixels, int C) {
+  const int C4 = C / 4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= (size_t)n_pixels * C4) return;
+  const int c = (int)(i % C4) * 4;
+  const size_t off = (size_t)b * n_pixels * C + i * 4;
+  const float4 v = *(const float4*)(x + off);
+  const float4 a = *(const float4*)(alpha + b * C + c), bb = *(const float4*)(beta + b * C + c);
+  float4 y = make_float4(v.x * a.x + bb.x, v.y * a.y + bb.y, v.z * a.z + bb.z, v.w * a.w + bb.w);
+  if (res) {
+    const float4 r = *(const float4*)(res + off);
+    y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+  }
+  *(float4*)(out + off) = make_float4(selu_(y.x), selu_(y.y), selu_(y.z), selu_(y.w));
+}
+
+__global__ __launch_bounds__(256) void al_clamp_kernel(float* __restrict__ x, size_t n, float lim) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = fminf(fmaxf(x[i], -lim), lim);
+}
+
+// ---------------------------------------------------------------------------
+// deformable conv (torchvision.ops.deform_conv2d semantics, call site ALN:322-329): thread = (pixel,
+// 32-channel output chunk); per tap the bilinear sample of all CIN channels is formed in registers.
+template <int CIN>
+__global__ __launch_bounds__(256) void al_deform_conv_kernel(const float* __restrict__ in, const float* __restrict__ offs, int off_c,
+                                                             const float* __restrict__ w, float* __restrict__ out, int cout, int H,
+                                                             int W) {
+  const int nchunk = cout / 32;
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= H * W * nchunk) return;
+  const int chunk = i % nchunk, p = i / nchunk, y = p / W, x = p - y * W;
+  const float* src = in + (size_t)b * H * W * CIN;
+  const float* of = offs + ((size_t)b * H * W + p) * off_c;
+  float acc[32];
+#pragma unroll
+  for (int co = 0; co < 32; ++co) acc[co] = 0.f;
+  for (int tap = 0; tap < 9; ++tap) {
+    const float py = (float)(y - 1 + tap / 3) + of[2 * tap], px = (float)(x - 1 + tap % 3) + of[2 * tap + 1];
+    if (!(py > -1.f && py < (float)H && px > -1.f && px < (float)W)) continue;
+    const float fy = floorf(py), fx = floorf(px);
+    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+    const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+    const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+    const bool v00 = y0 >= 0 && x0 >= 0, v01 = y0 >= 0 && x1 <= W - 1, v10 = y1 <= H - 1 && x0 >= 0, v11 = y1 <= H - 1 && x1 <= W - 1;
+    const float* wt = w + ((size_t)tap * CIN) * cout + chunk * 32;
+    for (int c4 = 0; c4 < CIN / 4; ++c4) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v00) { const float4 v = *(const float4*)(src + ((size_t)y0 * W + x0) * CIN + c4 * 4); s.x += w00 * v.x; s.y += w00 * v.y; s.z += w00 * v.z; s.w += w00 * v.w; }
+      if (v01) { const float4 v = *(const float4*)(src + ((size_t)y0 * W + x1) * CIN + c4 * 4); s.x += w01 * v.x; s.y += w01 * v.y; s.z += w01 * v.z; s.w += w01 * v.w; }
+      if (v10) { const float4 v = *(const float4*)(src + ((size_t)y1 * W + x0) * CIN + c4 * 4); s.x += w10 * v.x; s.y += w10 * v.y; s.z += w10 * v.z; s.w += w10 * v.w; }
+      if (v11) { const float4 v = *(const float4*)(src + ((size_t)y1 * W + x1) * CIN + c4 * 4); s.x += w11 * v.x; s.y += w11 * v.y; s.z += w11 * v.z; s.w += w11 * v.w; }
+      const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* wr = wt + (size_t)(c4 * 4 + j) * cout;
+#pragma unroll
+        for (int co = 0; co < 32; ++co) acc[co] = fmaf(sv[j], wr[co], acc[co]);
+      }
+    }
+  }
+  float* dst = out + ((size_t)b * H * W + p) * cout + chunk * 32;
+#pragma unroll
+  for (int co = 0; co < 32; co += 4) *(float4*)(dst + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+}
+
+// ---------------------------------------------------------------------------
+// bilinear upsampling with align_corners=True as ATen computes it (upsample_bilinear2d, fp32):
+// src = dst * (in-1)/(out-1); lambdas from the float source index.
+struct UpIdx { int i0, i1; float l0, l1; };
+__device__ __forceinline__ UpIdx up_index(int dst, int in_size, int out_size) {
+  const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  const float r = scale * (float)dst;
+  UpIdx u;
+  u.i0 = (int)r;
+  u.i1 = u.i0 + ((u.i0 < in_size - 1) ? 1 : 0);
+  u.l1 = r - (float)u.i0;
+  u.l0 = 1.f - u.l1;
+  return u;
+}
+// x1234 = cat[selu(conv1(x1)), up2(f2), up8(f3), up32(f4)] (ALN:657-664) and s8 = selu(score_head.0(x1234))
+// (ALN:666).  One pixel per thread; the 128-channel vector is produced and consumed 4 channels at a time.
+__global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restrict__ x1, const float* __restrict__ f2,
+                                                          const float* __restrict__ f3, const float* __restrict__ f4,
+                                                          const float* __restrict__ w1, const float* __restrict__ ws0,
+                                                          float* __restrict__ x1234, float* __restrict__ s8, int Hp, int Wp) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= Hp * Wp) return;
+  const int y = i / Wp, x = i - y * Wp;
+  float sacc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sacc[k] = 0.f;
+  float* dst = x1234 + ((size_t)b * Hp * Wp + i) * 128;
+  // --- f1 = selu(conv1x1 16->32 of x1)
+  {
+    const float* src = x1 + ((size_t)b * Hp * Wp + i) * 16;
+    float a[16];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) { const float4 v = *(const float4*)(src + c4 * 4); a[c4 * 4] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w; }
+#pragma unroll
+    for (int co = 0; co < 32; co += 4) {
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(a[ci], w1[ci * 32 + co + j], o[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = selu_(o[j]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc[k] = fmaf(o[j], ws0[(co + j) * 8 + k], sacc[k]);
+      }
+      *(float4*)(dst + co) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  // --- three bilinearly upsampled 32-channel maps
+  const float* maps[3] = {f2, f3, f4};
+  const int fac[3] = {2, 8, 32};
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int h = Hp / fac[m], w = Wp / fac[m];
+    const UpIdx uy = up_index(y, h, Hp), ux = up_index(x, w, Wp);
+    const float* base = maps[m] + (size_t)b * h * w * 32;
+    const float* p00 = base + ((size_t)uy.i0 * w + ux.i0) * 32;
+    const float* p01 = base + ((size_t)uy.i0 * w + ux.i1) * 32;
+    const float* p10 = base + ((size_t)uy.i1 * w + ux.i0) * 32;
+    const float* p11 = base + ((size_t)uy.i1 * w + ux.i1) * 32;
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+      const float4 a = *(const float4*)(p00 + c), bq = *(const float4*)(p01 + c), cq = *(const float4*)(p10 + c), d = *(const float4*)(p11 + c);
+      float o[4];
+      o[0] = uy.l0 * (ux.l0 * a.x + ux.l1 * bq.x) + uy.l1 * (ux.l0 * cq.x + ux.l1 * d.x);
+      o[1] = uy.l0 * (ux.l0 * a.y + ux.l1 * bq.y) + uy.l1 * (ux.l0 * cq.y + ux.l1 * d.y);
+      o[2] = uy.l0 * (ux.l0 * a.z + ux.l1 * bq.z) + uy.l1 * (ux.l0 * cq.z + ux.l1 * d.z);
+      o[3] = uy.l0 * (ux.l0 * a.w + ux.l1 * bq.w) + uy.l1 * (ux.l0 * cq.w + ux.l1 * d.w);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc[k] = fmaf(o[j], ws0[(32 * (m + 1) + c + j) * 8 + k], sacc[k]);
+      *(float4*)(dst + 32 * (m + 1) + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  float* sd = s8 + ((size_t)b * Hp * Wp + i) * 8;
+  *(float4*)sd = make_float4(selu_(sacc[0]), selu_(sacc[1]), selu_(sacc[2]), selu_(sacc[3]));
+  *(float4*)(sd + 4) = make_float4(selu_(sacc[4]), selu_(sacc[5]), selu_(sacc[6]), selu_(sacc[7]));
+}
+
+// ---------------------------------------------------------------------------
+// DKD soft-argmax refinement (ALN:176-216): one thread per keypoint.
+__global__ __launch_bounds__(256) void al_dkd_refine_kernel(const float* __restrict__ score, const float* __restrict__ kpts_px,
+                                                            const int* __restrict__ n_kpts, float* __restrict__ kpts_norm,
+                                                            float* __restrict__ disp, float* __restrict__ kscore,
+                                                            float* __restrict__ kpts_out, int H, int W, int capacity, int radius) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= n_kpts[b]) return;
+  const size_t k = (size_t)b * capacity + i;
+  const int x0 = (int)kpts_px[k * 2], y0 = (int)kpts_px[k * 2 + 1];
+  const float* sm = score + (size_t)b * H * W;
+  const int ks = 2 * radius + 1;
+  float mx = -INFINITY;
+  for (int dy = -radius; dy <= radius; ++dy)
+    for (int dx = -radius; dx <= radius; ++dx) {
+      const int yy = y0 + dy, xx = x0 + dx;
+      const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? sm[(size_t)yy * W + xx] : 0.f;  // nn.Unfold zero padding
+      mx = fmaxf(mx, v);
+    }
+  float se = 0.f, sx = 0.f, sy = 0.f;
+  for (int dy = -radius; dy <= radius; ++dy)
+    for (int dx = -radius; dx <= radius; ++dx) {
+      const int yy = y0 + dy, xx = x0 + dx;
+      const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? sm[(size_t)yy * W + xx] : 0.f;
+      const float e = expf((v - mx) / 0.1f);
+      se += e; sx += e * (float)dx; sy += e * (float)dy;
+    }
+  const float rx = sx / se, ry = sy / se;
+  float dsum = 0.f;
+  for (int dy = -radius; dy <= radius; ++dy)
+    for (int dx = -radius; dx <= radius; ++dx) {
+      const int yy = y0 + dy, xx = x0 + dx;
+      const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? sm[(size_t)yy * W + xx] : 0.f;
+      const float e = expf((v - mx) / 0.1f);
+      const float ux = ((float)dx - rx) / (float)radius, uy = ((float)dy - ry) / (float)radius;
+      const float nrm = sqrtf(ux * ux + uy * uy);
+      dsum += e * (nrm * nrm);
+    }
+  (void)ks;
+  const float wx = (float)(W - 1), wy = (float)(H - 1);
+  const float kx = ((float)x0 + rx) / wx * 2.f - 1.f, ky = ((float)y0 + ry) / wy * 2.f - 1.f;
+  kpts_norm[k * 2] = kx; kpts_norm[k * 2 + 1] = ky;
+  disp[k] = dsum / se;
+  // bilinear score at the refined position (grid_sample, align_corners=True, zeros padding)
+  const float ix = ((kx + 1.f) / 2.f) * wx, iy = ((ky + 1.f) / 2.f) * wy;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int xa = (int)fx, ya = (int)fy;
+  float val = 0.f;
+  const float wts[4] = {(fx + 1.f - ix) * (fy + 1.f - iy), (ix - fx) * (fy + 1.f - iy), (fx + 1.f - ix) * (iy - fy), (ix - fx) * (iy - fy)};
+  const int xs[4] = {xa, xa + 1, xa, xa + 1}, ys[4] = {ya, ya, ya + 1, ya + 1};
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (xs[c] >= 0 && xs[c] < W && ys[c] >= 0 && ys[c] < H) val += sm[(size_t)ys[c] * W + xs[c]] * wts[c];
+  kscore[k] = val;
+  // ALN:687: wh * (kpts + 1) / 2
+  kpts_out[k * 2] = wx * (kx + 1.f) / 2.f;
+  kpts_out[k * 2 + 1] = wy * (ky + 1.f) / 2.f;
+}
+
+// ---------------------------------------------------------------------------
+// SDDH (ALN:503-558).  The feature map is stored un-normalised (x1234, padded frame); every cell a
+// keypoint touches is L2-normalised on the fly (F.normalize over the 128 channels, ALN:669).
+// wave per (keypoint, patch cell): 3x3 patch of normalised features -> patches [kpt][9][128]
+__global__ __launch_bounds__(256) void al_sddh_patches_kernel(const float* __restrict__ x1234, const float* __restrict__ kpts_norm,
+                                                              const int* __restrict__ n_kpts, float* __restrict__ patches, int H,
+                                                              int W, int Hp, int Wp, int pad_t, int pad_l, int capacity) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int item = blockIdx.x * 4 + wv, b = blockIdx.y;
+  const int i = item / 9, cell = item % 9;
+  if (i >= n_kpts[b]) return;
+  const size_t k = (size_t)b * capacity + i;
+  const float kwx = (kpts_norm[k * 2] / 2.f + 0.5f) * (float)(W - 1), kwy = (kpts_norm[k * 2 + 1] / 2.f + 0.5f) * (float)(H - 1);
+  const int xl = (int)kwx, yl = (int)kwy;  // .long()
+  int cx = (int)((float)xl - 1.5f + 1.f), cy = (int)((float)yl - 1.5f + 1.f);  // (corner - ps/2 + 1).long(), truncation
+  cx = min(max(cx, 0), W - 1 - 3); cy = min(max(cy, 0), H - 1 - 3);
+  const int yy = cy + cell / 3, xx = cx + cell % 3;
+  const float* src = x1234 + (((size_t)b * Hp + yy + pad_t) * Wp + xx + pad_l) * 128;
+  const float2 v = *(const float2*)(src + lane * 2);
+  const float den = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);
+  // layout [kpt][ci][ky][kx] flattened as ci*9 + cell to match offset_conv.0.weight (32,128,3,3)
+  float* dst = patches + k * 1152;
+  dst[(lane * 2) * 9 + cell] = v.x / den;
+  dst[(lane * 2 + 1) * 9 + cell] = v.y / den;
+}
+// wave per keypoint: offsets = clamp(W2 * selu(hidden) + b2), then 16 bilinear samples of the
+// normalised feature map -> feats [kpt][16][128]
+__global__ __launch_bounds__(256) void al_sddh_sample_kernel(const float* __restrict__ x1234, const float* __restrict__ kpts_norm,
+                                                             const int* __restrict__ n_kpts, const float* __restrict__ hidden,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             float* __restrict__ feats, int H, int W, int Hp, int Wp, int pad_t,
+                                                             int pad_l, int capacity) {
+  __shared__ float offs[4][32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wv, b = blockIdx.y;
+  const bool live = i < n_kpts[b];
+  const size_t k = (size_t)b * capacity + (live ? i : 0);
+  const float max_off = (float)max(H, W) / 4.0f;
+  if (lane < 32) {  // offset_conv.2 (1x1, 32->32) on selu(hidden); w2 is [in][out]
+    float o = b2[lane];
+    for (int c = 0; c < 32; ++c) o = fmaf(selu_(hidden[k * 32 + c]), w2[c * 32 + lane], o);
+    offs[wv][lane] = fminf(fmaxf(o, -max_off), max_off);
+  }
+  __syncthreads();
+  if (!live) return;
+  const float wx = (float)(W - 1), wy = (float)(H - 1);
+  const float kwx = (kpts_norm[k * 2] / 2.f + 0.5f) * wx, kwy = (kpts_norm[k * 2 + 1] / 2.f + 0.5f) * wy;
+  for (int p = 0; p < 16; ++p) {
+    // offset[:, :, 0, 0].view(N, 2, M): channel p = x offset, channel M + p = y offset (ALN:540)
+    const float gx = 2.0f * (kwx + offs[wv][p]) / wx - 1.f, gy = 2.0f * (kwy + offs[wv][16 + p]) / wy - 1.f;
+    const float ix = ((gx + 1.f) / 2.f) * wx, iy = ((gy + 1.f) / 2.f) * wy;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int xa = (int)fx, ya = (int)fy;
+    const float wts[4] = {(fx + 1.f - ix) * (fy + 1.f - iy), (ix - fx) * (fy + 1.f - iy), (fx + 1.f - ix) * (iy - fy), (ix - fx) * (iy - fy)};
+    const int xs[4] = {xa, xa + 1, xa, xa + 1}, ys[4] = {ya, ya, ya + 1, ya + 1};
+    float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool in = xs[c] >= 0 && xs[c] < W && ys[c] >= 0 && ys[c] < H;  // wave-uniform
+      float2 v = make_float2(0.f, 0.f);
+      if (in) v = *(const float2*)(x1234 + (((size_t)b * Hp + ys[c] + pad_t) * Wp + xs[c] + pad_l) * 128 + lane * 2);
+      const float den = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);
+      if (in) { o0 += (v.x / den) * wts[c]; o1 += (v.y / den) * wts[c]; }
+    }
+    *(float2*)(feats + (k * 16 + p) * 128 + lane * 2) = make_float2(o0, o1);
+  }
+}
+// L2-normalise rows of [batch][capacity][C] (C = 128: two values per lane), wave per row
+__global__ __launch_bounds__(256) void al_normalize_rows_kernel(float* __restrict__ x, const int* __restrict__ n_rows, int capacity, int C) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (i >= n_rows[b]) return;
+  float* p = x + ((size_t)b * capacity + i) * C;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) ss += p[c] * p[c];
+  const float den = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+  for (int c = lane; c < C; c += 64) p[c] = p[c] / den;
+}
+
+// mean of a [batch][n] map (fp64 two-stage), for DKD's fallback threshold (ALN:165-168)
+__global__ __launch_bounds__(256) void al_mean_partial_kernel(const float* __restrict__ x, int n, double* __restrict__ partial) {
+  __shared__ double red[256];
+  const int b = blockIdx.y, t = threadIdx.x;
+  double s = 0.0;
+  for (int i = blockIdx.x * 256 + t; i < n; i += BN_BLOCKS * 256) s += (double)x[(size_t)b * n + i];
+  red[t] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  if (t == 0) partial[b * BN_BLOCKS + blockIdx.x] = red[0];
+}
+__global__ void al_mean_final_kernel(const double* __restrict__ partial, int n, float* __restrict__ mean) {
+  const int b = threadIdx.x;
+  double s = 0.0;
+  for (int k = 0; k < BN_BLOCKS; ++k) s += partial[b * BN_BLOCKS + k];
+  mean[b] = (float)(s / n);
+}
+__global__ void al_pick_threshold_kernel(const int* __restrict__ ncand, const float* __restrict__ mean, float thr, float* __restrict__ out) {
+  const int b = threadIdx.x;
+  out[b] = (thr > 0.f && ncand[b] > 0) ? thr : mean[b];  // ALN:163-168 (per image: DIM runs batch 1)
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+int launch_al_conv3x3(const float* in, int cin, const float* w, const float* bias, float* out, int cout, int batch, int H,
+                      int W, int act, int crop_y, int crop_x, int out_h, int out_w, hipStream_t s) {
+  const int tx = cdiv(W, 16), ty = cdiv(H, 16);
+  dim3 grid(tx * ty, 1, batch);
+#define AL_C3(CC, CIP, CO) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_conv3x3_kernel<CC, CO>), grid, dim3(256), 0, s, in, cin, CIP, w, bias, out, cout, H, W, act, tx, crop_y, crop_x, out_h, out_w)
+  if (cin == 3 && cout == 16) AL_C3(4, 4, 16);
+  else if (cin == 16 && cout == 16) AL_C3(16, 16, 16);
+  else if (cin == 16 && cout == 32) AL_C3(16, 16, 32);
+  else if (cin == 32 && cout == 32) AL_C3(32, 32, 32);
+  else if (cin == 32 && cout == 18) AL_C3(32, 32, 20);
+  else if (cin == 64 && cout == 18) AL_C3(32, 64, 20);
+  else if (cin == 128 && cout == 18) AL_C3(32, 128, 20);
+  else if (cin == 8 && cout == 4) AL_C3(8, 8, 4);
+  else if (cin == 4 && cout == 4) AL_C3(4, 4, 4);
+  else if (cin == 4 && cout == 1) AL_C3(4, 4, 4);
+  else { dim_set_error("aliked conv3x3: unsupported channels %d -> %d", cin, cout); return -2; }
+#undef AL_C3
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_conv1x1(const float* in, int cin, const float* w, const float* bias, float* out, int cout, int n_pixels, int act,
+                      hipStream_t s) {
+  dim3 grid(cdiv(n_pixels, 256));
+#define AL_C1(CI, CO) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_conv1x1_kernel<CI, CO>), grid, dim3(256), 0, s, in, w, bias, out, n_pixels, act)
+  if (cin == 16 && cout == 32) AL_C1(16, 32);
+  else if (cin == 32 && cout == 32) AL_C1(32, 32);
+  else if (cin == 32 && cout == 64) AL_C1(32, 64);
+  else if (cin == 64 && cout == 32) AL_C1(64, 32);
+  else if (cin == 64 && cout == 128) AL_C1(64, 128);
+  else if (cin == 128 && cout == 32) AL_C1(128, 32);
+  else { dim_set_error("aliked conv1x1: unsupported channels %d -> %d", cin, cout); return -2; }
+#undef AL_C1
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_pad_replicate(const float* img, float* out, int batch, int H, int W, int Hp, int Wp, int pad_t, int pad_l, int in_ch,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(al_pad_kernel, dim3(cdiv(Hp * Wp, 256), batch), dim3(256), 0, s, img, out, H, W, Hp, Wp, pad_t, pad_l, in_ch);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_avgpool(const float* in, float* out, int batch, int H, int W, int C, int k, hipStream_t s) {
+  hipLaunchKernelGGL(al_avgpool_kernel, dim3(cdiv((H / k) * (W / k) * (C / 4), 256), batch), dim3(256), 0, s, in, out, H, W, C, k);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_bn_stats(const float* x, int batch, int n_pixels, int C, const float* gamma, const float* beta_w, double* partial,
+                       float* alpha, float* beta, hipStream_t s) {
+  DIM_REQUIRE(C == 16 || C == 32 || C == 64 || C == 128, "aliked bn: C=%d unsupported", C);
+  hipLaunchKernelGGL(al_bn_partial_kernel, dim3(BN_BLOCKS, batch), dim3(256), 0, s, x, n_pixels, C, partial);
+  hipLaunchKernelGGL(al_bn_final_kernel, dim3(batch), dim3(128), 0, s, (const double*)partial, n_pixels, C, gamma, beta_w, alpha, beta);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_bn_apply(const float* x, const float* alpha, const float* beta, const float* residual, float* out, int batch,
+                       int n_pixels, int C, hipStream_t s) {
+  hipLaunchKernelGGL(al_bn_apply_kernel, dim3(cdiv(n_pixels * (C / 4), 256), batch), dim3(256), 0, s, x, alpha, beta, residual, out, n_pixels, C);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, float* out, int cout, int batch,
+                          int H, int W, hipStream_t s) {
+  DIM_REQUIRE(cout % 32 == 0, "aliked deform conv: cout %d", cout);
+  dim3 grid(cdiv(H * W * (cout / 32), 256), batch);
+  if (cin == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_conv_kernel<32>), grid, dim3(256), 0, s, in, offsets, off_c, w, out, cout, H, W);
+  else if (cin == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_conv_kernel<64>), grid, dim3(256), 0, s, in, offsets, off_c, w, out, cout, H, W);
+  else if (cin == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_conv_kernel<128>), grid, dim3(256), 0, s, in, offsets, off_c, w, out, cout, H, W);
+  else { dim_set_error("aliked deform conv: cin %d unsupported", cin); return -2; }
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_clamp(float* x, size_t n, float lim, hipStream_t s) {
+  hipLaunchKernelGGL(al_clamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, lim);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_assemble(const float* x1, const float* f2, const float* f3, const float* f4, const float* w1, const float* ws0,
+                       float* x1234, float* s8, int batch, int Hp, int Wp, hipStream_t s) {
+  hipLaunchKernelGGL(al_assemble_kernel, dim3(cdiv(Hp * Wp, 256), batch), dim3(256), 0, s, x1, f2, f3, f4, w1, ws0, x1234, s8, Hp, Wp);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_dkd_refine(const float* score, const float* kpts_px, const int* n_kpts, float* kpts_norm, float* disp, float* kscore,
+                         float* kpts_out, int batch, int H, int W, int capacity, int radius, hipStream_t s) {
+  hipLaunchKernelGGL(al_dkd_refine_kernel, dim3(cdiv(capacity, 256), batch), dim3(256), 0, s, score, kpts_px, n_kpts, kpts_norm, disp, kscore, kpts_out, H, W, capacity, radius);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_sddh_patches(const float* x1234, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H, int W,
+                           int Hp, int Wp, int pad_t, int pad_l, int capacity, hipStream_t s) {
+  hipLaunchKernelGGL(al_sddh_patches_kernel, dim3(cdiv(capacity * 9, 4), batch), dim3(256), 0, s, x1234, kpts_norm, n_kpts, patches, H, W, Hp, Wp, pad_t, pad_l, capacity);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_sddh_sample(const float* x1234, const float* kpts_norm, const int* n_kpts, const float* off_hidden, const float* w2,
+                          const float* b2, float* feats, int batch, int H, int W, int Hp, int Wp, int pad_t, int pad_l, int capacity,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(al_sddh_sample_kernel, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, x1234, kpts_norm, n_kpts, off_hidden, w2, b2, feats, H, W, Hp, Wp, pad_t, pad_l, capacity);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_normalize_rows(float* x, const int* n_rows, int batch, int capacity, int C, hipStream_t s) {
+  hipLaunchKernelGGL(al_normalize_rows_kernel, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, x, n_rows, capacity, C);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_mean(const float* x, int batch, int n, double* partial, float* mean, hipStream_t s) {
+  hipLaunchKernelGGL(al_mean_partial_kernel, dim3(BN_BLOCKS, batch), dim3(256), 0, s, x, n, partial);
+  hipLaunchKernelGGL(al_mean_final_kernel, dim3(1), dim3(batch), 0, s, (const double*)partial, n, mean);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_pick_threshold(const int* ncand, const float* mean, float thr, float* thr_out, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(al_pick_threshold_kernel, dim3(1), dim3(batch), 0, s, ncand, mean, thr, thr_out);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,249 @@
+// dim_aliked_* : resident ALIKED extractor (C ABI in include/dim_hip.h).
+// Replaces ALIKED.__init__/forward (ALN:561-693) as driven by AlikedExtractor._extract
+// (extractors/aliked.py:45-64), quirks Q7 (train-mode BatchNorm) and Q8 (scores = dispersity) included.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/dim_hip.h"
+#include "aliked_kernels.h"
+#include "sp_kernels.h"
+
+struct dim_aliked {
+  dim_aliked_config cfg;
+  int max_batch, max_h, max_w, capacity;
+  // weights (device, kernel layouts)
+  float *b1c1, *b1c2, *b2c1, *b2c2, *b2ds_w, *b2ds_b;
+  float *b3o1_w, *b3o1_b, *b3r1, *b3o2_w, *b3o2_b, *b3r2, *b3ds_w, *b3ds_b;
+  float *b4o1_w, *b4o1_b, *b4r1, *b4o2_w, *b4o2_b, *b4r2, *b4ds_w, *b4ds_b;
+  float *bn_g[8], *bn_b[8];
+  float *hc1, *hc2, *hc3, *hc4, *sh0, *sh2, *sh4, *sh6;
+  float *dh_o0_w, *dh_o0_b, *dh_o2_w, *dh_o2_b, *dh_sf, *dh_agg;
+  // activations
+  float *P, *raw, *act, *x1, *p2, *idn, *x2, *p3, *off, *x3, *p4, *x4, *f2, *f3, *f4, *x1234, *s8, *s4a, *s4b, *score, *nms;
+  float *cand_score, *kpts_px, *sc_tmp, *kpts_norm, *kscore, *patches, *hidden, *feats, *feats2, *bn_alpha, *bn_beta, *mean, *thr_eff;
+  double* partial;
+  int *cand_idx, *rowcount, *rowoff, *ncand;
+  int last_hp, last_wp, last_h, last_w;
+  std::vector<void*> allocs;
+};
+
+namespace {
+template <typename T>
+int dev_alloc(dim_aliked* h, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+  if (e != hipSuccess) {
+    dim_set_error("hipMalloc of %zu bytes failed: out of memory (%s)", count * sizeof(T), hipGetErrorString(e));
+    return -1;
+  }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+int upload(dim_aliked* h, float** dst, const std::vector<float>& v) {
+  if (dev_alloc(h, dst, v.size()) != 0) return -1;
+  if (hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    dim_set_error("weight upload failed");
+    return -1;
+  }
+  return 0;
+}
+// OIHW -> [tap][cin_pad][cout_pad] (zero padded)
+std::vector<float> relayout(const float* w, int co, int ci, int k, int ci_pad, int co_pad) {
+  std::vector<float> o((size_t)k * k * ci_pad * co_pad, 0.0f);
+  for (int a = 0; a < co; ++a)
+    for (int b = 0; b < ci; ++b)
+      for (int t = 0; t < k * k; ++t) o[((size_t)t * ci_pad + b) * co_pad + a] = w[((size_t)a * ci + b) * k * k + t];
+  return o;
+}
+std::vector<float> padvec(const float* b, int n, int n_pad) {
+  std::vector<float> v(n_pad, 0.0f);
+  for (int i = 0; i < n; ++i) v[i] = b[i];
+  return v;
+}
+}  // namespace
+
+extern "C" {
+
+void dim_aliked_destroy(dim_aliked* h) {
+  if (!h) return;
+  for (void* p : h->allocs) hipFree(p);
+  delete h;
+}
+
+int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg, int max_batch, int max_h, int max_w,
+                      int capacity, dim_aliked** out) {
+  DIM_REQUIRE(w && cfg && out, "dim_aliked_create: null argument");
+  DIM_REQUIRE(cfg->c1 == 16 && cfg->c2 == 32 && cfg->c3 == 64 && cfg->c4 == 128 && cfg->dim == 128 && cfg->K == 3 && cfg->M == 16,
+              "dim_aliked_create: only the aliked-n16 / aliked-n16rot geometry (16,32,64,128,128,3,16) is built in this round");
+  DIM_REQUIRE(cfg->detection_threshold > 0, "dim_aliked_create: detection_threshold must be > 0 (top-k-only mode not built)");
+  DIM_REQUIRE(cfg->nms_radius >= 1 && cfg->nms_radius <= 6, "dim_aliked_create: nms_radius %d", cfg->nms_radius);
+  DIM_REQUIRE(capacity > 0 && capacity <= 4096 && cfg->max_num_keypoints <= capacity, "dim_aliked_create: capacity %d (<= 4096) must cover max_num_keypoints %d", capacity, cfg->max_num_keypoints);
+  DIM_REQUIRE(max_batch > 0 && max_batch <= 64 && max_h >= 16 && max_w >= 16, "dim_aliked_create: bad sizes");
+  dim_aliked* h = new dim_aliked();
+  h->cfg = *cfg;
+  h->max_batch = max_batch; h->max_h = max_h; h->max_w = max_w; h->capacity = capacity;
+#define AL_TRY(x) do { if ((x) != 0) { dim_aliked_destroy(h); return -1; } } while (0)
+  AL_TRY(upload(h, &h->b1c1, relayout(w->block1_conv1, 16, 3, 3, 4, 16)));
+  AL_TRY(upload(h, &h->b1c2, relayout(w->block1_conv2, 16, 16, 3, 16, 16)));
+  AL_TRY(upload(h, &h->b2c1, relayout(w->block2_conv1, 32, 16, 3, 16, 32)));
+  AL_TRY(upload(h, &h->b2c2, relayout(w->block2_conv2, 32, 32, 3, 32, 32)));
+  AL_TRY(upload(h, &h->b2ds_w, relayout(w->block2_ds_w, 32, 16, 1, 16, 32))); AL_TRY(upload(h, &h->b2ds_b, padvec(w->block2_ds_b, 32, 32)));
+  AL_TRY(upload(h, &h->b3o1_w, relayout(w->block3_off1_w, 18, 32, 3, 32, 20))); AL_TRY(upload(h, &h->b3o1_b, padvec(w->block3_off1_b, 18, 20)));
+  AL_TRY(upload(h, &h->b3r1, relayout(w->block3_reg1, 64, 32, 3, 32, 64)));
+  AL_TRY(upload(h, &h->b3o2_w, relayout(w->block3_off2_w, 18, 64, 3, 64, 20))); AL_TRY(upload(h, &h->b3o2_b, padvec(w->block3_off2_b, 18, 20)));
+  AL_TRY(upload(h, &h->b3r2, relayout(w->block3_reg2, 64, 64, 3, 64, 64)));
+  AL_TRY(upload(h, &h->b3ds_w, relayout(w->block3_ds_w, 64, 32, 1, 32, 64))); AL_TRY(upload(h, &h->b3ds_b, padvec(w->block3_ds_b, 64, 64)));
+  AL_TRY(upload(h, &h->b4o1_w, relayout(w->block4_off1_w, 18, 64, 3, 64, 20))); AL_TRY(upload(h, &h->b4o1_b, padvec(w->block4_off1_b, 18, 20)));
+  AL_TRY(upload(h, &h->b4r1, relayout(w->block4_reg1, 128, 64, 3, 64, 128)));
+  AL_TRY(upload(h, &h->b4o2_w, relayout(w->block4_off2_w, 18, 128, 3, 128, 20))); AL_TRY(upload(h, &h->b4o2_b, padvec(w->block4_off2_b, 18, 20)));
+  AL_TRY(upload(h, &h->b4r2, relayout(w->block4_reg2, 128, 128, 3, 128, 128)));
+  AL_TRY(upload(h, &h->b4ds_w, relayout(w->block4_ds_w, 128, 64, 1, 64, 128))); AL_TRY(upload(h, &h->b4ds_b, padvec(w->block4_ds_b, 128, 128)));
+  const int bnc[8] = {16, 16, 32, 32, 64, 64, 128, 128};
+  for (int i = 0; i < 8; ++i) {
+    AL_TRY(upload(h, &h->bn_g[i], padvec(w->bn_weight[i], bnc[i], bnc[i])));
+    AL_TRY(upload(h, &h->bn_b[i], padvec(w->bn_bias[i], bnc[i], bnc[i])));
+  }
+  AL_TRY(upload(h, &h->hc1, relayout(w->conv1, 32, 16, 1, 16, 32))); AL_TRY(upload(h, &h->hc2, relayout(w->conv2, 32, 32, 1, 32, 32)));
+  AL_TRY(upload(h, &h->hc3, relayout(w->conv3, 32, 64, 1, 64, 32))); AL_TRY(upload(h, &h->hc4, relayout(w->conv4, 32, 128, 1, 128, 32)));
+  AL_TRY(upload(h, &h->sh0, relayout(w->score0, 8, 128, 1, 128, 8))); AL_TRY(upload(h, &h->sh2, relayout(w->score2, 4, 8, 3, 8, 4)));
+  AL_TRY(upload(h, &h->sh4, relayout(w->score4, 4, 4, 3, 4, 4))); AL_TRY(upload(h, &h->sh6, relayout(w->score6, 1, 4, 3, 4, 4)));
+  {  // SDDH: offset_conv.0 (32,128,3,3) -> GEMM operand [ci*9+tap][32]; offset_conv.2 (32,32,1,1) -> [in][out]
+    std::vector<float> o0((size_t)1152 * 32);
+    for (int co = 0; co < 32; ++co)
+      for (int k = 0; k < 1152; ++k) o0[(size_t)k * 32 + co] = w->desc_off0_w[(size_t)co * 1152 + k];
+    AL_TRY(upload(h, &h->dh_o0_w, o0)); AL_TRY(upload(h, &h->dh_o0_b, padvec(w->desc_off0_b, 32, 32)));
+    AL_TRY(upload(h, &h->dh_o2_w, relayout(w->desc_off2_w, 32, 32, 1, 32, 32))); AL_TRY(upload(h, &h->dh_o2_b, padvec(w->desc_off2_b, 32, 32)));
+    AL_TRY(upload(h, &h->dh_sf, relayout(w->desc_sf, 128, 128, 1, 128, 128)));
+    AL_TRY(upload(h, &h->dh_agg, padvec(w->desc_agg, 16 * 128 * 128, 16 * 128 * 128)));  // [p][c][d] == GEMM operand [p*128+c][d]
+  }
+  const size_t B = max_batch;
+  const size_t Hp = ((size_t)max_h + 31) / 32 * 32, Wp = ((size_t)max_w + 31) / 32 * 32, NP = Hp * Wp, cap = capacity;
+  AL_TRY(dev_alloc(h, &h->P, B * NP * 3)); AL_TRY(dev_alloc(h, &h->raw, B * NP * 16)); AL_TRY(dev_alloc(h, &h->act, B * NP * 16));
+  AL_TRY(dev_alloc(h, &h->x1, B * NP * 16)); AL_TRY(dev_alloc(h, &h->p2, B * NP / 4 * 16)); AL_TRY(dev_alloc(h, &h->idn, B * NP / 4 * 32));
+  AL_TRY(dev_alloc(h, &h->x2, B * NP / 4 * 32)); AL_TRY(dev_alloc(h, &h->p3, B * NP / 64 * 32)); AL_TRY(dev_alloc(h, &h->off, B * NP / 64 * 20));
+  AL_TRY(dev_alloc(h, &h->x3, B * NP / 64 * 64)); AL_TRY(dev_alloc(h, &h->p4, B * NP / 1024 * 64)); AL_TRY(dev_alloc(h, &h->x4, B * NP / 1024 * 128));
+  AL_TRY(dev_alloc(h, &h->f2, B * NP / 4 * 32)); AL_TRY(dev_alloc(h, &h->f3, B * NP / 64 * 32)); AL_TRY(dev_alloc(h, &h->f4, B * NP / 1024 * 32));
+  AL_TRY(dev_alloc(h, &h->x1234, B * NP * 128)); AL_TRY(dev_alloc(h, &h->s8, B * NP * 8)); AL_TRY(dev_alloc(h, &h->s4a, B * NP * 4));
+  AL_TRY(dev_alloc(h, &h->s4b, B * NP * 4)); AL_TRY(dev_alloc(h, &h->score, B * NP)); AL_TRY(dev_alloc(h, &h->nms, B * NP));
+  AL_TRY(dev_alloc(h, &h->cand_score, B * NP)); AL_TRY(dev_alloc(h, &h->cand_idx, B * NP)); AL_TRY(dev_alloc(h, &h->rowcount, B * Hp));
+  AL_TRY(dev_alloc(h, &h->rowoff, B * Hp)); AL_TRY(dev_alloc(h, &h->ncand, B)); AL_TRY(dev_alloc(h, &h->kpts_px, B * cap * 2));
+  AL_TRY(dev_alloc(h, &h->sc_tmp, B * cap)); AL_TRY(dev_alloc(h, &h->kpts_norm, B * cap * 2)); AL_TRY(dev_alloc(h, &h->kscore, B * cap));
+  AL_TRY(dev_alloc(h, &h->patches, B * cap * 1152)); AL_TRY(dev_alloc(h, &h->hidden, B * cap * 32)); AL_TRY(dev_alloc(h, &h->feats, B * cap * 2048));
+  AL_TRY(dev_alloc(h, &h->feats2, B * cap * 2048)); AL_TRY(dev_alloc(h, &h->bn_alpha, B * 128)); AL_TRY(dev_alloc(h, &h->bn_beta, B * 128));
+  AL_TRY(dev_alloc(h, &h->mean, B)); AL_TRY(dev_alloc(h, &h->thr_eff, B)); AL_TRY(dev_alloc(h, &h->partial, B * 64 * 128 * 2));
+#undef AL_TRY
+  *out = h;
+  return 0;
+}
+
+int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H, int W, int in_channels, float* kpts_xy_dev,
+                       float* scores_dev, float* desc_dev, int32_t* n_kpts_dev, void* stream) {
+  DIM_REQUIRE(h && images_dev && kpts_xy_dev && scores_dev && desc_dev && n_kpts_dev, "dim_aliked_extract: null argument");
+  DIM_REQUIRE(batch >= 1 && batch <= h->max_batch, "dim_aliked_extract: batch %d outside [1,%d]", batch, h->max_batch);
+  DIM_REQUIRE(in_channels == 1 || in_channels == 3, "dim_aliked_extract: in_channels %d (1 or 3)", in_channels);
+  DIM_REQUIRE(H >= 16 && W >= 16 && H <= h->max_h && W <= h->max_w, "dim_aliked_extract: image %dx%d outside the handle's %dx%d", H, W, h->max_h, h->max_w);
+  hipStream_t s = (hipStream_t)stream;
+  // InputPadder(div 32) (ALN:247-271,646-648)
+  const int ph = (((H / 32) + 1) * 32 - H) % 32, pw = (((W / 32) + 1) * 32 - W) % 32;
+  const int pad_t = ph / 2, pad_l = pw / 2, Hp = H + ph, Wp = W + pw;
+  const int H2 = Hp / 2, W2 = Wp / 2, H8 = Hp / 8, W8 = Wp / 8, H32 = Hp / 32, W32 = Wp / 32;
+  const int NP = Hp * Wp, r = h->cfg.nms_radius, cap = h->capacity;
+#define AL_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
+  auto bn = [&](const float* x, int npx, int C, int i, const float* res, float* dst) -> int {
+    int rc = launch_al_bn_stats(x, batch, npx, C, h->bn_g[i], h->bn_b[i], h->partial, h->bn_alpha, h->bn_beta, s);
+    if (rc) return rc;
+    return launch_al_bn_apply(x, h->bn_alpha, h->bn_beta, res, dst, batch, npx, C, s);
+  };
+  AL_RUN(launch_al_pad_replicate(images_dev, h->P, batch, H, W, Hp, Wp, pad_t, pad_l, in_channels, s));
+  // block1 (ConvBlock, ALN:367-393)
+  AL_RUN(launch_al_conv3x3(h->P, 3, h->b1c1, nullptr, h->raw, 16, batch, Hp, Wp, AL_ACT_NONE, 0, 0, Hp, Wp, s));
+  AL_RUN(bn(h->raw, NP, 16, 0, nullptr, h->act));
+  AL_RUN(launch_al_conv3x3(h->act, 16, h->b1c2, nullptr, h->raw, 16, batch, Hp, Wp, AL_ACT_NONE, 0, 0, Hp, Wp, s));
+  AL_RUN(bn(h->raw, NP, 16, 1, nullptr, h->x1));
+  // block2 (ResBlock, plain convs)
+  AL_RUN(launch_al_avgpool(h->x1, h->p2, batch, Hp, Wp, 16, 2, s));
+  AL_RUN(launch_al_conv3x3(h->p2, 16, h->b2c1, nullptr, h->raw, 32, batch, H2, W2, AL_ACT_NONE, 0, 0, H2, W2, s));
+  AL_RUN(bn(h->raw, H2 * W2, 32, 2, nullptr, h->act));
+  AL_RUN(launch_al_conv3x3(h->act, 32, h->b2c2, nullptr, h->raw, 32, batch, H2, W2, AL_ACT_NONE, 0, 0, H2, W2, s));
+  AL_RUN(launch_al_conv1x1(h->p2, 16, h->b2ds_w, h->b2ds_b, h->idn, 32, batch * H2 * W2, AL_ACT_NONE, s));
+  AL_RUN(bn(h->raw, H2 * W2, 32, 3, h->idn, h->x2));
+  // block3 / block4 (ResBlock with DeformableConv2d, ALN:274-330)
+  auto dcn_block = [&](const float* x, int Hh, int Ww, int ci, int co, const float* o1w, const float* o1b, const float* r1,
+                       const float* o2w, const float* o2b, const float* r2, const float* dsw, const float* dsb, int bni, float* dst) -> int {
+    const float lim = (float)(Hh > Ww ? Hh : Ww) / 4.0f;
+    int rc;
+    if ((rc = launch_al_conv3x3(x, ci, o1w, o1b, h->off, 18, batch, Hh, Ww, AL_ACT_NONE, 0, 0, Hh, Ww, s))) return rc;
+    if ((rc = launch_al_clamp(h->off, (size_t)batch * Hh * Ww * 18, lim, s))) return rc;
+    if ((rc = launch_al_deform_conv(x, ci, h->off, 18, r1, h->raw, co, batch, Hh, Ww, s))) return rc;
+    if ((rc = bn(h->raw, Hh * Ww, co, bni, nullptr, h->act))) return rc;
+    if ((rc = launch_al_conv3x3(h->act, co, o2w, o2b, h->off, 18, batch, Hh, Ww, AL_ACT_NONE, 0, 0, Hh, Ww, s))) return rc;
+    if ((rc = launch_al_clamp(h->off, (size_t)batch * Hh * Ww * 18, lim, s))) return rc;
+    if ((rc = launch_al_deform_conv(h->act, co, h->off, 18, r2, h->raw, co, batch, Hh, Ww, s))) return rc;
+    if ((rc = launch_al_conv1x1(x, ci, dsw, dsb, h->idn, co, batch * Hh * Ww, AL_ACT_NONE, s))) return rc;
+    return bn(h->raw, Hh * Ww, co, bni + 1, h->idn, dst);
+  };
+  AL_RUN(launch_al_avgpool(h->x2, h->p3, batch, H2, W2, 32, 4, s));
+  AL_RUN(dcn_block(h->p3, H8, W8, 32, 64, h->b3o1_w, h->b3o1_b, h->b3r1, h->b3o2_w, h->b3o2_b, h->b3r2, h->b3ds_w, h->b3ds_b, 4, h->x3));
+  AL_RUN(launch_al_avgpool(h->x3, h->p4, batch, H8, W8, 64, 4, s));
+  AL_RUN(dcn_block(h->p4, H32, W32, 64, 128, h->b4o1_w, h->b4o1_b, h->b4r1, h->b4o2_w, h->b4o2_b, h->b4r2, h->b4ds_w, h->b4ds_b, 6, h->x4));
+  // feature aggregation + score head (ALN:656-669)
+  AL_RUN(launch_al_conv1x1(h->x2, 32, h->hc2, nullptr, h->f2, 32, batch * H2 * W2, AL_ACT_SELU, s));
+  AL_RUN(launch_al_conv1x1(h->x3, 64, h->hc3, nullptr, h->f3, 32, batch * H8 * W8, AL_ACT_SELU, s));
+  AL_RUN(launch_al_conv1x1(h->x4, 128, h->hc4, nullptr, h->f4, 32, batch * H32 * W32, AL_ACT_SELU, s));
+  AL_RUN(launch_al_assemble(h->x1, h->f2, h->f3, h->f4, h->hc1, h->sh0, h->x1234, h->s8, batch, Hp, Wp, s));
+  AL_RUN(launch_al_conv3x3(h->s8, 8, h->sh2, nullptr, h->s4a, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));
+  AL_RUN(launch_al_conv3x3(h->s4a, 4, h->sh4, nullptr, h->s4b, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));
+  AL_RUN(launch_al_conv3x3(h->s4b, 4, h->sh6, nullptr, h->score, 1, batch, Hp, Wp, AL_ACT_SIGMOID, pad_t, pad_l, H, W, s));  // unpad (ALN:672-673)
+  // DKD (ALN:123-244): NMS, border, threshold (mean fallback), n_limit, soft-argmax refinement
+  AL_RUN(launch_nms(h->score, h->nms, batch, H, W, r, s));
+  AL_RUN(launch_al_mean(h->score, batch, H * W, h->partial, h->mean, s));
+  AL_RUN(launch_select_ex(h->nms, batch, H, W, (float)h->cfg.detection_threshold, nullptr, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 1, s));
+  AL_RUN(launch_al_pick_threshold(h->ncand, h->mean, (float)h->cfg.detection_threshold, h->thr_eff, batch, s));
+  AL_RUN(launch_select_ex(h->nms, batch, H, W, 0.f, h->thr_eff, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 0, s));
+  const int n_limit = h->cfg.max_num_keypoints > 0 ? h->cfg.max_num_keypoints : cap;
+  AL_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H, W, n_limit, cap, h->kpts_px, h->sc_tmp, n_kpts_dev, s));
+  // Q8: DIM's "scores" are the dispersities (ALN:682 unpacks DKD's return in the wrong order)
+  AL_RUN(launch_al_dkd_refine(h->score, h->kpts_px, n_kpts_dev, h->kpts_norm, scores_dev, h->kscore, kpts_xy_dev, batch, H, W, cap, r, s));
+  // SDDH (ALN:503-558)
+  AL_RUN(launch_al_sddh_patches(h->x1234, h->kpts_norm, n_kpts_dev, h->patches, batch, H, W, Hp, Wp, pad_t, pad_l, cap, s));
+  {
+    GemmArgs g;
+    g.A0 = h->patches; g.lda0 = 1152; g.strideA0 = (long long)cap * 1152; g.B = h->dh_o0_w; g.ldb = 32; g.bias = h->dh_o0_b;
+    g.C = h->hidden; g.ldc = 32; g.strideC = (long long)cap * 32; g.M = cap; g.N = 32; g.K = 1152; g.rows = n_kpts_dev;
+    AL_RUN(launch_gemm(g, batch, s));
+  }
+  AL_RUN(launch_al_sddh_sample(h->x1234, h->kpts_norm, n_kpts_dev, h->hidden, h->dh_o2_w, h->dh_o2_b, h->feats, batch, H, W, Hp, Wp, pad_t, pad_l, cap, s));
+  {
+    GemmArgs g;  // sf_conv 1x1 (128 -> 128) + SELU over the 16 sampled positions of every keypoint
+    g.A0 = h->feats; g.lda0 = 128; g.strideA0 = (long long)cap * 2048; g.B = h->dh_sf; g.ldb = 128;
+    g.C = h->feats2; g.ldc = 128; g.strideC = (long long)cap * 2048; g.M = cap * 16; g.N = 128; g.K = 128;
+    g.rows = n_kpts_dev; g.rows_scale = 16; g.relu = 2;
+    AL_RUN(launch_gemm(g, batch, s));
+  }
+  {
+    GemmArgs g;  // einsum("ncp,pcd->nd") with agg_weights [p][c][d] == [n][p*128+c] x [p*128+c][d]
+    g.A0 = h->feats2; g.lda0 = 2048; g.strideA0 = (long long)cap * 2048; g.B = h->dh_agg; g.ldb = 128;
+    g.C = desc_dev; g.ldc = 128; g.strideC = (long long)cap * 128; g.M = cap; g.N = 128; g.K = 2048; g.rows = n_kpts_dev;
+    AL_RUN(launch_gemm(g, batch, s));
+  }
+  AL_RUN(launch_al_normalize_rows(desc_dev, n_kpts_dev, batch, cap, 128, s));
+#undef AL_RUN
+  h->last_hp = Hp; h->last_wp = Wp; h->last_h = H; h->last_w = W;
+  return 0;
+}
+
+int dim_aliked_debug_buffers(dim_aliked* h, const float** x1234, const float** score_map, int* hp, int* wp, int* pad_t, int* pad_l) {
+  DIM_REQUIRE(h, "dim_aliked_debug_buffers: null handle");
+  if (x1234) *x1234 = h->x1234;
+  if (score_map) *score_map = h->score;
+  if (hp) *hp = h->last_hp;
+  if (wp) *wp = h->last_wp;
+  if (pad_t) *pad_t = (h->last_hp - h->last_h) / 2;
+  if (pad_l) *pad_l = (h->last_wp - h->last_w) / 2;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+// Launchers of the ALIKED kernels (aliked.hip).  All tensors NHWC fp32.
+#pragma once
+#include "dim_kernels.h"
+
+enum { AL_ACT_NONE = 0, AL_ACT_SELU = 1, AL_ACT_SIGMOID = 2 };
+
+// out[b][y][x][co] = act( sum in[b][y+dy][x+dx][ci] * w[tap][ci][co] + bias ), zero padding, over an H x W map;
+// only the window [crop_y, crop_y+out_h) x [crop_x, crop_x+out_w) is stored (out is [b][out_h][out_w][out_c]).
+int launch_al_conv3x3(const float* in, int cin, const float* w, const float* bias, float* out, int cout, int batch, int H,
+                      int W, int act, int crop_y, int crop_x, int out_h, int out_w, hipStream_t s);
+int launch_al_conv1x1(const float* in, int cin, const float* w, const float* bias, float* out, int cout, int n_pixels,
+                      int act, hipStream_t s);
+int launch_al_pad_replicate(const float* img, float* out, int batch, int H, int W, int Hp, int Wp, int pad_t, int pad_l,
+                            int in_ch, hipStream_t s);
+int launch_al_avgpool(const float* in, float* out, int batch, int H, int W, int C, int k, hipStream_t s);
+// BatchNorm in TRAINING mode (Q7), statistics per image: stats -> (alpha, beta) with y = x*alpha + beta
+int launch_al_bn_stats(const float* x, int batch, int n_pixels, int C, const float* gamma, const float* beta_w,
+                       double* partial, float* alpha, float* beta, hipStream_t s);
+int launch_al_bn_apply(const float* x, const float* alpha, const float* beta, const float* residual, float* out, int batch,
+                       int n_pixels, int C, hipStream_t s);
+// deformable 3x3 conv (ALN:274-330): offsets [b][H][W][off_c>=18] (dy,dx per tap, already clamped), no bias
+int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, float* out, int cout,
+                          int batch, int H, int W, hipStream_t s);
+int launch_al_clamp(float* x, size_t n, float lim, hipStream_t s);
+// feature aggregation + first score-head layer (ALN:657-668)
+int launch_al_assemble(const float* x1, const float* f2, const float* f3, const float* f4, const float* w1, const float* ws0,
+                       float* x1234, float* s8, int batch, int Hp, int Wp, hipStream_t s);
+// DKD sub-pixel refinement (ALN:176-216) and SDDH pieces (ALN:503-558)
+int launch_al_dkd_refine(const float* score, const float* kpts_px, const int* n_kpts, float* kpts_norm, float* disp,
+                         float* kscore, float* kpts_out, int batch, int H, int W, int capacity, int radius, hipStream_t s);
+int launch_al_sddh_patches(const float* x1234, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H,
+                           int W, int Hp, int Wp, int pad_t, int pad_l, int capacity, hipStream_t s);
+int launch_al_sddh_sample(const float* x1234, const float* kpts_norm, const int* n_kpts, const float* off_hidden,
+                          const float* w2, const float* b2, float* feats, int batch, int H, int W, int Hp, int Wp, int pad_t,
+                          int pad_l, int capacity, hipStream_t s);
+int launch_al_normalize_rows(float* x, const int* n_rows, int batch, int capacity, int C, hipStream_t s);
+int launch_al_mean(const float* x, int batch, int n, double* partial, float* mean, hipStream_t s);
+int launch_al_pick_threshold(const int* ncand, const float* mean, float thr, float* thr_out, int batch, hipStream_t s);

@@ -23,10 +23,10 @@ struct GemmArgs {
   const float* R = nullptr; int ldr = 0; long long strideR = 0;
   float* C = nullptr; int ldc = 0; long long strideC = 0;
   int M = 0, N = 0, K = 0;
-  const int* rows = nullptr; int rows_mul = 1, rows_off = 0;
+  const int* rows = nullptr; int rows_mul = 1, rows_off = 0, rows_scale = 1;
   const int* cols = nullptr; int cols_mul = 1, cols_off = 0;
   const int* flag = nullptr; int flag_shift = 0, flag_eq = 0;
-  int relu = 0;
+  int relu = 0;  // epilogue activation: 0 none, 1 ReLU, 2 SELU
 };
 int launch_gemm(const GemmArgs& a, int batch, hipStream_t s);
 

@@ -13,6 +13,8 @@
 //
 // Serves: SuperPoint 1x1 convolutions on NHWC maps (SPN:175,214) and every
 // LightGlue linear layer / similarity product (LGN:153,158,189-209,266-272).
+#include <math.h>
+
 #include "dim_kernels.h"
 
 namespace {
@@ -22,7 +24,7 @@ template <int BT>
 __global__ __launch_bounds__(256, 4) void gemm_mfma_kernel(GemmArgs a) {
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
-  const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] : a.M;
+  const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
   const int cols = (BT && a.cols) ? a.cols[z * a.cols_mul + a.cols_off] : a.N;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (m0 >= rows || n0 >= cols) return;
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_kernel(GemmArgs a) {
         if (row >= rows) continue;
         float v = acc[m][n][r] + bv;
         if (R) v += R[(size_t)row * a.ldr + col];
-        if (a.relu) v = fmaxf(v, 0.0f);
+        if (a.relu == 1) v = fmaxf(v, 0.0f);
+        else if (a.relu == 2) v = v <= 0.0f ? (expf(v) - 1.0f) * 1.7580993408473768599402175208123f : v * 1.0507009873554804934193349852946f;
         C[(size_t)row * a.ldc + col] = v;
       }
     }

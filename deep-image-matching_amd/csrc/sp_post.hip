@@ -131,10 +131,11 @@ __device__ __forceinline__ bool sp_is_candidate(float v, int y, int x, int H8, i
 
 // one wave per score-map row: count candidates
 __global__ __launch_bounds__(256) void count_rows_kernel(const float* __restrict__ nms, int* __restrict__ rowcount, int H8,
-                                                         int W8, float thr, int border) {
+                                                         int W8, float thr, int border, const float* __restrict__ thr_dev) {
   const int lane = threadIdx.x & 63;
   const int y = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
   if (y >= H8) return;
+  if (thr_dev) thr = thr_dev[b];
   const float* row = nms + ((size_t)b * H8 + y) * W8;
   int c = 0;
   for (int x = lane; x < W8; x += 64) c += sp_is_candidate(row[x], y, x, H8, W8, thr, border) ? 1 : 0;
@@ -170,10 +171,11 @@ __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__
 // one wave per row: ordered emission (row-major == torch.nonzero order, SPN:183-186)
 __global__ __launch_bounds__(256) void emit_rows_kernel(const float* __restrict__ nms, const int* __restrict__ rowoff,
                                                         float* __restrict__ cand_score, int* __restrict__ cand_idx, int H8,
-                                                        int W8, float thr, int border) {
+                                                        int W8, float thr, int border, const float* __restrict__ thr_dev) {
   const int lane = threadIdx.x & 63;
   const int y = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
   if (y >= H8) return;
+  if (thr_dev) thr = thr_dev[b];
   const float* row = nms + ((size_t)b * H8 + y) * W8;
   const size_t base_img = (size_t)b * H8 * W8;
   int base = rowoff[(size_t)b * H8 + y];
@@ -365,14 +367,19 @@ int launch_nms(const float* smap, float* out, int batch, int H8, int W8, int rad
   return 0;
 }
 
-int launch_select(const float* nms, int batch, int H8, int W8, float thr, int border, int* rowcount, int* rowoff,
-                  int* ncand, float* cand_score, int* cand_idx, hipStream_t s) {
+int launch_select_ex(const float* nms, int batch, int H8, int W8, float thr, const float* thr_dev, int border, int* rowcount,
+                     int* rowoff, int* ncand, float* cand_score, int* cand_idx, int count_only, hipStream_t s) {
   if (batch <= 0 || H8 <= 0 || W8 <= 0) return 0;
-  hipLaunchKernelGGL(count_rows_kernel, dim3(cdiv(H8, 4), batch), dim3(256), 0, s, nms, rowcount, H8, W8, thr, border);
+  hipLaunchKernelGGL(count_rows_kernel, dim3(cdiv(H8, 4), batch), dim3(256), 0, s, nms, rowcount, H8, W8, thr, border, thr_dev);
   hipLaunchKernelGGL(scan_rows_kernel, dim3(batch), dim3(1024), 0, s, (const int*)rowcount, rowoff, ncand, H8);
-  hipLaunchKernelGGL(emit_rows_kernel, dim3(cdiv(H8, 4), batch), dim3(256), 0, s, nms, (const int*)rowoff, cand_score, cand_idx, H8, W8, thr, border);
+  if (!count_only)
+    hipLaunchKernelGGL(emit_rows_kernel, dim3(cdiv(H8, 4), batch), dim3(256), 0, s, nms, (const int*)rowoff, cand_score, cand_idx, H8, W8, thr, border, thr_dev);
   DIM_LAUNCH_CHECK();
   return 0;
+}
+int launch_select(const float* nms, int batch, int H8, int W8, float thr, int border, int* rowcount, int* rowoff,
+                  int* ncand, float* cand_score, int* cand_idx, hipStream_t s) {
+  return launch_select_ex(nms, batch, H8, W8, thr, nullptr, border, rowcount, rowoff, ncand, cand_score, cand_idx, 0, s);
 }
 
 int launch_topk(const float* cand_score, const int* cand_idx, const int* ncand, int batch, int H8, int W8, int k,

@@ -108,3 +108,59 @@ def load_lightglue_state_dict(path: str | None = None, seed: int = 0, input_dim:
     if "confidence_thresholds" not in sd:
         sd["confidence_thresholds"] = lightglue_confidence_thresholds(n_layers)
     return {k: v.float().contiguous() for k, v in sd.items()}
+
+
+ALIKED_CFGS = {  # ALN:573-579  c1, c2, c3, c4, dim, K, M
+    "aliked-t16": (8, 16, 32, 64, 64, 3, 16),
+    "aliked-n16": (16, 32, 64, 128, 128, 3, 16),
+    "aliked-n16rot": (16, 32, 64, 128, 128, 3, 16),
+    "aliked-n32": (16, 32, 64, 128, 128, 3, 32),
+}
+
+
+def synthetic_aliked_state_dict(seed: int = 7, model_name: str = "aliked-n16rot") -> Dict[str, torch.Tensor]:
+    """Seeded synthetic ALIKED weights in the official key layout (the real
+    aliked-*.pth files live in the reference tree under thirdparty/ALIKED/models and load unchanged
+    through load_aliked_state_dict).  BN running stats are included for layout fidelity only: the
+    plugin runs BatchNorm in training mode (Q7) and never reads them."""
+    c1, c2, c3, c4, dim, K, M = ALIKED_CFGS[model_name]
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, co, ci, k, bias=False, gain=1.0):
+        sd[name + ".weight"] = torch.randn(co, ci, k, k, generator=g) * (gain * math.sqrt(2.0 / (ci * k * k)))
+        if bias:
+            sd[name + ".bias"] = torch.randn(co, generator=g) * 0.05
+
+    def bn(name, c):
+        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_mean"] = torch.zeros(c)
+        sd[name + ".running_var"] = torch.ones(c)
+        sd[name + ".num_batches_tracked"] = torch.tensor(0)
+
+    conv("block1.conv1", c1, 3, 3); bn("block1.bn1", c1); conv("block1.conv2", c1, c1, 3); bn("block1.bn2", c1)
+    conv("block2.conv1", c2, c1, 3); bn("block2.bn1", c2); conv("block2.conv2", c2, c2, 3); bn("block2.bn2", c2)
+    conv("block2.downsample", c2, c1, 1, bias=True)
+    for blk, ci, co in (("block3", c2, c3), ("block4", c3, c4)):
+        conv(blk + ".conv1.offset_conv", 2 * K * K, ci, 3, bias=True, gain=0.7)
+        conv(blk + ".conv1.regular_conv", co, ci, 3)
+        bn(blk + ".bn1", co)
+        conv(blk + ".conv2.offset_conv", 2 * K * K, co, 3, bias=True, gain=0.7)
+        conv(blk + ".conv2.regular_conv", co, co, 3)
+        bn(blk + ".bn2", co)
+        conv(blk + ".downsample", co, ci, 1, bias=True)
+    conv("conv1", dim // 4, c1, 1); conv("conv2", dim // 4, c2, 1); conv("conv3", dim // 4, c3, 1); conv("conv4", dim // 4, dim, 1)
+    conv("score_head.0", 8, dim, 1); conv("score_head.2", 4, 8, 3); conv("score_head.4", 4, 4, 3); conv("score_head.6", 1, 4, 3, gain=2.0)
+    sd["desc_head.agg_weights"] = torch.rand(M, dim, dim, generator=g) * (2.0 / math.sqrt(M * dim)) - (1.0 / math.sqrt(M * dim))
+    conv("desc_head.offset_conv.0", 2 * M, dim, K, bias=True)
+    conv("desc_head.offset_conv.2", 2 * M, 2 * M, 1, bias=True, gain=2.0)
+    conv("desc_head.sf_conv", dim, dim, 1)
+    return sd
+
+
+def load_aliked_state_dict(path: str | None = None, seed: int = 7, model_name: str = "aliked-n16rot") -> Dict[str, torch.Tensor]:
+    if path is None:
+        return synthetic_aliked_state_dict(seed, model_name)
+    sd = torch.load(str(Path(path)), map_location="cpu")
+    return {k: (v.float().contiguous() if v.is_floating_point() else v) for k, v in sd.items()}

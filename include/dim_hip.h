@@ -106,6 +106,47 @@ int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits,
 int dim_sp_candidate_counts(dim_sp* h, const int32_t** ncand_dev);
 
 /* ------------------------------------------------------------------------ */
+/* ALIKED (reference ALN = thirdparty/LightGlue/lightglue/aliked.py:561-693, driven by
+ * extractors/aliked.py:45-64)                                               */
+/* ------------------------------------------------------------------------ */
+
+/* Learnable tensors in the reference's state_dict layout (conv weights OIHW, host pointers;
+ * SURVEY.md Appendix A).  BatchNorm running statistics are NOT part of the interface: the
+ * reference plugin never calls .eval(), so BatchNorm normalises with the statistics of the
+ * current image (quirk Q7, ALX:40-43) and this library does the same. */
+typedef struct dim_aliked_weights {
+  const float *block1_conv1, *block1_conv2;            /* (16,3,3,3), (16,16,3,3) */
+  const float *block2_conv1, *block2_conv2, *block2_ds_w, *block2_ds_b;
+  const float *block3_off1_w, *block3_off1_b, *block3_reg1, *block3_off2_w, *block3_off2_b, *block3_reg2, *block3_ds_w, *block3_ds_b;
+  const float *block4_off1_w, *block4_off1_b, *block4_reg1, *block4_off2_w, *block4_off2_b, *block4_reg2, *block4_ds_w, *block4_ds_b;
+  const float *bn_weight[8], *bn_bias[8];             /* block1.bn1, block1.bn2, block2.bn1, ..., block4.bn2 */
+  const float *conv1, *conv2, *conv3, *conv4;          /* 1x1 heads (32,c,1,1) */
+  const float *score0, *score2, *score4, *score6;      /* score_head.{0,2,4,6}.weight */
+  const float *desc_off0_w, *desc_off0_b, *desc_off2_w, *desc_off2_b, *desc_sf, *desc_agg; /* desc_head.* */
+} dim_aliked_weights;
+
+/* ALIKED._default_conf (ALN:562-567) + the geometry row of ALIKED.cfgs (ALN:573-579). */
+typedef struct dim_aliked_config {
+  int c1, c2, c3, c4, dim, K, M;   /* aliked-n16 / n16rot: 16,32,64,128,128,3,16 */
+  int max_num_keypoints;           /* n_limit of DKD; -1 = capacity */
+  double detection_threshold;      /* > 0 */
+  int nms_radius;
+} dim_aliked_config;
+
+typedef struct dim_aliked dim_aliked;
+int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg, int max_batch, int max_h, int max_w,
+                      int capacity, dim_aliked** out);
+void dim_aliked_destroy(dim_aliked* h);
+/* images_dev: [batch][H][W][in_channels] fp32 (HWC, as the numpy image arrives; already /255,
+ *             extractors/aliked.py:66-78), in_channels 3 (RGB) or 1 (repeated to RGB, ALN:679-680).
+ * Outputs as dim_sp_extract with D = 128: kpts (x, y) sub-pixel pixel coordinates (ALN:687),
+ * scores = DIM's "scores" i.e. the score DISPERSITIES (quirk Q8), desc row-major (N, 128). */
+int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H, int W, int in_channels, float* kpts_xy_dev,
+                       float* scores_dev, float* desc_dev, int32_t* n_kpts_dev, void* stream);
+/* Parity taps: un-normalised feature map [batch][Hp][Wp][128] in the padded frame, score map [batch][H][W]. */
+int dim_aliked_debug_buffers(dim_aliked* h, const float** x1234, const float** score_map, int* hp, int* wp, int* pad_t, int* pad_l);
+
+/* ------------------------------------------------------------------------ */
 /* LightGlue (reference LGN:300-610)                                        */
 /* ------------------------------------------------------------------------ */
 

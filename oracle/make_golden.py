@@ -27,7 +27,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 REF = Path("/root/reference/src/deep_image_matching/thirdparty")
 
-from oracle import lightglue_ref, superpoint_ref  # noqa: E402
+from oracle import aliked_ref, lightglue_ref, superpoint_ref  # noqa: E402
 from tests import golden_cases as gc  # noqa: E402
 
 
@@ -65,6 +65,38 @@ def reference_lightglue(sd, conf, input_dim):
     missing, unexpected = net.load_state_dict(sd, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
     return net
+
+
+def reference_aliked(sd, cfg):
+    """Import the reference's aliked.py (ALN) with its absent third-party imports stubbed:
+    torchvision.ops.deform_conv2d -> the oracle's restatement (the op's source is not vendored),
+    torchvision.models.resnet.conv1x1/conv3x3 -> bias-free nn.Conv2d factories, kornia's
+    grayscale_to_rgb -> channel repeat.  The model is built WITHOUT .eval() (quirk Q7)."""
+    import types
+
+    tv, ops = types.ModuleType("torchvision"), types.ModuleType("torchvision.ops")
+    models, resnet = types.ModuleType("torchvision.models"), types.ModuleType("torchvision.models.resnet")
+    ops.deform_conv2d = lambda input, offset, weight, bias=None, padding=(1, 1), mask=None: aliked_ref.deform_conv2d(
+        input, offset, weight, bias, padding[0] if isinstance(padding, (tuple, list)) else padding)
+    resnet.conv1x1 = lambda i, o, stride=1: torch.nn.Conv2d(i, o, 1, stride=stride, bias=False)
+    resnet.conv3x3 = lambda i, o, stride=1, groups=1, dilation=1: torch.nn.Conv2d(i, o, 3, stride=stride, padding=dilation, bias=False)
+    tv.ops, tv.models, models.resnet = ops, models, resnet
+    kornia, color, cv2 = types.ModuleType("kornia"), types.ModuleType("kornia.color"), types.ModuleType("cv2")
+    color.grayscale_to_rgb = lambda x: x.repeat(1, 3, 1, 1)
+    kornia.color = color
+    for n, m in {"torchvision": tv, "torchvision.ops": ops, "torchvision.models": models, "torchvision.models.resnet": resnet,
+                 "kornia": kornia, "kornia.color": color, "cv2": cv2}.items():
+        sys.modules[n] = m
+    pkg = types.ModuleType("ref_lgpkg")
+    pkg.__path__ = [str(REF / "LightGlue/lightglue")]
+    sys.modules["ref_lgpkg"] = pkg
+    aln = importlib.import_module("ref_lgpkg.aliked")
+    orig = torch.hub.load_state_dict_from_url
+    torch.hub.load_state_dict_from_url = lambda *a, **k: sd
+    try:
+        return aln.ALIKED(**cfg)
+    finally:
+        torch.hub.load_state_dict_from_url = orig
 
 
 def main():
@@ -124,5 +156,33 @@ def main():
               f" max|dscore|={d_ms:.2e} ok (oracle == reference)")
 
 
+def main_aliked():
+    out_dir = ROOT / "tests" / "golden"
+    for name, case in gc.AL_CASES.items():
+        sd, img = gc.al_weights(case), gc.al_image(case)
+        net = reference_aliked(sd, case["cfg"])
+        with torch.no_grad():
+            ref = net({"image": img})
+        mine = aliked_ref.aliked_forward(img, sd, case["cfg"])
+        assert torch.equal(ref["keypoints"][0], mine["keypoints"]), name
+        assert torch.equal(ref["descriptors"][0].t(), mine["descriptors"]), name
+        assert torch.equal(ref["keypoint_scores"][0], mine["scores"]), name
+        np.savez_compressed(out_dir / f"al_{name}.npz", keypoints=ref["keypoints"][0].numpy(),
+                            descriptors=ref["descriptors"][0].t().contiguous().numpy(), scores=ref["keypoint_scores"][0].numpy())
+        print(f"al_{name}: N={ref['keypoints'].shape[1]} ok (oracle == reference, bit-exact)")
+    # also pin with the REAL aliked-n16rot.pth that ships inside the reference tree (not copied; not a golden)
+    real = REF / "ALIKED/models/aliked-n16rot.pth"
+    if real.exists():
+        sd = {k: v for k, v in torch.load(str(real), map_location="cpu").items()}
+        cfg = gc.AL_CASES["rgb_pad"]["cfg"]
+        img = gc.al_image(gc.AL_CASES["rgb_pad"])
+        with torch.no_grad():
+            ref = reference_aliked(sd, cfg)({"image": img})
+        mine = aliked_ref.aliked_forward(img, sd, cfg)
+        assert torch.equal(ref["keypoints"][0], mine["keypoints"]) and torch.equal(ref["keypoint_scores"][0], mine["scores"])
+        print(f"aliked real weights: N={mine['keypoints'].shape[0]} ok (oracle == reference, bit-exact)")
+
+
 if __name__ == "__main__":
     main()
+    main_aliked()

@@ -101,3 +101,22 @@ def lg_inputs(case):
     out.append({"kpts": k0.contiguous(), "desc": d0.contiguous(), "size": torch.tensor([h0, w0])})
     out.append({"kpts": k1.contiguous(), "desc": d1.contiguous(), "size": torch.tensor([h1, w1])})
     return out
+
+
+AL_CASES = {
+    # RGB, sides not multiples of 32 (InputPadder replicate padding), DIM's default config scaled down
+    "rgb_pad": {"seed": 21, "H": 70, "W": 100, "C": 3, "wseed": 7,
+                "cfg": {"model_name": "aliked-n16rot", "max_num_keypoints": 4000, "detection_threshold": 0.2, "nms_radius": 2}},
+    # gray input repeated to RGB, n_limit binding (more maxima than max_num_keypoints), radius 3
+    "gray_limit": {"seed": 22, "H": 64, "W": 96, "C": 1, "wseed": 8,
+                   "cfg": {"model_name": "aliked-n16rot", "max_num_keypoints": 60, "detection_threshold": 0.2, "nms_radius": 3}},
+}
+
+
+def al_weights(case):
+    return weights.synthetic_aliked_state_dict(case["wseed"])
+
+
+def al_image(case) -> torch.Tensor:
+    g = torch.Generator().manual_seed(case["seed"])
+    return torch.rand(1, case["C"], case["H"], case["W"], generator=g)

@@ -1,0 +1,48 @@
+"""CPU: the HIP ALIKED sources on the test emulator vs the oracle (which is pinned bit-exactly
+against the reference's aliked.py by oracle/make_golden.py) and vs the reference golden."""
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aliked_ref
+from tests import golden_cases as gc
+
+al_mod = importlib.import_module("deep-image-matching_amd.aliked_hip")
+GOLD = Path(__file__).parent / "golden"
+
+
+def compare_aliked(out, ref, kp_tol=2e-3, desc_tol=2e-3, score_tol=1e-3):
+    """Keypoints are sub-pixel: match each output keypoint to the reference keypoint with the same
+    integer NMS position (rounded), then compare coordinates / dispersity / descriptor."""
+    ka = {tuple(np.round(k).astype(int)): i for i, k in enumerate(out["keypoints"].numpy())}
+    kb = {tuple(np.round(k).astype(int)): i for i, k in enumerate(ref["keypoints"].numpy())}
+    common = sorted(set(ka) & set(kb))
+    res = {"n_out": len(ka), "n_ref": len(kb), "common": len(common)}
+    assert len(ka) == len(kb) and len(common) >= len(kb) - 2, res
+    ia = torch.tensor([ka[c] for c in common]); ib = torch.tensor([kb[c] for c in common])
+    res["kp"] = (out["keypoints"][ia] - ref["keypoints"][ib]).abs().max().item()
+    res["score"] = (out["scores"][ia] - ref["scores"][ib]).abs().max().item()
+    res["desc"] = (out["descriptors"][:, ia] - ref["descriptors"][:, ib]).abs().max().item()
+    assert res["kp"] <= kp_tol and res["score"] <= score_tol and res["desc"] <= desc_tol, res
+    return res
+
+
+@pytest.mark.parametrize("name", list(gc.AL_CASES))
+def test_aliked_emulated_vs_oracle_and_golden(emu_lib, name):
+    case = gc.AL_CASES[name]
+    sd, img = gc.al_weights(case), gc.al_image(case)
+    net = al_mod.AlikedHIP(sd, case["cfg"], max_batch=1, max_hw=(case["H"], case["W"]), capacity=4096, device="cpu", lib=emu_lib)
+    out = {k: v.cpu() for k, v in net(img).items()}
+    ref = aliked_ref.aliked_forward(img, sd, case["cfg"], taps=True)
+    taps = net.debug_taps()
+    pt, pl = taps["pad"]
+    H, W = case["H"], case["W"]
+    fm = torch.nn.functional.normalize(taps["x1234"][0, pt:pt + H, pl:pl + W].permute(2, 0, 1), dim=0)
+    assert (fm - ref["feature_map"][0]).abs().max().item() < 1e-3
+    res = compare_aliked(out, ref)
+    g = np.load(GOLD / f"al_{name}.npz")
+    gold = {k: torch.from_numpy(g[k]) for k in ("keypoints", "scores", "descriptors")}
+    compare_aliked(out, gold)
