@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import weights as _weights
+from .aliked_hip import AlikedHIP
 from .lightglue_hip import LightGlueHIP
 from .superpoint_hip import SuperPointHIP
 
@@ -120,6 +121,69 @@ class SuperPointExtractor(_ExtractorBase):
 
     def _frame2tensor(self, image: np.ndarray, device: str = "cuda"):
         """SPX:134-146."""
+        if len(image.shape) == 2:
+            image = image[None][None]
+        elif len(image.shape) == 3:
+            image = image.transpose(2, 0, 1)[None]
+        return torch.tensor(image / 255.0, dtype=torch.float).to(device)
+
+
+class AlikedExtractor(_ExtractorBase):
+    """extractors/aliked.py:10 — ALIKED on the gfx950 library (train-mode BatchNorm, Q7; scores are
+    the dispersities, Q8 — both reproduced inside the library)."""
+
+    _default_conf = {  # ALX:22-29 (the "name:" key with the stray colon is the reference's)
+        "name:": "aliked",
+        "model": "aliked-n16rot",
+        "device": "cuda",
+        "max_num_keypoints": 4000,
+        "detection_threshold": 0.2,
+        "nms_radius": 2,
+    }
+    required_inputs = []
+    grayscale = False
+    as_float = True
+    descriptor_size = 128
+    features_as_half = True
+
+    def __init__(self, config, _lib=None, _device=None):
+        super().__init__(config)
+        self._lib = _lib
+        if _device is not None:
+            self._device = _device
+        if _lib is None:
+            _require_gpu(self._device, "AlikedExtractor")
+        cfg = self.config.get("extractor")
+        # ALIKED(**cfg) reads conf.model_name (default "aliked-n16", ALN:562-567); DIM's "model" key is ignored by the net
+        self._net_cfg = {"model_name": cfg.get("model_name", "aliked-n16"), "max_num_keypoints": cfg["max_num_keypoints"],
+                         "detection_threshold": cfg["detection_threshold"], "nms_radius": cfg["nms_radius"]}
+        path = cfg.get("weights_path") or os.environ.get("DIM_ALIKED_WEIGHTS")
+        if path is None:
+            logger.warning("ALIKED: no weights_path / DIM_ALIKED_WEIGHTS given - using seeded SYNTHETIC weights "
+                           "(the real files are thirdparty/ALIKED/models/aliked-*.pth in the reference tree)")
+        self._sd = _weights.load_aliked_state_dict(path, model_name=self._net_cfg["model_name"])
+        self._net: Optional[AlikedHIP] = None
+        self._net_hw = (0, 0)
+
+    def _ensure(self, H: int, W: int):
+        if self._net is None or H > self._net_hw[0] or W > self._net_hw[1]:
+            hw = (max(H, self._net_hw[0]), max(W, self._net_hw[1]))
+            mk = self._net_cfg["max_num_keypoints"]
+            self._net = AlikedHIP(self._sd, self._net_cfg, max_batch=1, max_hw=hw, capacity=mk if mk > 0 else 4096,
+                                  device=self._device, lib=self._lib)
+            self._net_hw = hw
+
+    @torch.no_grad()
+    def _extract(self, image: np.ndarray) -> dict:
+        """image: float32 HxWx3 RGB (or HxW), 0..255.  Returns numpy keypoints (N,2), descriptors
+        (128,N) (ALX:57-58 transposes), scores (N,) (ALX:60-61 renames keypoint_scores)."""
+        image_ = self._frame2tensor(image, self._device)
+        self._ensure(image_.shape[-2], image_.shape[-1])
+        feats = self._net(image_)
+        return {k: v.cpu().numpy() for k, v in feats.items()}
+
+    def _frame2tensor(self, image: np.ndarray, device: str = "cuda"):
+        """ALX:66-78."""
         if len(image.shape) == 2:
             image = image[None][None]
         elif len(image.shape) == 3:

@@ -51,3 +51,19 @@ def test_lightglue_matcher_hook_contract(emu_lib):
     # empty side -> (0, 2) result, like the reference's "no keypoints" exit
     e = {"keypoints": np.zeros((0, 2), np.float32), "descriptors": np.zeros((0, 256), np.float32), "image_size": size}
     assert m._match_pairs(e, f1).shape == (0, 2)
+
+
+def test_aliked_extractor_hook_contract(emu_lib):
+    from oracle import aliked_ref
+
+    cfg = {"general": {}, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 50, "nms_radius": 2}}
+    ex = plugins.AlikedExtractor(cfg, _lib=emu_lib, _device="cpu")
+    assert not ex.grayscale and ex.descriptor_size == 128
+    img = (torch.rand(48, 64, 3, generator=torch.Generator().manual_seed(6)) * 255).numpy().astype(np.float32)  # HxWx3 RGB 0..255
+    f = ex._extract(img)
+    assert set(f) == {"keypoints", "scores", "descriptors"}
+    assert f["keypoints"].shape == (50, 2) and f["descriptors"].shape == (128, 50) and f["scores"].shape == (50,)
+    ref = aliked_ref.aliked_forward(torch.tensor(img.transpose(2, 0, 1)[None] / 255.0, dtype=torch.float), ex._sd, ex._net_cfg)
+    a = {tuple(np.round(k).astype(int)) for k in f["keypoints"]}
+    b = {tuple(np.round(k).astype(int)) for k in ref["keypoints"].numpy()}
+    assert len(a ^ b) <= 2
