@@ -24,6 +24,7 @@ from . import weights as _weights
 from .aliked_hip import AlikedHIP
 from .lightglue_hip import LightGlueHIP
 from .superpoint_hip import SuperPointHIP
+from .tiling import BatchedTilingMixin
 
 logger = logging.getLogger("dim")
 
@@ -64,7 +65,7 @@ def _require_gpu(device: str, what: str):
                            "use the reference's own plugin when general.force_cpu is set")
 
 
-class SuperPointExtractor(_ExtractorBase):
+class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
     """extractors/superpoint.py:64 — SuperPoint on the gfx950 library."""
 
     _default_conf = {
@@ -108,6 +109,17 @@ class SuperPointExtractor(_ExtractorBase):
                                       device=self._device, lib=self._lib)
             self._net_hw = hw
 
+    def _ensure_batch(self, H: int, W: int, batch: int):
+        """Separate resident handle for batched tile extraction (tiling.BatchedTilingMixin)."""
+        key = getattr(self, "_tile_key", None)
+        if key is None or H > key[0] or W > key[1] or batch > key[2]:
+            mk = self._net_cfg["max_keypoints"]
+            cap = mk if mk > 0 else min(4096 * 4, max(1024, (H // 8) * (W // 8) * 4))
+            self._tile_net = SuperPointHIP(self._sd, self._net_cfg, max_batch=batch, max_hw=(H, W), capacity=cap,
+                                           device=self._device, lib=self._lib)
+            self._tile_key = (H, W, batch)
+        return self._tile_net
+
     @torch.no_grad()
     def _extract(self, image: np.ndarray) -> dict:
         """image: float32 HxW, values 0..255 (extractor_base.py:197-202).  Returns numpy
@@ -128,7 +140,7 @@ class SuperPointExtractor(_ExtractorBase):
         return torch.tensor(image / 255.0, dtype=torch.float).to(device)
 
 
-class AlikedExtractor(_ExtractorBase):
+class AlikedExtractor(BatchedTilingMixin, _ExtractorBase):
     """extractors/aliked.py:10 — ALIKED on the gfx950 library (train-mode BatchNorm, Q7; scores are
     the dispersities, Q8 — both reproduced inside the library)."""
 
@@ -172,6 +184,15 @@ class AlikedExtractor(_ExtractorBase):
             self._net = AlikedHIP(self._sd, self._net_cfg, max_batch=1, max_hw=hw, capacity=mk if mk > 0 else 4096,
                                   device=self._device, lib=self._lib)
             self._net_hw = hw
+
+    def _ensure_batch(self, H: int, W: int, batch: int):
+        key = getattr(self, "_tile_key", None)
+        if key is None or H > key[0] or W > key[1] or batch > key[2]:
+            mk = self._net_cfg["max_num_keypoints"]
+            self._tile_net = AlikedHIP(self._sd, self._net_cfg, max_batch=batch, max_hw=(H, W), capacity=mk if mk > 0 else 4096,
+                                       device=self._device, lib=self._lib)
+            self._tile_key = (H, W, batch)
+        return self._tile_net
 
     @torch.no_grad()
     def _extract(self, image: np.ndarray) -> dict:

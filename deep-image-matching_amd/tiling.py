@@ -1,0 +1,116 @@
+"""Tile-wise extraction for large-format images, batched on the GPU.
+
+Host-side restatement of the reference's tiling glue —
+``Tiler.compute_tiles_by_size`` (utils/tiling.py:62-192, with kornia 0.8.1's
+``contrib.compute_padding`` restated since kornia is not a dependency here) and
+``ExtractorBase._extract_by_tile`` (extractors/extractor_base.py:279-390) — with ONE difference:
+the reference runs one network forward per tile, sequentially (EB:305-315); here all tiles of an
+image (16 for the 6000x4000 / 1500x1000 case of BASELINE config 5) go through the resident
+extractor as batches (``extract_batch``), and only the merge (origin shift, 2-px border mask,
+``np.unique`` de-duplication) stays on the host, exactly as in the reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple, Union
+
+import numpy as np
+import torch
+
+
+def compute_padding(original_size: Tuple[int, int], window_size: Tuple[int, int]) -> Tuple[int, int, int, int]:
+    """kornia.contrib.compute_padding (0.8.1) with stride = window, as DIM calls it
+    (utils/tiling.py:124): (top, bottom, left, right) making (size - window) % window == 0."""
+    pads = []
+    for size, win in zip(original_size, window_size):
+        rem = (size - win) % win
+        pad = win - rem if rem != 0 else 0
+        pads += [pad // 2, int(math.ceil(pad / 2))]
+    return tuple(pads)
+
+
+def compute_tiles_by_size(image: np.ndarray, window_size: Union[int, Tuple[int, int]], overlap: Union[int, Tuple[int, int]] = 0):
+    """utils/tiling.py:62-192 (kornia != 0.7.1 branch).  image (H,W) or (H,W,C) numpy.  window_size /
+    overlap are (x, y) when tuples.  Returns ({idx: tile (H_t,W_t,C)}, {idx: (x, y) origin in
+    UNPADDED coordinates}, (top, bottom, left, right))."""
+    if isinstance(window_size, int):
+        win = (window_size, window_size)
+    elif isinstance(window_size, (tuple, list)):
+        win = (window_size[1], window_size[0])  # -> (H, W)
+    else:
+        raise TypeError("window_size must be an integer or a tuple of integers")
+    if isinstance(overlap, int):
+        ov = (overlap, overlap)
+    elif isinstance(overlap, (tuple, list)):
+        ov = (overlap[1], overlap[0])
+    else:
+        raise TypeError("overlap must be an integer or a tuple of integers")
+    if not isinstance(image, np.ndarray):
+        raise TypeError("input must be a numpy array")
+    img = image if image.ndim == 3 else image[..., None]
+    H, W = img.shape[:2]
+    pad = compute_padding((H, W), win)
+    stride = (win[0] - ov[0], win[1] - ov[1])
+    padded = np.pad(img, ((pad[0], pad[1]), (pad[2], pad[3]), (0, 0)), mode="constant", constant_values=0)
+    ph, pw = padded.shape[:2]
+    tiles, k = {}, 0
+    for y in range(0, ph - win[0] + 1, stride[0]):
+        for x in range(0, pw - win[1] + 1, stride[1]):
+            tiles[k] = padded[y:y + win[0], x:x + win[1]]
+            k += 1
+    n_rows = (H + pad[0] + pad[1] - win[0]) // stride[0] + 1
+    n_cols = (W + pad[2] + pad[3] - win[1]) // stride[1] + 1
+    origins = {r * n_cols + c: (-pad[2] + c * stride[1], -pad[0] + r * stride[0]) for r in range(n_rows) for c in range(n_cols)}
+    return tiles, origins, pad
+
+
+def merge_tile_features(per_tile: Dict[int, dict], origins: Dict[int, Tuple[int, int]], image_shape, descriptor_size: int,
+                        select_unique: bool = True) -> dict:
+    """EB:330-390: shift to image coordinates, drop keypoints within 2 px of the (unpadded) image
+    border, concatenate, de-duplicate with np.unique (which re-sorts lexicographically by (x, y))."""
+    kl, dl, sl, tl = [], [], [], []
+    for idx, f in per_tile.items():
+        kp = f["keypoints"] + np.array(origins[idx], dtype=f["keypoints"].dtype)
+        thr = 2
+        m = (kp[:, 0] >= thr) & (kp[:, 0] < image_shape[1] - thr) & (kp[:, 1] >= thr) & (kp[:, 1] < image_shape[0] - thr)
+        kp = kp[m]
+        if len(kp) > 0:
+            kl.append(kp); dl.append(f["descriptors"][:, m]); sl.append(f["scores"][m]); tl.append(np.full(len(kp), idx, dtype=np.float32))
+    if kl:
+        kpts, desc, scores, tidx = np.vstack(kl), np.hstack(dl), np.concatenate(sl), np.concatenate(tl)
+    else:
+        kpts = np.array([], dtype=np.float32).reshape(0, 2)
+        desc = np.array([], dtype=np.float32).reshape(descriptor_size, 0)
+        scores, tidx = np.array([], dtype=np.float32), np.array([], dtype=np.float32)
+    if select_unique:
+        kpts, u = np.unique(kpts, axis=0, return_index=True)
+        desc, tidx, scores = desc[:, u], tidx[u], scores[u]
+    return {"keypoints": kpts, "descriptors": desc, "scores": scores, "tile_idx": tidx}
+
+
+class BatchedTilingMixin:
+    """Overrides ExtractorBase._extract_by_tile with the batched version.  Needs ``self._net``
+    (SuperPointHIP / AlikedHIP built by ``self._ensure_batch``), ``self.grayscale`` and
+    ``self.descriptor_size``."""
+
+    tile_batch = 16
+
+    @torch.no_grad()
+    def _extract_by_tile(self, image: np.ndarray, select_unique: bool = True) -> dict:
+        general = self.config["general"]
+        tiles, origins, _ = compute_tiles_by_size(image, general["tile_size"], general.get("tile_overlap", 0))
+        idxs = sorted(tiles)
+        th, tw = tiles[idxs[0]].shape[:2]
+        net = self._ensure_batch(th, tw, self.tile_batch)
+        per_tile = {}
+        for s in range(0, len(idxs), self.tile_batch):
+            chunk = idxs[s:s + self.tile_batch]
+            stack = np.stack([tiles[i] for i in chunk]).astype(np.float32) / 255.0  # _frame2tensor's /255
+            t = torch.from_numpy(stack)
+            t = t[..., 0].contiguous() if self.grayscale else t.contiguous()       # [B,H,W] or [B,H,W,C]
+            kp, sc, de, n = net.extract_batch(t.to(net.device))
+            kp, sc, de, n = kp.cpu().numpy(), sc.cpu().numpy(), de.cpu().numpy(), n.cpu().numpy()
+            for j, i in enumerate(chunk):
+                k = int(n[j])
+                per_tile[i] = {"keypoints": kp[j, :k].copy(), "scores": sc[j, :k].copy(), "descriptors": de[j, :k].T.copy()}
+        return merge_tile_features(per_tile, origins, image.shape, self.descriptor_size, select_unique)
