@@ -22,6 +22,9 @@ std::vector<hipEvent_t> g_prof_ev;  // begin/end pairs
 size_t g_prof_used = 0;
 }  // namespace
 
+static int g_precision_mode = 1;
+int dim_precision_mode() { return g_precision_mode; }
+
 void dim_prof_begin(int site, hipStream_t s) {
   if (!((g_prof_mask >> site) & 1ull)) return;
   if (g_prof_used + 2 > g_prof_ev.size()) {
@@ -87,8 +90,44 @@ int dim_op_simple_nms_f32(const float* score_map, float* out, int batch, int H, 
   return launch_nms(score_map, out, batch, H, W, radius, (hipStream_t)stream);
 }
 
+int dim_x3_create(const float* w_kn_host, int K, int N, void** out_dev, int* n_pad_out) {
+  DIM_REQUIRE(w_kn_host && out_dev && n_pad_out && K > 0 && N > 0, "dim_x3_create: bad argument");
+  const int n_pad = (N + 127) / 128 * 128;
+  std::vector<unsigned short> host((size_t)3 * n_pad * K);
+  split_weights_x3(w_kn_host, K, N, n_pad, host.data());
+  void* d = nullptr;
+  DIM_HIP(hipMalloc(&d, host.size() * 2));
+  DIM_HIP(hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+  *out_dev = d; *n_pad_out = n_pad;
+  return 0;
+}
+void dim_x3_destroy(void* dev) { if (dev) hipFree(dev); }
+int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3_dev, int n_pad, const float* bias, const float* residual, int ldr,
+                       float* C, int ldc, int M, int N, int K, int act, void* stream) {
+  GemmArgs g;
+  g.A0 = A; g.lda0 = lda; g.Bx3 = (const unsigned short*)w_x3_dev; g.n_pad = n_pad; g.bias = bias;
+  g.R = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = act;
+  return launch_gemm_x6(g, 1, (hipStream_t)stream);
+}
+
+int dim_convx6_create(const float* w_oihw_host, int cin, int cout, void** out_dev) {
+  DIM_REQUIRE(w_oihw_host && out_dev && (cin == 64 || cin == 128) && cout % 64 == 0, "dim_convx6_create: bad argument");
+  std::vector<unsigned short> host(conv_x6_weight_elems(cin, cout));
+  prepare_conv_weights_x6(w_oihw_host, cin, cout, host.data());
+  void* d = nullptr;
+  DIM_HIP(hipMalloc(&d, host.size() * 2));
+  DIM_HIP(hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+  *out_dev = d;
+  return 0;
+}
+int dim_op_conv3x3_x6_nhwc_f32(const float* in, const void* w_x6_dev, const float* bias, float* out, int batch, int H, int W,
+                               int cin, int cout, int pool2x2, int relu, void* stream) {
+  return launch_conv3x3_x6(in, (const unsigned short*)w_x6_dev, bias, out, batch, H, W, cin, cout, pool2x2, relu, (hipStream_t)stream);
+}
+
 int dim_tune_set(int key, int value) {
   if (key == 0) dim_conv_set_variant(value);
+  if (key == 1) g_precision_mode = value;
   return 0;
 }
 

@@ -1,0 +1,170 @@
+// 3x3 convolution on the bf16 matrix cores at fp32 accuracy ("bf16x6", see dim_common.h split3_pk and
+// gemm_x6.hip): the NHWC fp32 input tile is split EXACTLY into three bf16 planes while it is staged into
+// LDS, the weights are pre-split on the host, and every 32x32x16 MFMA step issues the six leading cross
+// terms (32 cycles each) instead of eight fp32 MFMAs (64 cycles each): 192 vs 512 cycles.
+//
+// Workgroup = 4 waves; output tile = 8 rows x 32 columns x 64 channels (wave w: rows 2w, 2w+1 x two
+// 32-channel slabs = 4 accumulators), as in conv.hip.  K loop: 16 input channels per chunk; inside a
+// chunk the weights are staged one kernel ROW (3 taps) at a time, which keeps LDS at 51 KB per
+// workgroup (3 workgroups per CU: the split/staging VALU work of one overlaps the MFMAs of the others):
+//   Ip[plane 3][k-half 2][pixel 10x34][8 bf16]   32,640 B   one 16-B ds_read_b128 = one A operand,
+//   Wp[plane 3][dx 3][k-half 2][cout 64][8 bf16] 18,432 B   one 16-B ds_read_b128 = one B operand;
+// consecutive lanes read consecutive 16-B slots in both images: conflict-free without padding.
+// The pre-split weight buffer is laid out so that each (cout block, chunk, kernel row) slice is one
+// contiguous 18,432-B run (a straight 16-B-per-lane copy).
+#include <string.h>
+
+#include "dim_kernels.h"
+
+namespace {
+constexpr int TH = 8, TW = 32, IW = TW + 2, IH = TH + 2, NPIX = IH * IW;  // 340 halo pixels
+constexpr int W_SLICE = 3 * 3 * 2 * 64 * 8;                              // bf16 elements per (cb, chunk, dy) slice
+
+template <int CIN, int POOL>
+__global__ __launch_bounds__(256, 3) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int H, int W,
+                                                            int cout, int relu, int tiles_x) {
+  __shared__ u32x4 Ip[3 * 2 * NPIX];
+  __shared__ u32x4 Wp[3 * 3 * 2 * 64];
+  constexpr int NCHUNK = CIN / 16;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6, lx = lane & 31, half = lane >> 5;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+  const int cb = blockIdx.y, b = blockIdx.z;
+  const int oy = ty * TH, ox = tx * TW;
+  const float* in_b = in + (size_t)b * H * W * CIN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  for (int c = 0; c < NCHUNK; ++c) {
+    __syncthreads();  // every wave is done with the previous chunk's Ip / Wp
+    // ---- stage + split the halo tile: 340 pixels x 16 channels, one float4 (4 channels) per item ----
+    for (int i = t; i < NPIX * 4; i += 256) {
+      const int p = i >> 2, q = i & 3;
+      const int py = p / IW, px = p - py * IW;
+      const int gy = oy + py - 1, gx = ox + px - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *(const float4*)(in_b + ((size_t)gy * W + gx) * CIN + c * 16 + q * 4);
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3_pk(v.x, v.y, h0, m0, l0);
+      split3_pk(v.z, v.w, h1, m1, l1);
+      // channels q*4..q*4+3 live in k-half q>>1, dwords (q&1)*2, +1 of that pixel's 16-B slot
+      unsigned* d = (unsigned*)&Ip[(q >> 1) * NPIX + p] + (q & 1) * 2;
+      d[0] = h0; d[1] = h1;
+      d[2 * NPIX * 4] = m0; d[2 * NPIX * 4 + 1] = m1;
+      d[4 * NPIX * 4] = l0; d[4 * NPIX * 4 + 1] = l1;
+    }
+    for (int dy = 0; dy < 3; ++dy) {
+      if (dy > 0) __syncthreads();  // previous kernel row's weights consumed
+      {
+        const u32x4* src = (const u32x4*)(wx + ((size_t)(cb * NCHUNK + c) * 3 + dy) * W_SLICE);
+        for (int i = t; i < W_SLICE / 8; i += 256) Wp[i] = src[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) fa[m][p] = Ip[(p * 2 + half) * NPIX + (2 * wv + m + dy) * IW + lx + dx];
+#pragma unroll
+          for (int n = 0; n < 2; ++n) fb[n][p] = Wp[((p * 3 + dx) * 2 + half) * 64 + n * 32 + lx];
+        }
+        const int ta[6] = {1, 0, 2, 0, 1, 0}, tb[6] = {1, 2, 0, 1, 0, 0};  // smallest cross terms first
+#pragma unroll
+        for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(fa[m][ta[tm]], fb[n][tb[tm]], acc[m][n]);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int co = cb * 64 + n * 32 + lx;
+    const float bv = bias[co];
+    if (POOL) {
+      const int Ho = H >> 1, Wo = W >> 1;
+      const int py = (oy >> 1) + wv;
+      float* out_b = out + (size_t)b * Ho * Wo * cout;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int px = (ox + mfma_row(r, half)) >> 1;
+        float v = fmaxf(fmaxf(acc[0][n][r], acc[0][n][r + 1]), fmaxf(acc[1][n][r], acc[1][n][r + 1])) + bv;
+        if (relu) v = fmaxf(v, 0.0f);
+        if (py < Ho && px < Wo) out_b[((size_t)py * Wo + px) * cout + co] = v;
+      }
+    } else {
+      float* out_b = out + (size_t)b * H * W * cout;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int y = oy + 2 * wv + m;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int x = ox + mfma_row(r, half);
+          float v = acc[m][n][r] + bv;
+          if (relu) v = fmaxf(v, 0.0f);
+          if (y < H && x < W) out_b[((size_t)y * W + x) * cout + co] = v;
+        }
+      }
+    }
+  }
+}
+
+unsigned short host_bf16_rne(float x) {
+  unsigned u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+}  // namespace
+
+// Host: OIHW fp32 3x3 weights -> [cout/64][cin/16][dy][plane][dx][k-half][64 co][8 ci] bf16 (RNE pieces).
+size_t conv_x6_weight_elems(int cin, int cout) { return (size_t)(cout / 64) * (cin / 16) * 3 * W_SLICE; }
+void prepare_conv_weights_x6(const float* w_oihw, int cin, int cout, unsigned short* out) {
+  const int nchunk = cin / 16;
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) {
+          float x = w_oihw[(((size_t)co * cin + ci) * 3 + dy) * 3 + dx];
+          const int cb = co / 64, col = co % 64, c = ci / 16, hf = (ci % 16) / 8, e = ci % 8;
+          for (int p = 0; p < 3; ++p) {
+            const unsigned short hb = host_bf16_rne(x);
+            const unsigned u = (unsigned)hb << 16;
+            float h;
+            memcpy(&h, &u, 4);
+            const size_t idx = ((((((size_t)(cb * nchunk + c) * 3 + dy) * 3 + p) * 3 + dx) * 2 + hf) * 64 + col) * 8 + e;
+            out[idx] = hb;
+            x = x - h;
+          }
+        }
+}
+
+int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bias, float* out, int batch, int H, int W, int cin,
+                      int cout, int pool, int relu, hipStream_t s) {
+  DIM_REQUIRE(cout % 64 == 0, "conv3x3_x6: cout=%d must be a multiple of 64", cout);
+  DIM_REQUIRE(cin == 64 || cin == 128, "conv3x3_x6: cin=%d unsupported (64 or 128)", cin);
+  if (batch <= 0 || H <= 0 || W <= 0) return 0;
+  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
+  dim3 grid(tiles_x * tiles_y, cout / 64, batch);
+#define DIM_CONV6(CI, P) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x)
+  if (cin == 64 && pool) DIM_CONV6(64, 1);
+  else if (cin == 64) DIM_CONV6(64, 0);
+  else if (pool) DIM_CONV6(128, 1);
+  else DIM_CONV6(128, 0);
+#undef DIM_CONV6
+  DIM_LAUNCH_CHECK();
+  return 0;
+}

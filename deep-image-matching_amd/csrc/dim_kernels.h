@@ -19,6 +19,7 @@ struct GemmArgs {
   long long strideA0 = 0, strideA1 = 0;
   const int* a_idx = nullptr;  // optional indirection: A0 of item z starts at A0 + a_idx[z]*strideA0
   const float* B = nullptr; int ldb = 0; long long strideB = 0; int bt = 0;
+  const unsigned short* Bx3 = nullptr; int n_pad = 0;  // bf16x6 path: weights pre-split into [3][n_pad][K] bf16 planes
   const float* bias = nullptr;
   const float* R = nullptr; int ldr = 0; long long strideR = 0;
   float* C = nullptr; int ldc = 0; long long strideC = 0;
@@ -29,6 +30,9 @@ struct GemmArgs {
   int relu = 0;  // epilogue activation: 0 none, 1 ReLU, 2 SELU
 };
 int launch_gemm(const GemmArgs& a, int batch, hipStream_t s);
+// fp32-accurate GEMM on the bf16 matrix cores (gemm_x6.hip); needs a.Bx3 / a.n_pad.
+int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s);
+void split_weights_x3(const float* w_kn, int K, int N, int n_pad, unsigned short* out);
 
 // ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution over NHWC fp32 images as an implicit GEMM
@@ -36,6 +40,12 @@ int launch_gemm(const GemmArgs& a, int batch, hipStream_t s);
 // SPN:163-171).  in: [B][H][W][cin], w: [9][cin][cout], out: [B][H'][W'][cout].
 int launch_conv3x3(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W,
                    int cin, int cout, int pool, int relu, hipStream_t s);
+// fp32-accurate 3x3 conv on the bf16 matrix cores (conv_x6.hip); weights pre-split by prepare_conv_weights_x6.
+size_t conv_x6_weight_elems(int cin, int cout);
+void prepare_conv_weights_x6(const float* w_oihw, int cin, int cout, unsigned short* out);
+int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bias, float* out, int batch, int H, int W, int cin,
+                      int cout, int pool, int relu, hipStream_t s);
+int dim_precision_mode();  // 1 (default): bf16x6 on the bf16 matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
 void dim_conv_set_variant(int v);  // tuning hook: selects the conv3x3 kernel variant (see conv.hip)
 // conv1a: 1 -> 64 channels, direct (VALU) convolution; in: [B][H][W], w: [9][64].
 int launch_conv1a(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W,

@@ -1,0 +1,167 @@
+// fp32-accurate GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand is split EXACTLY into three
+// bf16 pieces (dim_common.h: split3) and the six leading cross terms are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  Accuracy is fp32-class (hardware probe: 1.3e-7 of sum|a*b| at K = 1024, an
+// fp32 fmaf chain gives 1.2e-7) while the MFMA cost per fp32-equivalent 32x32x16 step drops from
+// 8 x 64 = 512 cycles (v_mfma_f32_32x32x2_f32) to 6 x 32 = 192 cycles: an effective dense peak of
+// 2.5 PF / 6 = 417 TFLOP/s instead of 157.
+//
+// Same tiling as gemm.hip (128x128 block, 4 waves of 64x64, K chunks of 32).  Weights are pre-split on
+// the host into three [N][K] bf16 planes (k contiguous: one 16-B LDS read is one MFMA operand);
+// activations are split while they are staged.  LDS images are [plane][128][40 bf16] — the 80-byte row
+// stride makes every 16-lane group of a ds_read_b128 cover all 64 banks exactly once.
+#include <math.h>
+#include <string.h>
+
+#include "dim_kernels.h"
+
+namespace {
+constexpr int BM = 128, BN = 128, KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
+
+__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs a) {
+  const int z = blockIdx.z;
+  if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
+  const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= rows || n0 >= a.N) return;
+
+  __shared__ unsigned Ap[3 * BM * RS];
+  __shared__ unsigned Bp[3 * BN * RS];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1, lx = lane & 31, half = lane >> 5;
+  const float* A0 = a.A0 + (size_t)(a.a_idx ? a.a_idx[z] : z) * a.strideA0;
+  const float* A1 = a.A1 ? a.A1 + (size_t)z * a.strideA1 : nullptr;
+  const unsigned short* Bx = a.Bx3;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  float4 ra[4];
+  u32x4 rb[6];
+  auto load_chunk = [&](int k0) {
+    const float* src; int ld, kk0;
+    if (A1 == nullptr || k0 < a.ksplit) { src = A0; ld = a.lda0; kk0 = k0; }
+    else { src = A1; ld = a.lda1; kk0 = k0 - a.ksplit; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + row < rows) ra[i] = *(const float4*)(src + (size_t)(m0 + row) * ld + kk0 + q * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = t + 256 * i, p = idx >> 9, rem = idx & 511, col = rem >> 2, part = rem & 3;
+      rb[i] = *(const u32x4*)(Bx + ((size_t)p * a.n_pad + n0 + col) * a.K + k0 + part * 8);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
+      unsigned h[2], m[2], l[2];
+      split3_pk(ra[i].x, ra[i].y, h[0], m[0], l[0]);
+      split3_pk(ra[i].z, ra[i].w, h[1], m[1], l[1]);
+      unsigned* d = &Ap[row * RS + q * 2];
+      d[0] = h[0]; d[1] = h[1];
+      d[BM * RS] = m[0]; d[BM * RS + 1] = m[1];
+      d[2 * BM * RS] = l[0]; d[2 * BM * RS + 1] = l[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = t + 256 * i, p = idx >> 9, rem = idx & 511, col = rem >> 2, part = rem & 3;
+      *(u32x4*)&Bp[(p * BN + col) * RS + part * 4] = rb[i];
+    }
+  };
+
+  load_chunk(0);
+  for (int k0 = 0; k0 < a.K; k0 += KC) {
+    store_chunk();
+    __syncthreads();
+    if (k0 + KC < a.K) load_chunk(k0 + KC);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * 64 + m * 32 + lx) * RS + ks * 8 + half * 4];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) fb[n][p] = *(const u32x4*)&Bp[(p * BN + wn * 64 + n * 32 + lx) * RS + ks * 8 + half * 4];
+      }
+      // six cross terms, smallest first; the four accumulators interleave so no MFMA waits on its predecessor
+      const int ta[6] = {1, 0, 2, 0, 1, 0}, tb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+      for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(fa[m][ta[tm]], fb[n][tb[tm]], acc[m][n]);
+    }
+    __syncthreads();
+  }
+
+  float* C = a.C + (size_t)z * a.strideC;
+  const float* R = a.R ? a.R + (size_t)z * a.strideR : nullptr;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = n0 + wn * 64 + n * 32 + lx;
+    if (col >= a.N) continue;
+    const float bv = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + m * 32 + mfma_row(r, half);
+        if (row >= rows) continue;
+        float v = acc[m][n][r] + bv;
+        if (R) v += R[(size_t)row * a.ldr + col];
+        if (a.relu == 1) v = fmaxf(v, 0.0f);
+        else if (a.relu == 2) v = v <= 0.0f ? (expf(v) - 1.0f) * 1.7580993408473768599402175208123f : v * 1.0507009873554804934193349852946f;
+        C[(size_t)row * a.ldc + col] = v;
+      }
+    }
+  }
+}
+}  // namespace
+
+int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
+  DIM_REQUIRE(a.Bx3 != nullptr && !a.bt, "gemm_x6: needs pre-split [3][n_pad][K] weights");
+  DIM_REQUIRE(a.K % KC == 0 && (a.A1 == nullptr || a.ksplit % KC == 0), "gemm_x6: K=%d / ksplit=%d must be multiples of %d", a.K, a.ksplit, KC);
+  DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
+  DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
+  if (batch <= 0 || a.M <= 0 || a.N <= 0) return 0;
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch);
+  hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), 0, s, a);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+// Host: nn.Linear-style operand [K][N] fp32 -> three bf16 planes [3][n_pad][K], round-to-nearest-even
+// pieces (the same rule as split3_pk on the device).
+static unsigned short host_bf16_rne(float x) {
+  unsigned u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);  // inf / nan: truncate
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+void split_weights_x3(const float* w_kn, int K, int N, int n_pad, unsigned short* out) {
+  for (size_t i = 0; i < (size_t)3 * n_pad * K; ++i) out[i] = 0;
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) {
+      float x = w_kn[(size_t)k * N + n];
+      for (int p = 0; p < 3; ++p) {
+        const unsigned short hb = host_bf16_rne(x);
+        const unsigned u = (unsigned)hb << 16;
+        float h;
+        memcpy(&h, &u, 4);
+        out[((size_t)p * n_pad + n) * K + k] = hb;
+        x = x - h;
+      }
+    }
+}

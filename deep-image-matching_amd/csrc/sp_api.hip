@@ -20,6 +20,7 @@ struct dim_sp {
   int max_batch, max_h, max_w, capacity;
   // weights (device)
   float* w1a; float* wk[12]; float* bias[12];
+  unsigned short* wx6[12];  // bf16x6 pre-split 3x3 weights (conv_x6.hip); nullptr for conv1a and the 1x1 layers
   // activations
   float *a1, *b1, *a2, *b2, *a3, *b3, *a4, *x, *pa, *logits, *da, *dd, *smap, *nms, *cand_score;
   int *cand_idx, *rowcount, *rowoff, *ncand;
@@ -75,6 +76,13 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
     for (int o = 0; o < co; ++o)
       for (int i = 0; i < ci; ++i)
         for (int t = 0; t < k * k; ++t) host[((size_t)t * ci + i) * co_pad + o] = w->conv_w[l][((size_t)o * ci + i) * k * k + t];
+    h->wx6[l] = nullptr;
+    if (k == 3 && ci >= 64) {
+      std::vector<unsigned short> hx(conv_x6_weight_elems(ci, co));
+      prepare_conv_weights_x6(w->conv_w[l], ci, co, hx.data());
+      SP_TRY(dev_alloc(h, &h->wx6[l], hx.size()));
+      if (hipMemcpy(h->wx6[l], hx.data(), hx.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
+    }
     SP_TRY(dev_alloc(h, &h->wk[l], host.size()));
     if (hipMemcpy(h->wk[l], host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
     std::vector<float> hb(co_pad, 0.0f);
@@ -120,17 +128,22 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   const int H8 = hh * 8, W8 = ww * 8;
 #define SP_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
 #define SP_SITE(id, x) do { dim_prof_begin(id, s); SP_RUN(x); dim_prof_end(id, s); } while (0)
+  const bool x6 = dim_precision_mode() != 0;  // default: fp32-accurate products on the bf16 matrix cores
+  auto conv = [&](int l, const float* in, float* out, int Hh, int Ww, int ci, int co, int pool) -> int {
+    return x6 ? launch_conv3x3_x6(in, h->wx6[l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s)
+              : launch_conv3x3(in, h->wk[l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s);
+  };
   // encoder (SPN:161-171)
   SP_SITE(DIM_PROF_SP_CONV1A, launch_conv1a(images_dev, h->wk[0], h->bias[0], h->a1, batch, H, W, s));
-  SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3(h->a1, h->wk[1], h->bias[1], h->b1, batch, H, W, 64, 64, 1, 1, s));
-  SP_SITE(DIM_PROF_SP_CONV2A, launch_conv3x3(h->b1, h->wk[2], h->bias[2], h->a2, batch, H2, W2, 64, 64, 0, 1, s));
-  SP_SITE(DIM_PROF_SP_CONV2B, launch_conv3x3(h->a2, h->wk[3], h->bias[3], h->b2, batch, H2, W2, 64, 64, 1, 1, s));
-  SP_SITE(DIM_PROF_SP_CONV3A, launch_conv3x3(h->b2, h->wk[4], h->bias[4], h->a3, batch, H4, W4, 64, 128, 0, 1, s));
-  SP_SITE(DIM_PROF_SP_CONV3B, launch_conv3x3(h->a3, h->wk[5], h->bias[5], h->b3, batch, H4, W4, 128, 128, 1, 1, s));
-  SP_SITE(DIM_PROF_SP_CONV4A, launch_conv3x3(h->b3, h->wk[6], h->bias[6], h->a4, batch, hh, ww, 128, 128, 0, 1, s));
-  SP_SITE(DIM_PROF_SP_CONV4B, launch_conv3x3(h->a4, h->wk[7], h->bias[7], h->x, batch, hh, ww, 128, 128, 0, 1, s));
+  SP_SITE(DIM_PROF_SP_CONV1B, conv(1, h->a1, h->b1, H, W, 64, 64, 1));
+  SP_SITE(DIM_PROF_SP_CONV2A, conv(2, h->b1, h->a2, H2, W2, 64, 64, 0));
+  SP_SITE(DIM_PROF_SP_CONV2B, conv(3, h->a2, h->b2, H2, W2, 64, 64, 1));
+  SP_SITE(DIM_PROF_SP_CONV3A, conv(4, h->b2, h->a3, H4, W4, 64, 128, 0));
+  SP_SITE(DIM_PROF_SP_CONV3B, conv(5, h->a3, h->b3, H4, W4, 128, 128, 1));
+  SP_SITE(DIM_PROF_SP_CONV4A, conv(6, h->b3, h->a4, hh, ww, 128, 128, 0));
+  SP_SITE(DIM_PROF_SP_CONV4B, conv(7, h->a4, h->x, hh, ww, 128, 128, 0));
   // detector head (SPN:174-180)
-  SP_SITE(DIM_PROF_SP_CONVPA, launch_conv3x3(h->x, h->wk[8], h->bias[8], h->pa, batch, hh, ww, 128, 256, 0, 1, s));
+  SP_SITE(DIM_PROF_SP_CONVPA, conv(8, h->x, h->pa, hh, ww, 128, 256, 0));
   {
     GemmArgs g;
     g.A0 = h->pa; g.lda0 = 256; g.B = h->wk[9]; g.ldb = 68; g.bias = h->bias[9];
@@ -145,7 +158,7 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   SP_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H8, W8, h->cfg.max_keypoints, h->capacity, kpts_xy_dev,
                      scores_dev, n_kpts_dev, s));
   // descriptor head (SPN:213-221)
-  SP_SITE(DIM_PROF_SP_CONVDA, launch_conv3x3(h->x, h->wk[10], h->bias[10], h->da, batch, hh, ww, 128, 256, 0, 1, s));
+  SP_SITE(DIM_PROF_SP_CONVDA, conv(10, h->x, h->da, hh, ww, 128, 256, 0));
   {
     GemmArgs g;
     g.A0 = h->da; g.lda0 = 256; g.B = h->wk[11]; g.ldb = 256; g.bias = h->bias[11];

@@ -35,7 +35,8 @@ extern "C" {
 const char* dim_last_error(void);
 int dim_abi_version(void);
 int dim_device_synchronize(void);
-/* Tuning hook (experiments / A-B benchmarking): key 0 = conv3x3 kernel variant. */
+/* Tuning hook (experiments / A-B benchmarking): key 0 = fp32 conv3x3 kernel variant; key 1 = matrix
+ * arithmetic: 1 (default) fp32-accurate products on the bf16 matrix cores ("bf16x6"), 0 = fp32 MFMA. */
 int dim_tune_set(int key, int value);
 
 /* Per-launch-site timing with HIP events recorded on the launch stream (bench.py's
@@ -228,6 +229,15 @@ int dim_lg_debug_desc(dim_lg* h, const float** desc, const int32_t** n_cur, cons
 int dim_op_gemm_f32(const float* A, int lda, const float* B, int ldb, int b_is_nk, const float* bias,
                     const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int relu, void* stream);
 
+/* fp32-accurate GEMM on the bf16 matrix cores (exact 3-way bf16 split, six cross terms; see
+ * csrc/gemm_x6.hip).  dim_x3_create splits a host [K][N] fp32 operand into the device layout
+ * [3][n_pad][K] bf16; dim_op_gemm_x6_f32 computes C = act(A*W + bias) (+ residual), act 0 none /
+ * 1 ReLU / 2 SELU.  K % 32 == 0. */
+int dim_x3_create(const float* w_kn_host, int K, int N, void** out_dev, int* n_pad_out);
+void dim_x3_destroy(void* dev);
+int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3_dev, int n_pad, const float* bias, const float* residual, int ldr,
+                       float* C, int ldc, int M, int N, int K, int act, void* stream);
+
 /* 3x3/s1/p1 conv, NHWC fp32, weights [9][cin][cout], bias+ReLU and optional
  * 2x2 max-pool fused (SPN:161-171).  cin in {64,128}, cout % 64 == 0. */
 int dim_op_conv3x3_nhwc_f32(const float* in, const float* w_tap_cin_cout, const float* bias, float* out, int batch,
@@ -235,6 +245,12 @@ int dim_op_conv3x3_nhwc_f32(const float* in, const float* w_tap_cin_cout, const 
 
 /* simple_nms (SPN:47-63) on [batch][H][W] score maps, radius 0..6; non-maxima -> 0. */
 int dim_op_simple_nms_f32(const float* score_map, float* out, int batch, int H, int W, int radius, void* stream);
+
+/* The same convolution on the bf16 matrix cores at fp32 accuracy (csrc/conv_x6.hip): weights are
+ * pre-split from the reference's OIHW fp32 layout by dim_convx6_create (free with dim_x3_destroy). */
+int dim_convx6_create(const float* w_oihw_host, int cin, int cout, void** out_dev);
+int dim_op_conv3x3_x6_nhwc_f32(const float* in, const void* w_x6_dev, const float* bias, float* out, int batch, int H, int W,
+                               int cin, int cout, int pool2x2, int relu, void* stream);
 
 /* conv1a: [batch][H][W] -> [batch][H][W][64], weights [9][64], bias, ReLU. */
 int dim_op_conv1a_f32(const float* in, const float* w_tap_cout, const float* bias, float* out, int batch, int H, int W,

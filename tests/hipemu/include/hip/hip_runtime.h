@@ -188,6 +188,32 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4(float a, float b, hipemu_f32x4 c)
   }
   return d;
 }
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31], fp32 accumulate.
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c) {
+  unsigned short ab[16];
+  memcpy(ab, &a, 16); memcpy(ab + 8, &b, 16);
+  unsigned stride; unsigned long long present;
+  const unsigned char* tab = hipemu::wave_exchange(ab, sizeof(ab), &stride, &present);
+  if (present != ~0ull) { fprintf(stderr, "hipemu: MFMA issued with a partial wave\n"); abort(); }
+  int l = hipemu::cur->lane, col = l & 31;
+  hipemu_f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      unsigned short ua, ub;
+      memcpy(&ua, tab + (size_t)(row + 32 * (k >> 3)) * stride + 2 * (k & 7), 2);
+      memcpy(&ub, tab + (size_t)(col + 32 * (k >> 3)) * stride + 16 + 2 * (k & 7), 2);
+      unsigned wa = (unsigned)ua << 16, wb = (unsigned)ub << 16;
+      float fa, fb; memcpy(&fa, &wa, 4); memcpy(&fb, &wb, 4);
+      acc = fmaf(fa, fb, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4((a), (b), (c))
 

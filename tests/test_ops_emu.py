@@ -52,3 +52,39 @@ def test_conv3x3_mfma(emu_lib, cin, cout, H, W, pool):
     if pool:
         ref = F.max_pool2d(ref, 2, 2)
     assert (out - ref.permute(0, 2, 3, 1)).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 65, 64), (130, 256, 512), (64, 130, 32)])
+def test_gemm_bf16x6_is_fp32_accurate(emu_lib, M, N, K):
+    """Exact 3-way bf16 split + six cross terms on the bf16 MFMA == fp32-class accuracy (vs fp64)."""
+    g = torch.Generator().manual_seed(K + M)
+    A, W = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g).contiguous()
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    C = torch.zeros(M, N)
+    dev, npad = ctypes.c_void_p(), ctypes.c_int()
+    assert emu_lib.dim_x3_create(p(W), K, N, ctypes.byref(dev), ctypes.byref(npad)) == 0
+    assert emu_lib.dim_op_gemm_x6_f32(p(A), K, dev, npad.value, p(bias), p(R), N, p(C), N, M, N, K, 0, None) == 0, emu_lib.dim_last_error()
+    emu_lib.dim_x3_destroy(dev)
+    ref = (A.double() @ W.double() + bias.double() + R.double())
+    mag = (A.abs().double() @ W.abs().double())
+    assert ((C.double() - ref).abs() / mag).max().item() < 4e-7
+
+
+@pytest.mark.parametrize("cin,cout,H,W,pool", [(64, 64, 20, 37, 1), (64, 128, 9, 33, 0), (128, 128, 16, 34, 1)])
+def test_conv3x3_bf16x6_is_fp32_accurate(emu_lib, cin, cout, H, W, pool):
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(2, cin, H, W, generator=g)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).contiguous()
+    b = torch.randn(cout, generator=g)
+    xin = x.permute(0, 2, 3, 1).contiguous()
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.full((2, Ho, Wo, cout), -7.0)
+    dev = ctypes.c_void_p()
+    assert emu_lib.dim_convx6_create(p(w), cin, cout, ctypes.byref(dev)) == 0
+    assert emu_lib.dim_op_conv3x3_x6_nhwc_f32(p(xin), dev, p(b), p(out), 2, H, W, cin, cout, pool, 1, None) == 0
+    emu_lib.dim_x3_destroy(dev)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    mag = F.conv2d(x.abs().double(), w.abs().double(), padding=1).max().item()
+    assert (out.double() - ref.permute(0, 2, 3, 1)).abs().max().item() / mag < 4e-7
