@@ -88,7 +88,7 @@ def build_emu(verbose: bool = False) -> Path:
     """Host-clang build of the same sources against tests/hipemu (CPU tests only)."""
     emu = ROOT / "tests" / "hipemu"
     out = emu / "libdim_hip_emu.so"
-    flags = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-Wno-psabi", "-Wno-unused-value", "-I", str(emu / "include")]
+    flags = ["-std=c++17", "-O2", "-march=native", "-fPIC", "-ffp-contract=off", "-Wno-psabi", "-Wno-unused-value", "-I", str(emu / "include")]
     srcs = _sources()
     objs, changed = _compile_all(
         emu / "build",

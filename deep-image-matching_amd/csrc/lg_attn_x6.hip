@@ -1,0 +1,201 @@
+// LightGlue attention on the bf16 matrix cores at fp32 accuracy ("bf16x6"; see dim_common.h split3_pk,
+// gemm_x6.hip).  Same algorithm and dataflow as lg_attn.hip — transposed score tile
+// S^T[key][query] = K·Q^T so that every lane owns one query column, probabilities fed back as the B
+// operand of O^T[d][query] += V^T·P^T without leaving registers, log2-domain online softmax with
+// deferred rescale — but each 32x32x16 step is six v_mfma_f32_32x32x16_bf16 (192 cycles) instead of
+// eight v_mfma_f32_32x32x2_f32 (512 cycles).
+//
+// Operand images (one 16-B ds_read_b128 = one MFMA operand, consecutive lanes -> consecutive slots):
+//   Kp[plane][d-block 8][key 32][8 bf16]          A operand of K·Q^T   (k = d)
+//   Vp[plane][step 2][k-half 2][d 64][8 keys]     A operand of V^T·P^T (k = key), keys stored in the
+//       order in which the MFMA C layout of S^T holds them: register 8u+e of lane-half h holds key
+//       (e&3) + 8*(2u + (e>>2)) + 4h, so registers 8u..8u+7 of P ARE the B operand of step u.
+//   Q is split once into registers (4 steps x 3 planes).
+#include <math.h>
+
+#include "lg_kernels.h"
+
+namespace {
+
+struct AttnArgs6 {
+  const float* q; const float* k; const float* v; float* o;
+  int ldq, ldk, ldv, ldo;
+  long long sq, sk, sv, so;
+  const int* n; const int* done;
+  int cross;
+  float scale;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
+  const int item = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+  if (a.done[item >> 1] != 0) return;
+  const int kitem = a.cross ? (item ^ 1) : item;
+  const int nq = a.n[item], nk = a.n[kitem];
+  if (q0 >= nq) return;
+
+  __shared__ u32x4 Kp[3 * 8 * 32];
+  __shared__ u32x4 Vp[3 * 2 * 2 * 64];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, lx = lane & 31, half = lane >> 5;
+  const int qrow = q0 + wv * 32 + lx;
+  const bool qok = qrow < nq;
+
+  // Q^T operand: lane (query lx, half) holds d = 16s + 8*half + 0..7 for s = 0..3, three planes each
+  u32x4 qf[4][3];
+  {
+    const float* qp = a.q + (size_t)item * a.sq + (size_t)(qok ? qrow : 0) * a.ldq + head * 64 + half * 8;
+    const float sc = a.scale * 1.44269504088896340736f;  // scores in the log2 domain
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+      if (qok) { x0 = *(const float4*)(qp + 16 * s); x1 = *(const float4*)(qp + 16 * s + 4); }
+      unsigned h[4], m[4], l[4];
+      split3_pk(x0.x * sc, x0.y * sc, h[0], m[0], l[0]); split3_pk(x0.z * sc, x0.w * sc, h[1], m[1], l[1]);
+      split3_pk(x1.x * sc, x1.y * sc, h[2], m[2], l[2]); split3_pk(x1.z * sc, x1.w * sc, h[3], m[3], l[3]);
+      qf[s][0] = u32x4{h[0], h[1], h[2], h[3]};
+      qf[s][1] = u32x4{m[0], m[1], m[2], m[3]};
+      qf[s][2] = u32x4{l[0], l[1], l[2], l[3]};
+    }
+  }
+  f32x16 oacc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[n][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  const float* kb = a.k + (size_t)kitem * a.sk + head * 64;
+  const float* vb = a.v + (size_t)kitem * a.sv + head * 64;
+
+  // staging roles: K — thread (key = t>>3, d-block = t&7) loads 8 consecutive d of one key;
+  //                V — thread (d = t&63, group g = t>>6 -> step u = g>>1, k-half h = g&1) loads its 8 keys of one d
+  const int k_key = t >> 3, k_blk = t & 7;
+  const int v_d = t & 63, v_u = t >> 7, v_h = (t >> 6) & 1;
+  float4 rk0, rk1;
+  float rv[8];
+  auto load_tile = [&](int kt) {
+    rk0 = make_float4(0.f, 0.f, 0.f, 0.f); rk1 = rk0;
+    if (kt + k_key < nk) {
+      const float* p = kb + (size_t)(kt + k_key) * a.ldk + k_blk * 8;
+      rk0 = *(const float4*)p; rk1 = *(const float4*)(p + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = (e & 3) + 8 * (2 * v_u + (e >> 2)) + 4 * v_h;
+      rv[e] = (kt + key < nk) ? vb[(size_t)(kt + key) * a.ldv + v_d] : 0.0f;
+    }
+  };
+  load_tile(0);
+  for (int kt = 0; kt < nk; kt += 32) {
+    {
+      unsigned h[4], m[4], l[4];
+      split3_pk(rk0.x, rk0.y, h[0], m[0], l[0]); split3_pk(rk0.z, rk0.w, h[1], m[1], l[1]);
+      split3_pk(rk1.x, rk1.y, h[2], m[2], l[2]); split3_pk(rk1.z, rk1.w, h[3], m[3], l[3]);
+      Kp[(0 * 8 + k_blk) * 32 + k_key] = u32x4{h[0], h[1], h[2], h[3]};
+      Kp[(1 * 8 + k_blk) * 32 + k_key] = u32x4{m[0], m[1], m[2], m[3]};
+      Kp[(2 * 8 + k_blk) * 32 + k_key] = u32x4{l[0], l[1], l[2], l[3]};
+      split3_pk(rv[0], rv[1], h[0], m[0], l[0]); split3_pk(rv[2], rv[3], h[1], m[1], l[1]);
+      split3_pk(rv[4], rv[5], h[2], m[2], l[2]); split3_pk(rv[6], rv[7], h[3], m[3], l[3]);
+      Vp[((0 * 2 + v_u) * 2 + v_h) * 64 + v_d] = u32x4{h[0], h[1], h[2], h[3]};
+      Vp[((1 * 2 + v_u) * 2 + v_h) * 64 + v_d] = u32x4{m[0], m[1], m[2], m[3]};
+      Vp[((2 * 2 + v_u) * 2 + v_h) * 64 + v_d] = u32x4{l[0], l[1], l[2], l[3]};
+    }
+    __syncthreads();
+    if (kt + 32 < nk) load_tile(kt + 32);
+
+    // ---- S^T = K · Q^T : 4 steps x 6 cross terms ----
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+    const int ta[6] = {1, 0, 2, 0, 1, 0}, tb[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4 kf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) kf[p] = Kp[(p * 8 + 2 * s + half) * 32 + lx];
+#pragma unroll
+      for (int tm = 0; tm < 6; ++tm) sacc = mfma_bf16(kf[ta[tm]], qf[s][tb[tm]], sacc);
+    }
+
+    // ---- online softmax (log2 domain, deferred rescale) ----
+    if (kt + 32 > nk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt + mfma_row(r, half) >= nk) sacc[r] = -INFINITY;
+    }
+    float tmax = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[r]), sacc[r + 1]);
+    tmax = fmaxf(tmax, sacc[15]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    constexpr float RESCALE_LOG2 = 8.0f;
+    if (__any(tmax > m_run + RESCALE_LOG2)) {
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
+      m_run = m_new;
+    }
+    float p[16];
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(sacc[r] - m_run);
+      psum += p[r];
+    }
+    l_run += psum;
+
+    // ---- O^T += V^T · P^T : registers 8u..8u+7 of p are the B operand of step u ----
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3_pk(p[8 * u + 2 * e], p[8 * u + 2 * e + 1], h[e], m[e], l[e]);
+      const u32x4 pf[3] = {u32x4{h[0], h[1], h[2], h[3]}, u32x4{m[0], m[1], m[2], m[3]}, u32x4{l[0], l[1], l[2], l[3]}};
+      u32x4 vf[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        vf[0][pl] = Vp[((pl * 2 + u) * 2 + half) * 64 + lx];
+        vf[1][pl] = Vp[((pl * 2 + u) * 2 + half) * 64 + 32 + lx];
+      }
+#pragma unroll
+      for (int tm = 0; tm < 6; ++tm) {
+        oacc[0] = mfma_bf16(vf[0][ta[tm]], pf[tb[tm]], oacc[0]);
+        oacc[1] = mfma_bf16(vf[1][ta[tm]], pf[tb[tm]], oacc[1]);
+      }
+    }
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (qok) {
+    float* op = a.o + (size_t)item * a.so + (size_t)qrow * a.ldo + head * 64;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // LGN:103-104: empty key set -> zeros
+        if (nk > 0) o = make_float4(oacc[n][4 * g] / l_tot, oacc[n][4 * g + 1] / l_tot, oacc[n][4 * g + 2] / l_tot, oacc[n][4 * g + 3] / l_tot);
+        *(float4*)(op + n * 32 + 8 * g + 4 * half) = o;
+      }
+  }
+}
+}  // namespace
+
+int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s) {
+  AttnArgs6 a;
+  const long long is = (long long)st.nmax * 768;
+  if (!cross) { a.q = st.qkv; a.k = st.qkv + 256; a.v = st.qkv + 512; }
+  else { a.q = st.qkv; a.k = st.qkv; a.v = st.qkv + 256; }
+  a.ldq = a.ldk = a.ldv = 768; a.sq = a.sk = a.sv = is;
+  a.o = st.ctx; a.ldo = 256; a.so = (long long)st.nmax * 256;
+  a.n = st.n_cur; a.done = st.done; a.cross = cross;
+  a.scale = 0.125f;
+  dim3 grid(cdiv(st.nmax, 128), 4, st.n_items);
+  hipLaunchKernelGGL(attn_x6_kernel, grid, dim3(256), 0, s, a);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}

@@ -49,6 +49,7 @@ struct Wave {
   unsigned arrived[2];
   unsigned long long present[2];
   unsigned char buf[2][64][kSlot];
+  unsigned char res[2][64][64];
 };
 
 static void* sched_sp;
@@ -94,6 +95,29 @@ const unsigned char* wave_exchange(const void* in, unsigned bytes, unsigned* str
   *stride = kSlot;
   *present = w.present[p];
   return &w.buf[p][0][0];
+}
+
+// Collective with a wave-level result: every lane deposits `bytes`; the LAST lane to arrive runs
+// `compute` once over the whole table (writing 64 x out_bytes results); every lane then copies its own.
+void wave_collective(const void* in, unsigned bytes, void (*compute)(const unsigned char* tab, unsigned stride, unsigned char* out),
+                     unsigned out_bytes, void* my_out) {
+  if (bytes > kSlot || out_bytes > 64) { fprintf(stderr, "hipemu: collective too large\n"); abort(); }
+  Fiber* f = cur;
+  Wave& w = waves[f->wave];
+  unsigned op = ++f->opcount;
+  unsigned p = op & 1;
+  if (w.opid[p] != op) { w.opid[p] = op; w.arrived[p] = 0; w.present[p] = 0; }
+  memcpy(w.buf[p][f->lane], in, bytes);
+  w.present[p] |= 1ull << f->lane;
+  w.arrived[p]++;
+  progress = true;
+  if (w.arrived[p] >= w.alive) {
+    if (w.present[p] != ~0ull) { fprintf(stderr, "hipemu: MFMA issued with a partial wave (exec mask %016llx)\n", w.present[p]); abort(); }
+    compute(&w.buf[p][0][0], kSlot, &w.res[p][0][0]);
+  } else {
+    while (w.arrived[p] < w.alive) yield();
+  }
+  memcpy(my_out, w.res[p][f->lane], out_bytes);
 }
 
 static void run_block(dim3 block) {

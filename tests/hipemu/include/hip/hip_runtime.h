@@ -79,6 +79,8 @@ void barrier();
 // mask of lanes that took part.
 const unsigned char* wave_exchange(const void* in, unsigned bytes, unsigned* stride, unsigned long long* present);
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void wave_collective(const void* in, unsigned bytes, void (*compute)(const unsigned char* tab, unsigned stride, unsigned char* out),
+                     unsigned out_bytes, void* my_out);
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur->tid)
@@ -190,27 +192,36 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4(float a, float b, hipemu_f32x4 c)
 }
 // v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31], fp32 accumulate.
 typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline void hipemu_mfma_bf16_compute(const unsigned char* tab, unsigned stride, unsigned char* out) {
+  // tab[lane]: 8 bf16 of A, 8 bf16 of B.  out[lane]: 16 floats = sum_k A[row][k] * B[k][col] (fp32 fmaf chain from 0)
+  float A[32][16], B[16][32];
+  for (int l = 0; l < 64; ++l)
+    for (int e = 0; e < 8; ++e) {
+      unsigned short ua, ub;
+      memcpy(&ua, tab + (size_t)l * stride + 2 * e, 2);
+      memcpy(&ub, tab + (size_t)l * stride + 16 + 2 * e, 2);
+      unsigned wa = (unsigned)ua << 16, wb = (unsigned)ub << 16;
+      memcpy(&A[l & 31][8 * (l >> 5) + e], &wa, 4);
+      memcpy(&B[8 * (l >> 5) + e][l & 31], &wb, 4);
+    }
+  for (int l = 0; l < 64; ++l) {
+    float* o = (float*)(out + (size_t)l * 64);
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      float acc = 0.f;
+      for (int k = 0; k < 16; ++k) acc = fmaf(A[row][k], B[k][col], acc);
+      o[r] = acc;
+    }
+  }
+}
 static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c) {
   unsigned short ab[16];
   memcpy(ab, &a, 16); memcpy(ab + 8, &b, 16);
-  unsigned stride; unsigned long long present;
-  const unsigned char* tab = hipemu::wave_exchange(ab, sizeof(ab), &stride, &present);
-  if (present != ~0ull) { fprintf(stderr, "hipemu: MFMA issued with a partial wave\n"); abort(); }
-  int l = hipemu::cur->lane, col = l & 31;
+  float prod[16];
+  hipemu::wave_collective(ab, sizeof(ab), hipemu_mfma_bf16_compute, 64, prod);
   hipemu_f32x16 d = c;
-  for (int r = 0; r < 16; ++r) {
-    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-    float acc = c[r];
-    for (int k = 0; k < 16; ++k) {
-      unsigned short ua, ub;
-      memcpy(&ua, tab + (size_t)(row + 32 * (k >> 3)) * stride + 2 * (k & 7), 2);
-      memcpy(&ub, tab + (size_t)(col + 32 * (k >> 3)) * stride + 16 + 2 * (k & 7), 2);
-      unsigned wa = (unsigned)ua << 16, wb = (unsigned)ub << 16;
-      float fa, fb; memcpy(&fa, &wa, 4); memcpy(&fb, &wb, 4);
-      acc = fmaf(fa, fb, acc);
-    }
-    d[r] = acc;
-  }
+  for (int r = 0; r < 16; ++r) d[r] = c[r] + prod[r];
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_32x32x16_bf16((a), (b), (c))
