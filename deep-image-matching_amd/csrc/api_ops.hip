@@ -128,6 +128,7 @@ int dim_op_conv3x3_x6_nhwc_f32(const float* in, const void* w_x6_dev, const floa
 int dim_tune_set(int key, int value) {
   if (key == 0) dim_conv_set_variant(value);
   if (key == 1) g_precision_mode = value;
+  if (key == 2) dim_conv_x6_set_variant(value);
   return 0;
 }
 

@@ -20,8 +20,10 @@ namespace {
 constexpr int TH = 8, TW = 32, IW = TW + 2, IH = TH + 2, NPIX = IH * IW;  // 340 halo pixels
 constexpr int W_SLICE = 3 * 3 * 2 * 64 * 8;                              // bf16 elements per (cb, chunk, dy) slice
 
-template <int CIN, int POOL>
-__global__ __launch_bounds__(256, 3) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
+// PF: 0 = no software prefetch, 1 = next weight slice fetched into registers behind the MFMAs,
+//     2 = additionally the next chunk's halo tile (24 more VGPRs: 2 instead of 3 workgroups per CU).
+template <int CIN, int POOL, int PF>
+__global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                             int cout, int relu, int tiles_x) {
   __shared__ u32x4 Ip[3 * 2 * NPIX];
@@ -43,31 +45,70 @@ __global__ __launch_bounds__(256, 3) void conv3x3_x6_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  for (int c = 0; c < NCHUNK; ++c) {
-    __syncthreads();  // every wave is done with the previous chunk's Ip / Wp
-    // ---- stage + split the halo tile: 340 pixels x 16 channels, one float4 (4 channels) per item ----
-    for (int i = t; i < NPIX * 4; i += 256) {
-      const int p = i >> 2, q = i & 3;
+  constexpr int NWV = (W_SLICE / 8 + 255) / 256;   // 16-B weight items per thread per slice (4.5 -> 5)
+  constexpr int NIN = (NPIX * 4 + 255) / 256;       // float4 halo items per thread per chunk (5.3 -> 6)
+  u32x4 rw[NWV];
+  float4 rin[NIN];
+  auto load_w = [&](int c, int dy) {
+    const u32x4* src = (const u32x4*)(wx + ((size_t)(cb * NCHUNK + c) * 3 + dy) * W_SLICE);
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < W_SLICE / 8) rw[i] = src[idx];
+    }
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < W_SLICE / 8) Wp[idx] = rw[i];
+    }
+  };
+  auto load_in = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = t + 256 * i;
+      const int p = idx >> 2, q = idx & 3;
       const int py = p / IW, px = p - py * IW;
       const int gy = oy + py - 1, gx = ox + px - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *(const float4*)(in_b + ((size_t)gy * W + gx) * CIN + c * 16 + q * 4);
-      unsigned h0, m0, l0, h1, m1, l1;
-      split3_pk(v.x, v.y, h0, m0, l0);
-      split3_pk(v.z, v.w, h1, m1, l1);
-      // channels q*4..q*4+3 live in k-half q>>1, dwords (q&1)*2, +1 of that pixel's 16-B slot
-      unsigned* d = (unsigned*)&Ip[(q >> 1) * NPIX + p] + (q & 1) * 2;
-      d[0] = h0; d[1] = h1;
-      d[2 * NPIX * 4] = m0; d[2 * NPIX * 4 + 1] = m1;
-      d[4 * NPIX * 4] = l0; d[4 * NPIX * 4 + 1] = l1;
+      rin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(in_b + ((size_t)gy * W + gx) * CIN + c * 16 + q * 4);
     }
+  };
+  auto store_in = [&]() {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < NPIX * 4) {
+        const int p = idx >> 2, q = idx & 3;
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3_pk(rin[i].x, rin[i].y, h0, m0, l0);
+        split3_pk(rin[i].z, rin[i].w, h1, m1, l1);
+        // channels q*4..q*4+3 live in k-half q>>1, dwords (q&1)*2, +1 of that pixel's 16-B slot
+        unsigned* d = (unsigned*)&Ip[(q >> 1) * NPIX + p] + (q & 1) * 2;
+        d[0] = h0; d[1] = h1;
+        d[2 * NPIX * 4] = m0; d[2 * NPIX * 4 + 1] = m1;
+        d[4 * NPIX * 4] = l0; d[4 * NPIX * 4 + 1] = l1;
+      }
+    }
+  };
+
+  if (PF >= 1) load_w(0, 0);
+  if (PF == 2) load_in(0);
+  for (int c = 0; c < NCHUNK; ++c) {
+    __syncthreads();  // every wave is done with the previous chunk's Ip / Wp
+    if (PF != 2) load_in(c);
+    store_in();
     for (int dy = 0; dy < 3; ++dy) {
       if (dy > 0) __syncthreads();  // previous kernel row's weights consumed
-      {
-        const u32x4* src = (const u32x4*)(wx + ((size_t)(cb * NCHUNK + c) * 3 + dy) * W_SLICE);
-        for (int i = t; i < W_SLICE / 8; i += 256) Wp[i] = src[i];
-      }
+      if (PF == 0) load_w(c, dy);
+      store_w();
       __syncthreads();
+      if (PF >= 1) {  // next slice (and, at the last kernel row, the next halo tile) behind the MFMAs
+        if (dy < 2) load_w(c, dy + 1);
+        else if (c + 1 < NCHUNK) load_w(c + 1, 0);
+      }
+      if (PF == 2 && dy == 2 && c + 1 < NCHUNK) load_in(c + 1);
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         u32x4 fa[2][3], fb[2][3];
@@ -152,6 +193,10 @@ void prepare_conv_weights_x6(const float* w_oihw, int cin, int cout, unsigned sh
         }
 }
 
+static int g_conv_x6_variant = 1;
+int dim_conv_x6_variant() { return g_conv_x6_variant; }
+void dim_conv_x6_set_variant(int v) { g_conv_x6_variant = v; }
+
 int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bias, float* out, int batch, int H, int W, int cin,
                       int cout, int pool, int relu, hipStream_t s) {
   DIM_REQUIRE(cout % 64 == 0, "conv3x3_x6: cout=%d must be a multiple of 64", cout);
@@ -159,11 +204,20 @@ int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bi
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-#define DIM_CONV6(CI, P) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x)
-  if (cin == 64 && pool) DIM_CONV6(64, 1);
-  else if (cin == 64) DIM_CONV6(64, 0);
-  else if (pool) DIM_CONV6(128, 1);
-  else DIM_CONV6(128, 0);
+#define DIM_CONV6(CI, P, PFV) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x)
+#define DIM_CONV6_V(PFV)                                  \
+  {                                                       \
+    if (cin == 64 && pool) DIM_CONV6(64, 1, PFV);         \
+    else if (cin == 64) DIM_CONV6(64, 0, PFV);            \
+    else if (pool) DIM_CONV6(128, 1, PFV);                \
+    else DIM_CONV6(128, 0, PFV);                          \
+  }
+  switch (dim_conv_x6_variant()) {
+    case 0: DIM_CONV6_V(0) break;
+    case 2: DIM_CONV6_V(2) break;
+    default: DIM_CONV6_V(1) break;
+  }
+#undef DIM_CONV6_V
 #undef DIM_CONV6
   DIM_LAUNCH_CHECK();
   return 0;

@@ -46,6 +46,7 @@ void prepare_conv_weights_x6(const float* w_oihw, int cin, int cout, unsigned sh
 int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bias, float* out, int batch, int H, int W, int cin,
                       int cout, int pool, int relu, hipStream_t s);
 int dim_precision_mode();  // 1 (default): bf16x6 on the bf16 matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
+void dim_conv_x6_set_variant(int v);  // tuning hook: prefetch variant of conv3x3_x6 (dim_tune_set key 2)
 void dim_conv_set_variant(int v);  // tuning hook: selects the conv3x3 kernel variant (see conv.hip)
 // conv1a: 1 -> 64 channels, direct (VALU) convolution; in: [B][H][W], w: [9][64].
 int launch_conv1a(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W,

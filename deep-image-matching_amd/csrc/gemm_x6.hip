@@ -5,10 +5,12 @@
 // 8 x 64 = 512 cycles (v_mfma_f32_32x32x2_f32) to 6 x 32 = 192 cycles: an effective dense peak of
 // 2.5 PF / 6 = 417 TFLOP/s instead of 157.
 //
-// Same tiling as gemm.hip (128x128 block, 4 waves of 64x64, K chunks of 32).  Weights are pre-split on
-// the host into three [N][K] bf16 planes (k contiguous: one 16-B LDS read is one MFMA operand);
-// activations are split while they are staged.  LDS images are [plane][128][40 bf16] — the 80-byte row
-// stride makes every 16-lane group of a ds_read_b128 cover all 64 banks exactly once.
+// Same tiling as gemm.hip (128x128 block, 4 waves of 64x64, K chunks of 32).  Activations are split
+// while they are staged into LDS ([plane][128][40 bf16]: the 80-byte row stride makes every 16-lane
+// group of a ds_read_b128 cover all 64 banks exactly once).  Weights are pre-split on the host and
+// stored in HBM directly in MFMA-fragment order, [plane][N/32][K/16][k-half][32 cols][8 k], so a
+// wave fetches a B operand with ONE fully coalesced 1-KiB global load and the weights never touch
+// LDS (they are L2-resident: at most 1.5 MB per layer).
 #include <math.h>
 #include <string.h>
 
@@ -17,7 +19,7 @@
 namespace {
 constexpr int BM = 128, BN = 128, KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
 
-__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
@@ -25,13 +27,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs a) {
   if (m0 >= rows || n0 >= a.N) return;
 
   __shared__ unsigned Ap[3 * BM * RS];
-  __shared__ unsigned Bp[3 * BN * RS];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1, lx = lane & 31, half = lane >> 5;
   const float* A0 = a.A0 + (size_t)(a.a_idx ? a.a_idx[z] : z) * a.strideA0;
   const float* A1 = a.A1 ? a.A1 + (size_t)z * a.strideA1 : nullptr;
-  const unsigned short* Bx = a.Bx3;
+  const int NB = a.n_pad / 32, KS = a.K / 16;
+  // this lane's slot inside a [k-half][32 cols] fragment block, for its two 32-column groups
+  const u32x4* Bf = (const u32x4*)a.Bx3;
+  const size_t nb0 = (size_t)(n0 + wn * 64) / 32;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -42,7 +46,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   float4 ra[4];
-  u32x4 rb[6];
   auto load_chunk = [&](int k0) {
     const float* src; int ld, kk0;
     if (A1 == nullptr || k0 < a.ksplit) { src = A0; ld = a.lda0; kk0 = k0; }
@@ -52,11 +55,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs a) {
       const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m0 + row < rows) ra[i] = *(const float4*)(src + (size_t)(m0 + row) * ld + kk0 + q * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int idx = t + 256 * i, p = idx >> 9, rem = idx & 511, col = rem >> 2, part = rem & 3;
-      rb[i] = *(const u32x4*)(Bx + ((size_t)p * a.n_pad + n0 + col) * a.K + k0 + part * 8);
     }
   };
   auto store_chunk = [&]() {
@@ -71,11 +69,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs a) {
       d[BM * RS] = m[0]; d[BM * RS + 1] = m[1];
       d[2 * BM * RS] = l[0]; d[2 * BM * RS + 1] = l[1];
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int idx = t + 256 * i, p = idx >> 9, rem = idx & 511, col = rem >> 2, part = rem & 3;
-      *(u32x4*)&Bp[(p * BN + col) * RS + part * 4] = rb[i];
-    }
   };
 
   load_chunk(0);
@@ -89,9 +82,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * 64 + m * 32 + lx) * RS + ks * 8 + half * 4];
+        for (int n = 0; n < 2; ++n) fb[n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + (k0 >> 4) + ks) * 2 + half) * 32 + lx];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) fb[n][p] = *(const u32x4*)&Bp[(p * BN + wn * 64 + n * 32 + lx) * RS + ks * 8 + half * 4];
+        for (int m = 0; m < 2; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * 64 + m * 32 + lx) * RS + ks * 8 + half * 4];
       }
       // six cross terms, smallest first; the four accumulators interleave so no MFMA waits on its predecessor
       const int ta[6] = {1, 0, 2, 0, 1, 0}, tb[6] = {1, 2, 0, 1, 0, 0};
@@ -131,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs a) {
 
 int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.Bx3 != nullptr && !a.bt, "gemm_x6: needs pre-split [3][n_pad][K] weights");
+  DIM_REQUIRE(a.K % 16 == 0, "gemm_x6: K");
   DIM_REQUIRE(a.K % KC == 0 && (a.A1 == nullptr || a.ksplit % KC == 0), "gemm_x6: K=%d / ksplit=%d must be multiples of %d", a.K, a.ksplit, KC);
   DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
   DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
@@ -151,16 +145,19 @@ static unsigned short host_bf16_rne(float x) {
   return (unsigned short)(u >> 16);
 }
 void split_weights_x3(const float* w_kn, int K, int N, int n_pad, unsigned short* out) {
+  // [plane][n_pad/32][K/16][k-half][32 cols][8 k]
+  const int NB = n_pad / 32, KS = K / 16;
   for (size_t i = 0; i < (size_t)3 * n_pad * K; ++i) out[i] = 0;
   for (int k = 0; k < K; ++k)
     for (int n = 0; n < N; ++n) {
       float x = w_kn[(size_t)k * N + n];
+      const int nb = n / 32, j = n % 32, ks = k / 16, hf = (k % 16) / 8, e = k % 8;
       for (int p = 0; p < 3; ++p) {
         const unsigned short hb = host_bf16_rne(x);
         const unsigned u = (unsigned)hb << 16;
         float h;
         memcpy(&h, &u, 4);
-        out[((size_t)p * n_pad + n) * K + k] = hb;
+        out[(((((size_t)p * NB + nb) * KS + ks) * 2 + hf) * 32 + j) * 8 + e] = hb;
         x = x - h;
       }
     }
