@@ -13,10 +13,18 @@ sharded across ranks (weak scaling: every rank runs K steps of `--pairs` pairs) 
 data-path collective; after the last step the per-rank match tables are exchanged with ONE
 RCCL all-gather (inside the timed region), as north_star asks.
 
+Arithmetic: fp32 results ("dtype": "f32").  Matrix products run on the bf16 matrix cores with every
+fp32 operand split exactly into three bf16 pieces and the six leading cross terms accumulated in
+fp32 ("bf16x6", csrc/gemm_x6.hip): fp32-class accuracy (hardware probe 1.3e-7 of sum|a*b| vs 1.2e-7
+for an fp32 fmaf chain) at 6 bf16 MFMAs per product step instead of 8 fp32 MFMAs.
+
 Rank 0 prints one JSON line carrying the contract fields plus
-  roofline     — the dominant kernel (conv3x3_mfma_kernel<64,1>: conv1b+conv2b, 54 % of SuperPoint's
-                 FLOPs) timed live with HIP events on the launch stream over the timed region,
-                 against the fp32-MFMA peak;
+  roofline     — the dominant kernel (conv3x3_x6_kernel<64,1>: conv1b+conv2b, 54 % of SuperPoint's
+                 FLOPs) timed live with HIP events on the launch stream over the timed region;
+                 `achieved` counts ALGORITHMIC fp32 FLOPs; `peak` is the dense bf16 MFMA peak of
+                 MI355X_MICROARCH.md divided by the six passes the fp32-accurate product needs
+                 (2500 / 6 = 416.7 TFLOP/s); the fraction of the plain fp32-MFMA peak (157.3) is
+                 reported beside it;
   cpu_baseline — the oracle (CPU restatement of the reference path) timed on this box's host
                  cores on a bounded sample of the same workload.
 """
@@ -42,6 +50,8 @@ LG_GFLOP_PER_PAIR = 229.8         # 2048 x 2048, 9 layers, fixed work
 CONV1B_GFLOP_PER_IMAGE = 2 * 38.655  # Appendix B: 3x3, 64->64 @1024^2 (+ReLU+pool)
 CONV2B_GFLOP_PER_IMAGE = 2 * 9.664   # Appendix B: 3x3, 64->64 @512^2  (+ReLU+pool) — same kernel instance
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+X6_PASSES = 6                     # bf16 MFMA terms per fp32-accurate product step (hh, hm, mh, hl, lh, mm)
 
 
 def parse():
@@ -147,7 +157,7 @@ def main():
     for i in range(W):
         step(i, 0)
     barrier()
-    # time every launch of conv3x3_mfma_kernel<64,1> (sites conv1b and conv2b) with HIP events on the launch stream
+    # time every launch of conv3x3_x6_kernel<64,1,*> (sites conv1b and conv2b) with HIP events on the launch stream
     capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong((1 << 1) | (1 << 3))))  # DIM_PROF_SP_CONV1B | DIM_PROF_SP_CONV2B
     t0 = time.perf_counter()
     for i in range(K):
@@ -187,16 +197,20 @@ def main():
             "metric": "image-pairs/s (SuperPoint+LightGlue, 1024^2, 2048 kpts)",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "arithmetic": "fp32 results; matrix products as exact 3-way bf16 splits x 6 bf16-MFMA cross terms (fp32-class accuracy)", "data": "synthetic",
             "config": {"workload": "configs[2]: SuperPoint+LightGlue, synthetic 1024x1024 grayscale pairs @2048 kpts, "
                                    "2 extractions + 1 match per pair, LightGlue fixed-work (9 layers, no early stop/pruning), "
                                    "seeded synthetic weights", "pairs_per_step_per_gpu": P, "image": "1024x1024",
                        "keypoints": 2048, "all_2048_kpts": n_kpts_ok, "gflop_per_pair": 2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR,
                        "sharding": f"pairs sharded over {world} rank(s), one RCCL all-gather of match tables at the end"},
             "end_to_end_tflops_per_gpu": (2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR) * value / world / 1e3,
-            "roofline": {"kernel": "conv3x3_mfma_kernel<64,1> (3x3 conv 64->64 + bias + ReLU + 2x2 max-pool; launch sites conv1b @1024^2 and conv2b @512^2)", "bound": "mfma",
-                         "achieved": conv_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1> (3x3 conv 64->64 + bias + ReLU + 2x2 max-pool, fp32-accurate on bf16 MFMA; "
+                                   "launch sites conv1b @1024^2 and conv2b @512^2)", "bound": "mfma",
+                         "achieved": conv_tflops, "peak": PEAK_BF16_MFMA_TFLOPS / X6_PASSES, "unit": "TFLOP/s",
+                         "frac": conv_tflops / (PEAK_BF16_MFMA_TFLOPS / X6_PASSES),
+                         "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMA passes per fp32-accurate product; "
+                                      "the kernel runs power-limited at ~1.65 GHz with ~74 % MFMA-busy (profiles/)",
+                         "frac_of_fp32_mfma_peak": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": conv_ms, "launches": launches.value,
                          "algorithmic_gflop_per_launch": gflop_per_launch},
         }
