@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=8, help="pairs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=3)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=4)
     return ap.parse_args()
 
 
@@ -70,7 +70,10 @@ def cpu_baseline(n_pairs: int):
     from oracle import lightglue_ref, superpoint_ref
 
     weights = importlib.import_module(PKG + ".weights")
-    cores = torch.get_num_threads()
+    # torch CPU peaks at 16-32 threads on this path (measured on the GPU box's 256-CPU host: 8 thr 0.25, 16 thr 0.28,
+    # 32 thr 0.28, 64 thr 0.19, 128 thr 0.08 pairs/s), so the baseline runs at its best setting
+    cores = min(16, os.cpu_count() or 16)
+    torch.set_num_threads(cores)
     sp_sd = weights.synthetic_superpoint_state_dict(1234)
     lg_sd = weights.synthetic_lightglue_state_dict(0, 256)
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
