@@ -154,6 +154,7 @@ int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pai
   LG_TRY(dev_alloc(h, &st.arg, I * N)); LG_TRY(dev_alloc(h, &st.n_cur, I)); LG_TRY(dev_alloc(h, &st.n_new, I));
   LG_TRY(dev_alloc(h, &st.n_orig, I)); LG_TRY(dev_alloc(h, &st.ind, I * N)); LG_TRY(dev_alloc(h, &st.dest, I * N));
   LG_TRY(dev_alloc(h, &st.prune, I * N)); LG_TRY(dev_alloc(h, &st.done, P)); LG_TRY(dev_alloc(h, &st.cnt_lt, P));
+  { unsigned char* kvp = nullptr; LG_TRY(dev_alloc(h, &kvp, I * 4 * ((N + 31) / 32) * 1536 * 16)); st.kv_img = kvp; }
   LG_TRY(dev_alloc(h, &st.tdesc, I * N * 256)); LG_TRY(dev_alloc(h, &st.tenc, I * N * 64)); LG_TRY(dev_alloc(h, &st.tind, I * N));
 #undef LG_TRY
   *out = h;
@@ -199,7 +200,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     const LayerW& w = h->L[i];
     // ---- self block (LGN:146-159) ----
     LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.qkv_w, w.qkv_x, 768, w.qkv_b, nullptr, st.qkv, 768, s768, 768, 256, 0));
-    LG_RUN(launch_lg_rotary(st, s));
+    if (!x6) LG_RUN(launch_lg_rotary(st, s));  // the bf16x6 attention applies the rotary embedding while it loads q / pre-splits k
     dim_prof_begin(DIM_PROF_LG_SELF_ATTN, s);
     LG_RUN(launch_lg_attention(st, 0, s));
     dim_prof_end(DIM_PROF_LG_SELF_ATTN, s);

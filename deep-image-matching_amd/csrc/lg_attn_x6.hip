@@ -10,7 +10,11 @@
 //   Vp[plane][step 2][k-half 2][d 64][8 keys]     A operand of V^T·P^T (k = key), keys stored in the
 //       order in which the MFMA C layout of S^T holds them: register 8u+e of lane-half h holds key
 //       (e&3) + 8*(2u + (e>>2)) + 4h, so registers 8u..8u+7 of P ARE the B operand of step u.
-//   Q is split once into registers (4 steps x 3 planes).
+//   Q is split once into registers (4 steps x 3 planes), with the rotary embedding applied on load.
+// K and V are split ONCE per layer by kv_prep_kernel (rotary applied to K for self-attention) into
+// per-tile images laid out exactly like Kp / Vp, so the 16 query blocks that share a (item, head)
+// stage a tile with six straight 16-byte copies per thread (no per-block split work, no LDS bank
+// conflicts: consecutive lanes write consecutive slots).
 #include <math.h>
 
 #include "lg_kernels.h"
@@ -24,7 +28,64 @@ struct AttnArgs6 {
   const int* n; const int* done;
   int cross;
   float scale;
+  const float* enc;      // [items][nmax][64] cos|sin; rotary is applied to q (and k) iff !cross
+  u32x4* kv_img;         // [items][4 heads][tiles][1536] pre-split K|V tile images (kv_prep_kernel)
+  int nmax, tiles;
 };
+
+constexpr int TILE_SLOTS = 3 * 8 * 32 + 3 * 2 * 2 * 64;  // 768 K slots + 768 V slots of 16 B
+
+// One workgroup per (key tile, head, item): rotary on K (self-attention only, LGN:41-54,155-156), exact
+// 3-way bf16 split of K and V, written in the LDS-image order of attn_x6_kernel.
+__global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
+  const int tile = blockIdx.x, head = blockIdx.y, item = blockIdx.z;
+  if (a.done[item >> 1] != 0) return;
+  const int nk = a.n[item], kt = tile * 32;
+  if (kt >= nk) return;
+  const int t = threadIdx.x;
+  const float* kb = a.k + (size_t)item * a.sk + head * 64;
+  const float* vb = a.v + (size_t)item * a.sv + head * 64;
+  u32x4* img = a.kv_img + (((size_t)item * 4 + head) * a.tiles + tile) * TILE_SLOTS;
+  {  // K: thread (key = t>>3, d-block = t&7)
+    const int key = t >> 3, blk = t & 7;
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (kt + key < nk) {
+      const float* p = kb + (size_t)(kt + key) * a.ldk + blk * 8;
+      const float4 x0 = *(const float4*)p, x1 = *(const float4*)(p + 4);
+      x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+      if (!a.cross) {
+        const float* e = a.enc + ((size_t)item * a.nmax + kt + key) * 64 + blk * 4;  // pairs 4*blk .. 4*blk+3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float c = e[i], sn = e[32 + i], t0 = x[2 * i], t1 = x[2 * i + 1];
+          x[2 * i] = t0 * c + (-t1) * sn;
+          x[2 * i + 1] = t1 * c + t0 * sn;
+        }
+      }
+    }
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split3_pk(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
+    img[(0 * 8 + blk) * 32 + key] = u32x4{h[0], h[1], h[2], h[3]};
+    img[(1 * 8 + blk) * 32 + key] = u32x4{m[0], m[1], m[2], m[3]};
+    img[(2 * 8 + blk) * 32 + key] = u32x4{l[0], l[1], l[2], l[3]};
+  }
+  {  // V: thread (d = t&63, step u = t>>7, k-half h = (t>>6)&1), keys in MFMA-C-layout order
+    const int d = t & 63, u = t >> 7, hh = (t >> 6) & 1;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hh;
+      x[e] = (kt + key < nk) ? vb[(size_t)(kt + key) * a.ldv + d] : 0.0f;
+    }
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split3_pk(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
+    img[768 + ((0 * 2 + u) * 2 + hh) * 64 + d] = u32x4{h[0], h[1], h[2], h[3]};
+    img[768 + ((1 * 2 + u) * 2 + hh) * 64 + d] = u32x4{m[0], m[1], m[2], m[3]};
+    img[768 + ((2 * 2 + u) * 2 + hh) * 64 + d] = u32x4{l[0], l[1], l[2], l[3]};
+  }
+}
 
 __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
   const int item = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
@@ -33,8 +94,9 @@ __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
   const int nq = a.n[item], nk = a.n[kitem];
   if (q0 >= nq) return;
 
-  __shared__ u32x4 Kp[3 * 8 * 32];
-  __shared__ u32x4 Vp[3 * 2 * 2 * 64];
+  __shared__ u32x4 img[TILE_SLOTS];
+  u32x4* Kp = img;
+  u32x4* Vp = img + 768;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, lx = lane & 31, half = lane >> 5;
   const int qrow = q0 + wv * 32 + lx;
@@ -47,11 +109,23 @@ __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
     const float sc = a.scale * 1.44269504088896340736f;  // scores in the log2 domain
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-      if (qok) { x0 = *(const float4*)(qp + 16 * s); x1 = *(const float4*)(qp + 16 * s + 4); }
+      float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (qok) {
+        const float4 x0 = *(const float4*)(qp + 16 * s), x1 = *(const float4*)(qp + 16 * s + 4);
+        x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+        if (!a.cross) {  // rotary (LGN:41-54,155): d = 16s + 8half + 2i, +1 <-> frequency 8s + 4half + i
+          const float* e = a.enc + ((size_t)item * a.nmax + qrow) * 64 + 8 * s + 4 * half;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float c = e[i], sn = e[32 + i], t0 = x[2 * i], t1 = x[2 * i + 1];
+            x[2 * i] = t0 * c + (-t1) * sn;
+            x[2 * i + 1] = t1 * c + t0 * sn;
+          }
+        }
+      }
       unsigned h[4], m[4], l[4];
-      split3_pk(x0.x * sc, x0.y * sc, h[0], m[0], l[0]); split3_pk(x0.z * sc, x0.w * sc, h[1], m[1], l[1]);
-      split3_pk(x1.x * sc, x1.y * sc, h[2], m[2], l[2]); split3_pk(x1.z * sc, x1.w * sc, h[3], m[3], l[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) split3_pk(x[2 * i] * sc, x[2 * i + 1] * sc, h[i], m[i], l[i]);
       qf[s][0] = u32x4{h[0], h[1], h[2], h[3]};
       qf[s][1] = u32x4{m[0], m[1], m[2], m[3]};
       qf[s][2] = u32x4{l[0], l[1], l[2], l[3]};
@@ -64,42 +138,18 @@ __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
     for (int r = 0; r < 16; ++r) oacc[n][r] = 0.0f;
   float m_run = -INFINITY, l_run = 0.0f;
 
-  const float* kb = a.k + (size_t)kitem * a.sk + head * 64;
-  const float* vb = a.v + (size_t)kitem * a.sv + head * 64;
-
-  // staging roles: K — thread (key = t>>3, d-block = t&7) loads 8 consecutive d of one key;
-  //                V — thread (d = t&63, group g = t>>6 -> step u = g>>1, k-half h = g&1) loads its 8 keys of one d
-  const int k_key = t >> 3, k_blk = t & 7;
-  const int v_d = t & 63, v_u = t >> 7, v_h = (t >> 6) & 1;
-  float4 rk0, rk1;
-  float rv[8];
+  // staging: six straight 16-byte copies per thread per tile (images pre-built by kv_prep_kernel)
+  const u32x4* src = a.kv_img + ((size_t)kitem * 4 + head) * a.tiles * TILE_SLOTS;
+  u32x4 rt[6];
   auto load_tile = [&](int kt) {
-    rk0 = make_float4(0.f, 0.f, 0.f, 0.f); rk1 = rk0;
-    if (kt + k_key < nk) {
-      const float* p = kb + (size_t)(kt + k_key) * a.ldk + k_blk * 8;
-      rk0 = *(const float4*)p; rk1 = *(const float4*)(p + 4);
-    }
+    const u32x4* p = src + (size_t)(kt >> 5) * TILE_SLOTS;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int key = (e & 3) + 8 * (2 * v_u + (e >> 2)) + 4 * v_h;
-      rv[e] = (kt + key < nk) ? vb[(size_t)(kt + key) * a.ldv + v_d] : 0.0f;
-    }
+    for (int i = 0; i < 6; ++i) rt[i] = p[t + 256 * i];
   };
   load_tile(0);
   for (int kt = 0; kt < nk; kt += 32) {
-    {
-      unsigned h[4], m[4], l[4];
-      split3_pk(rk0.x, rk0.y, h[0], m[0], l[0]); split3_pk(rk0.z, rk0.w, h[1], m[1], l[1]);
-      split3_pk(rk1.x, rk1.y, h[2], m[2], l[2]); split3_pk(rk1.z, rk1.w, h[3], m[3], l[3]);
-      Kp[(0 * 8 + k_blk) * 32 + k_key] = u32x4{h[0], h[1], h[2], h[3]};
-      Kp[(1 * 8 + k_blk) * 32 + k_key] = u32x4{m[0], m[1], m[2], m[3]};
-      Kp[(2 * 8 + k_blk) * 32 + k_key] = u32x4{l[0], l[1], l[2], l[3]};
-      split3_pk(rv[0], rv[1], h[0], m[0], l[0]); split3_pk(rv[2], rv[3], h[1], m[1], l[1]);
-      split3_pk(rv[4], rv[5], h[2], m[2], l[2]); split3_pk(rv[6], rv[7], h[3], m[3], l[3]);
-      Vp[((0 * 2 + v_u) * 2 + v_h) * 64 + v_d] = u32x4{h[0], h[1], h[2], h[3]};
-      Vp[((1 * 2 + v_u) * 2 + v_h) * 64 + v_d] = u32x4{m[0], m[1], m[2], m[3]};
-      Vp[((2 * 2 + v_u) * 2 + v_h) * 64 + v_d] = u32x4{l[0], l[1], l[2], l[3]};
-    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) img[t + 256 * i] = rt[i];
     __syncthreads();
     if (kt + 32 < nk) load_tile(kt + 32);
 
@@ -194,6 +244,8 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s) {
   a.o = st.ctx; a.ldo = 256; a.so = (long long)st.nmax * 256;
   a.n = st.n_cur; a.done = st.done; a.cross = cross;
   a.scale = 0.125f;
+  a.enc = st.enc; a.kv_img = (u32x4*)st.kv_img; a.nmax = st.nmax; a.tiles = cdiv(st.nmax, 32);
+  hipLaunchKernelGGL(kv_prep_kernel, dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
   dim3 grid(cdiv(st.nmax, 128), 4, st.n_items);
   hipLaunchKernelGGL(attn_x6_kernel, grid, dim3(256), 0, s, a);
   DIM_LAUNCH_CHECK();
