@@ -76,16 +76,21 @@ class SuperPointHIP:
         return None
 
     @torch.no_grad()
-    def extract_batch(self, images: torch.Tensor):
+    def extract_batch(self, images: torch.Tensor, out=None):
         """images [B,H,W] float32 in [0,1] on self.device.  Returns device tensors
-        (kpts [B,cap,2], scores [B,cap], desc [B,cap,256], n [B] int32); no host sync."""
+        (kpts [B,cap,2], scores [B,cap], desc [B,cap,256], n [B] int32); no host sync.
+        ``out`` = a previously returned tuple to write into (no allocation: needed when the call is
+        issued on a side stream)."""
         assert images.dim() == 3 and images.dtype == torch.float32 and images.is_contiguous()
         B, H, W = images.shape
         dev = images.device
-        kp = torch.empty(B, self.capacity, 2, dtype=torch.float32, device=dev)
-        sc = torch.empty(B, self.capacity, dtype=torch.float32, device=dev)
-        de = torch.empty(B, self.capacity, 256, dtype=torch.float32, device=dev)
-        n = torch.zeros(B, dtype=torch.int32, device=dev)
+        if out is not None:
+            kp, sc, de, n = out
+        else:
+            kp = torch.empty(B, self.capacity, 2, dtype=torch.float32, device=dev)
+            sc = torch.empty(B, self.capacity, dtype=torch.float32, device=dev)
+            de = torch.empty(B, self.capacity, 256, dtype=torch.float32, device=dev)
+            n = torch.zeros(B, dtype=torch.int32, device=dev)
         capi.check(self.lib, self.lib.dim_sp_extract(self._h, capi.ptr(images), B, H, W, capi.ptr(kp), capi.ptr(sc),
                                                      capi.ptr(de), capi.ptr(n), self._stream()))
         return kp, sc, de, n
