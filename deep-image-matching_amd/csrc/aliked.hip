@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void al_avgpool_kernel(const float* __restrict
 // BN training-mode statistics: stage 1 = per-block fp64 partial (sum, sumsq) per channel, stage 2 =
 // fixed-order reduction -> alpha = gamma/sqrt(var+eps), beta = bias - mean*alpha (ATen's contiguous
 // CPU path: out = x*alpha + beta).  Deterministic (no atomics).
-constexpr int BN_BLOCKS = 64;
+constexpr int BN_BLOCKS = 256;
 __global__ __launch_bounds__(256) void al_bn_partial_kernel(const float* __restrict__ x, int n_pixels, int C, double* __restrict__ partial) {
   __shared__ double red[256][2];
   const int b = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
@@ -204,48 +204,36 @@ __global__ __launch_bounds__(256) void al_clamp_kernel(float* __restrict__ x, si
 }
 
 // ---------------------------------------------------------------------------
-// deformable conv (torchvision.ops.deform_conv2d semantics, call site ALN:322-329): thread = (pixel,
-// 32-channel output chunk); per tap the bilinear sample of all CIN channels is formed in registers.
+// deformable conv (torchvision.ops.deform_conv2d semantics, call site ALN:322-329) = bilinear gather +
+// GEMM: this kernel forms cols[pixel][tap * CIN + c] (the deformed im2col row, K = 9 * CIN) and the
+// product with the [9 * CIN][cout] weight runs on the matrix cores (gemm.hip).  Thread = (pixel, tap,
+// 4 channels); a wave covers consecutive channels of one tap so every corner read is one contiguous run.
 template <int CIN>
-__global__ __launch_bounds__(256) void al_deform_conv_kernel(const float* __restrict__ in, const float* __restrict__ offs, int off_c,
-                                                             const float* __restrict__ w, float* __restrict__ out, int cout, int H,
-                                                             int W) {
-  const int nchunk = cout / 32;
-  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (i >= H * W * nchunk) return;
-  const int chunk = i % nchunk, p = i / nchunk, y = p / W, x = p - y * W;
-  const float* src = in + (size_t)b * H * W * CIN;
-  const float* of = offs + ((size_t)b * H * W + p) * off_c;
-  float acc[32];
-#pragma unroll
-  for (int co = 0; co < 32; ++co) acc[co] = 0.f;
-  for (int tap = 0; tap < 9; ++tap) {
-    const float py = (float)(y - 1 + tap / 3) + of[2 * tap], px = (float)(x - 1 + tap % 3) + of[2 * tap + 1];
-    if (!(py > -1.f && py < (float)H && px > -1.f && px < (float)W)) continue;
+__global__ __launch_bounds__(256) void al_deform_gather_kernel(const float* __restrict__ in, const float* __restrict__ offs, int off_c,
+                                                               float* __restrict__ cols, int H, int W, int n_rows) {
+  constexpr int C4 = CIN / 4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n_rows * 9 * C4) return;
+  const int c4 = (int)(i % C4);
+  const size_t r = i / C4;
+  const int tap = (int)(r % 9);
+  const size_t gp = r / 9;                  // b * H * W + p
+  const int b = (int)(gp / ((size_t)H * W)), p = (int)(gp - (size_t)b * H * W), y = p / W, x = p - y * W;
+  const float* src = in + (size_t)b * H * W * CIN + c4 * 4;
+  const float* of = offs + gp * off_c;
+  const float py = (float)(y - 1 + tap / 3) + of[2 * tap], px = (float)(x - 1 + tap % 3) + of[2 * tap + 1];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (py > -1.f && py < (float)H && px > -1.f && px < (float)W) {
     const float fy = floorf(py), fx = floorf(px);
     const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
     const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
     const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
-    const bool v00 = y0 >= 0 && x0 >= 0, v01 = y0 >= 0 && x1 <= W - 1, v10 = y1 <= H - 1 && x0 >= 0, v11 = y1 <= H - 1 && x1 <= W - 1;
-    const float* wt = w + ((size_t)tap * CIN) * cout + chunk * 32;
-    for (int c4 = 0; c4 < CIN / 4; ++c4) {
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v00) { const float4 v = *(const float4*)(src + ((size_t)y0 * W + x0) * CIN + c4 * 4); s.x += w00 * v.x; s.y += w00 * v.y; s.z += w00 * v.z; s.w += w00 * v.w; }
-      if (v01) { const float4 v = *(const float4*)(src + ((size_t)y0 * W + x1) * CIN + c4 * 4); s.x += w01 * v.x; s.y += w01 * v.y; s.z += w01 * v.z; s.w += w01 * v.w; }
-      if (v10) { const float4 v = *(const float4*)(src + ((size_t)y1 * W + x0) * CIN + c4 * 4); s.x += w10 * v.x; s.y += w10 * v.y; s.z += w10 * v.z; s.w += w10 * v.w; }
-      if (v11) { const float4 v = *(const float4*)(src + ((size_t)y1 * W + x1) * CIN + c4 * 4); s.x += w11 * v.x; s.y += w11 * v.y; s.z += w11 * v.z; s.w += w11 * v.w; }
-      const float sv[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* wr = wt + (size_t)(c4 * 4 + j) * cout;
-#pragma unroll
-        for (int co = 0; co < 32; ++co) acc[co] = fmaf(sv[j], wr[co], acc[co]);
-      }
-    }
+    if (y0 >= 0 && x0 >= 0) { const float4 v = *(const float4*)(src + ((size_t)y0 * W + x0) * CIN); s.x += w00 * v.x; s.y += w00 * v.y; s.z += w00 * v.z; s.w += w00 * v.w; }
+    if (y0 >= 0 && x1 <= W - 1) { const float4 v = *(const float4*)(src + ((size_t)y0 * W + x1) * CIN); s.x += w01 * v.x; s.y += w01 * v.y; s.z += w01 * v.z; s.w += w01 * v.w; }
+    if (y1 <= H - 1 && x0 >= 0) { const float4 v = *(const float4*)(src + ((size_t)y1 * W + x0) * CIN); s.x += w10 * v.x; s.y += w10 * v.y; s.z += w10 * v.z; s.w += w10 * v.w; }
+    if (y1 <= H - 1 && x1 <= W - 1) { const float4 v = *(const float4*)(src + ((size_t)y1 * W + x1) * CIN); s.x += w11 * v.x; s.y += w11 * v.y; s.z += w11 * v.z; s.w += w11 * v.w; }
   }
-  float* dst = out + ((size_t)b * H * W + p) * cout + chunk * 32;
-#pragma unroll
-  for (int co = 0; co < 32; co += 4) *(float4*)(dst + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+  *(float4*)(cols + gp * (9 * CIN) + tap * CIN + c4 * 4) = s;
 }
 
 // ---------------------------------------------------------------------------
@@ -263,21 +251,29 @@ __device__ __forceinline__ UpIdx up_index(int dst, int in_size, int out_size) {
   return u;
 }
 // x1234 = cat[selu(conv1(x1)), up2(f2), up8(f3), up32(f4)] (ALN:657-664) and s8 = selu(score_head.0(x1234))
-// (ALN:666).  One pixel per thread; the 128-channel vector is produced and consumed 4 channels at a time.
+// (ALN:666).  Workgroup = 64 pixels x 4 channel groups: lane (pixel, g) produces the 32 channels of group g
+// (g = 0: the 16->32 1x1 conv of x1; g = 1..3: one bilinearly up-sampled map; one wave per group) and its
+// share of the 128->8 score projection (reduced over the 4 waves through LDS); the 64 x 128 tile goes through LDS so
+// that the 512 B/pixel feature map is written as one contiguous 32-KiB run.  The product path runs
+// STORE = false: only s8 is written; the 128-channel map (512 MB per 1024^2 image) is never materialised,
+// SDDH re-evaluates it at the cells it touches (feat_pair below).  STORE = true serves the debug tap.
+template <bool STORE>
 __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restrict__ x1, const float* __restrict__ f2,
                                                           const float* __restrict__ f3, const float* __restrict__ f4,
                                                           const float* __restrict__ w1, const float* __restrict__ ws0,
                                                           float* __restrict__ x1234, float* __restrict__ s8, int Hp, int Wp) {
-  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (i >= Hp * Wp) return;
-  const int y = i / Wp, x = i - y * Wp;
+  __shared__ float tile[STORE ? 64 * 132 : 4];
+  __shared__ float spart[3][8][64];
+  const int t = threadIdx.x, g = __builtin_amdgcn_readfirstlane(t >> 6), pl = t & 63, b = blockIdx.y;  // g is wave-uniform: weights come through scalar loads
+  const int i = blockIdx.x * 64 + pl;
+  const bool ok = i < Hp * Wp;
+  const int y = ok ? i / Wp : 0, x = ok ? i - y * Wp : 0;
   float sacc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) sacc[k] = 0.f;
-  float* dst = x1234 + ((size_t)b * Hp * Wp + i) * 128;
-  // --- f1 = selu(conv1x1 16->32 of x1)
-  {
-    const float* src = x1 + ((size_t)b * Hp * Wp + i) * 16;
+  float* trow = &tile[STORE ? pl * 132 + g * 32 : 0];
+  if (g == 0) {
+    const float* src = x1 + ((size_t)b * Hp * Wp + (ok ? i : 0)) * 16;
     float a[16];
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) { const float4 v = *(const float4*)(src + c4 * 4); a[c4 * 4] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w; }
@@ -294,17 +290,14 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < 8; ++k) sacc[k] = fmaf(o[j], ws0[(co + j) * 8 + k], sacc[k]);
       }
-      *(float4*)(dst + co) = make_float4(o[0], o[1], o[2], o[3]);
+      if (STORE) *(float4*)(trow + co) = make_float4(o[0], o[1], o[2], o[3]);
     }
-  }
-  // --- three bilinearly upsampled 32-channel maps
-  const float* maps[3] = {f2, f3, f4};
-  const int fac[3] = {2, 8, 32};
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    const int h = Hp / fac[m], w = Wp / fac[m];
+  } else {
+    const int fac = g == 1 ? 2 : (g == 2 ? 8 : 32);
+    const float* map = g == 1 ? f2 : (g == 2 ? f3 : f4);
+    const int h = Hp / fac, w = Wp / fac;
     const UpIdx uy = up_index(y, h, Hp), ux = up_index(x, w, Wp);
-    const float* base = maps[m] + (size_t)b * h * w * 32;
+    const float* base = map + (size_t)b * h * w * 32;
     const float* p00 = base + ((size_t)uy.i0 * w + ux.i0) * 32;
     const float* p01 = base + ((size_t)uy.i0 * w + ux.i1) * 32;
     const float* p10 = base + ((size_t)uy.i1 * w + ux.i0) * 32;
@@ -320,13 +313,31 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sacc[k] = fmaf(o[j], ws0[(32 * (m + 1) + c + j) * 8 + k], sacc[k]);
-      *(float4*)(dst + 32 * (m + 1) + c) = make_float4(o[0], o[1], o[2], o[3]);
+        for (int k = 0; k < 8; ++k) sacc[k] = fmaf(o[j], ws0[(32 * g + c + j) * 8 + k], sacc[k]);
+      if (STORE) *(float4*)(trow + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
-  float* sd = s8 + ((size_t)b * Hp * Wp + i) * 8;
-  *(float4*)sd = make_float4(selu_(sacc[0]), selu_(sacc[1]), selu_(sacc[2]), selu_(sacc[3]));
-  *(float4*)(sd + 4) = make_float4(selu_(sacc[4]), selu_(sacc[5]), selu_(sacc[6]), selu_(sacc[7]));
+  // the reference sums the 128 products of score_head.0 in channel order; here (g0 + g1) + (g2 + g3)
+  if (g > 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) spart[g - 1][k][pl] = sacc[k];
+  }
+  __syncthreads();
+  if (g == 0 && ok) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sacc[k] = (sacc[k] + spart[0][k][pl]) + (spart[1][k][pl] + spart[2][k][pl]);
+    float* sd = s8 + ((size_t)b * Hp * Wp + i) * 8;
+    *(float4*)sd = make_float4(selu_(sacc[0]), selu_(sacc[1]), selu_(sacc[2]), selu_(sacc[3]));
+    *(float4*)(sd + 4) = make_float4(selu_(sacc[4]), selu_(sacc[5]), selu_(sacc[6]), selu_(sacc[7]));
+  }
+  if (!STORE) return;
+  const int p0 = blockIdx.x * 64;
+  float* dst = x1234 + ((size_t)b * Hp * Wp + p0) * 128;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = t + 256 * k, pix = idx >> 5, c4 = idx & 31;
+    if (p0 + pix < Hp * Wp) *(float4*)(dst + (size_t)pix * 128 + c4 * 4) = *(const float4*)&tile[pix * 132 + c4 * 4];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -389,12 +400,41 @@ __global__ __launch_bounds__(256) void al_dkd_refine_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------
-// SDDH (ALN:503-558).  The feature map is stored un-normalised (x1234, padded frame); every cell a
-// keypoint touches is L2-normalised on the fly (F.normalize over the 128 channels, ALN:669).
+// SDDH (ALN:503-558).  The 128-channel map x1234 is not stored: each cell a keypoint touches is
+// re-evaluated from its sources with the arithmetic of al_assemble_kernel (lane -> channels 2*lane,
+// 2*lane+1: lanes 0-15 the 16->32 conv of x1, then one up-sampled map per 16 lanes) and L2-normalised
+// on the fly (F.normalize over the 128 channels, ALN:669).
+__device__ __forceinline__ float2 feat_pair(const AlFeat& F, int b, int Y, int X, int lane) {
+  const int g = lane >> 4, cc = (lane & 15) * 2;
+  if (g == 0) {
+    const float* src = F.x1 + (((size_t)b * F.Hp + Y) * F.Wp + X) * 16;
+    float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float4 v = *(const float4*)(src + c4 * 4);
+      const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float2 w = *(const float2*)(F.w1 + (c4 * 4 + j) * 32 + cc);
+        o0 = fmaf(a[j], w.x, o0); o1 = fmaf(a[j], w.y, o1);
+      }
+    }
+    return make_float2(selu_(o0), selu_(o1));
+  }
+  const int fac = g == 1 ? 2 : (g == 2 ? 8 : 32);
+  const float* map = g == 1 ? F.f2 : (g == 2 ? F.f3 : F.f4);
+  const int h = F.Hp / fac, w = F.Wp / fac;
+  const UpIdx uy = up_index(Y, h, F.Hp), ux = up_index(X, w, F.Wp);
+  const float* base = map + (size_t)b * h * w * 32 + cc;
+  const float2 a = *(const float2*)(base + ((size_t)uy.i0 * w + ux.i0) * 32), bq = *(const float2*)(base + ((size_t)uy.i0 * w + ux.i1) * 32);
+  const float2 cq = *(const float2*)(base + ((size_t)uy.i1 * w + ux.i0) * 32), d = *(const float2*)(base + ((size_t)uy.i1 * w + ux.i1) * 32);
+  return make_float2(uy.l0 * (ux.l0 * a.x + ux.l1 * bq.x) + uy.l1 * (ux.l0 * cq.x + ux.l1 * d.x),
+                     uy.l0 * (ux.l0 * a.y + ux.l1 * bq.y) + uy.l1 * (ux.l0 * cq.y + ux.l1 * d.y));
+}
 // wave per (keypoint, patch cell): 3x3 patch of normalised features -> patches [kpt][9][128]
-__global__ __launch_bounds__(256) void al_sddh_patches_kernel(const float* __restrict__ x1234, const float* __restrict__ kpts_norm,
+__global__ __launch_bounds__(256) void al_sddh_patches_kernel(AlFeat F, const float* __restrict__ kpts_norm,
                                                               const int* __restrict__ n_kpts, float* __restrict__ patches, int H,
-                                                              int W, int Hp, int Wp, int pad_t, int pad_l, int capacity) {
+                                                              int W, int pad_t, int pad_l, int capacity) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int item = blockIdx.x * 4 + wv, b = blockIdx.y;
   const int i = item / 9, cell = item % 9;
@@ -405,8 +445,7 @@ __global__ __launch_bounds__(256) void al_sddh_patches_kernel(const float* __res
   int cx = (int)((float)xl - 1.5f + 1.f), cy = (int)((float)yl - 1.5f + 1.f);  // (corner - ps/2 + 1).long(), truncation
   cx = min(max(cx, 0), W - 1 - 3); cy = min(max(cy, 0), H - 1 - 3);
   const int yy = cy + cell / 3, xx = cx + cell % 3;
-  const float* src = x1234 + (((size_t)b * Hp + yy + pad_t) * Wp + xx + pad_l) * 128;
-  const float2 v = *(const float2*)(src + lane * 2);
+  const float2 v = feat_pair(F, b, yy + pad_t, xx + pad_l, lane);
   const float den = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);
   // layout [kpt][ci][ky][kx] flattened as ci*9 + cell to match offset_conv.0.weight (32,128,3,3)
   float* dst = patches + k * 1152;
@@ -415,11 +454,10 @@ __global__ __launch_bounds__(256) void al_sddh_patches_kernel(const float* __res
 }
 // wave per keypoint: offsets = clamp(W2 * selu(hidden) + b2), then 16 bilinear samples of the
 // normalised feature map -> feats [kpt][16][128]
-__global__ __launch_bounds__(256) void al_sddh_sample_kernel(const float* __restrict__ x1234, const float* __restrict__ kpts_norm,
+__global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const float* __restrict__ kpts_norm,
                                                              const int* __restrict__ n_kpts, const float* __restrict__ hidden,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
-                                                             float* __restrict__ feats, int H, int W, int Hp, int Wp, int pad_t,
-                                                             int pad_l, int capacity) {
+                                                             float* __restrict__ feats, int H, int W, int pad_t, int pad_l, int capacity) {
   __shared__ float offs[4][32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wv, b = blockIdx.y;
@@ -448,7 +486,7 @@ __global__ __launch_bounds__(256) void al_sddh_sample_kernel(const float* __rest
     for (int c = 0; c < 4; ++c) {
       const bool in = xs[c] >= 0 && xs[c] < W && ys[c] >= 0 && ys[c] < H;  // wave-uniform
       float2 v = make_float2(0.f, 0.f);
-      if (in) v = *(const float2*)(x1234 + (((size_t)b * Hp + ys[c] + pad_t) * Wp + xs[c] + pad_l) * 128 + lane * 2);
+      if (in) v = feat_pair(F, b, ys[c] + pad_t, xs[c] + pad_l, lane);
       const float den = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);
       if (in) { o0 += (v.x / den) * wts[c]; o1 += (v.y / den) * wts[c]; }
     }
@@ -551,16 +589,18 @@ int launch_al_bn_apply(const float* x, const float* alpha, const float* beta, co
   DIM_LAUNCH_CHECK();
   return 0;
 }
-int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, float* out, int cout, int batch,
-                          int H, int W, hipStream_t s) {
-  DIM_REQUIRE(cout % 32 == 0, "aliked deform conv: cout %d", cout);
-  dim3 grid(cdiv(H * W * (cout / 32), 256), batch);
-  if (cin == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_conv_kernel<32>), grid, dim3(256), 0, s, in, offsets, off_c, w, out, cout, H, W);
-  else if (cin == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_conv_kernel<64>), grid, dim3(256), 0, s, in, offsets, off_c, w, out, cout, H, W);
-  else if (cin == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_conv_kernel<128>), grid, dim3(256), 0, s, in, offsets, off_c, w, out, cout, H, W);
-  else { dim_set_error("aliked deform conv: cin %d unsupported", cin); return -2; }
+int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, float* cols, float* out, int cout,
+                          int batch, int H, int W, hipStream_t s) {
+  DIM_REQUIRE(cout % 32 == 0 && (cin == 32 || cin == 64 || cin == 128), "deform conv: cin %d cout %d", cin, cout);
+  const int rows = batch * H * W;
+  const dim3 grid((unsigned)(((size_t)rows * 9 * (cin / 4) + 255) / 256));
+  if (cin == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_gather_kernel<32>), grid, dim3(256), 0, s, in, offsets, off_c, cols, H, W, rows);
+  else if (cin == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_gather_kernel<64>), grid, dim3(256), 0, s, in, offsets, off_c, cols, H, W, rows);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_gather_kernel<128>), grid, dim3(256), 0, s, in, offsets, off_c, cols, H, W, rows);
   DIM_LAUNCH_CHECK();
-  return 0;
+  GemmArgs g;
+  g.A0 = cols; g.lda0 = 9 * cin; g.B = w; g.ldb = cout; g.C = out; g.ldc = cout; g.M = rows; g.N = cout; g.K = 9 * cin;
+  return launch_gemm(g, 1, s);
 }
 int launch_al_clamp(float* x, size_t n, float lim, hipStream_t s) {
   hipLaunchKernelGGL(al_clamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, lim);
@@ -569,7 +609,8 @@ int launch_al_clamp(float* x, size_t n, float lim, hipStream_t s) {
 }
 int launch_al_assemble(const float* x1, const float* f2, const float* f3, const float* f4, const float* w1, const float* ws0,
                        float* x1234, float* s8, int batch, int Hp, int Wp, hipStream_t s) {
-  hipLaunchKernelGGL(al_assemble_kernel, dim3(cdiv(Hp * Wp, 256), batch), dim3(256), 0, s, x1, f2, f3, f4, w1, ws0, x1234, s8, Hp, Wp);
+  if (x1234) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_assemble_kernel<true>), dim3(cdiv(Hp * Wp, 64), batch), dim3(256), 0, s, x1, f2, f3, f4, w1, ws0, x1234, s8, Hp, Wp);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(al_assemble_kernel<false>), dim3(cdiv(Hp * Wp, 64), batch), dim3(256), 0, s, x1, f2, f3, f4, w1, ws0, x1234, s8, Hp, Wp);
   DIM_LAUNCH_CHECK();
   return 0;
 }
@@ -579,16 +620,15 @@ int launch_al_dkd_refine(const float* score, const float* kpts_px, const int* n_
   DIM_LAUNCH_CHECK();
   return 0;
 }
-int launch_al_sddh_patches(const float* x1234, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H, int W,
-                           int Hp, int Wp, int pad_t, int pad_l, int capacity, hipStream_t s) {
-  hipLaunchKernelGGL(al_sddh_patches_kernel, dim3(cdiv(capacity * 9, 4), batch), dim3(256), 0, s, x1234, kpts_norm, n_kpts, patches, H, W, Hp, Wp, pad_t, pad_l, capacity);
+int launch_al_sddh_patches(const AlFeat& F, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H, int W,
+                           int pad_t, int pad_l, int capacity, hipStream_t s) {
+  hipLaunchKernelGGL(al_sddh_patches_kernel, dim3(cdiv(capacity * 9, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, patches, H, W, pad_t, pad_l, capacity);
   DIM_LAUNCH_CHECK();
   return 0;
 }
-int launch_al_sddh_sample(const float* x1234, const float* kpts_norm, const int* n_kpts, const float* off_hidden, const float* w2,
-                          const float* b2, float* feats, int batch, int H, int W, int Hp, int Wp, int pad_t, int pad_l, int capacity,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(al_sddh_sample_kernel, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, x1234, kpts_norm, n_kpts, off_hidden, w2, b2, feats, H, W, Hp, Wp, pad_t, pad_l, capacity);
+int launch_al_sddh_sample(const AlFeat& F, const float* kpts_norm, const int* n_kpts, const float* off_hidden, const float* w2,
+                          const float* b2, float* feats, int batch, int H, int W, int pad_t, int pad_l, int capacity, hipStream_t s) {
+  hipLaunchKernelGGL(al_sddh_sample_kernel, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, off_hidden, w2, b2, feats, H, W, pad_t, pad_l, capacity);
   DIM_LAUNCH_CHECK();
   return 0;
 }

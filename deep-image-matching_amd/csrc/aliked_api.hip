@@ -22,10 +22,11 @@ struct dim_aliked {
   float *dh_o0_w, *dh_o0_b, *dh_o2_w, *dh_o2_b, *dh_sf, *dh_agg;
   // activations
   float *P, *raw, *act, *x1, *p2, *idn, *x2, *p3, *off, *x3, *p4, *x4, *f2, *f3, *f4, *x1234, *s8, *s4a, *s4b, *score, *nms;
-  float *cand_score, *kpts_px, *sc_tmp, *kpts_norm, *kscore, *patches, *hidden, *feats, *feats2, *bn_alpha, *bn_beta, *mean, *thr_eff;
+  float *cand_score, *kpts_px, *sc_tmp, *kpts_norm, *kscore, *patches, *hidden, *feats, *feats2, *bn_alpha, *bn_beta, *mean, *thr_eff, *cols;
   double* partial;
   int *cand_idx, *rowcount, *rowoff, *ncand;
-  int last_hp, last_wp, last_h, last_w;
+  int last_hp, last_wp, last_h, last_w, last_batch;
+  float* dbg_x1234;  // debug tap only: materialised on request by dim_aliked_debug_buffers
   std::vector<void*> allocs;
 };
 
@@ -70,6 +71,7 @@ extern "C" {
 void dim_aliked_destroy(dim_aliked* h) {
   if (!h) return;
   for (void* p : h->allocs) hipFree(p);
+  if (h->dbg_x1234) hipFree(h->dbg_x1234);
   delete h;
 }
 
@@ -121,19 +123,20 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
   }
   const size_t B = max_batch;
   const size_t Hp = ((size_t)max_h + 31) / 32 * 32, Wp = ((size_t)max_w + 31) / 32 * 32, NP = Hp * Wp, cap = capacity;
+  AL_TRY(dev_alloc(h, &h->cols, B * NP / 64 * 576));  // deformed im2col rows: block3 (1/8 res, K = 9*64) is the largest
   AL_TRY(dev_alloc(h, &h->P, B * NP * 3)); AL_TRY(dev_alloc(h, &h->raw, B * NP * 16)); AL_TRY(dev_alloc(h, &h->act, B * NP * 16));
   AL_TRY(dev_alloc(h, &h->x1, B * NP * 16)); AL_TRY(dev_alloc(h, &h->p2, B * NP / 4 * 16)); AL_TRY(dev_alloc(h, &h->idn, B * NP / 4 * 32));
   AL_TRY(dev_alloc(h, &h->x2, B * NP / 4 * 32)); AL_TRY(dev_alloc(h, &h->p3, B * NP / 64 * 32)); AL_TRY(dev_alloc(h, &h->off, B * NP / 64 * 20));
   AL_TRY(dev_alloc(h, &h->x3, B * NP / 64 * 64)); AL_TRY(dev_alloc(h, &h->p4, B * NP / 1024 * 64)); AL_TRY(dev_alloc(h, &h->x4, B * NP / 1024 * 128));
   AL_TRY(dev_alloc(h, &h->f2, B * NP / 4 * 32)); AL_TRY(dev_alloc(h, &h->f3, B * NP / 64 * 32)); AL_TRY(dev_alloc(h, &h->f4, B * NP / 1024 * 32));
-  AL_TRY(dev_alloc(h, &h->x1234, B * NP * 128)); AL_TRY(dev_alloc(h, &h->s8, B * NP * 8)); AL_TRY(dev_alloc(h, &h->s4a, B * NP * 4));
+  AL_TRY(dev_alloc(h, &h->s8, B * NP * 8)); AL_TRY(dev_alloc(h, &h->s4a, B * NP * 4));
   AL_TRY(dev_alloc(h, &h->s4b, B * NP * 4)); AL_TRY(dev_alloc(h, &h->score, B * NP)); AL_TRY(dev_alloc(h, &h->nms, B * NP));
   AL_TRY(dev_alloc(h, &h->cand_score, B * NP)); AL_TRY(dev_alloc(h, &h->cand_idx, B * NP)); AL_TRY(dev_alloc(h, &h->rowcount, B * Hp));
   AL_TRY(dev_alloc(h, &h->rowoff, B * Hp)); AL_TRY(dev_alloc(h, &h->ncand, B)); AL_TRY(dev_alloc(h, &h->kpts_px, B * cap * 2));
   AL_TRY(dev_alloc(h, &h->sc_tmp, B * cap)); AL_TRY(dev_alloc(h, &h->kpts_norm, B * cap * 2)); AL_TRY(dev_alloc(h, &h->kscore, B * cap));
   AL_TRY(dev_alloc(h, &h->patches, B * cap * 1152)); AL_TRY(dev_alloc(h, &h->hidden, B * cap * 32)); AL_TRY(dev_alloc(h, &h->feats, B * cap * 2048));
   AL_TRY(dev_alloc(h, &h->feats2, B * cap * 2048)); AL_TRY(dev_alloc(h, &h->bn_alpha, B * 128)); AL_TRY(dev_alloc(h, &h->bn_beta, B * 128));
-  AL_TRY(dev_alloc(h, &h->mean, B)); AL_TRY(dev_alloc(h, &h->thr_eff, B)); AL_TRY(dev_alloc(h, &h->partial, B * 64 * 128 * 2));
+  AL_TRY(dev_alloc(h, &h->mean, B)); AL_TRY(dev_alloc(h, &h->thr_eff, B)); AL_TRY(dev_alloc(h, &h->partial, B * 256 * 128 * 2));
 #undef AL_TRY
   *out = h;
   return 0;
@@ -152,6 +155,13 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   const int H2 = Hp / 2, W2 = Wp / 2, H8 = Hp / 8, W8 = Wp / 8, H32 = Hp / 32, W32 = Wp / 32;
   const int NP = Hp * Wp, r = h->cfg.nms_radius, cap = h->capacity;
 #define AL_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
+  // 1x1 convolutions on NHWC maps are plain GEMMs over pixels (weights already [cin][cout])
+  auto conv1x1 = [&](const float* in, int ci, const float* w1, const float* bias, float* out, int co, int npx, int act) -> int {
+    GemmArgs g;
+    g.A0 = in; g.lda0 = ci; g.B = w1; g.ldb = co; g.bias = bias; g.C = out; g.ldc = co; g.M = npx; g.N = co; g.K = ci;
+    g.relu = act == AL_ACT_SELU ? 2 : 0;
+    return launch_gemm(g, 1, s);
+  };
   auto bn = [&](const float* x, int npx, int C, int i, const float* res, float* dst) -> int {
     int rc = launch_al_bn_stats(x, batch, npx, C, h->bn_g[i], h->bn_b[i], h->partial, h->bn_alpha, h->bn_beta, s);
     if (rc) return rc;
@@ -168,7 +178,7 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   AL_RUN(launch_al_conv3x3(h->p2, 16, h->b2c1, nullptr, h->raw, 32, batch, H2, W2, AL_ACT_NONE, 0, 0, H2, W2, s));
   AL_RUN(bn(h->raw, H2 * W2, 32, 2, nullptr, h->act));
   AL_RUN(launch_al_conv3x3(h->act, 32, h->b2c2, nullptr, h->raw, 32, batch, H2, W2, AL_ACT_NONE, 0, 0, H2, W2, s));
-  AL_RUN(launch_al_conv1x1(h->p2, 16, h->b2ds_w, h->b2ds_b, h->idn, 32, batch * H2 * W2, AL_ACT_NONE, s));
+  AL_RUN(launch_al_conv1x1(h->p2, 16, h->b2ds_w, h->b2ds_b, h->idn, 32, batch * H2 * W2, AL_ACT_NONE, s));  // K = 16: below the GEMM's K granule
   AL_RUN(bn(h->raw, H2 * W2, 32, 3, h->idn, h->x2));
   // block3 / block4 (ResBlock with DeformableConv2d, ALN:274-330)
   auto dcn_block = [&](const float* x, int Hh, int Ww, int ci, int co, const float* o1w, const float* o1b, const float* r1,
@@ -177,12 +187,12 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     int rc;
     if ((rc = launch_al_conv3x3(x, ci, o1w, o1b, h->off, 18, batch, Hh, Ww, AL_ACT_NONE, 0, 0, Hh, Ww, s))) return rc;
     if ((rc = launch_al_clamp(h->off, (size_t)batch * Hh * Ww * 18, lim, s))) return rc;
-    if ((rc = launch_al_deform_conv(x, ci, h->off, 18, r1, h->raw, co, batch, Hh, Ww, s))) return rc;
+    if ((rc = launch_al_deform_conv(x, ci, h->off, 18, r1, h->cols, h->raw, co, batch, Hh, Ww, s))) return rc;
     if ((rc = bn(h->raw, Hh * Ww, co, bni, nullptr, h->act))) return rc;
     if ((rc = launch_al_conv3x3(h->act, co, o2w, o2b, h->off, 18, batch, Hh, Ww, AL_ACT_NONE, 0, 0, Hh, Ww, s))) return rc;
     if ((rc = launch_al_clamp(h->off, (size_t)batch * Hh * Ww * 18, lim, s))) return rc;
-    if ((rc = launch_al_deform_conv(h->act, co, h->off, 18, r2, h->raw, co, batch, Hh, Ww, s))) return rc;
-    if ((rc = launch_al_conv1x1(x, ci, dsw, dsb, h->idn, co, batch * Hh * Ww, AL_ACT_NONE, s))) return rc;
+    if ((rc = launch_al_deform_conv(h->act, co, h->off, 18, r2, h->cols, h->raw, co, batch, Hh, Ww, s))) return rc;
+    if ((rc = conv1x1(x, ci, dsw, dsb, h->idn, co, batch * Hh * Ww, AL_ACT_NONE))) return rc;
     return bn(h->raw, Hh * Ww, co, bni + 1, h->idn, dst);
   };
   AL_RUN(launch_al_avgpool(h->x2, h->p3, batch, H2, W2, 32, 4, s));
@@ -190,10 +200,11 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   AL_RUN(launch_al_avgpool(h->x3, h->p4, batch, H8, W8, 64, 4, s));
   AL_RUN(dcn_block(h->p4, H32, W32, 64, 128, h->b4o1_w, h->b4o1_b, h->b4r1, h->b4o2_w, h->b4o2_b, h->b4r2, h->b4ds_w, h->b4ds_b, 6, h->x4));
   // feature aggregation + score head (ALN:656-669)
-  AL_RUN(launch_al_conv1x1(h->x2, 32, h->hc2, nullptr, h->f2, 32, batch * H2 * W2, AL_ACT_SELU, s));
-  AL_RUN(launch_al_conv1x1(h->x3, 64, h->hc3, nullptr, h->f3, 32, batch * H8 * W8, AL_ACT_SELU, s));
-  AL_RUN(launch_al_conv1x1(h->x4, 128, h->hc4, nullptr, h->f4, 32, batch * H32 * W32, AL_ACT_SELU, s));
-  AL_RUN(launch_al_assemble(h->x1, h->f2, h->f3, h->f4, h->hc1, h->sh0, h->x1234, h->s8, batch, Hp, Wp, s));
+  AL_RUN(conv1x1(h->x2, 32, h->hc2, nullptr, h->f2, 32, batch * H2 * W2, AL_ACT_SELU));
+  AL_RUN(conv1x1(h->x3, 64, h->hc3, nullptr, h->f3, 32, batch * H8 * W8, AL_ACT_SELU));
+  AL_RUN(conv1x1(h->x4, 128, h->hc4, nullptr, h->f4, 32, batch * H32 * W32, AL_ACT_SELU));
+  AL_RUN(launch_al_assemble(h->x1, h->f2, h->f3, h->f4, h->hc1, h->sh0, nullptr, h->s8, batch, Hp, Wp, s));  // s8 only; x1234 stays virtual
+  const AlFeat F{h->x1, h->f2, h->f3, h->f4, h->hc1, Hp, Wp};
   AL_RUN(launch_al_conv3x3(h->s8, 8, h->sh2, nullptr, h->s4a, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));
   AL_RUN(launch_al_conv3x3(h->s4a, 4, h->sh4, nullptr, h->s4b, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));
   AL_RUN(launch_al_conv3x3(h->s4b, 4, h->sh6, nullptr, h->score, 1, batch, Hp, Wp, AL_ACT_SIGMOID, pad_t, pad_l, H, W, s));  // unpad (ALN:672-673)
@@ -208,14 +219,14 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   // Q8: DIM's "scores" are the dispersities (ALN:682 unpacks DKD's return in the wrong order)
   AL_RUN(launch_al_dkd_refine(h->score, h->kpts_px, n_kpts_dev, h->kpts_norm, scores_dev, h->kscore, kpts_xy_dev, batch, H, W, cap, r, s));
   // SDDH (ALN:503-558)
-  AL_RUN(launch_al_sddh_patches(h->x1234, h->kpts_norm, n_kpts_dev, h->patches, batch, H, W, Hp, Wp, pad_t, pad_l, cap, s));
+  AL_RUN(launch_al_sddh_patches(F, h->kpts_norm, n_kpts_dev, h->patches, batch, H, W, pad_t, pad_l, cap, s));
   {
     GemmArgs g;
     g.A0 = h->patches; g.lda0 = 1152; g.strideA0 = (long long)cap * 1152; g.B = h->dh_o0_w; g.ldb = 32; g.bias = h->dh_o0_b;
     g.C = h->hidden; g.ldc = 32; g.strideC = (long long)cap * 32; g.M = cap; g.N = 32; g.K = 1152; g.rows = n_kpts_dev;
     AL_RUN(launch_gemm(g, batch, s));
   }
-  AL_RUN(launch_al_sddh_sample(h->x1234, h->kpts_norm, n_kpts_dev, h->hidden, h->dh_o2_w, h->dh_o2_b, h->feats, batch, H, W, Hp, Wp, pad_t, pad_l, cap, s));
+  AL_RUN(launch_al_sddh_sample(F, h->kpts_norm, n_kpts_dev, h->hidden, h->dh_o2_w, h->dh_o2_b, h->feats, batch, H, W, pad_t, pad_l, cap, s));
   {
     GemmArgs g;  // sf_conv 1x1 (128 -> 128) + SELU over the 16 sampled positions of every keypoint
     g.A0 = h->feats; g.lda0 = 128; g.strideA0 = (long long)cap * 2048; g.B = h->dh_sf; g.ldb = 128;
@@ -231,13 +242,21 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   }
   AL_RUN(launch_al_normalize_rows(desc_dev, n_kpts_dev, batch, cap, 128, s));
 #undef AL_RUN
-  h->last_hp = Hp; h->last_wp = Wp; h->last_h = H; h->last_w = W;
+  h->last_hp = Hp; h->last_wp = Wp; h->last_h = H; h->last_w = W; h->last_batch = batch;
   return 0;
 }
 
 int dim_aliked_debug_buffers(dim_aliked* h, const float** x1234, const float** score_map, int* hp, int* wp, int* pad_t, int* pad_l) {
   DIM_REQUIRE(h, "dim_aliked_debug_buffers: null handle");
-  if (x1234) *x1234 = h->x1234;
+  if (x1234) {  // the product path never stores the 128-channel map: rebuild it for the last batch
+    DIM_REQUIRE(h->last_batch > 0, "dim_aliked_debug_buffers: no extract call yet");
+    if (h->dbg_x1234) hipFree(h->dbg_x1234);
+    h->dbg_x1234 = nullptr;
+    DIM_HIP(hipMalloc((void**)&h->dbg_x1234, (size_t)h->last_batch * h->last_hp * h->last_wp * 128 * sizeof(float)));
+    if (launch_al_assemble(h->x1, h->f2, h->f3, h->f4, h->hc1, h->sh0, h->dbg_x1234, h->s8, h->last_batch, h->last_hp, h->last_wp, nullptr)) return -1;
+    DIM_HIP(hipDeviceSynchronize());
+    *x1234 = h->dbg_x1234;
+  }
   if (score_map) *score_map = h->score;
   if (hp) *hp = h->last_hp;
   if (wp) *wp = h->last_wp;

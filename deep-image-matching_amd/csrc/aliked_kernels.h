@@ -19,7 +19,7 @@ int launch_al_bn_stats(const float* x, int batch, int n_pixels, int C, const flo
 int launch_al_bn_apply(const float* x, const float* alpha, const float* beta, const float* residual, float* out, int batch,
                        int n_pixels, int C, hipStream_t s);
 // deformable 3x3 conv (ALN:274-330): offsets [b][H][W][off_c>=18] (dy,dx per tap, already clamped), no bias
-int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, float* out, int cout,
+int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, float* cols, float* out, int cout,
                           int batch, int H, int W, hipStream_t s);
 int launch_al_clamp(float* x, size_t n, float lim, hipStream_t s);
 // feature aggregation + first score-head layer (ALN:657-668)
@@ -28,11 +28,12 @@ int launch_al_assemble(const float* x1, const float* f2, const float* f3, const 
 // DKD sub-pixel refinement (ALN:176-216) and SDDH pieces (ALN:503-558)
 int launch_al_dkd_refine(const float* score, const float* kpts_px, const int* n_kpts, float* kpts_norm, float* disp,
                          float* kscore, float* kpts_out, int batch, int H, int W, int capacity, int radius, hipStream_t s);
-int launch_al_sddh_patches(const float* x1234, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H,
-                           int W, int Hp, int Wp, int pad_t, int pad_l, int capacity, hipStream_t s);
-int launch_al_sddh_sample(const float* x1234, const float* kpts_norm, const int* n_kpts, const float* off_hidden,
-                          const float* w2, const float* b2, float* feats, int batch, int H, int W, int Hp, int Wp, int pad_t,
-                          int pad_l, int capacity, hipStream_t s);
+// sources of the (never materialised) 128-channel feature map x1234, padded frame Hp x Wp
+struct AlFeat { const float *x1, *f2, *f3, *f4, *w1; int Hp, Wp; };
+int launch_al_sddh_patches(const AlFeat& F, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H, int W,
+                           int pad_t, int pad_l, int capacity, hipStream_t s);
+int launch_al_sddh_sample(const AlFeat& F, const float* kpts_norm, const int* n_kpts, const float* off_hidden, const float* w2,
+                          const float* b2, float* feats, int batch, int H, int W, int pad_t, int pad_l, int capacity, hipStream_t s);
 int launch_al_normalize_rows(float* x, const int* n_rows, int batch, int capacity, int C, hipStream_t s);
 int launch_al_mean(const float* x, int batch, int n, double* partial, float* mean, hipStream_t s);
 int launch_al_pick_threshold(const int* ncand, const float* mean, float thr, float* thr_out, int batch, hipStream_t s);

@@ -238,6 +238,8 @@ template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if
 
 #define __expf(x) expf(x)
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+// only ever applied to wave-uniform values in this code base
+static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 #define __logf(x) logf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
