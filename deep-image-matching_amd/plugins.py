@@ -24,6 +24,7 @@ from . import weights as _weights
 from .aliked_hip import AlikedHIP
 from .lightglue_hip import LightGlueHIP
 from .superpoint_hip import SuperPointHIP
+from .tile_matching import BatchedTileMatchingMixin
 from .tiling import BatchedTilingMixin
 
 logger = logging.getLogger("dim")
@@ -237,7 +238,7 @@ def featuresDict2Lightglue(feats: dict) -> dict:
     return out
 
 
-class LightGlueMatcher(_MatcherBase):
+class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
     """matchers/lightglue.py:77 — LightGlue on the gfx950 library."""
 
     _default_conf = {
@@ -282,6 +283,16 @@ class LightGlueMatcher(_MatcherBase):
             self._net_n = max(256, 1 << (max(n, 1) - 1).bit_length())
             dev = self._device if isinstance(self._device, (str, torch.device)) else "cuda"
             self._net = LightGlueHIP(self._sd, self._conf, max_pairs=1, max_kpts=self._net_n, device=dev, lib=self._lib)
+
+    def _ensure_pairs(self, n: int, pairs: int):
+        """Batched instance for tile-pair matching (tile_matching.BatchedTileMatchingMixin)."""
+        cur = getattr(self, "_net_b", None)
+        if cur is None or n > self._net_b_n or pairs > self._net_b_p:
+            self._net_b_n = max(256, 1 << (max(n, 1) - 1).bit_length(), getattr(self, "_net_b_n", 0))
+            self._net_b_p = max(pairs, getattr(self, "_net_b_p", 0))
+            dev = self._device if isinstance(self._device, (str, torch.device)) else "cuda"
+            self._net_b = LightGlueHIP(self._sd, self._conf, max_pairs=self._net_b_p, max_kpts=self._net_b_n, device=dev, lib=self._lib)
+        return self._net_b
 
     @torch.no_grad()
     def _match_pairs(self, feats0: dict, feats1: dict) -> np.ndarray:

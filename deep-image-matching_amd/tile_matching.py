@@ -1,0 +1,284 @@
+"""Tile-wise matching for large-format images, batched on the GPU.
+
+Host-side restatement of ``MatcherBase._match_by_tile`` (matchers/matcher_base.py:362-460) and
+``tile_selection`` (matchers/matcher_base.py:989-1140: EXHAUSTIVE / GRID / PRESELECTION with the
+superpoint+lightglue pipeline) with two differences that do not change results:
+
+* the reference calls ``_match_pairs`` once per tile pair, sequentially (MB:417-425); here the tiles of
+  both images form ONE device feature table and all selected tile pairs go through
+  ``LightGlueHIP.match_batch`` in batches (pair -> table-row indirection, no per-pair upload);
+* the reference re-runs the preselection SuperPoint on both (re-read, re-decoded) images for every image
+  pair (MB:1021-1024, 1072-1074); here the down-sampled features are cached per image, and the whole
+  preselection — INTER_AREA down-sampling, SuperPoint (nms 5 / 4000 kpts / thr 0.005), LightGlue
+  (depth 0.9 / width 0.95 / filter 0.3), per-tile-pair vote count — stays on the device
+  (``dim_op_resize_area_f32``, ``dim_sp_extract``, ``dim_lg_match``, ``dim_op_tile_pair_votes``).
+
+Per-tile geometric verification (``geometric_verification_per_tile``, MB:427-441) is cv2 RANSAC in the
+reference and is not rebuilt: with that option set the mixin defers to the base class.
+"""
+from __future__ import annotations
+
+import ctypes
+import logging
+from collections import OrderedDict
+from itertools import product
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import capi
+from . import weights as _weights
+from .lightglue_hip import LightGlueHIP
+from .superpoint_hip import SuperPointHIP
+from .tiling import compute_padding
+
+logger = logging.getLogger("dim_amd")
+
+# MatcherBase.__init__ (MB:136-149): the preselection networks' settings
+PRESELECTION_SP_CONF = {"nms_radius": 5, "max_keypoints": 4000, "keypoint_threshold": 0.005}
+PRESELECTION_LG_CONF = {"n_layers": 9, "depth_confidence": 0.9, "width_confidence": 0.95, "filter_threshold": 0.3}
+_QUALITY_FACTOR = {"HIGHEST": 2, "HIGH": 1, "MEDIUM": 1 / 2, "LOW": 1 / 4, "LOWEST": 1 / 8}  # constants.py:76-88
+
+
+def get_features_by_tile(features: dict, tile_idx: int):
+    """MB:1380-1391."""
+    if "tile_idx" not in features:
+        raise KeyError("tile_idx not found in features")
+    sel = features["tile_idx"] == tile_idx
+    idx = np.where(sel)[0]
+    return ({"keypoints": features["keypoints"][sel], "descriptors": features["descriptors"][:, sel],
+             "scores": features["scores"][sel], "image_size": features["image_size"]}, idx)
+
+
+def tile_grid(shape_hw: Tuple[int, int], tile_size, overlap=0) -> Dict[int, Tuple[int, int]]:
+    """Tile ids and (x, y) origins of ``Tiler.compute_tiles_by_size`` (utils/tiling.py:62-192) from the
+    image shape alone (tile_selection only uses the keys and origins, MB:1036-1041)."""
+    win = (tile_size, tile_size) if isinstance(tile_size, int) else (tile_size[1], tile_size[0])  # (H, W)
+    ov = (overlap, overlap) if isinstance(overlap, int) else (overlap[1], overlap[0])
+    H, W = int(shape_hw[0]), int(shape_hw[1])
+    pad = compute_padding((H, W), win)
+    stride = (win[0] - ov[0], win[1] - ov[1])
+    n_rows = (H + pad[0] + pad[1] - win[0]) // stride[0] + 1
+    n_cols = (W + pad[2] + pad[3] - win[1]) // stride[1] + 1
+    return {r * n_cols + c: (-pad[2] + c * stride[1], -pad[0] + r * stride[0]) for r in range(n_rows) for c in range(n_cols)}
+
+
+def select_tile_pairs(method: str, keys0: Sequence[int], keys1: Sequence[int], votes: Optional[np.ndarray] = None,
+                      min_matches_per_tile: int = 5) -> List[Tuple[int, int]]:
+    """MB:1042-1052 and 1124-1133.  ``votes[a, b]`` is indexed by the sorted tile keys."""
+    if method == "EXHAUSTIVE":
+        return sorted(product(keys0, keys1))
+    if method == "GRID":
+        return sorted(zip(keys0, keys1))
+    if method == "PRESELECTION":
+        if votes is None:
+            raise ValueError("PRESELECTION needs the vote table")
+        k0, k1 = sorted(keys0), sorted(keys1)
+        return sorted((k0[a], k1[b]) for a in range(len(k0)) for b in range(len(k1)) if votes[a, b] > min_matches_per_tile)
+    raise ValueError(f"tile selection method {method} is not built on the MI355X path")
+
+
+class TilePreselector:
+    """Device-resident PRESELECTION (MB:1054-1133): votes[t0, t1] for an image pair."""
+
+    def __init__(self, sp_state_dict, lg_state_dict, tile_preselection_size: int = 1024, device="cuda", lib=None, cache_size: int = 64):
+        self.size = int(tile_preselection_size)
+        self.device = torch.device(device)
+        self.lib = lib if lib is not None else capi.load()
+        self._sp_sd, self._lg_sd = sp_state_dict, lg_state_dict
+        self._sp: Optional[SuperPointHIP] = None
+        self._sp_hw = (0, 0)
+        self._lg: Optional[LightGlueHIP] = None
+        self._cache: "OrderedDict[str, tuple]" = OrderedDict()
+        self._cache_size = cache_size
+
+    def _stream(self):
+        return ctypes_stream(self.device)
+
+    def downsample(self, image: np.ndarray) -> Tuple[torch.Tensor, float]:
+        """cv2.resize(i, size_new, INTER_AREA) then frame2tensor's /255 (MB:1062-1073), on the device."""
+        H, W = image.shape[:2]
+        scale = self.size / max(W, H)
+        w, h = int(round(W * scale)), int(round(H * scale))
+        src = torch.as_tensor(np.ascontiguousarray(image, dtype=np.float32)).to(self.device)
+        dst = torch.empty(h, w, dtype=torch.float32, device=self.device)
+        capi.check(self.lib, self.lib.dim_op_resize_area_f32(capi.ptr(src), H, W, capi.ptr(dst), h, w, 1, self._stream()))
+        return dst, scale
+
+    def features(self, key: str, image: np.ndarray):
+        """(kpts [1,cap,2], desc [1,cap,256], n [1] int32, scale) of the down-sampled image, cached by key."""
+        if key in self._cache:
+            self._cache.move_to_end(key)
+            return self._cache[key]
+        small, scale = self.downsample(image)
+        h, w = small.shape
+        if self._sp is None or h > self._sp_hw[0] or w > self._sp_hw[1]:
+            self._sp_hw = (max(h, self._sp_hw[0], self.size), max(w, self._sp_hw[1], self.size))
+            self._sp = SuperPointHIP(self._sp_sd, PRESELECTION_SP_CONF, max_batch=1, max_hw=self._sp_hw, capacity=4096,
+                                     device=self.device, lib=self.lib)
+        kp, _, de, n = self._sp.extract_batch(small[None].contiguous())
+        ent = (kp, de, n, scale)
+        self._cache[key] = ent
+        while len(self._cache) > self._cache_size:
+            self._cache.popitem(last=False)
+        return ent
+
+    def match(self, f0, f1):
+        """LightGlue on two cached feature sets; image_size is absent in the reference's call (MB:1077-1079),
+        so the keypoint extent is used (LGN:26-27)."""
+        if self._lg is None:
+            self._lg = LightGlueHIP(self._lg_sd, PRESELECTION_LG_CONF, max_pairs=1, max_kpts=4096, device=self.device, lib=self.lib)
+        kt = torch.cat([f0[0], f1[0]]).contiguous()
+        dt = torch.cat([f0[1], f1[1]]).contiguous()
+        nt = torch.cat([f0[2], f1[2]]).contiguous()
+        sizes = []
+        for kp, n in ((f0[0][0], f0[2]), (f1[0][0], f1[2])):
+            k = kp[: int(n.item())]
+            sizes.append(1 + k.max(0).values - k.min(0).values if k.numel() else torch.ones(2, device=self.device))
+        st = torch.stack(sizes).to(torch.float32).contiguous()
+        return self._lg.match_batch(kt, dt, nt, st, n_pairs=1)
+
+    def votes(self, key0: str, image0: np.ndarray, key1: str, image1: np.ndarray, origins0: Dict[int, Tuple[int, int]],
+              origins1: Dict[int, Tuple[int, int]], tile_size) -> np.ndarray:
+        f0, f1 = self.features(key0, image0), self.features(key1, image1)
+        o = self.match(f0, f1)
+        k0, k1 = sorted(origins0), sorted(origins1)
+        og0 = torch.tensor([origins0[k] for k in k0], dtype=torch.int32, device=self.device).contiguous()
+        og1 = torch.tensor([origins1[k] for k in k1], dtype=torch.int32, device=self.device).contiguous()
+        votes = torch.empty(len(k0), len(k1), dtype=torch.int32, device=self.device)
+        capi.check(self.lib, self.lib.dim_op_tile_pair_votes(
+            capi.ptr(f0[0]), capi.ptr(f1[0]), capi.ptr(o["matches"]), capi.ptr(o["n_matches"]), int(o["matches"].shape[1]),
+            ctypes_float(f0[3]), ctypes_float(f1[3]), capi.ptr(og0), len(k0), capi.ptr(og1), len(k1), int(tile_size[0]), int(tile_size[1]),
+            capi.ptr(votes), self._stream()))
+        return votes.cpu().numpy().astype(np.int64)
+
+
+def ctypes_stream(device):
+    if torch.device(device).type == "cuda":
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return None
+
+
+def ctypes_float(x):
+    return ctypes.c_float(float(np.float32(x)))
+
+
+def match_tile_pairs_batched(net_for, features0: dict, features1: dict, tile_pairs: Sequence[Tuple[int, int]], device,
+                             pair_batch: int = 8, select_unique: bool = True) -> np.ndarray:
+    """The loop of MB:414-460, batched.  ``net_for(n_kpts, n_pairs)`` returns a LightGlueHIP sized for it."""
+    full = np.array([], dtype=np.int64).reshape(0, 2)
+    if len(tile_pairs) == 0:
+        return full
+    t0s, t1s = sorted({p[0] for p in tile_pairs}), sorted({p[1] for p in tile_pairs})
+    sub0 = {t: get_features_by_tile(features0, t) for t in t0s}
+    sub1 = {t: get_features_by_tile(features1, t) for t in t1s}
+    # A tile without keypoints cannot match anything.  (The reference would raise inside LightGlue on the
+    # empty max() of LGN:26-27 and lose the whole image pair at image_matching.py:476-486; here only the
+    # empty tile pairs are dropped.)
+    tile_pairs = [(a, b) for a, b in tile_pairs if len(sub0[a][1]) > 0 and len(sub1[b][1]) > 0]
+    if len(tile_pairs) == 0:
+        return full
+    items = [sub0[t] for t in t0s] + [sub1[t] for t in t1s]
+    row0 = {t: i for i, t in enumerate(t0s)}
+    row1 = {t: len(t0s) + i for i, t in enumerate(t1s)}
+    D = features0["descriptors"].shape[0]
+    cap = max(1, max(f["keypoints"].shape[0] for f, _ in items))
+    kt = np.zeros((len(items), cap, 2), dtype=np.float32)
+    dt = np.zeros((len(items), cap, D), dtype=np.float32)
+    nt = np.zeros(len(items), dtype=np.int32)
+    st = np.zeros((len(items), 2), dtype=np.float32)
+    for i, (f, _) in enumerate(items):
+        n = f["keypoints"].shape[0]
+        kt[i, :n], dt[i, :n], nt[i] = f["keypoints"], f["descriptors"].T, n
+        st[i] = np.asarray(f["image_size"], dtype=np.float32).reshape(2)
+    dev = torch.device(device)
+    kt_d, dt_d, nt_d, st_d = (torch.from_numpy(a).to(dev) for a in (kt, dt, nt, st))
+    net = net_for(cap, min(pair_batch, len(tile_pairs)))
+    chunks = []
+    for s in range(0, len(tile_pairs), pair_batch):
+        chunk = tile_pairs[s:s + pair_batch]
+        pidx = torch.tensor([[row0[a], row1[b]] for a, b in chunk], dtype=torch.int32, device=dev).contiguous()
+        o = net.match_batch(kt_d, dt_d, nt_d, st_d, pair_idx=pidx, n_pairs=len(chunk))
+        cnt = o["n_matches"].cpu().numpy()
+        m = o["matches"].cpu().numpy()
+        for j, (a, b) in enumerate(chunk):
+            c = m[j, : int(cnt[j])]
+            orig = np.zeros_like(c)
+            orig[:, 0] = sub0[a][1][c[:, 0]]
+            orig[:, 1] = sub1[b][1][c[:, 1]]
+            chunks.append(orig)
+    full = np.vstack([full] + chunks)
+    if select_unique:
+        full, counts = np.unique(full, axis=0, return_counts=True)
+        if np.any(counts > 1):
+            logger.warning("Found %d duplicate matches across tile pairs", int(np.sum(counts > 1)))
+    return full
+
+
+def _read_band1(path: Path) -> np.ndarray:
+    """rasterio ``src.read(1).astype(float32)`` (MB:1021-1024): the FIRST band, not a grey conversion."""
+    try:
+        import rasterio  # type: ignore
+        with rasterio.open(str(path)) as src:
+            return src.read(1).astype(np.float32)
+    except ImportError:
+        from PIL import Image  # decoder difference (rasterio/GDAL vs PIL) is outside the parity claim
+        im = Image.open(str(path))
+        return np.asarray(im.getchannel(0) if im.mode not in ("L", "I", "F", "I;16") else im, dtype=np.float32)
+
+
+class BatchedTileMatchingMixin:
+    """Overrides MatcherBase._match_by_tile.  Needs ``self._ensure_pairs(n_kpts, n_pairs)`` (LightGlueHIP),
+    ``self._device``, ``self._lib`` and ``self.config['general']``."""
+
+    tile_pair_batch = 8
+
+    def _preselector(self) -> TilePreselector:
+        if getattr(self, "_tile_preselector", None) is None:
+            import os
+            sp_path = self.config["general"].get("preselection_superpoint_weights") or os.environ.get("DIM_SUPERPOINT_WEIGHTS")
+            lg_path = self.config["general"].get("preselection_lightglue_weights") or os.environ.get("DIM_LIGHTGLUE_WEIGHTS")
+            if sp_path is None or lg_path is None:
+                logger.warning("tile preselection: no SuperPoint/LightGlue weights given - using seeded SYNTHETIC weights")
+            self._tile_preselector = TilePreselector(
+                _weights.load_superpoint_state_dict(sp_path), _weights.load_lightglue_state_dict(lg_path, input_dim=256, n_layers=9),
+                tile_preselection_size=int(self.config["general"].get("tile_preselection_size", 1024)),
+                device=self._device if isinstance(self._device, (str, torch.device)) else "cuda", lib=self._lib)
+        return self._tile_preselector
+
+    def tile_selection(self, img0, img1, method: str, image0: Optional[np.ndarray] = None, image1: Optional[np.ndarray] = None):
+        """tile_selection (MB:989-1140) -> sorted list of (tile0, tile1)."""
+        general = self.config["general"]
+        quality = getattr(general.get("quality", "HIGH"), "name", general.get("quality", "HIGH"))
+        i0 = image0 if image0 is not None else _read_band1(Path(img0))
+        i1 = image1 if image1 is not None else _read_band1(Path(img1))
+        if quality != "HIGH":
+            if method == "PRESELECTION":
+                raise NotImplementedError("tile preselection with quality != HIGH needs the reference's cv2 resize; not built")
+            f = _QUALITY_FACTOR[quality]
+            shape0, shape1 = (int(i0.shape[0] * f), int(i0.shape[1] * f)), (int(i1.shape[0] * f), int(i1.shape[1] * f))
+        else:
+            shape0, shape1 = i0.shape[:2], i1.shape[:2]
+        tile_size, overlap = general["tile_size"], general.get("tile_overlap", 0)
+        origins0, origins1 = tile_grid(shape0, tile_size, overlap), tile_grid(shape1, tile_size, overlap)
+        votes = None
+        if method == "PRESELECTION":
+            if general.get("preselection_pipeline", "superpoint+lightglue") != "superpoint+lightglue":
+                raise ValueError("Only the superpoint+lightglue preselection pipeline is built on the MI355X path")
+            votes = self._preselector().votes(str(img0), i0, str(img1), i1, origins0, origins1, tile_size)
+        return select_tile_pairs(method, list(origins0), list(origins1), votes, int(getattr(self, "min_matches_per_tile", general.get("min_matches_per_tile", 5))))
+
+    @torch.no_grad()
+    def _match_by_tile(self, img0, img1, features0: dict, features1: dict, method="PRESELECTION", select_unique: bool = True) -> np.ndarray:
+        general = self.config["general"]
+        if general.get("geometric_verification_per_tile"):
+            return super()._match_by_tile(img0, img1, features0, features1, method=method, select_unique=select_unique)
+        name = getattr(method, "name", method)
+        tile_pairs = self.tile_selection(img0, img1, name)
+        if len(tile_pairs) == 0:
+            logger.debug("No tile pairs selected.")
+            return np.array([], dtype=np.int64).reshape(0, 2)
+        dev = self._device if isinstance(self._device, (str, torch.device)) else "cuda"
+        return match_tile_pairs_batched(self._ensure_pairs, features0, features1, tile_pairs, dev, self.tile_pair_batch, select_unique)

@@ -183,6 +183,67 @@ def main_aliked():
         print(f"aliked real weights: N={mine['keypoints'].shape[0]} ok (oracle == reference, bit-exact)")
 
 
+def reference_tile_helpers():
+    """The reference's tile helpers cannot be imported (matcher_base.py pulls cv2/rasterio/h5py at module
+    level), so the three pure-numpy functions are executed from its source through ``ast``."""
+    import ast
+    src = (REF.parent / "matchers" / "matcher_base.py").read_text()
+    tree = ast.parse(src)
+    want = {"get_features_by_tile", "get_tile_bounding_box", "points_in_rect"}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert {n.name for n in body} == want
+    for n in body:  # drop the type annotations (FeaturesDict is not importable)
+        n.returns = None
+        for a in n.args.args:
+            a.annotation = None
+    ns = {"np": np}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "matcher_base_tile_helpers", "exec"), ns)
+    return ns
+
+
+def main_tile():
+    """tests/golden/tile_votes.npz: PRESELECTION vote counts and tile feature subsets produced by the
+    reference's own helper functions (loop of matcher_base.py:1124-1131)."""
+    from itertools import product
+    from oracle import tile_ref
+    ns = reference_tile_helpers()
+    rng = np.random.default_rng(7)
+    tile_size = (150, 100)
+    origins0 = {r * 4 + c: (-10 + c * 150, -6 + r * 100) for r in range(3) for c in range(4)}
+    origins1 = {r * 3 + c: (-20 + c * 140, r * 95) for r in range(4) for c in range(3)}   # overlapping tiles
+    n = 700
+    kp0 = (rng.random((n, 2)) * np.array([600, 300])).astype(np.float32)
+    kp1 = (rng.random((n, 2)) * np.array([420, 380])).astype(np.float32)
+    kp0[:40] = np.round(kp0[:40] / 50) * 50       # points exactly on tile edges (strict inequalities)
+    kp1[:40] = np.round(kp1[:40] / 35) * 35
+    scale0, scale1 = 1024 / 6000, 1024 / 4000
+    m = np.stack([rng.permutation(n)[:500], rng.permutation(n)[:500]], 1).astype(np.int64)
+    a, b = kp0[m[:, 0]] / scale0, kp1[m[:, 1]] / scale1
+    o0 = {k: (int(v[0] / scale0), int(v[1] / scale0)) for k, v in origins0.items()}
+    o1 = {k: (int(v[0] / scale1), int(v[1] / scale1)) for k, v in origins1.items()}
+    ts = (int(150 / scale0), int(100 / scale0))
+    votes = np.zeros((len(o0), len(o1)), dtype=np.int64)
+    for t0, t1 in sorted(product(o0.keys(), o1.keys())):
+        r0 = ns["points_in_rect"](a, ns["get_tile_bounding_box"](o0[t0], ts))
+        r1 = ns["points_in_rect"](b, ns["get_tile_bounding_box"](o1[t1], ts))
+        votes[t0, t1] = sum(r0 & r1)
+    assert np.array_equal(votes, tile_ref.tile_pair_votes(a, b, o0, o1, ts)), "oracle vote count differs from the reference"
+    feats = {"keypoints": kp0, "descriptors": rng.standard_normal((8, n)).astype(np.float32), "scores": rng.random(n).astype(np.float32),
+             "tile_idx": rng.integers(0, 12, n).astype(np.float32), "image_size": np.array([300, 600], dtype=np.int32)}
+    ft, idx = ns["get_features_by_tile"](feats, 5)
+    fo, io = tile_ref.get_features_by_tile(feats, 5)
+    assert np.array_equal(idx, io) and all(np.array_equal(ft[k], fo[k]) for k in ft)
+    np.savez_compressed(ROOT / "tests" / "golden" / "tile_votes.npz", kp0=kp0, kp1=kp1, matches=m, scale0=np.float64(scale0),
+                        scale1=np.float64(scale1), origins0=np.array([o0[k] for k in sorted(o0)], dtype=np.int32),
+                        origins1=np.array([o1[k] for k in sorted(o1)], dtype=np.int32), tile_size=np.array(ts, dtype=np.int32),
+                        votes=votes, tile_idx=feats["tile_idx"], tile5_idx=idx)
+    print("tile_votes.npz: votes total", int(votes.sum()), "pinned against matcher_base.py helpers")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "tile":
+        main_tile()
+        sys.exit(0)
     main()
     main_aliked()
+    main_tile()

@@ -1,0 +1,156 @@
+"""CPU: tile-wise matching (MatcherBase._match_by_tile / tile_selection restated + batched) through the
+emulator-built library, against oracle/tile_ref.py and the golden pinned to the reference's helpers."""
+import ctypes
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lightglue_ref, superpoint_ref, tile_ref
+
+tm = importlib.import_module("deep-image-matching_amd.tile_matching")
+plugins = importlib.import_module("deep-image-matching_amd.plugins")
+weights = importlib.import_module("deep-image-matching_amd.weights")
+GOLD = Path(__file__).parent / "golden"
+
+
+def _resize(lib, img, h, w, div255=0):
+    src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))
+    dst = torch.empty(h, w, dtype=torch.float32)
+    rc = lib.dim_op_resize_area_f32(ctypes.c_void_p(src.data_ptr()), img.shape[0], img.shape[1], ctypes.c_void_p(dst.data_ptr()), h, w, div255, None)
+    assert rc == 0, lib.dim_last_error()
+    return dst.numpy()
+
+
+@pytest.mark.parametrize("shape,out", [((37, 53), (16, 20)), ((64, 48), (16, 12)), ((60, 50), (20, 23)), ((41, 64), (41, 16)), ((30, 30), (30, 30))])
+def test_resize_area_matches_oracle_bit_exact(emu_lib, shape, out):
+    rng = np.random.default_rng(3)
+    img = (rng.random(shape) * 255).astype(np.float32)
+    ref = tile_ref.resize_area(img, (out[1], out[0]))
+    got = _resize(emu_lib, img, out[0], out[1])
+    assert np.array_equal(got, ref)
+    assert abs(float(got.mean()) - float(img.mean())) < 2.0  # area averaging preserves the mean
+    got255 = _resize(emu_lib, img, out[0], out[1], 1)
+    assert np.array_equal(got255, ref / np.float32(255.0))
+
+
+def test_resize_area_refuses_enlargement(emu_lib):
+    src = torch.zeros(8, 8)
+    dst = torch.zeros(16, 16)
+    assert emu_lib.dim_op_resize_area_f32(ctypes.c_void_p(src.data_ptr()), 8, 8, ctypes.c_void_p(dst.data_ptr()), 16, 16, 0, None) != 0
+    assert b"decimation" in emu_lib.dim_last_error()
+
+
+def _votes(lib, g):
+    k0, k1 = torch.from_numpy(g["kp0"]), torch.from_numpy(g["kp1"])
+    m = torch.from_numpy(g["matches"]).contiguous()
+    n = torch.tensor([m.shape[0]], dtype=torch.int32)
+    o0, o1 = torch.from_numpy(g["origins0"]).contiguous(), torch.from_numpy(g["origins1"]).contiguous()
+    v = torch.full((o0.shape[0], o1.shape[0]), -7, dtype=torch.int32)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.dim_op_tile_pair_votes(p(k0), p(k1), p(m), p(n), m.shape[0], ctypes.c_float(float(np.float32(g["scale0"]))),
+                                    ctypes.c_float(float(np.float32(g["scale1"]))), p(o0), o0.shape[0], p(o1), o1.shape[0],
+                                    int(g["tile_size"][0]), int(g["tile_size"][1]), p(v), None)
+    assert rc == 0, lib.dim_last_error()
+    return v.numpy()
+
+
+def test_tile_pair_votes_match_the_reference_golden(emu_lib):
+    g = np.load(GOLD / "tile_votes.npz")
+    # the golden was produced by the reference's points_in_rect / get_tile_bounding_box on kp / scale (fp64 scale there;
+    # the vote table is identical for the fp32 division numpy performs on fp32 keypoint arrays, checked here)
+    a = g["kp0"][g["matches"][:, 0]] / np.float32(g["scale0"])
+    b = g["kp1"][g["matches"][:, 1]] / np.float32(g["scale1"])
+    o0 = {i: tuple(v) for i, v in enumerate(g["origins0"])}
+    o1 = {i: tuple(v) for i, v in enumerate(g["origins1"])}
+    assert np.array_equal(tile_ref.tile_pair_votes(a, b, o0, o1, tuple(g["tile_size"])), g["votes"])
+    assert np.array_equal(_votes(emu_lib, g), g["votes"])
+    f, idx = tm.get_features_by_tile({"keypoints": g["kp0"], "descriptors": np.zeros((4, len(g["kp0"])), np.float32),
+                                      "scores": np.zeros(len(g["kp0"]), np.float32), "tile_idx": g["tile_idx"], "image_size": np.array([1, 1])}, 5)
+    assert np.array_equal(idx, g["tile5_idx"]) and f["descriptors"].shape == (4, len(idx))
+    with pytest.raises(KeyError):
+        tm.get_features_by_tile({"keypoints": g["kp0"]}, 0)
+
+
+def test_tile_grid_and_pair_selection_follow_the_reference():
+    tiling = importlib.import_module("deep-image-matching_amd.tiling")
+    img = np.zeros((100, 130), np.float32)
+    tiles, origins, _ = tiling.compute_tiles_by_size(img, (40, 30), 0)
+    assert tm.tile_grid(img.shape, (40, 30), 0) == origins and sorted(tiles) == sorted(origins)
+    k0, k1 = [0, 1, 2], [0, 1]
+    assert tm.select_tile_pairs("EXHAUSTIVE", k0, k1) == tile_ref.select_tile_pairs("EXHAUSTIVE", k0, k1) == [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1)]
+    assert tm.select_tile_pairs("GRID", k0, k1) == [(0, 0), (1, 1)]
+    votes = np.array([[6, 5], [0, 9], [5, 100]])
+    assert tm.select_tile_pairs("PRESELECTION", k0, k1, votes, 5) == tile_ref.select_tile_pairs("PRESELECTION", k0, k1, votes, 5) == [(0, 0), (1, 1), (2, 1)]
+    with pytest.raises(ValueError):
+        tm.select_tile_pairs("PRESELECTION_AFFINE_TRANSFORM", k0, k1)
+
+
+def _tiled_features(seed, n, n_tiles, hw):
+    g = torch.Generator().manual_seed(seed)
+    k = (torch.rand(n, 2, generator=g) * torch.tensor([hw[1], hw[0]])).numpy().astype(np.float32)
+    d = torch.nn.functional.normalize(torch.randn(n, 256, generator=g), dim=-1).t().numpy().copy()
+    t = torch.randint(0, n_tiles, (n,), generator=g).numpy().astype(np.float32)
+    return {"keypoints": k, "descriptors": d, "scores": np.ones(n, np.float32), "tile_idx": t, "image_size": np.array(hw, np.int32)}
+
+
+def test_batched_match_by_tile_equals_the_sequential_reference_loop(emu_lib):
+    cfg = {"general": {"tile_size": (60, 50), "tile_overlap": 0},
+           "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0}}
+    m = plugins.LightGlueMatcher(cfg, _lib=emu_lib, _device="cpu")
+    m.tile_pair_batch = 3
+    f0, f1 = _tiled_features(0, 90, 4, (100, 120)), _tiled_features(1, 70, 3, (100, 120))
+    f1["tile_idx"][f1["tile_idx"] == 2] = 1  # tile 2 of image 1 is empty
+    pairs = [(0, 0), (0, 1), (1, 1), (2, 0), (3, 1), (3, 2), (1, 2)]
+    got = tm.match_tile_pairs_batched(m._ensure_pairs, f0, f1, pairs, "cpu", pair_batch=3)
+
+    def seq(a, b):  # oracle LightGlue per tile pair, as the reference's loop calls _match_pairs
+        sz = torch.tensor([100.0, 120.0])
+        r = lightglue_ref.lightglue_forward(torch.from_numpy(a["keypoints"]), torch.from_numpy(a["descriptors"].T.copy()), sz,
+                                            torch.from_numpy(b["keypoints"]), torch.from_numpy(b["descriptors"].T.copy()), sz, m._sd, {**m._conf})
+        return r["matches"].numpy()
+
+    ref = tile_ref.match_by_tile(f0, f1, [p for p in pairs if p[1] != 2], seq)
+    assert got.dtype == np.int64 and np.array_equal(got, ref) and len(got) > 0
+    # the hook itself, GRID selection from the configured tile grid (image shapes given instead of files)
+    grid = m.tile_selection("a", "b", "GRID", image0=np.zeros((100, 120), np.float32), image1=np.zeros((100, 120), np.float32))
+    assert grid == [(0, 0), (1, 1), (2, 2), (3, 3)]
+    assert tm.match_tile_pairs_batched(m._ensure_pairs, f0, f1, [], "cpu").shape == (0, 2)
+
+
+def test_device_preselection_matches_the_oracle_pipeline(emu_lib):
+    """resize -> SuperPoint -> LightGlue -> votes on the library vs the same chain on the oracle."""
+    rng = np.random.default_rng(11)
+    imgs = [(rng.random((150, 200)) * 255).astype(np.float32), (rng.random((160, 190)) * 255).astype(np.float32)]
+    sp_sd = weights.synthetic_superpoint_state_dict(0)
+    lg_sd = weights.synthetic_lightglue_state_dict(0, 256)
+    old_sp, old_lg = dict(tm.PRESELECTION_SP_CONF), dict(tm.PRESELECTION_LG_CONF)
+    tm.PRESELECTION_SP_CONF.update(max_keypoints=60, nms_radius=2)       # emulator-sized
+    tm.PRESELECTION_LG_CONF.update(n_layers=2, filter_threshold=0.0)
+    try:
+        pre = tm.TilePreselector(sp_sd, lg_sd, tile_preselection_size=64, device="cpu", lib=emu_lib)
+        origins0, origins1 = tm.tile_grid(imgs[0].shape, (100, 75), 0), tm.tile_grid(imgs[1].shape, (100, 80), 0)
+        votes = pre.votes("i0", imgs[0], "i1", imgs[1], origins0, origins1, (100, 75))
+        assert pre.features("i0", imgs[0]) is pre._cache["i0"]           # cached: no second extraction
+
+        feats, scales = [], []
+        for im in imgs:
+            size, scale, new = tile_ref.preselection_sizes(im.shape, 64)
+            small = tile_ref.resize_area(im, new)
+            assert np.array_equal(pre.downsample(im)[0].numpy(), small / np.float32(255.0))
+            r = superpoint_ref.superpoint_forward(torch.from_numpy(small / np.float32(255.0))[None, None], sp_sd, pre._sp.cfg)
+            feats.append(r); scales.append(scale)
+        k0, k1 = feats[0]["keypoints"].float(), feats[1]["keypoints"].float()
+        s0, s1 = 1 + k0.max(0).values - k0.min(0).values, 1 + k1.max(0).values - k1.min(0).values
+        r = lightglue_ref.lightglue_forward(k0, feats[0]["descriptors"].t().contiguous(), s0, k1, feats[1]["descriptors"].t().contiguous(), s1,
+                                            lg_sd, dict(tm.PRESELECTION_LG_CONF))
+        mm = r["matches"].numpy()
+        a = k0.numpy()[mm[:, 0]] / np.float32(scales[0])
+        b = k1.numpy()[mm[:, 1]] / np.float32(scales[1])
+        ref = tile_ref.tile_pair_votes(a, b, origins0, origins1, (100, 75))
+        assert len(mm) > 0 and np.array_equal(votes, ref)
+    finally:
+        tm.PRESELECTION_SP_CONF.clear(); tm.PRESELECTION_SP_CONF.update(old_sp)
+        tm.PRESELECTION_LG_CONF.clear(); tm.PRESELECTION_LG_CONF.update(old_lg)

@@ -1,0 +1,82 @@
+"""GPU: tile-wise matching at BASELINE config-5 sizes (6000x4000 images, 1500x1000 tiles) through the C ABI."""
+import ctypes
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tile_ref
+
+pytestmark = pytest.mark.gpu
+tm = importlib.import_module("deep-image-matching_amd.tile_matching")
+plugins = importlib.import_module("deep-image-matching_amd.plugins")
+weights = importlib.import_module("deep-image-matching_amd.weights")
+capi = importlib.import_module("deep-image-matching_amd.capi")
+GOLD = Path(__file__).parent / "golden"
+
+
+def test_resize_area_full_size_bit_exact(hip_lib):
+    rng = np.random.default_rng(5)
+    for shape, out in (((4000, 6000), (683, 1024)), ((2048, 3072), (512, 768)), ((1000, 1500), (683, 1024))):
+        img = (rng.random(shape) * 255).astype(np.float32)
+        src = torch.from_numpy(img).cuda()
+        dst = torch.empty(out, dtype=torch.float32, device="cuda")
+        capi.check(hip_lib, hip_lib.dim_op_resize_area_f32(capi.ptr(src), shape[0], shape[1], capi.ptr(dst), out[0], out[1], 0, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), tile_ref.resize_area(img, (out[1], out[0])))
+
+
+def test_tile_pair_votes_golden(hip_lib):
+    g = np.load(GOLD / "tile_votes.npz")
+    dev = lambda a: torch.from_numpy(a).cuda().contiguous()
+    k0, k1, m, o0, o1 = dev(g["kp0"]), dev(g["kp1"]), dev(g["matches"]), dev(g["origins0"]), dev(g["origins1"])
+    n = torch.tensor([m.shape[0]], dtype=torch.int32, device="cuda")
+    v = torch.full((o0.shape[0], o1.shape[0]), -1, dtype=torch.int32, device="cuda")
+    capi.check(hip_lib, hip_lib.dim_op_tile_pair_votes(capi.ptr(k0), capi.ptr(k1), capi.ptr(m), capi.ptr(n), m.shape[0],
+                                                       ctypes.c_float(float(np.float32(g["scale0"]))), ctypes.c_float(float(np.float32(g["scale1"]))),
+                                                       capi.ptr(o0), o0.shape[0], capi.ptr(o1), o1.shape[0], int(g["tile_size"][0]),
+                                                       int(g["tile_size"][1]), capi.ptr(v), None))
+    assert np.array_equal(v.cpu().numpy(), g["votes"])
+
+
+def _tiled_features(seed, n_per_tile, n_tiles, hw, dim=128):
+    g = torch.Generator().manual_seed(seed)
+    n = n_per_tile * n_tiles
+    k = (torch.rand(n, 2, generator=g) * torch.tensor([hw[1], hw[0]])).numpy().astype(np.float32)
+    d = torch.nn.functional.normalize(torch.randn(n, dim, generator=g), dim=-1).t().numpy().copy()
+    t = (torch.arange(n) % n_tiles).numpy().astype(np.float32)
+    return {"keypoints": k, "descriptors": d, "scores": np.ones(n, np.float32), "tile_idx": t, "image_size": np.array(hw, np.int32)}
+
+
+def test_batched_tile_pairs_equal_one_call_per_pair(hip_lib):
+    """16 x 16 tiles with 1000 ALIKED-sized keypoints each; the batched table path must give exactly the
+    list the reference's loop builds from one _match_pairs call per tile pair (same kernels, batch 1)."""
+    cfg = {"general": {"tile_size": (1500, 1000), "tile_overlap": 0},
+           "matcher": {"name": "lightglue", "depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.0}}
+    m = plugins.LightGlueMatcher(cfg, local_features="aliked")
+    f0, f1 = _tiled_features(0, 1000, 16, (4000, 6000)), _tiled_features(1, 900, 16, (4000, 6000))
+    pairs = tm.select_tile_pairs("GRID", range(16), range(16)) + [(0, 5), (7, 2), (15, 0)]
+    got = tm.match_tile_pairs_batched(m._ensure_pairs, f0, f1, pairs, "cuda", pair_batch=8)
+    ref = tile_ref.match_by_tile(f0, f1, pairs, m._match_pairs)
+    assert got.shape[1] == 2 and len(got) > 0 and np.array_equal(got, ref)
+
+
+def test_preselection_end_to_end_runs_on_device(hip_lib):
+    rng = np.random.default_rng(2)
+    base = (rng.random((4000, 6000)) * 255).astype(np.float32)
+    i0, i1 = base, np.roll(base, (500, 750), axis=(0, 1)).copy()  # a shifted copy: matches must vote for shifted tile pairs
+    pre = tm.TilePreselector(weights.synthetic_superpoint_state_dict(0), weights.synthetic_lightglue_state_dict(0, 256), 1024, "cuda", hip_lib)
+    og = tm.tile_grid(i0.shape, (1500, 1000), 0)
+    v = pre.votes("a", i0, "b", i1, og, og, (1500, 1000))
+    assert v.shape == (16, 16) and v.dtype == np.int64 and v.min() >= 0
+    f0, f1 = pre.features("a", i0), pre.features("b", i1)
+    assert int(f0[2].item()) == 4000 and f0[0].shape == (1, 4096, 2)
+    # votes are consistent with the match list the same LightGlue call returns
+    o = pre.match(f0, f1)
+    S = int(o["n_matches"][0].item())
+    mm = o["matches"][0, :S].cpu().numpy()
+    a = f0[0][0].cpu().numpy()[mm[:, 0]] / np.float32(f0[3])
+    b = f1[0][0].cpu().numpy()[mm[:, 1]] / np.float32(f1[3])
+    assert np.array_equal(v, tile_ref.tile_pair_votes(a, b, og, og, (1500, 1000))) and int(v.sum()) <= S
