@@ -47,8 +47,8 @@ PKG = "deep-image-matching_amd"
 
 SP_GFLOP_PER_IMAGE = 177.85       # SURVEY.md §8(d), torch flop counter on the reference module
 LG_GFLOP_PER_PAIR = 229.8         # 2048 x 2048, 9 layers, fixed work
+CONV1A_GFLOP_PER_IMAGE = 2 * 0.604   # Appendix B: 3x3, 1->64 @1024^2 (+ReLU), fused into the conv1b kernel
 CONV1B_GFLOP_PER_IMAGE = 2 * 38.655  # Appendix B: 3x3, 64->64 @1024^2 (+ReLU+pool)
-CONV2B_GFLOP_PER_IMAGE = 2 * 9.664   # Appendix B: 3x3, 64->64 @512^2  (+ReLU+pool) — same kernel instance
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 X6_PASSES = 6                     # bf16 MFMA terms per fp32-accurate product step (hh, hm, mh, hl, lh, mm)
@@ -190,8 +190,8 @@ def main():
     if W > 0:
         run(W, 0)
     barrier()
-    # time every launch of conv3x3_x6_kernel<64,1,*> (sites conv1b and conv2b) with HIP events on the launch stream
-    capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong((1 << 1) | (1 << 3))))  # DIM_PROF_SP_CONV1B | DIM_PROF_SP_CONV2B
+    # time every launch of conv3x3_x6_kernel<64,1,1,true> (conv1a fused into conv1b) with HIP events on the launch stream
+    capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong(1 << 1)))  # DIM_PROF_SP_CONV1B: the fused conv1a+conv1b kernel
     t0 = time.perf_counter()
     n_last = run(K, W)
     if dist is not None:  # one collective for the whole job: per-rank match tables -> every rank
@@ -208,7 +208,7 @@ def main():
 
     # the same kernel timed again with nothing else on the GPU (2 extraction-only batches after the timed region)
     iso_ms, iso_n = ctypes.c_double(), ctypes.c_int()
-    capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong((1 << 1) | (1 << 3))))
+    capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong(1 << 1)))
     for i in range(2):
         ext.extract_batch(pool[i % n_pool], out=feats[0])
     torch.cuda.synchronize()
@@ -224,7 +224,7 @@ def main():
         pairs_total = world * K * P
         value = pairs_total / dt
         conv_ms = tot_ms.value / max(1, launches.value)
-        gflop_per_launch = (CONV1B_GFLOP_PER_IMAGE + CONV2B_GFLOP_PER_IMAGE) / 2 * 2 * P  # mean over its two launch sites
+        gflop_per_launch = (CONV1A_GFLOP_PER_IMAGE + CONV1B_GFLOP_PER_IMAGE) * 2 * P  # one launch = the 2P images of a step
         conv_tflops = gflop_per_launch / conv_ms  # GFLOP / ms == TFLOP/s
         traffic = None
         pmc = ROOT / "profiles" / "conv1b_hbm_bytes.json"
@@ -245,8 +245,8 @@ def main():
                        "sharding": f"pairs sharded over {world} rank(s), one RCCL all-gather of match tables at the end",
                        "streams": "extraction of batch i+1 overlaps matching of batch i (2 HIP streams)" if overlap else "single stream"},
             "end_to_end_tflops_per_gpu": (2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR) * value / world / 1e3,
-            "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1> (3x3 conv 64->64 + bias + ReLU + 2x2 max-pool, fp32-accurate on bf16 MFMA; "
-                                   "launch sites conv1b @1024^2 and conv2b @512^2)", "bound": "mfma",
+            "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1,true> (SuperPoint conv1a 1->64 evaluated in the halo staging + conv1b 64->64 3x3 "
+                                   "+ bias + ReLU + 2x2 max-pool, fp32-accurate on bf16 MFMA; 1024^2 images)", "bound": "mfma",
                          "achieved": conv_tflops, "peak": PEAK_BF16_MFMA_TFLOPS / X6_PASSES, "unit": "TFLOP/s",
                          "frac": conv_tflops / (PEAK_BF16_MFMA_TFLOPS / X6_PASSES),
                          "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMA passes per fp32-accurate product; "

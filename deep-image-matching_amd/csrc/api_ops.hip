@@ -24,6 +24,8 @@ size_t g_prof_used = 0;
 
 static int g_precision_mode = 1;
 int dim_precision_mode() { return g_precision_mode; }
+static int g_fuse_conv1a = 1;
+int dim_fuse_conv1a() { return g_fuse_conv1a; }
 
 void dim_prof_begin(int site, hipStream_t s) {
   if (!((g_prof_mask >> site) & 1ull)) return;
@@ -129,6 +131,7 @@ int dim_tune_set(int key, int value) {
   if (key == 0) dim_conv_set_variant(value);
   if (key == 1) g_precision_mode = value;
   if (key == 2) dim_conv_x6_set_variant(value);
+  if (key == 3) g_fuse_conv1a = value;
   return 0;
 }
 

@@ -22,12 +22,19 @@ constexpr int W_SLICE = 3 * 3 * 2 * 64 * 8;                              // bf16
 
 // PF: 0 = no software prefetch, 1 = next weight slice fetched into registers behind the MFMAs,
 //     2 = additionally the next chunk's halo tile (24 more VGPRs: 2 instead of 3 workgroups per CU).
-template <int CIN, int POOL, int PF>
+// F1A: the input is the 1-channel image and the kernel computes SuperPoint's conv1a (1 -> 64, 3x3, bias,
+//      ReLU; SPN:161) on the fly while it stages its own halo tile, with the arithmetic of conv1a_kernel
+//      (conv.hip: fmaf chain over the 9 taps from 0, then + bias, ReLU): the 268-MB conv1a map of a 1024^2
+//      image is neither written nor read back.  CIN must be 64.
+template <int CIN, int POOL, int PF, bool F1A>
 __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
-                                                            int cout, int relu, int tiles_x) {
+                                                            int cout, int relu, int tiles_x, const float* __restrict__ w1a,
+                                                            const float* __restrict__ b1a) {
   __shared__ u32x4 Ip[3 * 2 * NPIX];
   __shared__ u32x4 Wp[3 * 3 * 2 * 64];
+  constexpr int IMW = IW + 2, IMH = IH + 2;  // image tile of the fused conv1a: halo of the halo
+  __shared__ float Img[F1A ? IMH * IMW : 1];
   constexpr int NCHUNK = CIN / 16;
 
   const int t = threadIdx.x;
@@ -35,7 +42,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
   const int cb = blockIdx.y, b = blockIdx.z;
   const int oy = ty * TH, ox = tx * TW;
-  const float* in_b = in + (size_t)b * H * W * CIN;
+  const float* in_b = in + (size_t)b * H * W * (F1A ? 1 : CIN);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -93,11 +100,50 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
     }
   };
 
+  // fused conv1a: this thread's quad of channels is fixed (q = t & 3); per chunk it needs 9 x 4 weights
+  auto conv1a_in = [&](int c) {
+    const int q = t & 3;
+    float wr[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 v = *(const float4*)(w1a + k * 64 + c * 16 + q * 4);
+      wr[k][0] = v.x; wr[k][1] = v.y; wr[k][2] = v.z; wr[k][3] = v.w;
+    }
+    const float4 bv = *(const float4*)(b1a + c * 16 + q * 4);
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = t + 256 * i;
+      const int p = idx >> 2;
+      const int py = p / IW, px = p - py * IW;
+      const int gy = oy + py - 1, gx = ox + px - 1;
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+      if (idx < NPIX * 4) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float v = Img[(py + k / 3) * IMW + px + k % 3];
+          o0 = fmaf(v, wr[k][0], o0); o1 = fmaf(v, wr[k][1], o1);
+          o2 = fmaf(v, wr[k][2], o2); o3 = fmaf(v, wr[k][3], o3);
+        }
+      }
+      const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;  // outside the image conv1b sees its zero padding
+      rin[i] = inside ? make_float4(fmaxf(o0 + bv.x, 0.f), fmaxf(o1 + bv.y, 0.f), fmaxf(o2 + bv.z, 0.f), fmaxf(o3 + bv.w, 0.f))
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (F1A) {
+    for (int idx = t; idx < IMH * IMW; idx += 256) {
+      const int r = idx / IMW, cc = idx - r * IMW;
+      const int gy = oy + r - 2, gx = ox + cc - 2;
+      Img[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in_b[(size_t)gy * W + gx] : 0.0f;
+    }
+  }
+
   if (PF >= 1) load_w(0, 0);
-  if (PF == 2) load_in(0);
+  if (PF == 2 && !F1A) load_in(0);
   for (int c = 0; c < NCHUNK; ++c) {
-    __syncthreads();  // every wave is done with the previous chunk's Ip / Wp
-    if (PF != 2) load_in(c);
+    __syncthreads();  // every wave is done with the previous chunk's Ip / Wp (and Img is complete)
+    if (F1A) conv1a_in(c);
+    else if (PF != 2) load_in(c);
     store_in();
     for (int dy = 0; dy < 3; ++dy) {
       if (dy > 0) __syncthreads();  // previous kernel row's weights consumed
@@ -108,7 +154,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
         if (dy < 2) load_w(c, dy + 1);
         else if (c + 1 < NCHUNK) load_w(c + 1, 0);
       }
-      if (PF == 2 && dy == 2 && c + 1 < NCHUNK) load_in(c + 1);
+      if (PF == 2 && !F1A && dy == 2 && c + 1 < NCHUNK) load_in(c + 1);
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         u32x4 fa[2][3], fb[2][3];
@@ -204,7 +250,7 @@ int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bi
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-#define DIM_CONV6(CI, P, PFV) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x)
+#define DIM_CONV6(CI, P, PFV) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV, false>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr)
 #define DIM_CONV6_V(PFV)                                  \
   {                                                       \
     if (cin == 64 && pool) DIM_CONV6(64, 1, PFV);         \
@@ -219,6 +265,19 @@ int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bi
   }
 #undef DIM_CONV6_V
 #undef DIM_CONV6
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+// conv1a (1 -> 64) fused into the 64 -> cout convolution that consumes it (SuperPoint conv1a + conv1b, SPN:161-162).
+int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const unsigned short* wx, const float* bias,
+                              float* out, int batch, int H, int W, int cout, int pool, int relu, hipStream_t s) {
+  DIM_REQUIRE(cout % 64 == 0, "conv3x3_x6 fused conv1a: cout=%d must be a multiple of 64", cout);
+  if (batch <= 0 || H <= 0 || W <= 0) return 0;
+  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
+  dim3 grid(tiles_x * tiles_y, cout / 64, batch);
+  if (pool) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, 1, 1, true>), grid, dim3(256), 0, s, image, wx, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, 0, 1, true>), grid, dim3(256), 0, s, image, wx, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a);
   DIM_LAUNCH_CHECK();
   return 0;
 }

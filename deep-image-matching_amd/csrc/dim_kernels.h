@@ -45,7 +45,11 @@ size_t conv_x6_weight_elems(int cin, int cout);
 void prepare_conv_weights_x6(const float* w_oihw, int cin, int cout, unsigned short* out);
 int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bias, float* out, int batch, int H, int W, int cin,
                       int cout, int pool, int relu, hipStream_t s);
+// conv1a (image -> 64 channels, weights [9][64]) computed on the fly inside the following 64 -> cout conv
+int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const unsigned short* wx, const float* bias,
+                              float* out, int batch, int H, int W, int cout, int pool, int relu, hipStream_t s);
 int dim_precision_mode();  // 1 (default): bf16x6 on the bf16 matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
+int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
 void dim_conv_x6_set_variant(int v);  // tuning hook: prefetch variant of conv3x3_x6 (dim_tune_set key 2)
 void dim_conv_set_variant(int v);  // tuning hook: selects the conv3x3 kernel variant (see conv.hip)
 // conv1a: 1 -> 64 channels, direct (VALU) convolution; in: [B][H][W], w: [9][64].

@@ -93,7 +93,7 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
   // ---- activations ----
   const size_t B = max_batch, H = max_h, W = max_w;
   const size_t H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, hh = H4 / 2, ww = W4 / 2;
-  SP_TRY(dev_alloc(h, &h->a1, B * H * W * 64));
+  h->a1 = nullptr;  // conv1a's 64-channel full-resolution map: only the unfused A/B path needs it, allocated on first use
   SP_TRY(dev_alloc(h, &h->b1, B * H2 * W2 * 64));
   SP_TRY(dev_alloc(h, &h->a2, B * H2 * W2 * 64));
   SP_TRY(dev_alloc(h, &h->b2, B * H4 * W4 * 64));
@@ -134,8 +134,13 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
               : launch_conv3x3(in, h->wk[l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s);
   };
   // encoder (SPN:161-171)
-  SP_SITE(DIM_PROF_SP_CONV1A, launch_conv1a(images_dev, h->wk[0], h->bias[0], h->a1, batch, H, W, s));
-  SP_SITE(DIM_PROF_SP_CONV1B, conv(1, h->a1, h->b1, H, W, 64, 64, 1));
+  if (x6 && dim_fuse_conv1a()) {  // conv1a evaluated inside conv1b's halo staging: its 64-channel full-resolution map never exists
+    SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_x6_fused1a(images_dev, h->wk[0], h->bias[0], h->wx6[1], h->bias[1], h->b1, batch, H, W, 64, 1, 1, s));
+  } else {
+    if (!h->a1) SP_RUN(dev_alloc(h, &h->a1, (size_t)h->max_batch * h->max_h * h->max_w * 64));
+    SP_SITE(DIM_PROF_SP_CONV1A, launch_conv1a(images_dev, h->wk[0], h->bias[0], h->a1, batch, H, W, s));
+    SP_SITE(DIM_PROF_SP_CONV1B, conv(1, h->a1, h->b1, H, W, 64, 64, 1));
+  }
   SP_SITE(DIM_PROF_SP_CONV2A, conv(2, h->b1, h->a2, H2, W2, 64, 64, 0));
   SP_SITE(DIM_PROF_SP_CONV2B, conv(3, h->a2, h->b2, H2, W2, 64, 64, 1));
   SP_SITE(DIM_PROF_SP_CONV3A, conv(4, h->b2, h->a3, H4, W4, 64, 128, 0));

@@ -40,3 +40,22 @@ def test_superpoint_emulated_vs_golden_and_oracle(emu_lib, name):
     res = compare_superpoint({k: v.cpu() for k, v in out.items()}, gold)
     k = case["cfg"]["max_keypoints"]
     order_is_reference_like(out, k_limited=(k >= 0 and res["n_out"] == k))
+
+
+def test_fused_conv1a_equals_the_two_kernel_path(emu_lib):
+    """conv1a evaluated inside conv1b's halo staging (conv_x6.hip, F1A) must reproduce the separate
+    conv1a kernel + conv1b bit for bit: same fmaf chain, same zero padding on both levels."""
+    name = next(iter(gc.SP_CASES))
+    case = gc.SP_CASES[name]
+    sd = gc.sp_weights(case)
+    img = torch.rand(1, 1, 44, 70, generator=torch.Generator().manual_seed(9))  # ragged: partial tiles on both axes
+    net = sp_mod.SuperPointHIP(sd, case["cfg"], max_batch=1, max_hw=(44, 70), capacity=512, device="cpu", lib=emu_lib)
+    try:
+        emu_lib.dim_tune_set(3, 1)
+        a = net(img); ta = net.debug_taps()
+        emu_lib.dim_tune_set(3, 0)
+        b = net(img); tb = net.debug_taps()
+    finally:
+        emu_lib.dim_tune_set(3, 1)
+    assert torch.equal(ta["encoder"], tb["encoder"]) and torch.equal(ta["score_map"], tb["score_map"])
+    assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
