@@ -13,17 +13,19 @@ sharded across ranks (weak scaling: every rank runs K steps of `--pairs` pairs) 
 data-path collective; after the last step the per-rank match tables are exchanged with ONE
 RCCL all-gather (inside the timed region), as north_star asks.
 
-Arithmetic: fp32 results ("dtype": "f32").  Matrix products run on the bf16 matrix cores with every
-fp32 operand split exactly into three bf16 pieces and the six leading cross terms accumulated in
-fp32 ("bf16x6", csrc/gemm_x6.hip): fp32-class accuracy (hardware probe 1.3e-7 of sum|a*b| vs 1.2e-7
-for an fp32 fmaf chain) at 6 bf16 MFMAs per product step instead of 8 fp32 MFMAs.
+Arithmetic: fp32 results ("dtype": "f32").  Matrix products run on the 16-bit matrix cores with every
+fp32 operand (scaled by an exact power of two) split into two fp16 pieces and the three leading cross
+terms accumulated in fp32 ("fp16x3", csrc/dim_common.h SplitMma<2>): fp32-class accuracy (hardware probe
+scripts/probe/mfma_f16_probe.hip: 0.7-1.7e-7 of sum|a*b| where an fp32 fmaf chain gives 1.2-4.5e-7) at
+3 fp16 MFMAs per product step instead of 8 fp32 MFMAs.  `dim_tune_set(1, 1)` selects the exact 3-way
+bf16 split with six terms ("bf16x6"), `dim_tune_set(1, 0)` plain fp32 MFMA.
 
 Rank 0 prints one JSON line carrying the contract fields plus
-  roofline     — the dominant kernel (conv3x3_x6_kernel<64,1>: conv1b+conv2b, 54 % of SuperPoint's
-                 FLOPs) timed live with HIP events on the launch stream over the timed region;
-                 `achieved` counts ALGORITHMIC fp32 FLOPs; `peak` is the dense bf16 MFMA peak of
-                 MI355X_MICROARCH.md divided by the six passes the fp32-accurate product needs
-                 (2500 / 6 = 416.7 TFLOP/s); the fraction of the plain fp32-MFMA peak (157.3) is
+  roofline     — the dominant kernel (conv3x3_x6_kernel<64,1,1,true,2>: conv1a fused into conv1b, 44 % of
+                 SuperPoint's FLOPs) timed live with HIP events on the launch stream over the timed
+                 region; `achieved` counts ALGORITHMIC fp32 FLOPs; `peak` is the dense fp16 MFMA peak
+                 of MI355X_MICROARCH.md divided by the three passes the fp32-accurate product needs
+                 (2500 / 3 = 833.3 TFLOP/s); the fraction of the plain fp32-MFMA peak (157.3) is
                  reported beside it;
   cpu_baseline — the oracle (CPU restatement of the reference path) timed on this box's host
                  cores on a bounded sample of the same workload.
@@ -51,7 +53,7 @@ CONV1A_GFLOP_PER_IMAGE = 2 * 0.604   # Appendix B: 3x3, 1->64 @1024^2 (+ReLU), f
 CONV1B_GFLOP_PER_IMAGE = 2 * 38.655  # Appendix B: 3x3, 64->64 @1024^2 (+ReLU+pool)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-X6_PASSES = 6                     # bf16 MFMA terms per fp32-accurate product step (hh, hm, mh, hl, lh, mm)
+X6_PASSES = 3                     # fp16 MFMA terms per fp32-accurate product step (lh, hl, hh)
 
 
 def parse():
@@ -237,7 +239,7 @@ def main():
             "metric": "image-pairs/s (SuperPoint+LightGlue, 1024^2, 2048 kpts)",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "arithmetic": "fp32 results; matrix products as exact 3-way bf16 splits x 6 bf16-MFMA cross terms (fp32-class accuracy)", "data": "synthetic",
+            "dtype": "f32", "arithmetic": "fp32 results; matrix products as 2-way fp16 splits of power-of-two-scaled operands x 3 fp16-MFMA cross terms (fp32-class accuracy, measured <= the fp32 fmaf chain's error)", "data": "synthetic",
             "config": {"workload": "configs[2]: SuperPoint+LightGlue, synthetic 1024x1024 grayscale pairs @2048 kpts, "
                                    "2 extractions + 1 match per pair, LightGlue fixed-work (9 layers, no early stop/pruning), "
                                    "seeded synthetic weights", "pairs_per_step_per_gpu": P, "image": "1024x1024",
@@ -245,12 +247,12 @@ def main():
                        "sharding": f"pairs sharded over {world} rank(s), one RCCL all-gather of match tables at the end",
                        "streams": "extraction of batch i+1 overlaps matching of batch i (2 HIP streams)" if overlap else "single stream"},
             "end_to_end_tflops_per_gpu": (2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR) * value / world / 1e3,
-            "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1,true> (SuperPoint conv1a 1->64 evaluated in the halo staging + conv1b 64->64 3x3 "
-                                   "+ bias + ReLU + 2x2 max-pool, fp32-accurate on bf16 MFMA; 1024^2 images)", "bound": "mfma",
+            "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1,true,2> (SuperPoint conv1a 1->64 evaluated in the halo staging + conv1b 64->64 3x3 "
+                                   "+ bias + ReLU + 2x2 max-pool, fp32-accurate on the fp16 MFMA (fp16x3); 1024^2 images)", "bound": "mfma",
                          "achieved": conv_tflops, "peak": PEAK_BF16_MFMA_TFLOPS / X6_PASSES, "unit": "TFLOP/s",
                          "frac": conv_tflops / (PEAK_BF16_MFMA_TFLOPS / X6_PASSES),
-                         "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMA passes per fp32-accurate product; "
-                                      "the kernel runs power-limited at ~1.65 GHz with ~74 % MFMA-busy (profiles/)",
+                         "peak_note": "dense fp16 MFMA peak 2500 TFLOP/s / 3 fp16 MFMA passes per fp32-accurate product; "
+                                      "clock and MFMA-busy fraction per kernel: profiles/r01_pmc_mfma_summary.txt",
                          "frac_of_fp32_mfma_peak": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "isolated": {"note": "same kernel, same launches, timed right after the timed region with no LightGlue work "
                                               "sharing the GPU (in the timed region the two streams overlap, so a launch is stretched)",

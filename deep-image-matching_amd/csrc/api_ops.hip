@@ -22,7 +22,7 @@ std::vector<hipEvent_t> g_prof_ev;  // begin/end pairs
 size_t g_prof_used = 0;
 }  // namespace
 
-static int g_precision_mode = 1;
+static int g_precision_mode = 2;
 int dim_precision_mode() { return g_precision_mode; }
 static int g_fuse_conv1a = 1;
 int dim_fuse_conv1a() { return g_fuse_conv1a; }
@@ -92,39 +92,60 @@ int dim_op_simple_nms_f32(const float* score_map, float* out, int batch, int H, 
   return launch_nms(score_map, out, batch, H, W, radius, (hipStream_t)stream);
 }
 
+// Op-level handles: a host struct holding the pre-split device operand for the precision mode that was active
+// at creation (dim_tune_set key 1: 2 = fp16x3, 1 = bf16x6).
 int dim_x3_create(const float* w_kn_host, int K, int N, void** out_dev, int* n_pad_out) {
   DIM_REQUIRE(w_kn_host && out_dev && n_pad_out && K > 0 && N > 0, "dim_x3_create: bad argument");
+  const int mode = g_precision_mode == 1 ? 1 : 2;
   const int n_pad = (N + 127) / 128 * 128;
-  std::vector<unsigned short> host((size_t)3 * n_pad * K);
-  split_weights_x3(w_kn_host, K, N, n_pad, host.data());
+  std::vector<unsigned short> host(gemm_split_weight_elems(K, n_pad, mode));
+  SplitWeights* w = new SplitWeights();
+  split_weights(w_kn_host, K, N, n_pad, mode, host.data(), &w->inv_scale);
   void* d = nullptr;
-  DIM_HIP(hipMalloc(&d, host.size() * 2));
-  DIM_HIP(hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice));
-  *out_dev = d; *n_pad_out = n_pad;
+  if (hipMalloc(&d, host.size() * 2) != hipSuccess || hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+    delete w;
+    dim_set_error("dim_x3_create: device allocation / upload failed (out of memory?)");
+    return -1;
+  }
+  w->dev = (const unsigned short*)d; w->mode = mode; w->n_pad = n_pad;
+  *out_dev = w; *n_pad_out = n_pad;
   return 0;
 }
-void dim_x3_destroy(void* dev) { if (dev) hipFree(dev); }
-int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3_dev, int n_pad, const float* bias, const float* residual, int ldr,
+void dim_x3_destroy(void* handle) {
+  if (!handle) return;
+  SplitWeights* w = (SplitWeights*)handle;
+  hipFree((void*)w->dev);
+  delete w;
+}
+int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3, int n_pad, const float* bias, const float* residual, int ldr,
                        float* C, int ldc, int M, int N, int K, int act, void* stream) {
+  DIM_REQUIRE(w_x3 && ((const SplitWeights*)w_x3)->n_pad == n_pad, "dim_op_gemm_x6_f32: bad weight handle");
   GemmArgs g;
-  g.A0 = A; g.lda0 = lda; g.Bx3 = (const unsigned short*)w_x3_dev; g.n_pad = n_pad; g.bias = bias;
+  g.A0 = A; g.lda0 = lda; g.set_split(*(const SplitWeights*)w_x3); g.bias = bias;
   g.R = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = act;
   return launch_gemm_x6(g, 1, (hipStream_t)stream);
 }
 
 int dim_convx6_create(const float* w_oihw_host, int cin, int cout, void** out_dev) {
   DIM_REQUIRE(w_oihw_host && out_dev && (cin == 64 || cin == 128) && cout % 64 == 0, "dim_convx6_create: bad argument");
-  std::vector<unsigned short> host(conv_x6_weight_elems(cin, cout));
-  prepare_conv_weights_x6(w_oihw_host, cin, cout, host.data());
+  const int mode = g_precision_mode == 1 ? 1 : 2;
+  std::vector<unsigned short> host(conv_split_weight_elems(cin, cout, mode));
+  SplitWeights* w = new SplitWeights();
+  prepare_conv_weights_split(w_oihw_host, cin, cout, mode, host.data(), &w->inv_scale);
   void* d = nullptr;
-  DIM_HIP(hipMalloc(&d, host.size() * 2));
-  DIM_HIP(hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice));
-  *out_dev = d;
+  if (hipMalloc(&d, host.size() * 2) != hipSuccess || hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+    delete w;
+    dim_set_error("dim_convx6_create: device allocation / upload failed (out of memory?)");
+    return -1;
+  }
+  w->dev = (const unsigned short*)d; w->mode = mode;
+  *out_dev = w;
   return 0;
 }
-int dim_op_conv3x3_x6_nhwc_f32(const float* in, const void* w_x6_dev, const float* bias, float* out, int batch, int H, int W,
+int dim_op_conv3x3_x6_nhwc_f32(const float* in, const void* w_x6, const float* bias, float* out, int batch, int H, int W,
                                int cin, int cout, int pool2x2, int relu, void* stream) {
-  return launch_conv3x3_x6(in, (const unsigned short*)w_x6_dev, bias, out, batch, H, W, cin, cout, pool2x2, relu, (hipStream_t)stream);
+  DIM_REQUIRE(w_x6, "dim_op_conv3x3_x6_nhwc_f32: null weight handle");
+  return launch_conv3x3_x6(in, *(const SplitWeights*)w_x6, bias, out, batch, H, W, cin, cout, pool2x2, relu, (hipStream_t)stream);
 }
 
 int dim_tune_set(int key, int value) {

@@ -18,7 +18,7 @@
 
 namespace {
 constexpr int TH = 8, TW = 32, IW = TW + 2, IH = TH + 2, NPIX = IH * IW;  // 340 halo pixels
-constexpr int W_SLICE = 3 * 3 * 2 * 64 * 8;                              // bf16 elements per (cb, chunk, dy) slice
+constexpr int w_slice(int npl) { return npl * 3 * 2 * 64 * 8; }              // 16-bit elements per (cb, chunk, dy) slice
 
 // PF: 0 = no software prefetch, 1 = next weight slice fetched into registers behind the MFMAs,
 //     2 = additionally the next chunk's halo tile (24 more VGPRs: 2 instead of 3 workgroups per CU).
@@ -26,13 +26,17 @@ constexpr int W_SLICE = 3 * 3 * 2 * 64 * 8;                              // bf16
 //      ReLU; SPN:161) on the fly while it stages its own halo tile, with the arithmetic of conv1a_kernel
 //      (conv.hip: fmaf chain over the 9 taps from 0, then + bias, ReLU): the 268-MB conv1a map of a 1024^2
 //      image is neither written nor read back.  CIN must be 64.
-template <int CIN, int POOL, int PF, bool F1A>
+// MODE: SplitMma policy (dim_common.h) — 1: three bf16 planes x six cross terms, 2: two fp16 planes x three
+//       cross terms (activations scaled by act_scale(), weights pre-scaled; inv_scale undoes both exactly).
+template <int CIN, int POOL, int PF, bool F1A, int MODE>
 __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                             int cout, int relu, int tiles_x, const float* __restrict__ w1a,
-                                                            const float* __restrict__ b1a) {
-  __shared__ u32x4 Ip[3 * 2 * NPIX];
-  __shared__ u32x4 Wp[3 * 3 * 2 * 64];
+                                                            const float* __restrict__ b1a, float inv_scale) {
+  using S = SplitMma<MODE>;
+  constexpr int NPL = S::NPL, W_SLICE = w_slice(NPL);
+  __shared__ u32x4 Ip[NPL * 2 * NPIX];
+  __shared__ u32x4 Wp[NPL * 3 * 2 * 64];
   constexpr int IMW = IW + 2, IMH = IH + 2;  // image tile of the fused conv1a: halo of the halo
   __shared__ float Img[F1A ? IMH * IMW : 1];
   constexpr int NCHUNK = CIN / 16;
@@ -88,14 +92,13 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       const int idx = t + 256 * i;
       if (idx < NPIX * 4) {
         const int p = idx >> 2, q = idx & 3;
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3_pk(rin[i].x, rin[i].y, h0, m0, l0);
-        split3_pk(rin[i].z, rin[i].w, h1, m1, l1);
+        unsigned p0[NPL], p1[NPL];
+        S::split(rin[i].x, rin[i].y, S::act_scale(), p0);
+        S::split(rin[i].z, rin[i].w, S::act_scale(), p1);
         // channels q*4..q*4+3 live in k-half q>>1, dwords (q&1)*2, +1 of that pixel's 16-B slot
         unsigned* d = (unsigned*)&Ip[(q >> 1) * NPIX + p] + (q & 1) * 2;
-        d[0] = h0; d[1] = h1;
-        d[2 * NPIX * 4] = m0; d[2 * NPIX * 4 + 1] = m1;
-        d[4 * NPIX * 4] = l0; d[4 * NPIX * 4 + 1] = l1;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) { d[pl * 2 * NPIX * 4] = p0[pl]; d[pl * 2 * NPIX * 4 + 1] = p1[pl]; }
       }
     }
   };
@@ -157,21 +160,20 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       if (PF == 2 && !F1A && dy == 2 && c + 1 < NCHUNK) load_in(c + 1);
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        u32x4 fa[2][3], fb[2][3];
+        u32x4 fa[2][NPL], fb[2][NPL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
 #pragma unroll
           for (int m = 0; m < 2; ++m) fa[m][p] = Ip[(p * 2 + half) * NPIX + (2 * wv + m + dy) * IW + lx + dx];
 #pragma unroll
           for (int n = 0; n < 2; ++n) fb[n][p] = Wp[((p * 3 + dx) * 2 + half) * 64 + n * 32 + lx];
         }
-        const int ta[6] = {1, 0, 2, 0, 1, 0}, tb[6] = {1, 2, 0, 1, 0, 0};  // smallest cross terms first
 #pragma unroll
-        for (int tm = 0; tm < 6; ++tm)
+        for (int tm = 0; tm < S::NT; ++tm)  // smallest cross terms first
 #pragma unroll
           for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(fa[m][ta[tm]], fb[n][tb[tm]], acc[m][n]);
+            for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[n][S::tb(tm)], acc[m][n]);
       }
     }
   }
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const int px = (ox + mfma_row(r, half)) >> 1;
-        float v = fmaxf(fmaxf(acc[0][n][r], acc[0][n][r + 1]), fmaxf(acc[1][n][r], acc[1][n][r + 1])) + bv;
+        float v = fmaxf(fmaxf(acc[0][n][r], acc[0][n][r + 1]), fmaxf(acc[1][n][r], acc[1][n][r + 1])) * inv_scale + bv;
         if (relu) v = fmaxf(v, 0.0f);
         if (py < Ho && px < Wo) out_b[((size_t)py * Wo + px) * cout + co] = v;
       }
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int x = ox + mfma_row(r, half);
-          float v = acc[m][n][r] + bv;
+          float v = acc[m][n][r] * inv_scale + bv;
           if (relu) v = fmaxf(v, 0.0f);
           if (y < H && x < W) out_b[((size_t)y * W + x) * cout + co] = v;
         }
@@ -217,24 +219,43 @@ unsigned short host_bf16_rne(float x) {
 }
 }  // namespace
 
-// Host: OIHW fp32 3x3 weights -> [cout/64][cin/16][dy][plane][dx][k-half][64 co][8 ci] bf16 (RNE pieces).
-size_t conv_x6_weight_elems(int cin, int cout) { return (size_t)(cout / 64) * (cin / 16) * 3 * W_SLICE; }
-void prepare_conv_weights_x6(const float* w_oihw, int cin, int cout, unsigned short* out) {
-  const int nchunk = cin / 16;
+// Host: OIHW fp32 3x3 weights -> [cout/64][cin/16][dy][plane][dx][k-half][64 co][8 ci] 16-bit pieces.
+// mode 1: three bf16 planes (RNE pieces, inv_scale 1); mode 2: two fp16 planes of w * 2^sw with 2^sw chosen so
+// that max|w| lands in [8192, 16384) — inv_scale = 1 / (2^sw * DIM_F16_ACT_SCALE), exact.
+size_t conv_split_weight_elems(int cin, int cout, int mode) { return (size_t)(cout / 64) * (cin / 16) * 3 * w_slice(mode == 2 ? 2 : 3); }
+void prepare_conv_weights_split(const float* w_oihw, int cin, int cout, int mode, unsigned short* out, float* inv_scale) {
+  const int nchunk = cin / 16, npl = mode == 2 ? 2 : 3;
+  float wscale = 1.0f;
+  if (mode == 2) {
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)cout * cin * 9; ++i) mx = fmaxf(mx, fabsf(w_oihw[i]));
+    int e = 0;
+    if (mx > 0.f) { frexpf(mx, &e); wscale = ldexpf(1.0f, 14 - e); }  // mx = f * 2^e, f in [0.5, 1) -> mx * wscale in [8192, 16384)
+    *inv_scale = 1.0f / (wscale * DIM_F16_ACT_SCALE);
+  } else {
+    *inv_scale = 1.0f;
+  }
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci)
       for (int dy = 0; dy < 3; ++dy)
         for (int dx = 0; dx < 3; ++dx) {
-          float x = w_oihw[(((size_t)co * cin + ci) * 3 + dy) * 3 + dx];
+          float x = w_oihw[(((size_t)co * cin + ci) * 3 + dy) * 3 + dx] * wscale;
           const int cb = co / 64, col = co % 64, c = ci / 16, hf = (ci % 16) / 8, e = ci % 8;
-          for (int p = 0; p < 3; ++p) {
-            const unsigned short hb = host_bf16_rne(x);
-            const unsigned u = (unsigned)hb << 16;
-            float h;
-            memcpy(&h, &u, 4);
-            const size_t idx = ((((((size_t)(cb * nchunk + c) * 3 + dy) * 3 + p) * 3 + dx) * 2 + hf) * 64 + col) * 8 + e;
-            out[idx] = hb;
-            x = x - h;
+          for (int p = 0; p < npl; ++p) {
+            unsigned short bits;
+            float piece;
+            if (mode == 2) {
+              const _Float16 hv = (_Float16)x;
+              memcpy(&bits, &hv, 2);
+              piece = (float)hv;
+            } else {
+              bits = host_bf16_rne(x);
+              const unsigned u = (unsigned)bits << 16;
+              memcpy(&piece, &u, 4);
+            }
+            const size_t idx = ((((((size_t)(cb * nchunk + c) * 3 + dy) * npl + p) * 3 + dx) * 2 + hf) * 64 + col) * 8 + e;
+            out[idx] = bits;
+            x = x - piece;
           }
         }
 }
@@ -243,25 +264,32 @@ static int g_conv_x6_variant = 1;
 int dim_conv_x6_variant() { return g_conv_x6_variant; }
 void dim_conv_x6_set_variant(int v) { g_conv_x6_variant = v; }
 
-int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bias, float* out, int batch, int H, int W, int cin,
+int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
                       int cout, int pool, int relu, hipStream_t s) {
   DIM_REQUIRE(cout % 64 == 0, "conv3x3_x6: cout=%d must be a multiple of 64", cout);
   DIM_REQUIRE(cin == 64 || cin == 128, "conv3x3_x6: cin=%d unsupported (64 or 128)", cin);
+  DIM_REQUIRE(wt.dev && (wt.mode == 1 || wt.mode == 2), "conv3x3_x6: weights not prepared (mode %d)", wt.mode);
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-#define DIM_CONV6(CI, P, PFV) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV, false>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr)
-#define DIM_CONV6_V(PFV)                                  \
+  const unsigned short* wx = wt.dev;
+  const float inv = wt.inv_scale;
+#define DIM_CONV6(CI, P, PFV, MD) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV, false, MD>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, inv)
+#define DIM_CONV6_V(PFV, MD)                              \
   {                                                       \
-    if (cin == 64 && pool) DIM_CONV6(64, 1, PFV);         \
-    else if (cin == 64) DIM_CONV6(64, 0, PFV);            \
-    else if (pool) DIM_CONV6(128, 1, PFV);                \
-    else DIM_CONV6(128, 0, PFV);                          \
+    if (cin == 64 && pool) DIM_CONV6(64, 1, PFV, MD);     \
+    else if (cin == 64) DIM_CONV6(64, 0, PFV, MD);        \
+    else if (pool) DIM_CONV6(128, 1, PFV, MD);            \
+    else DIM_CONV6(128, 0, PFV, MD);                      \
   }
-  switch (dim_conv_x6_variant()) {
-    case 0: DIM_CONV6_V(0) break;
-    case 2: DIM_CONV6_V(2) break;
-    default: DIM_CONV6_V(1) break;
+  if (wt.mode == 2) {
+    DIM_CONV6_V(1, 2)
+  } else {
+    switch (dim_conv_x6_variant()) {
+      case 0: DIM_CONV6_V(0, 1) break;
+      case 2: DIM_CONV6_V(2, 1) break;
+      default: DIM_CONV6_V(1, 1) break;
+    }
   }
 #undef DIM_CONV6_V
 #undef DIM_CONV6
@@ -270,14 +298,17 @@ int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bi
 }
 
 // conv1a (1 -> 64) fused into the 64 -> cout convolution that consumes it (SuperPoint conv1a + conv1b, SPN:161-162).
-int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const unsigned short* wx, const float* bias,
+int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
                               float* out, int batch, int H, int W, int cout, int pool, int relu, hipStream_t s) {
   DIM_REQUIRE(cout % 64 == 0, "conv3x3_x6 fused conv1a: cout=%d must be a multiple of 64", cout);
+  DIM_REQUIRE(wt.dev && (wt.mode == 1 || wt.mode == 2), "conv3x3_x6: weights not prepared (mode %d)", wt.mode);
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-  if (pool) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, 1, 1, true>), grid, dim3(256), 0, s, image, wx, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, 0, 1, true>), grid, dim3(256), 0, s, image, wx, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a);
+#define DIM_CONV6F(P, MD) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_scale)
+  if (wt.mode == 2) { if (pool) DIM_CONV6F(1, 2); else DIM_CONV6F(0, 2); }
+  else { if (pool) DIM_CONV6F(1, 1); else DIM_CONV6F(0, 1); }
+#undef DIM_CONV6F
   DIM_LAUNCH_CHECK();
   return 0;
 }

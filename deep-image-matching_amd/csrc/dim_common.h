@@ -45,6 +45,54 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, unsigned& h, unsig
   const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
   l = cvt_pk_bf16(s0, s1);
 }
+// ---- fp16 pieces ("fp16x3") -----------------------------------------------------------------------
+// v_mfma_f32_32x32x16_f16 has the bf16 instruction's lane map and rate and keeps fp16 subnormal inputs
+// (scripts/probe/mfma_f16_probe.hip).  A 2-way split x = h + l into fp16 pieces (11 + 11 mantissa bits)
+// with the three cross terms lh, hl, hh carries a product to ~2^-22 of |x y|: measured on hardware
+// 0.7-1.7e-7 of sum|a*b| at K = 1024 where the fp32 fmaf chain gives 1.2-4.5e-7 — fp32-class at 3 instead
+// of 6 MFMA passes.  fp16's narrow exponent is handled by power-of-two scales (exact): activations are
+// multiplied by DIM_F16_ACT_SCALE before the split and clamped to +-65504 (|x| up to 4094 is exact in
+// range; below ~2e-3 the low piece turns subnormal and the element's relative accuracy decays towards
+// 2^-11 while its absolute error stays <= 2^-29 — invisible next to any O(0.01+) term of the same dot
+// product); weights are pre-scaled per tensor on the host; the accumulator is multiplied by the exact
+// inverse in the epilogue.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+#define DIM_F16_ACT_SCALE 16.0f
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {  // round-to-nearest-even
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ void split2_pk(float x0, float x1, float scale, unsigned& h, unsigned& l) {
+  x0 = __builtin_amdgcn_fmed3f(x0 * scale, -65504.0f, 65504.0f);
+  x1 = __builtin_amdgcn_fmed3f(x1 * scale, -65504.0f, 65504.0f);
+  h = cvt_pk_f16(x0, x1);
+  const f16x2 hv = __builtin_bit_cast(f16x2, h);
+  l = cvt_pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+}
+// Split policy shared by conv_x6 / gemm_x6 / lg_attn_x6: MODE 1 = three bf16 planes, six cross terms;
+// MODE 2 = two fp16 planes, three cross terms.  Cross terms are issued smallest first.
+template <int MODE> struct SplitMma;
+template <> struct SplitMma<1> {
+  static constexpr int NPL = 3, NT = 6;
+  __device__ static __forceinline__ float act_scale() { return 1.0f; }
+  __device__ static __forceinline__ void split(float x0, float x1, float, unsigned (&p)[3]) { split3_pk(x0, x1, p[0], p[1], p[2]); }
+  __device__ static __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) { return mfma_bf16(a, b, c); }
+  __device__ static __forceinline__ int ta(int t) { const int v[6] = {1, 0, 2, 0, 1, 0}; return v[t]; }
+  __device__ static __forceinline__ int tb(int t) { const int v[6] = {1, 2, 0, 1, 0, 0}; return v[t]; }
+};
+template <> struct SplitMma<2> {
+  static constexpr int NPL = 2, NT = 3;
+  __device__ static __forceinline__ float act_scale() { return DIM_F16_ACT_SCALE; }
+  __device__ static __forceinline__ void split(float x0, float x1, float scale, unsigned (&p)[2]) { split2_pk(x0, x1, scale, p[0], p[1]); }
+  __device__ static __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) { return mfma_f16(a, b, c); }
+  __device__ static __forceinline__ int ta(int t) { const int v[3] = {1, 0, 0}; return v[t]; }
+  __device__ static __forceinline__ int tb(int t) { const int v[3] = {0, 1, 0}; return v[t]; }
+};
+
 // row index inside a 32x32 MFMA tile held by (lane-half h, register r)
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 

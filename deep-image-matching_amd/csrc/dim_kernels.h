@@ -13,13 +13,24 @@
 // Raggedness: rows of item z = rows[z*rows_mul + rows_off] (device array) when
 // rows != nullptr, else M; same for cols (bt mode only).  flag gating: the item
 // is skipped unless flag[z >> flag_shift] == flag_eq (flag == nullptr: always run).
+// A matrix-core operand pre-split on the host into 16-bit planes (SplitMma policy, dim_common.h):
+// mode 1 = three bf16 planes, mode 2 = two fp16 planes of the power-of-two-scaled weights; inv_scale is the
+// exact factor the accumulator is multiplied by in the epilogue (1 for mode 1).
+struct SplitWeights {
+  const unsigned short* dev = nullptr;
+  int mode = 0;
+  float inv_scale = 1.0f;
+  int n_pad = 0;  // GEMM operands: padded column count
+};
 struct GemmArgs {
   const float* A0 = nullptr; const float* A1 = nullptr;
   int lda0 = 0, lda1 = 0, ksplit = 0;
   long long strideA0 = 0, strideA1 = 0;
   const int* a_idx = nullptr;  // optional indirection: A0 of item z starts at A0 + a_idx[z]*strideA0
   const float* B = nullptr; int ldb = 0; long long strideB = 0; int bt = 0;
-  const unsigned short* Bx3 = nullptr; int n_pad = 0;  // bf16x6 path: weights pre-split into [3][n_pad][K] bf16 planes
+  const unsigned short* Bx3 = nullptr; int n_pad = 0;  // split path: weights pre-split into [planes][n_pad][K] 16-bit pieces
+  int split_mode = 1; float inv_scale = 1.0f;           //   (SplitWeights::mode / inv_scale)
+  void set_split(const SplitWeights& w) { Bx3 = w.dev; n_pad = w.n_pad; split_mode = w.mode; inv_scale = w.inv_scale; }
   const float* bias = nullptr;
   const float* R = nullptr; int ldr = 0; long long strideR = 0;
   float* C = nullptr; int ldc = 0; long long strideC = 0;
@@ -30,9 +41,11 @@ struct GemmArgs {
   int relu = 0;  // epilogue activation: 0 none, 1 ReLU, 2 SELU
 };
 int launch_gemm(const GemmArgs& a, int batch, hipStream_t s);
-// fp32-accurate GEMM on the bf16 matrix cores (gemm_x6.hip); needs a.Bx3 / a.n_pad.
+// fp32-accurate GEMM on the 16-bit matrix cores (gemm_x6.hip); needs a.set_split(...).
 int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s);
-void split_weights_x3(const float* w_kn, int K, int N, int n_pad, unsigned short* out);
+// host: [K][N] fp32 -> the pre-split device layout; elems = planes * n_pad * K 16-bit values
+size_t gemm_split_weight_elems(int K, int n_pad, int mode);
+void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, float* inv_scale);
 
 // ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution over NHWC fp32 images as an implicit GEMM
@@ -40,15 +53,15 @@ void split_weights_x3(const float* w_kn, int K, int N, int n_pad, unsigned short
 // SPN:163-171).  in: [B][H][W][cin], w: [9][cin][cout], out: [B][H'][W'][cout].
 int launch_conv3x3(const float* in, const float* w, const float* bias, float* out, int batch, int H, int W,
                    int cin, int cout, int pool, int relu, hipStream_t s);
-// fp32-accurate 3x3 conv on the bf16 matrix cores (conv_x6.hip); weights pre-split by prepare_conv_weights_x6.
-size_t conv_x6_weight_elems(int cin, int cout);
-void prepare_conv_weights_x6(const float* w_oihw, int cin, int cout, unsigned short* out);
-int launch_conv3x3_x6(const float* in, const unsigned short* wx, const float* bias, float* out, int batch, int H, int W, int cin,
+// fp32-accurate 3x3 conv on the 16-bit matrix cores (conv_x6.hip); weights pre-split by prepare_conv_weights_split.
+size_t conv_split_weight_elems(int cin, int cout, int mode);
+void prepare_conv_weights_split(const float* w_oihw, int cin, int cout, int mode, unsigned short* out, float* inv_scale);
+int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
                       int cout, int pool, int relu, hipStream_t s);
 // conv1a (image -> 64 channels, weights [9][64]) computed on the fly inside the following 64 -> cout conv
-int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const unsigned short* wx, const float* bias,
+int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
                               float* out, int batch, int H, int W, int cout, int pool, int relu, hipStream_t s);
-int dim_precision_mode();  // 1 (default): bf16x6 on the bf16 matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
+int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
 void dim_conv_x6_set_variant(int v);  // tuning hook: prefetch variant of conv3x3_x6 (dim_tune_set key 2)
 void dim_conv_set_variant(int v);  // tuning hook: selects the conv3x3 kernel variant (see conv.hip)

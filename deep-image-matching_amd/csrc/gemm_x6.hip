@@ -19,14 +19,17 @@
 namespace {
 constexpr int BM = 128, BN = 128, KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
 
+template <int MODE>
 __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
+  using S = SplitMma<MODE>;
+  constexpr int NPL = S::NPL;
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (m0 >= rows || n0 >= a.N) return;
 
-  __shared__ unsigned Ap[3 * BM * RS];
+  __shared__ unsigned Ap[NPL * BM * RS];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1, lx = lane & 31, half = lane >> 5;
@@ -61,13 +64,12 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
-      unsigned h[2], m[2], l[2];
-      split3_pk(ra[i].x, ra[i].y, h[0], m[0], l[0]);
-      split3_pk(ra[i].z, ra[i].w, h[1], m[1], l[1]);
+      unsigned p0[NPL], p1[NPL];
+      S::split(ra[i].x, ra[i].y, S::act_scale(), p0);
+      S::split(ra[i].z, ra[i].w, S::act_scale(), p1);
       unsigned* d = &Ap[row * RS + q * 2];
-      d[0] = h[0]; d[1] = h[1];
-      d[BM * RS] = m[0]; d[BM * RS + 1] = m[1];
-      d[2 * BM * RS] = l[0]; d[2 * BM * RS + 1] = l[1];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) { d[pl * BM * RS] = p0[pl]; d[pl * BM * RS + 1] = p1[pl]; }
     }
   };
 
@@ -78,22 +80,21 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
     if (k0 + KC < a.K) load_chunk(k0 + KC);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 fa[2][3], fb[2][3];
+      u32x4 fa[2][NPL], fb[2][NPL];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) fb[n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + (k0 >> 4) + ks) * 2 + half) * 32 + lx];
 #pragma unroll
         for (int m = 0; m < 2; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * 64 + m * 32 + lx) * RS + ks * 8 + half * 4];
       }
       // six cross terms, smallest first; the four accumulators interleave so no MFMA waits on its predecessor
-      const int ta[6] = {1, 0, 2, 0, 1, 0}, tb[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-      for (int tm = 0; tm < 6; ++tm)
+      for (int tm = 0; tm < S::NT; ++tm)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(fa[m][ta[tm]], fb[n][tb[tm]], acc[m][n]);
+          for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[n][S::tb(tm)], acc[m][n]);
     }
     __syncthreads();
   }
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + m * 32 + mfma_row(r, half);
         if (row >= rows) continue;
-        float v = acc[m][n][r] + bv;
+        float v = acc[m][n][r] * a.inv_scale + bv;
         if (R) v += R[(size_t)row * a.ldr + col];
         if (a.relu == 1) v = fmaxf(v, 0.0f);
         else if (a.relu == 2) v = v <= 0.0f ? (expf(v) - 1.0f) * 1.7580993408473768599402175208123f : v * 1.0507009873554804934193349852946f;
@@ -123,20 +124,22 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
 }  // namespace
 
 int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
-  DIM_REQUIRE(a.Bx3 != nullptr && !a.bt, "gemm_x6: needs pre-split [3][n_pad][K] weights");
+  DIM_REQUIRE(a.Bx3 != nullptr && !a.bt && (a.split_mode == 1 || a.split_mode == 2), "gemm_x6: needs pre-split [planes][n_pad][K] weights");
   DIM_REQUIRE(a.K % 16 == 0, "gemm_x6: K");
   DIM_REQUIRE(a.K % KC == 0 && (a.A1 == nullptr || a.ksplit % KC == 0), "gemm_x6: K=%d / ksplit=%d must be multiples of %d", a.K, a.ksplit, KC);
   DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
   DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
   if (batch <= 0 || a.M <= 0 || a.N <= 0) return 0;
   dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch);
-  hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), 0, s, a);
+  if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<1>), grid, dim3(256), 0, s, a);
   DIM_LAUNCH_CHECK();
   return 0;
 }
 
-// Host: nn.Linear-style operand [K][N] fp32 -> three bf16 planes [3][n_pad][K], round-to-nearest-even
-// pieces (the same rule as split3_pk on the device).
+// Host: nn.Linear-style operand [K][N] fp32 -> 16-bit planes [plane][n_pad/32][K/16][k-half][32 cols][8 k].
+// mode 1: three bf16 planes, round-to-nearest-even pieces (the same rule as split3_pk on the device);
+// mode 2: two fp16 planes of w * 2^sw (max|w| scaled into [8192, 16384)), inv_scale = 1 / (2^sw * DIM_F16_ACT_SCALE).
 static unsigned short host_bf16_rne(float x) {
   unsigned u;
   memcpy(&u, &x, 4);
@@ -144,21 +147,37 @@ static unsigned short host_bf16_rne(float x) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
-void split_weights_x3(const float* w_kn, int K, int N, int n_pad, unsigned short* out) {
-  // [plane][n_pad/32][K/16][k-half][32 cols][8 k]
-  const int NB = n_pad / 32, KS = K / 16;
-  for (size_t i = 0; i < (size_t)3 * n_pad * K; ++i) out[i] = 0;
+size_t gemm_split_weight_elems(int K, int n_pad, int mode) { return (size_t)(mode == 2 ? 2 : 3) * n_pad * K; }
+void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, float* inv_scale) {
+  const int NB = n_pad / 32, KS = K / 16, npl = mode == 2 ? 2 : 3;
+  float wscale = 1.0f;
+  *inv_scale = 1.0f;
+  if (mode == 2) {
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)K * N; ++i) mx = fmaxf(mx, fabsf(w_kn[i]));
+    int e = 0;
+    if (mx > 0.f) { frexpf(mx, &e); wscale = ldexpf(1.0f, 14 - e); }
+    *inv_scale = 1.0f / (wscale * DIM_F16_ACT_SCALE);
+  }
+  for (size_t i = 0; i < gemm_split_weight_elems(K, n_pad, mode); ++i) out[i] = 0;
   for (int k = 0; k < K; ++k)
     for (int n = 0; n < N; ++n) {
-      float x = w_kn[(size_t)k * N + n];
+      float x = w_kn[(size_t)k * N + n] * wscale;
       const int nb = n / 32, j = n % 32, ks = k / 16, hf = (k % 16) / 8, e = k % 8;
-      for (int p = 0; p < 3; ++p) {
-        const unsigned short hb = host_bf16_rne(x);
-        const unsigned u = (unsigned)hb << 16;
-        float h;
-        memcpy(&h, &u, 4);
-        out[(((((size_t)p * NB + nb) * KS + ks) * 2 + hf) * 32 + j) * 8 + e] = hb;
-        x = x - h;
+      for (int p = 0; p < npl; ++p) {
+        unsigned short bits;
+        float piece;
+        if (mode == 2) {
+          const _Float16 hv = (_Float16)x;
+          memcpy(&bits, &hv, 2);
+          piece = (float)hv;
+        } else {
+          bits = host_bf16_rne(x);
+          const unsigned u = (unsigned)bits << 16;
+          memcpy(&piece, &u, 4);
+        }
+        out[(((((size_t)p * NB + nb) * KS + ks) * 2 + hf) * 32 + j) * 8 + e] = bits;
+        x = x - piece;
       }
     }
 }

@@ -15,8 +15,8 @@ struct LayerW {
   float *qkv_w, *qkv_b, *out_w, *out_b, *sffn0_w, *sffn0_b, *sln_w, *sln_b, *sffn3_w, *sffn3_b;
   float *cqkv_w, *cqkv_b, *cout_w, *cout_b, *cffn0_w, *cffn0_b, *cln_w, *cln_b, *cffn3_w, *cffn3_b;
   float *match_w, *match_b, *proj_w, *proj_b, *tok_w, *tok_b;
-  // bf16x6 pre-split copies of the GEMM operands ([3][n_pad][K] bf16, gemm_x6.hip)
-  unsigned short *qkv_x, *out_x, *sffn0_x, *sffn3_x, *cqkv_x, *cout_x, *cffn0_x, *cffn3_x, *proj_x;
+  // pre-split copies of the GEMM operands for the split modes 1 (bf16x6) and 2 (fp16x3), gemm_x6.hip; index = mode
+  SplitWeights qkv_x[3], out_x[3], sffn0_x[3], sffn3_x[3], cqkv_x[3], cout_x[3], cffn0_x[3], cffn3_x[3], proj_x[3];
 };
 }  // namespace
 
@@ -51,15 +51,19 @@ int upload(dim_lg* h, float** dst, const std::vector<float>& v) {
   }
   return 0;
 }
-// [K][N] fp32 GEMM operand -> device bf16x6 planes
-int upload_x3(dim_lg* h, unsigned short** dst, const std::vector<float>& w_kn, int K, int N) {
+// [K][N] fp32 GEMM operand -> device split planes for both split modes
+int upload_x3(dim_lg* h, SplitWeights* dst, const std::vector<float>& w_kn, int K, int N) {
   const int n_pad = (N + 127) / 128 * 128;
-  std::vector<unsigned short> host((size_t)3 * n_pad * K);
-  split_weights_x3(w_kn.data(), K, N, n_pad, host.data());
-  if (dev_alloc(h, dst, host.size()) != 0) return -1;
-  if (hipMemcpy(*dst, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
-    dim_set_error("weight upload failed");
-    return -1;
+  for (int mode = 1; mode <= 2; ++mode) {
+    std::vector<unsigned short> host(gemm_split_weight_elems(K, n_pad, mode));
+    split_weights(w_kn.data(), K, N, n_pad, mode, host.data(), &dst[mode].inv_scale);
+    unsigned short* d = nullptr;
+    if (dev_alloc(h, &d, host.size()) != 0) return -1;
+    if (hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+      dim_set_error("weight upload failed");
+      return -1;
+    }
+    dst[mode].dev = d; dst[mode].mode = mode; dst[mode].n_pad = n_pad;
   }
   return 0;
 }
@@ -116,11 +120,11 @@ int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pai
           qkvb[c] = s.self_Wqkv_b[o];
           for (int k = 0; k < 256; ++k) qkv[(size_t)k * 768 + c] = s.self_Wqkv_w[(size_t)o * 256 + k];
         }
-    LG_TRY(upload(h, &d.qkv_w, qkv)); LG_TRY(upload(h, &d.qkv_b, qkvb)); LG_TRY(upload_x3(h, &d.qkv_x, qkv, 256, 768));
-    LG_TRY(upload(h, &d.out_w, transpose(s.self_out_w, 256, 256))); LG_TRY(upload_x3(h, &d.out_x, transpose(s.self_out_w, 256, 256), 256, 256)); LG_TRY(upload(h, &d.out_b, vec(s.self_out_b, 256)));
-    LG_TRY(upload(h, &d.sffn0_w, transpose(s.self_ffn0_w, 512, 512))); LG_TRY(upload_x3(h, &d.sffn0_x, transpose(s.self_ffn0_w, 512, 512), 512, 512)); LG_TRY(upload(h, &d.sffn0_b, vec(s.self_ffn0_b, 512)));
+    LG_TRY(upload(h, &d.qkv_w, qkv)); LG_TRY(upload(h, &d.qkv_b, qkvb)); LG_TRY(upload_x3(h, d.qkv_x, qkv, 256, 768));
+    LG_TRY(upload(h, &d.out_w, transpose(s.self_out_w, 256, 256))); LG_TRY(upload_x3(h, d.out_x, transpose(s.self_out_w, 256, 256), 256, 256)); LG_TRY(upload(h, &d.out_b, vec(s.self_out_b, 256)));
+    LG_TRY(upload(h, &d.sffn0_w, transpose(s.self_ffn0_w, 512, 512))); LG_TRY(upload_x3(h, d.sffn0_x, transpose(s.self_ffn0_w, 512, 512), 512, 512)); LG_TRY(upload(h, &d.sffn0_b, vec(s.self_ffn0_b, 512)));
     LG_TRY(upload(h, &d.sln_w, vec(s.self_ln_w, 512))); LG_TRY(upload(h, &d.sln_b, vec(s.self_ln_b, 512)));
-    LG_TRY(upload(h, &d.sffn3_w, transpose(s.self_ffn3_w, 256, 512))); LG_TRY(upload_x3(h, &d.sffn3_x, transpose(s.self_ffn3_w, 256, 512), 512, 256)); LG_TRY(upload(h, &d.sffn3_b, vec(s.self_ffn3_b, 256)));
+    LG_TRY(upload(h, &d.sffn3_w, transpose(s.self_ffn3_w, 256, 512))); LG_TRY(upload_x3(h, d.sffn3_x, transpose(s.self_ffn3_w, 256, 512), 512, 256)); LG_TRY(upload(h, &d.sffn3_b, vec(s.self_ffn3_b, 256)));
     // to_qk and to_v fused into one [256][512] operand: columns [qk | v]
     std::vector<float> cq((size_t)256 * 512), cqb(512);
     for (int o = 0; o < 256; ++o) {
@@ -130,14 +134,14 @@ int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pai
         cq[(size_t)k * 512 + 256 + o] = s.cross_v_w[(size_t)o * 256 + k];
       }
     }
-    LG_TRY(upload(h, &d.cqkv_w, cq)); LG_TRY(upload(h, &d.cqkv_b, cqb)); LG_TRY(upload_x3(h, &d.cqkv_x, cq, 256, 512));
-    LG_TRY(upload(h, &d.cout_w, transpose(s.cross_out_w, 256, 256))); LG_TRY(upload_x3(h, &d.cout_x, transpose(s.cross_out_w, 256, 256), 256, 256)); LG_TRY(upload(h, &d.cout_b, vec(s.cross_out_b, 256)));
-    LG_TRY(upload(h, &d.cffn0_w, transpose(s.cross_ffn0_w, 512, 512))); LG_TRY(upload_x3(h, &d.cffn0_x, transpose(s.cross_ffn0_w, 512, 512), 512, 512)); LG_TRY(upload(h, &d.cffn0_b, vec(s.cross_ffn0_b, 512)));
+    LG_TRY(upload(h, &d.cqkv_w, cq)); LG_TRY(upload(h, &d.cqkv_b, cqb)); LG_TRY(upload_x3(h, d.cqkv_x, cq, 256, 512));
+    LG_TRY(upload(h, &d.cout_w, transpose(s.cross_out_w, 256, 256))); LG_TRY(upload_x3(h, d.cout_x, transpose(s.cross_out_w, 256, 256), 256, 256)); LG_TRY(upload(h, &d.cout_b, vec(s.cross_out_b, 256)));
+    LG_TRY(upload(h, &d.cffn0_w, transpose(s.cross_ffn0_w, 512, 512))); LG_TRY(upload_x3(h, d.cffn0_x, transpose(s.cross_ffn0_w, 512, 512), 512, 512)); LG_TRY(upload(h, &d.cffn0_b, vec(s.cross_ffn0_b, 512)));
     LG_TRY(upload(h, &d.cln_w, vec(s.cross_ln_w, 512))); LG_TRY(upload(h, &d.cln_b, vec(s.cross_ln_b, 512)));
-    LG_TRY(upload(h, &d.cffn3_w, transpose(s.cross_ffn3_w, 256, 512))); LG_TRY(upload_x3(h, &d.cffn3_x, transpose(s.cross_ffn3_w, 256, 512), 512, 256)); LG_TRY(upload(h, &d.cffn3_b, vec(s.cross_ffn3_b, 256)));
+    LG_TRY(upload(h, &d.cffn3_w, transpose(s.cross_ffn3_w, 256, 512))); LG_TRY(upload_x3(h, d.cffn3_x, transpose(s.cross_ffn3_w, 256, 512), 512, 256)); LG_TRY(upload(h, &d.cffn3_b, vec(s.cross_ffn3_b, 256)));
     LG_TRY(upload(h, &d.match_w, vec(s.assign_match_w, 256))); LG_TRY(upload(h, &d.match_b, vec(s.assign_match_b, 1)));
     // final_proj / d^0.25 (LGN:268-270): 256^0.25 = 4, a power of two -> folding the scale is exact
-    LG_TRY(upload(h, &d.proj_w, transpose(s.assign_proj_w, 256, 256, 0.25f))); LG_TRY(upload_x3(h, &d.proj_x, transpose(s.assign_proj_w, 256, 256, 0.25f), 256, 256)); LG_TRY(upload(h, &d.proj_b, vec(s.assign_proj_b, 256, 0.25f)));
+    LG_TRY(upload(h, &d.proj_w, transpose(s.assign_proj_w, 256, 256, 0.25f))); LG_TRY(upload_x3(h, d.proj_x, transpose(s.assign_proj_w, 256, 256, 0.25f), 256, 256)); LG_TRY(upload(h, &d.proj_b, vec(s.assign_proj_b, 256, 0.25f)));
     d.tok_w = d.tok_b = nullptr;
     if (s.token_w) { LG_TRY(upload(h, &d.tok_w, vec(s.token_w, 256))); LG_TRY(upload(h, &d.tok_b, vec(s.token_b, 1))); }
     DIM_REQUIRE(i == w->n_layers - 1 || s.token_w, "dim_lg_create: token_confidence.%d missing", i);
@@ -178,15 +182,16 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
 #define LG_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
   LG_RUN(launch_lg_init(st, kpts_tab_dev, desc_tab_dev, n_tab_dev, size_tab_dev, pair_idx_dev, cap, h->input_dim, h->Wr,
                         h->input_dim == 256 ? 1 : 0, s));
-  const bool x6 = dim_precision_mode() != 0;  // fp32-accurate products on the bf16 matrix cores (default)
+  const int pmode = dim_precision_mode();  // 2 fp16x3 (default) / 1 bf16x6: fp32-accurate products on the 16-bit matrix cores; 0 fp32 MFMA
+  const bool x6 = pmode != 0;
   auto gemm_items = [&](const float* A, int lda, long long sA, const float* A1, int lda1, long long sA1, int ksplit,
-                        const float* B, const unsigned short* Bx, int ldb, const float* bias, const float* R, float* C, int ldc,
+                        const float* B, const SplitWeights* Bx, int ldb, const float* bias, const float* R, float* C, int ldc,
                         long long sC, int Nn, int K, int flag_eq) -> int {
     GemmArgs g;
     g.A0 = A; g.lda0 = lda; g.strideA0 = sA; g.A1 = A1; g.lda1 = lda1; g.strideA1 = sA1; g.ksplit = ksplit;
     g.B = B; g.ldb = ldb; g.bias = bias; g.R = R; g.ldr = ldc; g.strideR = sC; g.C = C; g.ldc = ldc; g.strideC = sC;
     g.M = N; g.N = Nn; g.K = K; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = flag_eq;
-    if (x6) { g.Bx3 = Bx; g.n_pad = (Nn + 127) / 128 * 128; return launch_gemm_x6(g, I, s); }
+    if (x6) { g.set_split(Bx[pmode]); return launch_gemm_x6(g, I, s); }
     return launch_gemm(g, I, s);
   };
   if (h->input_dim != 256) {  // input_proj (LGN:473-474) straight from the feature table

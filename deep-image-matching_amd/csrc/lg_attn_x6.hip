@@ -33,11 +33,15 @@ struct AttnArgs6 {
   int nmax, tiles;
 };
 
-constexpr int TILE_SLOTS = 3 * 8 * 32 + 3 * 2 * 2 * 64;  // 768 K slots + 768 V slots of 16 B
+constexpr int TILE_STRIDE = 3 * 8 * 32 + 3 * 2 * 2 * 64;  // slots of 16 B reserved per tile image in HBM (mode 1 fills all 1536)
+constexpr int tile_slots(int npl) { return npl * 512; }    // npl * 256 K slots + npl * 256 V slots
 
 // One workgroup per (key tile, head, item): rotary on K (self-attention only, LGN:41-54,155-156), exact
 // 3-way bf16 split of K and V, written in the LDS-image order of attn_x6_kernel.
+template <int MODE>
 __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
+  using S = SplitMma<MODE>;
+  constexpr int NPL = S::NPL, KSL = NPL * 256;
   const int tile = blockIdx.x, head = blockIdx.y, item = blockIdx.z;
   if (a.done[item >> 1] != 0) return;
   const int nk = a.n[item], kt = tile * 32;
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
   const int t = threadIdx.x;
   const float* kb = a.k + (size_t)item * a.sk + head * 64;
   const float* vb = a.v + (size_t)item * a.sv + head * 64;
-  u32x4* img = a.kv_img + (((size_t)item * 4 + head) * a.tiles + tile) * TILE_SLOTS;
+  u32x4* img = a.kv_img + (((size_t)item * 4 + head) * a.tiles + tile) * TILE_STRIDE;
   {  // K: thread (key = t>>3, d-block = t&7)
     const int key = t >> 3, blk = t & 7;
     float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -63,12 +67,11 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
         }
       }
     }
-    unsigned h[4], m[4], l[4];
+    unsigned pc[4][NPL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split3_pk(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
-    img[(0 * 8 + blk) * 32 + key] = u32x4{h[0], h[1], h[2], h[3]};
-    img[(1 * 8 + blk) * 32 + key] = u32x4{m[0], m[1], m[2], m[3]};
-    img[(2 * 8 + blk) * 32 + key] = u32x4{l[0], l[1], l[2], l[3]};
+    for (int i = 0; i < 4; ++i) S::split(x[2 * i], x[2 * i + 1], S::act_scale(), pc[i]);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) img[(pl * 8 + blk) * 32 + key] = u32x4{pc[0][pl], pc[1][pl], pc[2][pl], pc[3][pl]};
   }
   {  // V: thread (d = t&63, step u = t>>7, k-half h = (t>>6)&1), keys in MFMA-C-layout order
     const int d = t & 63, u = t >> 7, hh = (t >> 6) & 1;
@@ -78,16 +81,20 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
       const int key = (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hh;
       x[e] = (kt + key < nk) ? vb[(size_t)(kt + key) * a.ldv + d] : 0.0f;
     }
-    unsigned h[4], m[4], l[4];
+    unsigned pc[4][NPL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split3_pk(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
-    img[768 + ((0 * 2 + u) * 2 + hh) * 64 + d] = u32x4{h[0], h[1], h[2], h[3]};
-    img[768 + ((1 * 2 + u) * 2 + hh) * 64 + d] = u32x4{m[0], m[1], m[2], m[3]};
-    img[768 + ((2 * 2 + u) * 2 + hh) * 64 + d] = u32x4{l[0], l[1], l[2], l[3]};
+    for (int i = 0; i < 4; ++i) S::split(x[2 * i], x[2 * i + 1], S::act_scale(), pc[i]);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) img[KSL + ((pl * 2 + u) * 2 + hh) * 64 + d] = u32x4{pc[0][pl], pc[1][pl], pc[2][pl], pc[3][pl]};
   }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
+  using S = SplitMma<MODE>;
+  constexpr int NPL = S::NPL, TILE_SLOTS = tile_slots(NPL), KSL = NPL * 256, NCP = TILE_SLOTS / 256;
+  // K, Q, V and P are multiplied by the (power-of-two) activation scale before the split: exact factors
+  const float inv_qk = 1.0f / (S::act_scale() * S::act_scale()), inv_pv = inv_qk;
   const int item = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
   if (a.done[item >> 1] != 0) return;
   const int kitem = a.cross ? (item ^ 1) : item;
@@ -96,14 +103,14 @@ __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
 
   __shared__ u32x4 img[TILE_SLOTS];
   u32x4* Kp = img;
-  u32x4* Vp = img + 768;
+  u32x4* Vp = img + KSL;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, lx = lane & 31, half = lane >> 5;
   const int qrow = q0 + wv * 32 + lx;
   const bool qok = qrow < nq;
 
   // Q^T operand: lane (query lx, half) holds d = 16s + 8*half + 0..7 for s = 0..3, three planes each
-  u32x4 qf[4][3];
+  u32x4 qf[4][NPL];
   {
     const float* qp = a.q + (size_t)item * a.sq + (size_t)(qok ? qrow : 0) * a.ldq + head * 64 + half * 8;
     const float sc = a.scale * 1.44269504088896340736f;  // scores in the log2 domain
@@ -123,12 +130,11 @@ __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
           }
         }
       }
-      unsigned h[4], m[4], l[4];
+      unsigned pc[4][NPL];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) split3_pk(x[2 * i] * sc, x[2 * i + 1] * sc, h[i], m[i], l[i]);
-      qf[s][0] = u32x4{h[0], h[1], h[2], h[3]};
-      qf[s][1] = u32x4{m[0], m[1], m[2], m[3]};
-      qf[s][2] = u32x4{l[0], l[1], l[2], l[3]};
+      for (int i = 0; i < 4; ++i) S::split(x[2 * i] * sc, x[2 * i + 1] * sc, S::act_scale(), pc[i]);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) qf[s][pl] = u32x4{pc[0][pl], pc[1][pl], pc[2][pl], pc[3][pl]};
     }
   }
   f32x16 oacc[2];
@@ -138,18 +144,18 @@ __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
     for (int r = 0; r < 16; ++r) oacc[n][r] = 0.0f;
   float m_run = -INFINITY, l_run = 0.0f;
 
-  // staging: six straight 16-byte copies per thread per tile (images pre-built by kv_prep_kernel)
-  const u32x4* src = a.kv_img + ((size_t)kitem * 4 + head) * a.tiles * TILE_SLOTS;
-  u32x4 rt[6];
+  // staging: NCP (6 / 4) straight 16-byte copies per thread per tile (images pre-built by kv_prep_kernel)
+  const u32x4* src = a.kv_img + ((size_t)kitem * 4 + head) * a.tiles * TILE_STRIDE;
+  u32x4 rt[NCP];
   auto load_tile = [&](int kt) {
-    const u32x4* p = src + (size_t)(kt >> 5) * TILE_SLOTS;
+    const u32x4* p = src + (size_t)(kt >> 5) * TILE_STRIDE;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rt[i] = p[t + 256 * i];
+    for (int i = 0; i < NCP; ++i) rt[i] = p[t + 256 * i];
   };
   load_tile(0);
   for (int kt = 0; kt < nk; kt += 32) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) img[t + 256 * i] = rt[i];
+    for (int i = 0; i < NCP; ++i) img[t + 256 * i] = rt[i];
     __syncthreads();
     if (kt + 32 < nk) load_tile(kt + 32);
 
@@ -157,14 +163,17 @@ __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
-    const int ta[6] = {1, 0, 2, 0, 1, 0}, tb[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      u32x4 kf[3];
+      u32x4 kf[NPL];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) kf[p] = Kp[(p * 8 + 2 * s + half) * 32 + lx];
+      for (int p = 0; p < NPL; ++p) kf[p] = Kp[(p * 8 + 2 * s + half) * 32 + lx];
 #pragma unroll
-      for (int tm = 0; tm < 6; ++tm) sacc = mfma_bf16(kf[ta[tm]], qf[s][tb[tm]], sacc);
+      for (int tm = 0; tm < S::NT; ++tm) sacc = S::mma(kf[S::ta(tm)], qf[s][S::tb(tm)], sacc);
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] *= inv_qk;
     }
 
     // ---- online softmax (log2 domain, deferred rescale) ----
@@ -201,26 +210,28 @@ __global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
     // ---- O^T += V^T · P^T : registers 8u..8u+7 of p are the B operand of step u ----
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      unsigned h[4], m[4], l[4];
+      unsigned pc[4][NPL];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split3_pk(p[8 * u + 2 * e], p[8 * u + 2 * e + 1], h[e], m[e], l[e]);
-      const u32x4 pf[3] = {u32x4{h[0], h[1], h[2], h[3]}, u32x4{m[0], m[1], m[2], m[3]}, u32x4{l[0], l[1], l[2], l[3]}};
-      u32x4 vf[2][3];
+      for (int e = 0; e < 4; ++e) S::split(p[8 * u + 2 * e], p[8 * u + 2 * e + 1], S::act_scale(), pc[e]);
+      u32x4 pf[NPL];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl) pf[pl] = u32x4{pc[0][pl], pc[1][pl], pc[2][pl], pc[3][pl]};
+      u32x4 vf[2][NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
         vf[0][pl] = Vp[((pl * 2 + u) * 2 + half) * 64 + lx];
         vf[1][pl] = Vp[((pl * 2 + u) * 2 + half) * 64 + 32 + lx];
       }
 #pragma unroll
-      for (int tm = 0; tm < 6; ++tm) {
-        oacc[0] = mfma_bf16(vf[0][ta[tm]], pf[tb[tm]], oacc[0]);
-        oacc[1] = mfma_bf16(vf[1][ta[tm]], pf[tb[tm]], oacc[1]);
+      for (int tm = 0; tm < S::NT; ++tm) {
+        oacc[0] = S::mma(vf[0][S::ta(tm)], pf[S::tb(tm)], oacc[0]);
+        oacc[1] = S::mma(vf[1][S::ta(tm)], pf[S::tb(tm)], oacc[1]);
       }
     }
     __syncthreads();
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (MODE == 2 ? 1.0f / inv_pv : 1.0f);  // the scaled V·P accumulator is divided by scale^2 * l
   if (qok) {
     float* op = a.o + (size_t)item * a.so + (size_t)qrow * a.ldo + head * 64;
 #pragma unroll
@@ -245,9 +256,14 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s) {
   a.n = st.n_cur; a.done = st.done; a.cross = cross;
   a.scale = 0.125f;
   a.enc = st.enc; a.kv_img = (u32x4*)st.kv_img; a.nmax = st.nmax; a.tiles = cdiv(st.nmax, 32);
-  hipLaunchKernelGGL(kv_prep_kernel, dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
   dim3 grid(cdiv(st.nmax, 128), 4, st.n_items);
-  hipLaunchKernelGGL(attn_x6_kernel, grid, dim3(256), 0, s, a);
+  if (dim_precision_mode() == 2) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<2>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<1>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<1>), grid, dim3(256), 0, s, a);
+  }
   DIM_LAUNCH_CHECK();
   return 0;
 }

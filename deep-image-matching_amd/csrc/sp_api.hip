@@ -20,7 +20,7 @@ struct dim_sp {
   int max_batch, max_h, max_w, capacity;
   // weights (device)
   float* w1a; float* wk[12]; float* bias[12];
-  unsigned short* wx6[12];  // bf16x6 pre-split 3x3 weights (conv_x6.hip); nullptr for conv1a and the 1x1 layers
+  SplitWeights wsp[3][12];  // [precision mode 1 = bf16x6, 2 = fp16x3] pre-split 3x3 weights (conv_x6.hip); empty for conv1a and the 1x1 layers
   // activations
   float *a1, *b1, *a2, *b2, *a3, *b3, *a4, *x, *pa, *logits, *da, *dd, *smap, *nms, *cand_score;
   int *cand_idx, *rowcount, *rowoff, *ncand;
@@ -76,12 +76,16 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
     for (int o = 0; o < co; ++o)
       for (int i = 0; i < ci; ++i)
         for (int t = 0; t < k * k; ++t) host[((size_t)t * ci + i) * co_pad + o] = w->conv_w[l][((size_t)o * ci + i) * k * k + t];
-    h->wx6[l] = nullptr;
     if (k == 3 && ci >= 64) {
-      std::vector<unsigned short> hx(conv_x6_weight_elems(ci, co));
-      prepare_conv_weights_x6(w->conv_w[l], ci, co, hx.data());
-      SP_TRY(dev_alloc(h, &h->wx6[l], hx.size()));
-      if (hipMemcpy(h->wx6[l], hx.data(), hx.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
+      for (int mode = 1; mode <= 2; ++mode) {
+        std::vector<unsigned short> hx(conv_split_weight_elems(ci, co, mode));
+        SplitWeights& sw = h->wsp[mode][l];
+        prepare_conv_weights_split(w->conv_w[l], ci, co, mode, hx.data(), &sw.inv_scale);
+        unsigned short* d = nullptr;
+        SP_TRY(dev_alloc(h, &d, hx.size()));
+        if (hipMemcpy(d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
+        sw.dev = d; sw.mode = mode;
+      }
     }
     SP_TRY(dev_alloc(h, &h->wk[l], host.size()));
     if (hipMemcpy(h->wk[l], host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
@@ -128,14 +132,15 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   const int H8 = hh * 8, W8 = ww * 8;
 #define SP_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
 #define SP_SITE(id, x) do { dim_prof_begin(id, s); SP_RUN(x); dim_prof_end(id, s); } while (0)
-  const bool x6 = dim_precision_mode() != 0;  // default: fp32-accurate products on the bf16 matrix cores
+  const int pmode = dim_precision_mode();  // 2 (default) fp16x3 / 1 bf16x6: fp32-accurate products on the 16-bit matrix cores; 0: fp32 MFMA
+  const bool x6 = pmode != 0;
   auto conv = [&](int l, const float* in, float* out, int Hh, int Ww, int ci, int co, int pool) -> int {
-    return x6 ? launch_conv3x3_x6(in, h->wx6[l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s)
+    return x6 ? launch_conv3x3_x6(in, h->wsp[pmode][l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s)
               : launch_conv3x3(in, h->wk[l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s);
   };
   // encoder (SPN:161-171)
   if (x6 && dim_fuse_conv1a()) {  // conv1a evaluated inside conv1b's halo staging: its 64-channel full-resolution map never exists
-    SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_x6_fused1a(images_dev, h->wk[0], h->bias[0], h->wx6[1], h->bias[1], h->b1, batch, H, W, 64, 1, 1, s));
+    SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_x6_fused1a(images_dev, h->wk[0], h->bias[0], h->wsp[pmode][1], h->bias[1], h->b1, batch, H, W, 64, 1, 1, s));
   } else {
     if (!h->a1) SP_RUN(dev_alloc(h, &h->a1, (size_t)h->max_batch * h->max_h * h->max_w * 64));
     SP_SITE(DIM_PROF_SP_CONV1A, launch_conv1a(images_dev, h->wk[0], h->bias[0], h->a1, batch, H, W, s));

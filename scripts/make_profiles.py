@@ -20,7 +20,7 @@ for n in names[:26]:
     f = out['FETCH_SIZE'][n]; w = out['WRITE_SIZE'].get(n, [1, 0.0])
     L.append("%-40s %6d %14.1f %14.1f %14.1f %6s %7s %5s" % (n[:40], f[0], f[1] / f[0], 2 * f[1] / f[0], w[1] / max(1, w[0]), f[2], f[3], f[4]))
 open(f'profiles/{tag}_pmc_hbm_summary.txt', 'w').write('\n'.join(L) + '\n')
-k = [n for n in names if n.startswith('conv3x3_x6_kernel<64, 1, 1, true')][0]
+k = [n for n in names if n.startswith('conv3x3_x6_kernel<64, 1, 1, true, 2')][0]
 f = out['FETCH_SIZE'][k]; w = out['WRITE_SIZE'][k]
 hb = (2 * f[1] / f[0] + w[1] / w[0]) * 1024
 json.dump({"kernel": k, "hbm_bytes_per_launch": hb, "fetch_bytes_corrected_x2": 2 * f[1] / f[0] * 1024, "write_bytes": w[1] / w[0] * 1024,

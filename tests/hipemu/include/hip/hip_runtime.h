@@ -225,6 +225,40 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_32x32x16_bf16((a), (b), (c))
+// v_mfma_f32_32x32x16_f16: same lane map (scripts/probe/mfma_f16_probe.hip), fp16 inputs incl. subnormals, fp32 accumulate.
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+static inline void hipemu_mfma_f16_compute(const unsigned char* tab, unsigned stride, unsigned char* out) {
+  float A[32][16], B[16][32];
+  for (int l = 0; l < 64; ++l)
+    for (int e = 0; e < 8; ++e) {
+      _Float16 ua, ub;
+      memcpy(&ua, tab + (size_t)l * stride + 2 * e, 2);
+      memcpy(&ub, tab + (size_t)l * stride + 16 + 2 * e, 2);
+      A[l & 31][8 * (l >> 5) + e] = (float)ua;
+      B[8 * (l >> 5) + e][l & 31] = (float)ub;
+    }
+  for (int l = 0; l < 64; ++l) {
+    float* o = (float*)(out + (size_t)l * 64);
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      float acc = 0.f;
+      for (int k = 0; k < 16; ++k) acc = fmaf(A[row][k], B[k][col], acc);
+      o[r] = acc;
+    }
+  }
+}
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x16 c) {
+  unsigned short ab[16];
+  memcpy(ab, &a, 16); memcpy(ab + 8, &b, 16);
+  float prod[16];
+  hipemu::wave_collective(ab, sizeof(ab), hipemu_mfma_f16_compute, 64, prod);
+  hipemu_f32x16 d = c;
+  for (int r = 0; r < 16; ++r) d[r] = c[r] + prod[r];
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma_32x32x16_f16((a), (b), (c))
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(fmaxf(a, b), c), fminf(a, b)); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4((a), (b), (c))
 

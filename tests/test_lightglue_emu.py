@@ -37,3 +37,16 @@ def test_lightglue_emulated_vs_golden_and_oracle(emu_lib, name):
                                                              "matches", "scores", "prune0", "prune1")}
     gold["stop"] = int(g["stop"])
     compare_lightglue(out, gold)
+
+
+def test_lightglue_bf16x6_mode_still_matches_the_oracle(emu_lib):
+    """The default split mode is fp16x3 (two fp16 planes, three MFMA terms); the bf16x6 mode (three bf16
+    planes, six terms) and the plain fp32-MFMA mode stay selectable (dim_tune_set key 1) and parity-green."""
+    name = next(iter(gc.LG_CASES))
+    try:
+        for mode in (1, 0):
+            emu_lib.dim_tune_set(1, mode)
+            out, ref = run_case(emu_lib, gc.LG_CASES[name])
+            compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+    finally:
+        emu_lib.dim_tune_set(1, 2)

@@ -54,9 +54,18 @@ def test_conv3x3_mfma(emu_lib, cin, cout, H, W, pool):
     assert (out - ref.permute(0, 2, 3, 1)).abs().max() < 1e-4
 
 
+@pytest.fixture(params=[2, 1], ids=["fp16x3", "bf16x6"])
+def split_mode(request, emu_lib):
+    """Both split-precision modes of the matrix-core kernels (dim_tune_set key 1); the default is restored."""
+    emu_lib.dim_tune_set(1, request.param)
+    yield request.param
+    emu_lib.dim_tune_set(1, 2)
+
+
 @pytest.mark.parametrize("M,N,K", [(200, 65, 64), (130, 256, 512), (64, 130, 32)])
-def test_gemm_bf16x6_is_fp32_accurate(emu_lib, M, N, K):
-    """Exact 3-way bf16 split + six cross terms on the bf16 MFMA == fp32-class accuracy (vs fp64)."""
+def test_gemm_split_precision_is_fp32_accurate(emu_lib, split_mode, M, N, K):
+    """bf16x6 (exact 3-way bf16 split, six cross terms) and fp16x3 (2-way fp16 split of the scaled operands,
+    three cross terms) on the 16-bit MFMA == fp32-class accuracy (vs fp64)."""
     g = torch.Generator().manual_seed(K + M)
     A, W = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g).contiguous()
     bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
@@ -71,7 +80,7 @@ def test_gemm_bf16x6_is_fp32_accurate(emu_lib, M, N, K):
 
 
 @pytest.mark.parametrize("cin,cout,H,W,pool", [(64, 64, 20, 37, 1), (64, 128, 9, 33, 0), (128, 128, 16, 34, 1)])
-def test_conv3x3_bf16x6_is_fp32_accurate(emu_lib, cin, cout, H, W, pool):
+def test_conv3x3_split_precision_is_fp32_accurate(emu_lib, split_mode, cin, cout, H, W, pool):
     g = torch.Generator().manual_seed(cin + H)
     x = torch.randn(2, cin, H, W, generator=g)
     w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).contiguous()
@@ -88,3 +97,25 @@ def test_conv3x3_bf16x6_is_fp32_accurate(emu_lib, cin, cout, H, W, pool):
         ref = F.max_pool2d(ref, 2, 2)
     mag = F.conv2d(x.abs().double(), w.abs().double(), padding=1).max().item()
     assert (out.double() - ref.permute(0, 2, 3, 1)).abs().max().item() / mag < 4e-7
+
+
+@pytest.mark.parametrize("regime", ["tiny", "large", "overflow"])
+def test_fp16x3_range_behaviour(emu_lib, regime):
+    """fp16x3's narrow exponent: activations are scaled by 16 and clamped to +-65504 before the split.
+    tiny (1e-3): still ~1e-6-accurate relative to sum|a||b|; large (up to 4000): exact range; beyond 4094:
+    saturates to a finite value (never inf/nan)."""
+    emu_lib.dim_tune_set(1, 2)
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 64, 64, 256
+    scale = {"tiny": 1e-3, "large": 4000.0, "overflow": 1e6}[regime]
+    A = (torch.rand(M, K, generator=g) * scale).contiguous()
+    W = (torch.randn(K, N, generator=g) * 0.05).contiguous()
+    C = torch.zeros(M, N)
+    dev, npad = ctypes.c_void_p(), ctypes.c_int()
+    assert emu_lib.dim_x3_create(p(W), K, N, ctypes.byref(dev), ctypes.byref(npad)) == 0
+    assert emu_lib.dim_op_gemm_x6_f32(p(A), K, dev, npad.value, None, None, 0, p(C), N, M, N, K, 0, None) == 0
+    emu_lib.dim_x3_destroy(dev)
+    assert torch.isfinite(C).all()
+    if regime != "overflow":
+        ref, mag = A.double() @ W.double(), A.abs().double() @ W.abs().double()
+        assert ((C.double() - ref).abs() / mag).max().item() < (2e-6 if regime == "tiny" else 4e-7)

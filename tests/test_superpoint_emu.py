@@ -59,3 +59,19 @@ def test_fused_conv1a_equals_the_two_kernel_path(emu_lib):
         emu_lib.dim_tune_set(3, 1)
     assert torch.equal(ta["encoder"], tb["encoder"]) and torch.equal(ta["score_map"], tb["score_map"])
     assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
+
+
+def test_superpoint_bf16x6_and_fp32_modes_agree_with_the_default(emu_lib):
+    name = next(iter(gc.SP_CASES))
+    case = gc.SP_CASES[name]
+    sd, img = gc.sp_weights(case), gc.sp_image(case)
+    net = sp_mod.SuperPointHIP(sd, case["cfg"], max_batch=1, max_hw=(case["H"], case["W"]), capacity=512, device="cpu", lib=emu_lib)
+    base = net(img); tb = net.debug_taps()
+    try:
+        for mode in (1, 0):
+            emu_lib.dim_tune_set(1, mode)
+            out = net(img); t = net.debug_taps()
+            np.testing.assert_allclose(t["encoder"].numpy(), tb["encoder"].numpy(), atol=2e-4, rtol=1e-4)
+            assert set(map(tuple, out["keypoints"].long().tolist())) == set(map(tuple, base["keypoints"].long().tolist()))
+    finally:
+        emu_lib.dim_tune_set(1, 2)
