@@ -63,6 +63,7 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
                               float* out, int batch, int H, int W, int cout, int pool, int relu, hipStream_t s);
 int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
+int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)
 void dim_conv_x6_set_variant(int v);  // tuning hook: prefetch variant of conv3x3_x6 (dim_tune_set key 2)
 void dim_conv_set_variant(int v);  // tuning hook: selects the conv3x3 kernel variant (see conv.hip)
 // conv1a: 1 -> 64 channels, direct (VALU) convolution; in: [B][H][W], w: [9][64].

@@ -17,6 +17,9 @@ struct LayerW {
   float *match_w, *match_b, *proj_w, *proj_b, *tok_w, *tok_b;
   // pre-split copies of the GEMM operands for the split modes 1 (bf16x6) and 2 (fp16x3), gemm_x6.hip; index = mode
   SplitWeights qkv_x[3], out_x[3], sffn0_x[3], sffn3_x[3], cqkv_x[3], cout_x[3], cffn0_x[3], cffn3_x[3], proj_x[3];
+  // out_proj folded into ffn.0 (split modes): [desc | ctx] * [W1a ; Wout*W1b] + (b1 + bout*W1b)
+  SplitWeights sffn0f_x[3], cffn0f_x[3];
+  float *sffn0f_b, *cffn0f_b;
 };
 }  // namespace
 
@@ -66,6 +69,25 @@ int upload_x3(dim_lg* h, SplitWeights* dst, const std::vector<float>& w_kn, int 
     dst[mode].dev = d; dst[mode].mode = mode; dst[mode].n_pad = n_pad;
   }
   return 0;
+}
+// ffn.0([x | out_proj(ctx)]) = x*W1a + (ctx*Wout + bout)*W1b + b1 = [x | ctx] * [W1a ; Wout*W1b] + (b1 + bout*W1b):
+// folding the 256x256 out_proj into the first FFN layer (products formed in fp64, rounded once to fp32) removes one
+// GEMM launch and the message tensor per block.  wout [256][256] and w1 [512][512] are [in][out] operands.
+void fold_out_proj(const std::vector<float>& wout, const std::vector<float>& bout, const std::vector<float>& w1,
+                   const std::vector<float>& b1, std::vector<float>& wf, std::vector<float>& bf) {
+  wf = w1;
+  bf = b1;
+  for (int o = 0; o < 512; ++o) {
+    double sb = b1[o];
+    for (int j = 0; j < 256; ++j) sb += (double)bout[j] * w1[(size_t)(256 + j) * 512 + o];
+    bf[o] = (float)sb;
+  }
+  for (int i = 0; i < 256; ++i)
+    for (int o = 0; o < 512; ++o) {
+      double sw = 0.0;
+      for (int j = 0; j < 256; ++j) sw += (double)wout[(size_t)i * 256 + j] * w1[(size_t)(256 + j) * 512 + o];
+      wf[(size_t)(256 + i) * 512 + o] = (float)sw;
+    }
 }
 // nn.Linear weight [out][in] -> GEMM operand [in][out] (optionally scaled)
 std::vector<float> transpose(const float* w, int out_f, int in_f, float scale = 1.0f) {
@@ -139,6 +161,13 @@ int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pai
     LG_TRY(upload(h, &d.cffn0_w, transpose(s.cross_ffn0_w, 512, 512))); LG_TRY(upload_x3(h, d.cffn0_x, transpose(s.cross_ffn0_w, 512, 512), 512, 512)); LG_TRY(upload(h, &d.cffn0_b, vec(s.cross_ffn0_b, 512)));
     LG_TRY(upload(h, &d.cln_w, vec(s.cross_ln_w, 512))); LG_TRY(upload(h, &d.cln_b, vec(s.cross_ln_b, 512)));
     LG_TRY(upload(h, &d.cffn3_w, transpose(s.cross_ffn3_w, 256, 512))); LG_TRY(upload_x3(h, d.cffn3_x, transpose(s.cross_ffn3_w, 256, 512), 512, 256)); LG_TRY(upload(h, &d.cffn3_b, vec(s.cross_ffn3_b, 256)));
+    {
+      std::vector<float> wf, bf;
+      fold_out_proj(transpose(s.self_out_w, 256, 256), vec(s.self_out_b, 256), transpose(s.self_ffn0_w, 512, 512), vec(s.self_ffn0_b, 512), wf, bf);
+      LG_TRY(upload_x3(h, d.sffn0f_x, wf, 512, 512)); LG_TRY(upload(h, &d.sffn0f_b, bf));
+      fold_out_proj(transpose(s.cross_out_w, 256, 256), vec(s.cross_out_b, 256), transpose(s.cross_ffn0_w, 512, 512), vec(s.cross_ffn0_b, 512), wf, bf);
+      LG_TRY(upload_x3(h, d.cffn0f_x, wf, 512, 512)); LG_TRY(upload(h, &d.cffn0f_b, bf));
+    }
     LG_TRY(upload(h, &d.match_w, vec(s.assign_match_w, 256))); LG_TRY(upload(h, &d.match_b, vec(s.assign_match_b, 1)));
     // final_proj / d^0.25 (LGN:268-270): 256^0.25 = 4, a power of two -> folding the scale is exact
     LG_TRY(upload(h, &d.proj_w, transpose(s.assign_proj_w, 256, 256, 0.25f))); LG_TRY(upload_x3(h, d.proj_x, transpose(s.assign_proj_w, 256, 256, 0.25f), 256, 256)); LG_TRY(upload(h, &d.proj_b, vec(s.assign_proj_b, 256, 0.25f)));
@@ -184,6 +213,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
                         h->input_dim == 256 ? 1 : 0, s));
   const int pmode = dim_precision_mode();  // 2 fp16x3 (default) / 1 bf16x6: fp32-accurate products on the 16-bit matrix cores; 0 fp32 MFMA
   const bool x6 = pmode != 0;
+  const bool fold = x6 && dim_fold_out_proj();  // split modes: out_proj folded into ffn.0 (one GEMM less per block)
   auto gemm_items = [&](const float* A, int lda, long long sA, const float* A1, int lda1, long long sA1, int ksplit,
                         const float* B, const SplitWeights* Bx, int ldb, const float* bias, const float* R, float* C, int ldc,
                         long long sC, int Nn, int K, int flag_eq) -> int {
@@ -209,8 +239,12 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     dim_prof_begin(DIM_PROF_LG_SELF_ATTN, s);
     LG_RUN(launch_lg_attention(st, 0, s));
     dim_prof_end(DIM_PROF_LG_SELF_ATTN, s);
-    LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.out_w, w.out_x, 256, w.out_b, nullptr, st.msg, 256, s256, 256, 256, 0));
-    LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.sffn0_w, w.sffn0_x, 512, w.sffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+    if (fold) {  // out_proj folded into ffn.0: A = [desc | ctx]
+      LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.sffn0f_x, 512, w.sffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+    } else {
+      LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.out_w, w.out_x, 256, w.out_b, nullptr, st.msg, 256, s256, 256, 256, 0));
+      LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.sffn0_w, w.sffn0_x, 512, w.sffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+    }
     LG_RUN(launch_lg_ln_gelu(st, w.sln_w, w.sln_b, s));
     LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.sffn3_w, w.sffn3_x, 256, w.sffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0));
     // ---- cross block (LGN:186-211) ----
@@ -218,8 +252,12 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     dim_prof_begin(DIM_PROF_LG_CROSS_ATTN, s);
     LG_RUN(launch_lg_attention(st, 1, s));
     dim_prof_end(DIM_PROF_LG_CROSS_ATTN, s);
-    LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.cout_w, w.cout_x, 256, w.cout_b, nullptr, st.msg, 256, s256, 256, 256, 0));
-    LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.cffn0_w, w.cffn0_x, 512, w.cffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+    if (fold) {
+      LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.cffn0f_x, 512, w.cffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+    } else {
+      LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.cout_w, w.cout_x, 256, w.cout_b, nullptr, st.msg, 256, s256, 256, 256, 0));
+      LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.cffn0_w, w.cffn0_x, 512, w.cffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+    }
     LG_RUN(launch_lg_ln_gelu(st, w.cln_w, w.cln_b, s));
     LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.cffn3_w, w.cffn3_x, 256, w.cffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0));
     // ---- adaptive depth / width (LGN:494-516) ----

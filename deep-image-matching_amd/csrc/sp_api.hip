@@ -87,6 +87,21 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
         sw.dev = d; sw.mode = mode;
       }
     }
+    if (k == 1) {  // the two 1x1 heads (convPb 256 -> 65, convDb 256 -> 256) run on the split GEMM
+      std::vector<float> kn((size_t)ci * co);
+      for (int o = 0; o < co; ++o)
+        for (int i = 0; i < ci; ++i) kn[(size_t)i * co + o] = w->conv_w[l][(size_t)o * ci + i];
+      const int n_pad = (co + 127) / 128 * 128;
+      for (int mode = 1; mode <= 2; ++mode) {
+        std::vector<unsigned short> hx(gemm_split_weight_elems(ci, n_pad, mode));
+        SplitWeights& sw = h->wsp[mode][l];
+        split_weights(kn.data(), ci, co, n_pad, mode, hx.data(), &sw.inv_scale);
+        unsigned short* d = nullptr;
+        SP_TRY(dev_alloc(h, &d, hx.size()));
+        if (hipMemcpy(d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
+        sw.dev = d; sw.mode = mode; sw.n_pad = n_pad;
+      }
+    }
     SP_TRY(dev_alloc(h, &h->wk[l], host.size()));
     if (hipMemcpy(h->wk[l], host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
     std::vector<float> hb(co_pad, 0.0f);
@@ -158,7 +173,8 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
     GemmArgs g;
     g.A0 = h->pa; g.lda0 = 256; g.B = h->wk[9]; g.ldb = 68; g.bias = h->bias[9];
     g.C = h->logits; g.ldc = 65; g.M = batch * hh * ww; g.N = 65; g.K = 256;
-    SP_RUN(launch_gemm(g, 1, s));
+    if (x6) { g.set_split(h->wsp[pmode][9]); SP_RUN(launch_gemm_x6(g, 1, s)); }
+    else SP_RUN(launch_gemm(g, 1, s));
   }
   SP_RUN(launch_softmax_d2s(h->logits, h->smap, batch, hh, ww, s));
   SP_RUN(launch_nms(h->smap, h->nms, batch, H8, W8, h->cfg.nms_radius, s));
@@ -173,7 +189,8 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
     GemmArgs g;
     g.A0 = h->da; g.lda0 = 256; g.B = h->wk[11]; g.ldb = 256; g.bias = h->bias[11];
     g.C = h->dd; g.ldc = 256; g.M = batch * hh * ww; g.N = 256; g.K = 256;
-    SP_RUN(launch_gemm(g, 1, s));
+    if (x6) { g.set_split(h->wsp[pmode][11]); SP_RUN(launch_gemm_x6(g, 1, s)); }
+    else SP_RUN(launch_gemm(g, 1, s));
   }
   SP_RUN(launch_sample_desc(h->dd, kpts_xy_dev, n_kpts_dev, desc_dev, batch, hh, ww, h->capacity, h->cfg.fix_sampling, s));
 #undef SP_SITE
