@@ -36,8 +36,9 @@ from .tiling import compute_padding
 
 logger = logging.getLogger("dim_amd")
 
-# MatcherBase.__init__ (MB:136-149): the preselection networks' settings
-PRESELECTION_SP_CONF = {"nms_radius": 5, "max_keypoints": 4000, "keypoint_threshold": 0.005}
+# MatcherBase.__init__ (MB:136-149): the preselection networks' settings.  The extractor is hloc's SuperPoint wrapper
+# (MB:18), whose defaults add remove_borders 4 and fix_sampling True (thirdparty/hloc/extractors/superpoint.py:24-31, Q3).
+PRESELECTION_SP_CONF = {"nms_radius": 5, "max_keypoints": 4000, "keypoint_threshold": 0.005, "remove_borders": 4, "fix_sampling": True}
 PRESELECTION_LG_CONF = {"n_layers": 9, "depth_confidence": 0.9, "width_confidence": 0.95, "filter_threshold": 0.3}
 _QUALITY_FACTOR = {"HIGHEST": 2, "HIGH": 1, "MEDIUM": 1 / 2, "LOW": 1 / 4, "LOWEST": 1 / 8}  # constants.py:76-88
 
