@@ -56,8 +56,10 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + row < rows) ra[i] = *(const float4*)(src + (size_t)(m0 + row) * ld + kk0 + q * 4);
+      // rows past the ragged end re-read the last valid row (always mapped): GEMM rows are independent and the
+      // epilogue never stores them, so they need no zeroing — no branch, and no VALU touching the prefetch
+      // registers before the split (anything earlier would drag the wait for them into the MFMA phase)
+      ra[i] = *(const float4*)(src + (size_t)min(m0 + row, rows - 1) * ld + kk0 + q * 4);
     }
   };
   auto store_chunk = [&]() {
@@ -77,46 +79,74 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
   for (int k0 = 0; k0 < a.K; k0 += KC) {
     store_chunk();
     __syncthreads();
-    if (k0 + KC < a.K) load_chunk(k0 + KC);
+    // Issue order matters: vector-memory loads retire in order, so the weight fragments this chunk's MFMAs
+    // need are requested BEFORE the next chunk's activation prefetch — the wait in front of the first MFMA
+    // then covers the (L2-resident) fragments only and the HBM latency of the prefetch hides behind the MFMAs.
+    u32x4 fb[2][2][NPL];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) fb[ks][n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + (k0 >> 4) + ks) * 2 + half) * 32 + lx];
+    // unconditional (the last iteration harmlessly re-reads its own chunk): a branch here would make the compiler
+    // size every wait in the MFMA phase for the path WITHOUT the prefetch, i.e. wait for the prefetch on the other
+    __builtin_amdgcn_sched_barrier(0);
+    load_chunk(min(k0 + KC, a.K - KC));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 fa[2][NPL], fb[2][NPL];
+      u32x4 fa[2][NPL];
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) fb[n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + (k0 >> 4) + ks) * 2 + half) * 32 + lx];
+      for (int p = 0; p < NPL; ++p)
 #pragma unroll
         for (int m = 0; m < 2; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * 64 + m * 32 + lx) * RS + ks * 8 + half * 4];
-      }
-      // six cross terms, smallest first; the four accumulators interleave so no MFMA waits on its predecessor
+      // cross terms smallest first; the four accumulators interleave so no MFMA waits on its predecessor
 #pragma unroll
       for (int tm = 0; tm < S::NT; ++tm)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[n][S::tb(tm)], acc[m][n]);
+          for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[ks][n][S::tb(tm)], acc[m][n]);
     }
     __syncthreads();
   }
 
+  // Epilogue: per (m, n) tile all 16 residual values are requested before any is used, the uniform decisions
+  // (residual? activation?) are hoisted, out-of-range lanes are masked at the store only.
   float* C = a.C + (size_t)z * a.strideC;
   const float* R = a.R ? a.R + (size_t)z * a.strideR : nullptr;
+  const float inv = a.inv_scale;
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = n0 + wn * 64 + n * 32 + lx;
-    if (col >= a.N) continue;
-    const float bv = a.bias ? a.bias[col] : 0.0f;
+    const bool colok = col < a.N;
+    const int colc = colok ? col : a.N - 1;
+    const float bv = a.bias ? a.bias[colc] : 0.0f;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
+      const int rbase = m0 + wm * 64 + m * 32;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[m][n][r] * inv + bv;
+      if (R) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = R[(size_t)min(rbase + mfma_row(r, half), rows - 1) * a.ldr + colc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += rv[r];
+      }
+      if (a.relu == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+      } else if (a.relu == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v[r] <= 0.0f ? (expf(v[r]) - 1.0f) * 1.7580993408473768599402175208123f : v[r] * 1.0507009873554804934193349852946f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + m * 32 + mfma_row(r, half);
-        if (row >= rows) continue;
-        float v = acc[m][n][r] * a.inv_scale + bv;
-        if (R) v += R[(size_t)row * a.ldr + col];
-        if (a.relu == 1) v = fmaxf(v, 0.0f);
-        else if (a.relu == 2) v = v <= 0.0f ? (expf(v) - 1.0f) * 1.7580993408473768599402175208123f : v * 1.0507009873554804934193349852946f;
-        C[(size_t)row * a.ldc + col] = v;
+        const int row = rbase + mfma_row(r, half);
+        if (colok && row < rows) C[(size_t)row * a.ldc + col] = v[r];
       }
     }
   }
