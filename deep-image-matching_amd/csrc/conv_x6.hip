@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
   __shared__ u32x4 Wp[NPL * 3 * 2 * 64];
   constexpr int IMW = IW + 2, IMH = IH + 2;  // image tile of the fused conv1a: halo of the halo
   __shared__ float Img[F1A ? IMH * IMW : 1];
+  __shared__ float W1a[F1A ? 9 * 64 + 64 : 1];  // conv1a weights [tap][64] + bias[64]: read per chunk from LDS, not from L2
   constexpr int NCHUNK = CIN / 16;
 
   const int t = threadIdx.x;
@@ -109,10 +110,10 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
     float wr[9][4];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const float4 v = *(const float4*)(w1a + k * 64 + c * 16 + q * 4);
+      const float4 v = *(const float4*)&W1a[k * 64 + c * 16 + q * 4];
       wr[k][0] = v.x; wr[k][1] = v.y; wr[k][2] = v.z; wr[k][3] = v.w;
     }
-    const float4 bv = *(const float4*)(b1a + c * 16 + q * 4);
+    const float4 bv = *(const float4*)&W1a[9 * 64 + c * 16 + q * 4];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       const int idx = t + 256 * i;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       const int gy = oy + r - 2, gx = ox + cc - 2;
       Img[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in_b[(size_t)gy * W + gx] : 0.0f;
     }
+    for (int idx = t; idx < 9 * 64 + 64; idx += 256) W1a[idx] = idx < 9 * 64 ? w1a[idx] : b1a[idx - 9 * 64];
   }
 
   if (PF >= 1) load_w(0, 0);

@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
   }
 }
 
+// fp16x3: 16 KB of LDS and <= 128 VGPRs -> 4 workgroups per CU, so the 1024 workgroups of a 16-item batch
+// (16 query blocks x 4 heads x 16 items) run as ONE round on 256 CUs instead of 1.33 rounds at 3 per CU
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn_x6_kernel(AttnArgs6 a) {
+__global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnArgs6 a) {
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, TILE_SLOTS = tile_slots(NPL), KSL = NPL * 256, NCP = TILE_SLOTS / 256;
   // K, Q, V and P are multiplied by the (power-of-two) activation scale before the split: exact factors
