@@ -232,19 +232,43 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
     __syncthreads();
     const unsigned long long prefix = sh_prefix;
     const unsigned long long himask = (byte == 7) ? 0ull : (~0ull << (8 * (byte + 1)));
+    // a thread's consecutive hits of one bin are merged into a single atomic: the leading bytes of positive float
+    // scores are (nearly) constant, which would otherwise serialise every key of the image on one LDS counter
+    int run_bin = -1, run_cnt = 0;
     for (int i = t; i < n; i += 1024) {
       const unsigned long long key = ((unsigned long long)__float_as_uint(cs[i]) << 32) | (unsigned)(~ci[i]);
-      if ((key & himask) == prefix) atomicAdd(&hist[(int)((key >> (8 * byte)) & 0xffull)], 1);
-    }
-    __syncthreads();
-    if (t == 0) {
-      int krem = sh_krem, d = 255;
-      for (; d > 0; --d) {
-        if (hist[d] >= krem) break;
-        krem -= hist[d];
+      if ((key & himask) == prefix) {
+        const int bin = (int)((key >> (8 * byte)) & 0xffull);
+        if (bin == run_bin) {
+          ++run_cnt;
+        } else {
+          if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
+          run_bin = bin; run_cnt = 1;
+        }
       }
-      sh_krem = krem;
-      sh_prefix = prefix | ((unsigned long long)d << (8 * byte));
+    }
+    if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
+    __syncthreads();
+    if (t < 64) {  // wave 0: digit d with  above(d) < krem <= above(d) + hist[d],  above(d) = keys in higher bins
+      const int krem = sh_krem;
+      const int h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+      const int tot = h0 + h1 + h2 + h3;
+      int suf = tot;  // inclusive suffix sum over lanes t..63
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_down(suf, o);
+        if (t + o < 64) suf += v;
+      }
+      const int a3 = suf - tot, a2 = a3 + h3, a1 = a2 + h2, a0 = a1 + h1;  // keys above bins 4t+3 .. 4t
+      int d = -1, above = 0;
+      if (a3 < krem && krem <= a3 + h3) { d = 4 * t + 3; above = a3; }
+      else if (a2 < krem && krem <= a2 + h2) { d = 4 * t + 2; above = a2; }
+      else if (a1 < krem && krem <= a1 + h1) { d = 4 * t + 1; above = a1; }
+      else if (a0 < krem && krem <= a0 + h0) { d = 4 * t; above = a0; }
+      if (d >= 0) {  // exactly one lane (the prefix always holds >= krem keys)
+        sh_krem = krem - above;
+        sh_prefix = prefix | ((unsigned long long)d << (8 * byte));
+      }
     }
     __syncthreads();
   }
