@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=8, help="pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=16, help="pairs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="time the two-stream schedule (extraction of batch i+1 overlapping matching "
                     "of batch i) as the main region; by default it is measured after it and reported as two_stream_overlap")
@@ -247,7 +247,8 @@ def main():
         pmc = ROOT / "profiles" / "conv1b_hbm_bytes.json"
         if pmc.exists():
             try:
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+                rec = json.loads(pmc.read_text())  # measured at rec["batch_images_per_launch"] images per launch; scales with the batch
+                traffic = rec.get("hbm_bytes_per_launch") * (2 * P) / rec.get("batch_images_per_launch", 2 * P)
             except Exception:
                 traffic = None
         line = {

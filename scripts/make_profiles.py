@@ -1,6 +1,7 @@
 """Build the committed profile summaries (profiles/) from the rocprofv3 outputs merged into gpurun_out/."""
 import csv, collections, json, re, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+images_per_launch = int(sys.argv[2]) if len(sys.argv) > 2 else 32  # bench.py default: 16 pairs per step = 32 images per conv launch
 def clean(n):
     n = re.sub(r'\(anonymous namespace\)::', '', n); n = re.sub(r'^void ', '', n); return n.split('(')[0]
 shutil.copy(f'gpurun_out/prof_{tag}/bench_kernel_stats.csv', f'profiles/{tag}_bench_kernel_stats.csv')
@@ -13,7 +14,7 @@ for C in ('FETCH_SIZE', 'WRITE_SIZE'):
     out[C] = agg
 names = sorted(out['FETCH_SIZE'], key=lambda n: -out['FETCH_SIZE'][n][1])
 L = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
-     "# counter unit: KiB per dispatch (WRITE_SIZE checks out exactly against known byte counts: conv1a writes 16 x 268,435,456 B = 4,194,304 KiB).",
+     "# counter unit: KiB per dispatch (WRITE_SIZE checks out exactly against known byte counts: e.g. the pooled conv1b map of 32 images is 32 x 67,108,864 B = 2,097,152 KiB).",
      "# gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads -> 'fetch_x2' column.",
      "%-40s %6s %14s %14s %14s %6s %7s %5s" % ("kernel", "calls", "fetch_KiB_avg", "fetch_x2_KiB", "write_KiB_avg", "vgpr", "lds_B", "sgpr")]
 for n in names[:26]:
@@ -25,7 +26,7 @@ f = out['FETCH_SIZE'][k]; w = out['WRITE_SIZE'][k]
 hb = (2 * f[1] / f[0] + w[1] / w[0]) * 1024
 json.dump({"kernel": k, "hbm_bytes_per_launch": hb, "fetch_bytes_corrected_x2": 2 * f[1] / f[0] * 1024, "write_bytes": w[1] / w[0] * 1024,
            "source": f"profiles/{tag}_pmc_hbm_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)",
-           "batch_images_per_launch": 16}, open('profiles/conv1b_hbm_bytes.json', 'w'), indent=1)
+           "batch_images_per_launch": images_per_launch}, open('profiles/conv1b_hbm_bytes.json', 'w'), indent=1)
 # MFMA / clock summary
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); dur = collections.defaultdict(float); seen = set()
 for r in csv.DictReader(open(f'gpurun_out/pmc_{tag}_MFMA/pmc_counter_collection.csv')):
