@@ -60,6 +60,22 @@ except Exception:  # noqa: BLE001
         _role = "matcher"
 
 
+_ARITHMETIC = {"fp16x3": 2, "bf16x6": 1, "fp32": 0}
+
+
+def _apply_arithmetic(conf: dict, lib) -> None:
+    """Optional plugin option ``arithmetic``: "fp16x3" (library default: 2-way fp16 splits x 3 MFMA terms; activations
+    exact up to |x| = 4094), "bf16x6" (exact 3-way bf16 splits x 6 terms, no range limit) or "fp32" (plain fp32 MFMA).
+    The switch is process-wide (dim_tune_set key 1), like the reference's module-global sampler patch (Q3)."""
+    name = (conf or {}).get("arithmetic")
+    if name is None:
+        return
+    if name not in _ARITHMETIC:
+        raise ValueError(f"arithmetic must be one of {sorted(_ARITHMETIC)}, got {name!r}")
+    from . import capi
+    (lib if lib is not None else capi.load()).dim_tune_set(1, _ARITHMETIC[name])
+
+
 def _require_gpu(device: str, what: str):
     if str(device) != "cuda" and not str(device).startswith("cuda"):
         raise RuntimeError(f"{what}: the MI355X plugin has no CPU path (device={device!r}); "
@@ -92,6 +108,7 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
         if _lib is None:
             _require_gpu(self._device, "SuperPointExtractor")
         cfg = self.config.get("extractor")
+        _apply_arithmetic(cfg, _lib)
         path = cfg.get("weights_path") or os.environ.get("DIM_SUPERPOINT_WEIGHTS")
         if path is None:
             logger.warning("SuperPoint: no weights_path / DIM_SUPERPOINT_WEIGHTS given - using seeded SYNTHETIC weights "
@@ -263,6 +280,7 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
         if _lib is None:
             _require_gpu(getattr(self._device, "type", self._device), "LightGlueMatcher")
         cfg = {**self._default_conf, **self.config.get("matcher", {})}
+        _apply_arithmetic(cfg, _lib)
         if cfg.get("mp"):
             logger.warning("LightGlue: mixed precision ('mp') is not implemented on the MI355X path; running fp32")
         self._conf = {k: cfg[k] for k in ("depth_confidence", "width_confidence", "filter_threshold")}

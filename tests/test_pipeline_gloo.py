@@ -79,3 +79,50 @@ def test_sharding_helpers():
     cover = torch.cat([pl.shard_indices(10000, r, 8) for r in range(8)]).sort().values
     assert torch.equal(cover, torch.arange(10000))
     assert max(len(pl.shard_indices(10000, r, 8)) for r in range(8)) - min(len(pl.shard_indices(10000, r, 8)) for r in range(8)) <= 1
+
+
+def _lowres_counts(lib_path, rank, world):
+    import ctypes
+
+    import numpy as np
+
+    sys.path.insert(0, str(ROOT))
+    pairs_mod = importlib.import_module("deep-image-matching_amd.pairs")
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    lib = ctypes.CDLL(lib_path)
+    lib.dim_last_error.restype = ctypes.c_char_p
+    pairs_mod.LOWRES_SP_CONF.update(max_keypoints=24, nms_radius=2)  # emulator-sized (process-local)
+    pairs_mod.LOWRES_LG_CONF.update(n_layers=2, filter_threshold=0.0)
+    rng = np.random.default_rng(3)
+    images = [(rng.random((40, 56)) * 255).astype(np.float32) for _ in range(4)]
+    sel = pairs_mod.LowresPairSelector(weights.synthetic_superpoint_state_dict(5), weights.synthetic_lightglue_state_dict(2, 256, n_layers=2, gain=2.0),
+                                       resize_max=32, min_matches=1, pair_batch=2, device="cpu", lib=lib, rank=rank, world=world)
+    idx = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    return sel.match_counts(sel.extract(images), idx)
+
+
+def _lowres_worker(rank, world, port, lib_path, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    c = _lowres_counts(lib_path, rank, world)
+    torch.save(torch.from_numpy(c), os.path.join(out_dir, f"lowres{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_lowres_pair_counts_equal_single_process(tmp_path):
+    """pairs.LowresPairSelector shards the image pairs over ranks and sums the disjoint count vectors."""
+    build = importlib.import_module("deep-image-matching_amd.build")
+    lib_path = str(build.build_emu())
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_lowres_worker, args=(2, port, lib_path, str(tmp_path)), nprocs=2, join=True)
+    ref = mp.get_context("spawn").Pool(1).apply(_lowres_counts, (lib_path, 0, 1))  # separate process: keeps this one's confs untouched
+    for r in range(2):
+        assert torch.equal(torch.load(tmp_path / f"lowres{r}.pt"), torch.from_numpy(ref))

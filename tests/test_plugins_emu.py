@@ -67,3 +67,25 @@ def test_aliked_extractor_hook_contract(emu_lib):
     a = {tuple(np.round(k).astype(int)) for k in f["keypoints"]}
     b = {tuple(np.round(k).astype(int)) for k in ref["keypoints"].numpy()}
     assert len(a ^ b) <= 2
+
+
+def test_plugin_arithmetic_option_switches_the_library_mode(emu_lib):
+    cfg = {"general": {}, "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1,
+                                      "filter_threshold": 0.0, "arithmetic": "bf16x6"}}
+    try:
+        m = plugins.LightGlueMatcher(cfg, _lib=emu_lib, _device="cpu")
+        g = torch.Generator().manual_seed(1)
+        k0, k1 = torch.rand(20, 2, generator=g) * 100, torch.rand(28, 2, generator=g) * 100
+        d0 = torch.nn.functional.normalize(torch.randn(20, 256, generator=g), dim=-1)
+        d1 = torch.nn.functional.normalize(torch.randn(28, 256, generator=g), dim=-1)
+        size = np.array([100, 120], np.int32)
+        f0 = {"keypoints": k0.numpy(), "descriptors": d0.t().numpy(), "image_size": size}
+        f1 = {"keypoints": k1.numpy(), "descriptors": d1.t().numpy(), "image_size": size}
+        a = m._match_pairs(f0, f1)
+        emu_lib.dim_tune_set(1, 2)
+        b = m._match_pairs(f0, f1)
+        assert np.array_equal(a, b)  # both modes are fp32-class: same matches
+        with pytest.raises(ValueError):
+            plugins.LightGlueMatcher({"general": {}, "matcher": {"name": "lightglue", "arithmetic": "fp8"}}, _lib=emu_lib, _device="cpu")
+    finally:
+        emu_lib.dim_tune_set(1, 2)
