@@ -97,18 +97,37 @@ class BatchedTilingMixin:
 
     @torch.no_grad()
     def _extract_by_tile(self, image: np.ndarray, select_unique: bool = True) -> dict:
+        """The image goes to the device ONCE (one H2D copy of the caller's array); zero padding, tile slicing and
+        _frame2tensor's /255 happen there (IEEE fp32 division: bit-identical to the host's), so no host pass touches
+        the 288 MB of a 6000x4000 RGB float image."""
         general = self.config["general"]
-        tiles, origins, _ = compute_tiles_by_size(image, general["tile_size"], general.get("tile_overlap", 0))
-        idxs = sorted(tiles)
-        th, tw = tiles[idxs[0]].shape[:2]
+        win, ov = general["tile_size"], general.get("tile_overlap", 0)
+        win_hw = (win, win) if isinstance(win, int) else (win[1], win[0])
+        ov_hw = (ov, ov) if isinstance(ov, int) else (ov[1], ov[0])
+        if not isinstance(image, np.ndarray):
+            raise TypeError("input must be a numpy array")
+        H, W = image.shape[:2]
+        pad = compute_padding((H, W), win_hw)
+        stride = (win_hw[0] - ov_hw[0], win_hw[1] - ov_hw[1])
+        n_rows = (H + pad[0] + pad[1] - win_hw[0]) // stride[0] + 1
+        n_cols = (W + pad[2] + pad[3] - win_hw[1]) // stride[1] + 1
+        origins = {r * n_cols + c: (-pad[2] + c * stride[1], -pad[0] + r * stride[0]) for r in range(n_rows) for c in range(n_cols)}
+        th, tw = win_hw
         net = self._ensure_batch(th, tw, self.tile_batch)
+        dev = net.device
+        src = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).to(dev)
+        if src.dim() == 2:
+            src = src[..., None]
+        padded = torch.zeros(H + pad[0] + pad[1], W + pad[2] + pad[3], src.shape[2], dtype=torch.float32, device=dev)
+        padded[pad[0]:pad[0] + H, pad[2]:pad[2] + W] = src
+        idxs = sorted(origins)
         per_tile = {}
         for s in range(0, len(idxs), self.tile_batch):
             chunk = idxs[s:s + self.tile_batch]
-            stack = np.stack([tiles[i] for i in chunk]).astype(np.float32) / 255.0  # _frame2tensor's /255
-            t = torch.from_numpy(stack)
-            t = t[..., 0].contiguous() if self.grayscale else t.contiguous()       # [B,H,W] or [B,H,W,C]
-            kp, sc, de, n = net.extract_batch(t.to(net.device))
+            stack = torch.stack([padded[(i // n_cols) * stride[0]:(i // n_cols) * stride[0] + th,
+                                        (i % n_cols) * stride[1]:(i % n_cols) * stride[1] + tw] for i in chunk]) / 255.0
+            t = stack[..., 0].contiguous() if self.grayscale else stack.contiguous()  # [B,H,W] or [B,H,W,C]
+            kp, sc, de, n = net.extract_batch(t)
             kp, sc, de, n = kp.cpu().numpy(), sc.cpu().numpy(), de.cpu().numpy(), n.cpu().numpy()
             for j, i in enumerate(chunk):
                 k = int(n[j])
