@@ -28,6 +28,8 @@ static int g_fuse_conv1a = 1;
 int dim_fuse_conv1a() { return g_fuse_conv1a; }
 static int g_fold_out_proj = 1;
 int dim_fold_out_proj() { return g_fold_out_proj; }
+static int g_presplit = 1;
+int dim_presplit_activations() { return g_presplit; }
 
 void dim_prof_begin(int site, hipStream_t s) {
   if (!((g_prof_mask >> site) & 1ull)) return;
@@ -156,6 +158,7 @@ int dim_tune_set(int key, int value) {
   if (key == 2) dim_conv_x6_set_variant(value);
   if (key == 3) g_fuse_conv1a = value;
   if (key == 4) g_fold_out_proj = value;
+  if (key == 5) g_presplit = value;
   return 0;
 }
 

@@ -28,11 +28,19 @@ constexpr int w_slice(int npl) { return npl * 3 * 2 * 64 * 8; }              // 
 //      image is neither written nor read back.  CIN must be 64.
 // MODE: SplitMma policy (dim_common.h) — 1: three bf16 planes x six cross terms, 2: two fp16 planes x three
 //       cross terms (activations scaled by act_scale(), weights pre-scaled; inv_scale undoes both exactly).
-template <int CIN, int POOL, int PF, bool F1A, int MODE>
+// PIN / POUT (mode 2 only): the input / output lives in HBM as two NHWC fp16 planes (h then l, `plane_in` /
+//      `plane_out` elements apart; together exactly the bytes of the fp32 tensor they replace) holding the 2-way
+//      split of 16 x the activation, clamped to +-65504.  A producer splits each value ONCE in its epilogue; a
+//      consumer stages its halo tile with straight 16-byte copies — no per-consumer split VALU (every element
+//      used to be split (cout / 64) x 1.33 times, ~5 VALU each).
+template <int CIN, int POOL, int PF, bool F1A, int MODE, bool PIN, bool POUT>
 __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                             int cout, int relu, int tiles_x, const float* __restrict__ w1a,
-                                                            const float* __restrict__ b1a, float inv_scale) {
+                                                            const float* __restrict__ b1a, float inv_scale, size_t plane_in,
+                                                            size_t plane_out) {
+  static_assert(!(PIN || POUT) || MODE == 2, "pre-split planes exist for the fp16x3 mode only");
+  static_assert(!(PIN && F1A), "the fused conv1a computes its own input");
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, W_SLICE = w_slice(NPL);
   __shared__ u32x4 Ip[NPL * 2 * NPIX];
@@ -84,7 +92,10 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       const int py = p / IW, px = p - py * IW;
       const int gy = oy + py - 1, gx = ox + px - 1;
       rin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(in_b + ((size_t)gy * W + gx) * CIN + c * 16 + q * 4);
+      if (PIN) {  // q = plane * 2 + k-half: 8 consecutive channels of one plane = one 16-byte item
+        const unsigned short* pl = (const unsigned short*)in + (size_t)(q >> 1) * plane_in + (size_t)b * H * W * CIN;
+        if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(pl + ((size_t)gy * W + gx) * CIN + c * 16 + (q & 1) * 8);
+      } else if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(in_b + ((size_t)gy * W + gx) * CIN + c * 16 + q * 4);
     }
   };
   auto store_in = [&]() {
@@ -93,6 +104,10 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       const int idx = t + 256 * i;
       if (idx < NPIX * 4) {
         const int p = idx >> 2, q = idx & 3;
+        if (PIN) {  // already split: the item IS the LDS slot of (plane, k-half) = q
+          Ip[q * NPIX + p] = __builtin_bit_cast(u32x4, rin[i]);
+          continue;
+        }
         unsigned p0[NPL], p1[NPL];
         S::split(rin[i].x, rin[i].y, S::act_scale(), p0);
         S::split(rin[i].z, rin[i].w, S::act_scale(), p1);
@@ -180,6 +195,13 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
     }
   }
 
+  // pre-split output: value pairs are split together (split2_pk packs two), each 16-bit piece goes to its pixel
+  auto put_planes = [&](unsigned short* oh, size_t i0, size_t i1, bool ok0, bool ok1, float v0, float v1) {
+    unsigned h, l;
+    split2_pk(v0, v1, DIM_F16_ACT_SCALE, h, l);
+    if (ok0) { oh[i0] = (unsigned short)(h & 0xffffu); oh[plane_out + i0] = (unsigned short)(l & 0xffffu); }
+    if (ok1) { oh[i1] = (unsigned short)(h >> 16); oh[plane_out + i1] = (unsigned short)(l >> 16); }
+  };
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int co = cb * 64 + n * 32 + lx;
@@ -188,24 +210,37 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       const int Ho = H >> 1, Wo = W >> 1;
       const int py = (oy >> 1) + wv;
       float* out_b = out + (size_t)b * Ho * Wo * cout;
+      unsigned short* oh = (unsigned short*)out + (size_t)b * Ho * Wo * cout;
+      float pv[8];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const int px = (ox + mfma_row(r, half)) >> 1;
         float v = fmaxf(fmaxf(acc[0][n][r], acc[0][n][r + 1]), fmaxf(acc[1][n][r], acc[1][n][r + 1])) * inv_scale + bv;
         if (relu) v = fmaxf(v, 0.0f);
-        if (py < Ho && px < Wo) out_b[((size_t)py * Wo + px) * cout + co] = v;
+        pv[r >> 1] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const int px0 = (ox + mfma_row(2 * j, half)) >> 1, px1 = (ox + mfma_row(2 * j + 2, half)) >> 1;
+        const bool ok0 = py < Ho && px0 < Wo, ok1 = py < Ho && px1 < Wo;
+        const size_t i0 = ((size_t)py * Wo + px0) * cout + co, i1 = ((size_t)py * Wo + px1) * cout + co;
+        if (POUT) put_planes(oh, i0, i1, ok0, ok1, pv[j], pv[j + 1]);
+        else { if (ok0) out_b[i0] = pv[j]; if (ok1) out_b[i1] = pv[j + 1]; }
       }
     } else {
       float* out_b = out + (size_t)b * H * W * cout;
+      unsigned short* oh = (unsigned short*)out + (size_t)b * H * W * cout;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int y = oy + 2 * wv + m;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int x = ox + mfma_row(r, half);
-          float v = acc[m][n][r] * inv_scale + bv;
-          if (relu) v = fmaxf(v, 0.0f);
-          if (y < H && x < W) out_b[((size_t)y * W + x) * cout + co] = v;
+        for (int r = 0; r < 16; r += 2) {
+          const int x0 = ox + mfma_row(r, half), x1 = ox + mfma_row(r + 1, half);
+          float v0 = acc[m][n][r] * inv_scale + bv, v1 = acc[m][n][r + 1] * inv_scale + bv;
+          if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+          const bool ok0 = y < H && x0 < W, ok1 = y < H && x1 < W;
+          const size_t i0 = ((size_t)y * W + x0) * cout + co, i1 = ((size_t)y * W + x1) * cout + co;
+          if (POUT) put_planes(oh, i0, i1, ok0, ok1, v0, v1);
+          else { if (ok0) out_b[i0] = v0; if (ok1) out_b[i1] = v1; }
         }
       }
     }
@@ -276,7 +311,7 @@ int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
   const unsigned short* wx = wt.dev;
   const float inv = wt.inv_scale;
-#define DIM_CONV6(CI, P, PFV, MD) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV, false, MD>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, inv)
+#define DIM_CONV6(CI, P, PFV, MD) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV, false, MD, false, false>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, inv, (size_t)0, (size_t)0)
 #define DIM_CONV6_V(PFV, MD)                              \
   {                                                       \
     if (cin == 64 && pool) DIM_CONV6(64, 1, PFV, MD);     \
@@ -301,16 +336,46 @@ int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias
 
 // conv1a (1 -> 64) fused into the 64 -> cout convolution that consumes it (SuperPoint conv1a + conv1b, SPN:161-162).
 int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
-                              float* out, int batch, int H, int W, int cout, int pool, int relu, hipStream_t s) {
+                              float* out, int batch, int H, int W, int cout, int pool, int relu, int planes_out, hipStream_t s) {
   DIM_REQUIRE(cout % 64 == 0, "conv3x3_x6 fused conv1a: cout=%d must be a multiple of 64", cout);
   DIM_REQUIRE(wt.dev && (wt.mode == 1 || wt.mode == 2), "conv3x3_x6: weights not prepared (mode %d)", wt.mode);
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-#define DIM_CONV6F(P, MD) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_scale)
-  if (wt.mode == 2) { if (pool) DIM_CONV6F(1, 2); else DIM_CONV6F(0, 2); }
-  else { if (pool) DIM_CONV6F(1, 1); else DIM_CONV6F(0, 1); }
+  const size_t plane_out = (size_t)batch * (pool ? (H / 2) * (W / 2) : H * W) * cout;
+  DIM_REQUIRE(!planes_out || wt.mode == 2, "conv3x3_x6: pre-split output planes exist for the fp16x3 mode only");
+#define DIM_CONV6F(P, MD, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD, false, PO>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_scale, (size_t)0, plane_out)
+  if (wt.mode == 2 && planes_out) { if (pool) DIM_CONV6F(1, 2, true); else DIM_CONV6F(0, 2, true); }
+  else if (wt.mode == 2) { if (pool) DIM_CONV6F(1, 2, false); else DIM_CONV6F(0, 2, false); }
+  else { if (pool) DIM_CONV6F(1, 1, false); else DIM_CONV6F(0, 1, false); }
 #undef DIM_CONV6F
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+// fp16x3 convolution whose input and / or output are pre-split fp16 planes (see PIN / POUT above)
+int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
+                             int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s) {
+  DIM_REQUIRE(cout % 64 == 0 && (cin == 64 || cin == 128), "conv3x3_x6 planes: cin=%d cout=%d", cin, cout);
+  DIM_REQUIRE(wt.dev && wt.mode == 2, "conv3x3_x6 planes: fp16x3 weights required (mode %d)", wt.mode);
+  if (batch <= 0 || H <= 0 || W <= 0) return 0;
+  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
+  dim3 grid(tiles_x * tiles_y, cout / 64, batch);
+  const size_t plane_in = (size_t)batch * H * W * cin, plane_out = (size_t)batch * (pool ? (H / 2) * (W / 2) : H * W) * cout;
+#define DIM_CONV6P(CI, P, PI, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, 1, false, 2, PI, PO>), grid, dim3(256), 0, s, in, wt.dev, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, wt.inv_scale, plane_in, plane_out)
+#define DIM_CONV6P_IO(CI, P)                                   \
+  {                                                            \
+    if (planes_in && planes_out) DIM_CONV6P(CI, P, true, true); \
+    else if (planes_in) DIM_CONV6P(CI, P, true, false);        \
+    else if (planes_out) DIM_CONV6P(CI, P, false, true);       \
+    else DIM_CONV6P(CI, P, false, false);                      \
+  }
+  if (cin == 64 && pool) DIM_CONV6P_IO(64, 1)
+  else if (cin == 64) DIM_CONV6P_IO(64, 0)
+  else if (pool) DIM_CONV6P_IO(128, 1)
+  else DIM_CONV6P_IO(128, 0)
+#undef DIM_CONV6P_IO
+#undef DIM_CONV6P
   DIM_LAUNCH_CHECK();
   return 0;
 }

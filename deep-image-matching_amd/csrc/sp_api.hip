@@ -154,19 +154,34 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
               : launch_conv3x3(in, h->wk[l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s);
   };
   // encoder (SPN:161-171)
+  // fp16x3 + fused conv1a: the conv-to-conv activations b1 .. a4 are stored as pre-split fp16 planes (conv_x6.hip PIN / POUT):
+  // each value is split once by its producer instead of ~1.3 x (cout / 64) times by its consumers
+  const bool planes = pmode == 2 && dim_fuse_conv1a() && dim_presplit_activations();
+  auto convp = [&](int l, const float* in, float* out, int Hh, int Ww, int ci, int co, int pool, int pin, int pout) -> int {
+    return launch_conv3x3_x6_planes(in, h->wsp[2][l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, pin, pout, s);
+  };
   if (x6 && dim_fuse_conv1a()) {  // conv1a evaluated inside conv1b's halo staging: its 64-channel full-resolution map never exists
-    SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_x6_fused1a(images_dev, h->wk[0], h->bias[0], h->wsp[pmode][1], h->bias[1], h->b1, batch, H, W, 64, 1, 1, s));
+    SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_x6_fused1a(images_dev, h->wk[0], h->bias[0], h->wsp[pmode][1], h->bias[1], h->b1, batch, H, W, 64, 1, 1, planes ? 1 : 0, s));
   } else {
     if (!h->a1) SP_RUN(dev_alloc(h, &h->a1, (size_t)h->max_batch * h->max_h * h->max_w * 64));
     SP_SITE(DIM_PROF_SP_CONV1A, launch_conv1a(images_dev, h->wk[0], h->bias[0], h->a1, batch, H, W, s));
     SP_SITE(DIM_PROF_SP_CONV1B, conv(1, h->a1, h->b1, H, W, 64, 64, 1));
   }
-  SP_SITE(DIM_PROF_SP_CONV2A, conv(2, h->b1, h->a2, H2, W2, 64, 64, 0));
-  SP_SITE(DIM_PROF_SP_CONV2B, conv(3, h->a2, h->b2, H2, W2, 64, 64, 1));
-  SP_SITE(DIM_PROF_SP_CONV3A, conv(4, h->b2, h->a3, H4, W4, 64, 128, 0));
-  SP_SITE(DIM_PROF_SP_CONV3B, conv(5, h->a3, h->b3, H4, W4, 128, 128, 1));
-  SP_SITE(DIM_PROF_SP_CONV4A, conv(6, h->b3, h->a4, hh, ww, 128, 128, 0));
-  SP_SITE(DIM_PROF_SP_CONV4B, conv(7, h->a4, h->x, hh, ww, 128, 128, 0));
+  if (planes) {
+    SP_SITE(DIM_PROF_SP_CONV2A, convp(2, h->b1, h->a2, H2, W2, 64, 64, 0, 1, 1));
+    SP_SITE(DIM_PROF_SP_CONV2B, convp(3, h->a2, h->b2, H2, W2, 64, 64, 1, 1, 1));
+    SP_SITE(DIM_PROF_SP_CONV3A, convp(4, h->b2, h->a3, H4, W4, 64, 128, 0, 1, 1));
+    SP_SITE(DIM_PROF_SP_CONV3B, convp(5, h->a3, h->b3, H4, W4, 128, 128, 1, 1, 1));
+    SP_SITE(DIM_PROF_SP_CONV4A, convp(6, h->b3, h->a4, hh, ww, 128, 128, 0, 1, 1));
+    SP_SITE(DIM_PROF_SP_CONV4B, convp(7, h->a4, h->x, hh, ww, 128, 128, 0, 1, 0));  // the encoder output stays fp32 (debug tap, heads)
+  } else {
+    SP_SITE(DIM_PROF_SP_CONV2A, conv(2, h->b1, h->a2, H2, W2, 64, 64, 0));
+    SP_SITE(DIM_PROF_SP_CONV2B, conv(3, h->a2, h->b2, H2, W2, 64, 64, 1));
+    SP_SITE(DIM_PROF_SP_CONV3A, conv(4, h->b2, h->a3, H4, W4, 64, 128, 0));
+    SP_SITE(DIM_PROF_SP_CONV3B, conv(5, h->a3, h->b3, H4, W4, 128, 128, 1));
+    SP_SITE(DIM_PROF_SP_CONV4A, conv(6, h->b3, h->a4, hh, ww, 128, 128, 0));
+    SP_SITE(DIM_PROF_SP_CONV4B, conv(7, h->a4, h->x, hh, ww, 128, 128, 0));
+  }
   // detector head (SPN:174-180)
   SP_SITE(DIM_PROF_SP_CONVPA, conv(8, h->x, h->pa, hh, ww, 128, 256, 0));
   {

@@ -38,7 +38,8 @@ int dim_device_synchronize(void);
 /* Tuning hook (experiments / A-B benchmarking): key 0 = fp32 conv3x3 kernel variant; key 1 = matrix
  * arithmetic: 1 (default) fp32-accurate products on the bf16 matrix cores ("bf16x6"), 0 = fp32 MFMA;
  * key 2 = bf16x6 conv prefetch variant; key 3 = 1 (default) SuperPoint conv1a fused into conv1b, 0 = separate kernels;
- * key 4 = 1 (default) LightGlue out_proj folded into ffn.0 (split modes), 0 = separate GEMMs. */
+ * key 4 = 1 (default) LightGlue out_proj folded into ffn.0 (split modes), 0 = separate GEMMs;
+ * key 5 = 1 (default) SuperPoint conv-to-conv activations stored as pre-split fp16 planes (fp16x3), 0 = fp32. */
 int dim_tune_set(int key, int value);
 
 /* Per-launch-site timing with HIP events recorded on the launch stream (bench.py's

@@ -75,3 +75,22 @@ def test_superpoint_bf16x6_and_fp32_modes_agree_with_the_default(emu_lib):
             assert set(map(tuple, out["keypoints"].long().tolist())) == set(map(tuple, base["keypoints"].long().tolist()))
     finally:
         emu_lib.dim_tune_set(1, 2)
+
+
+def test_presplit_activation_planes_are_bit_identical_to_consumer_side_splits(emu_lib):
+    """fp16x3: conv-to-conv activations stored as pre-split fp16 planes (producer splits once) vs fp32 storage with
+    the split in every consumer: the pieces are the same function of the same fp32 value, so nothing may change."""
+    name = next(iter(gc.SP_CASES))
+    case = gc.SP_CASES[name]
+    sd = gc.sp_weights(case)
+    img = torch.rand(1, 1, 52, 70, generator=torch.Generator().manual_seed(10))  # ragged tiles at every scale
+    net = sp_mod.SuperPointHIP(sd, case["cfg"], max_batch=1, max_hw=(52, 70), capacity=512, device="cpu", lib=emu_lib)
+    try:
+        emu_lib.dim_tune_set(5, 1)
+        a = net(img); ta = net.debug_taps()
+        emu_lib.dim_tune_set(5, 0)
+        b = net(img); tb = net.debug_taps()
+    finally:
+        emu_lib.dim_tune_set(5, 1)
+    assert torch.equal(ta["encoder"], tb["encoder"]) and torch.equal(ta["score_map"], tb["score_map"])
+    assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
