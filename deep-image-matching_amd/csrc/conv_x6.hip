@@ -247,6 +247,14 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
   }
 }
 
+// debug / inspection: pre-split planes back to fp32 (h + l is exact in fp32; / 16 undoes the activation scale)
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const unsigned short* __restrict__ planes, size_t plane, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const _Float16 hv = __builtin_bit_cast(_Float16, planes[i]), lv = __builtin_bit_cast(_Float16, planes[plane + i]);
+  out[i] = ((float)hv + (float)lv) / DIM_F16_ACT_SCALE;
+}
+
 unsigned short host_bf16_rne(float x) {
   unsigned u;
   memcpy(&u, &x, 4);
@@ -376,6 +384,13 @@ int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const floa
   else DIM_CONV6P_IO(128, 0)
 #undef DIM_CONV6P_IO
 #undef DIM_CONV6P
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_planes_to_f32(const void* planes, size_t n, float* out, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned short*)planes, n, out, n);
   DIM_LAUNCH_CHECK();
   return 0;
 }

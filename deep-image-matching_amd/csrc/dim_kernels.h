@@ -64,6 +64,7 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
 // fp16x3 only: input and / or output as pre-split fp16 planes (two NHWC fp16 tensors, h then l, in the bytes of the fp32 tensor)
 int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
                              int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s);
+int launch_planes_to_f32(const void* planes, size_t n, float* out, hipStream_t s);  // n = elements per plane
 int dim_presplit_activations();  // 1 (default): SuperPoint's conv-to-conv activations are stored pre-split (dim_tune_set key 5)
 int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)

@@ -25,6 +25,8 @@ struct dim_sp {
   float *a1, *b1, *a2, *b2, *a3, *b3, *a4, *x, *pa, *logits, *da, *dd, *smap, *nms, *cand_score;
   int *cand_idx, *rowcount, *rowoff, *ncand;
   int last_h, last_w, last_batch;
+  bool x_is_planes;   // the last extract stored the encoder output as pre-split planes
+  float* x_dbg;       // fp32 copy of it, built on request by dim_sp_debug_buffers
   std::vector<void*> allocs;
 };
 
@@ -173,7 +175,7 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
     SP_SITE(DIM_PROF_SP_CONV3A, convp(4, h->b2, h->a3, H4, W4, 64, 128, 0, 1, 1));
     SP_SITE(DIM_PROF_SP_CONV3B, convp(5, h->a3, h->b3, H4, W4, 128, 128, 1, 1, 1));
     SP_SITE(DIM_PROF_SP_CONV4A, convp(6, h->b3, h->a4, hh, ww, 128, 128, 0, 1, 1));
-    SP_SITE(DIM_PROF_SP_CONV4B, convp(7, h->a4, h->x, hh, ww, 128, 128, 0, 1, 0));  // the encoder output stays fp32 (debug tap, heads)
+    SP_SITE(DIM_PROF_SP_CONV4B, convp(7, h->a4, h->x, hh, ww, 128, 128, 0, 1, 1));  // the encoder output feeds 8 cout blocks of the two heads
   } else {
     SP_SITE(DIM_PROF_SP_CONV2A, conv(2, h->b1, h->a2, H2, W2, 64, 64, 0));
     SP_SITE(DIM_PROF_SP_CONV2B, conv(3, h->a2, h->b2, H2, W2, 64, 64, 1));
@@ -183,7 +185,9 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
     SP_SITE(DIM_PROF_SP_CONV4B, conv(7, h->a4, h->x, hh, ww, 128, 128, 0));
   }
   // detector head (SPN:174-180)
-  SP_SITE(DIM_PROF_SP_CONVPA, conv(8, h->x, h->pa, hh, ww, 128, 256, 0));
+  h->x_is_planes = planes;
+  if (planes) SP_SITE(DIM_PROF_SP_CONVPA, convp(8, h->x, h->pa, hh, ww, 128, 256, 0, 1, 0));
+  else SP_SITE(DIM_PROF_SP_CONVPA, conv(8, h->x, h->pa, hh, ww, 128, 256, 0));
   {
     GemmArgs g;
     g.A0 = h->pa; g.lda0 = 256; g.B = h->wk[9]; g.ldb = 68; g.bias = h->bias[9];
@@ -199,7 +203,8 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   SP_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H8, W8, h->cfg.max_keypoints, h->capacity, kpts_xy_dev,
                      scores_dev, n_kpts_dev, s));
   // descriptor head (SPN:213-221)
-  SP_SITE(DIM_PROF_SP_CONVDA, conv(10, h->x, h->da, hh, ww, 128, 256, 0));
+  if (planes) SP_SITE(DIM_PROF_SP_CONVDA, convp(10, h->x, h->da, hh, ww, 128, 256, 0, 1, 0));
+  else SP_SITE(DIM_PROF_SP_CONVDA, conv(10, h->x, h->da, hh, ww, 128, 256, 0));
   {
     GemmArgs g;
     g.A0 = h->da; g.lda0 = 256; g.B = h->wk[11]; g.ldb = 256; g.bias = h->bias[11];
@@ -217,7 +222,16 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
 int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits, const float** score_map,
                          const float** nms_map, const float** dense_desc, int* h8, int* w8) {
   DIM_REQUIRE(h, "dim_sp_debug_buffers: null handle");
-  if (encoder) *encoder = h->x;
+  if (encoder) {
+    *encoder = h->x;
+    if (h->x_is_planes) {  // rebuild fp32 from the planes of the last batch
+      const size_t n = (size_t)h->last_batch * h->last_h * h->last_w * 128;
+      if (!h->x_dbg && dev_alloc(h, &h->x_dbg, (size_t)h->max_batch * (h->max_h / 8) * (h->max_w / 8) * 128) != 0) return -1;
+      if (launch_planes_to_f32(h->x, n, h->x_dbg, nullptr) != 0) return -1;
+      DIM_HIP(hipDeviceSynchronize());
+      *encoder = h->x_dbg;
+    }
+  }
   if (logits) *logits = h->logits;
   if (score_map) *score_map = h->smap;
   if (nms_map) *nms_map = h->nms;

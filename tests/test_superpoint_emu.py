@@ -57,7 +57,9 @@ def test_fused_conv1a_equals_the_two_kernel_path(emu_lib):
         b = net(img); tb = net.debug_taps()
     finally:
         emu_lib.dim_tune_set(3, 1)
-    assert torch.equal(ta["encoder"], tb["encoder"]) and torch.equal(ta["score_map"], tb["score_map"])
+    # (with pre-split planes the encoder tap is rebuilt from (h + l) / 16, hence the 3e-7; everything downstream is exact)
+    np.testing.assert_allclose(ta["encoder"].numpy(), tb["encoder"].numpy(), rtol=3e-7, atol=4e-9)  # small values: the low piece is an fp16 subnormal (absolute step 2^-24 / 16)
+    assert torch.equal(ta["score_map"], tb["score_map"]) and torch.equal(ta["logits"], tb["logits"])
     assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
 
 
@@ -92,5 +94,8 @@ def test_presplit_activation_planes_are_bit_identical_to_consumer_side_splits(em
         b = net(img); tb = net.debug_taps()
     finally:
         emu_lib.dim_tune_set(5, 1)
-    assert torch.equal(ta["encoder"], tb["encoder"]) and torch.equal(ta["score_map"], tb["score_map"])
+    # the encoder tap of the planes path is rebuilt from (h + l) / 16: 22 of fp32's 24 mantissa bits; everything
+    # computed FROM the planes is bit-identical
+    np.testing.assert_allclose(ta["encoder"].numpy(), tb["encoder"].numpy(), rtol=3e-7, atol=4e-9)  # small values: the low piece is an fp16 subnormal (absolute step 2^-24 / 16)
+    assert torch.equal(ta["score_map"], tb["score_map"]) and torch.equal(ta["logits"], tb["logits"])
     assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
