@@ -195,12 +195,19 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
     }
   }
 
-  // pre-split output: value pairs are split together (split2_pk packs two), each 16-bit piece goes to its pixel
-  auto put_planes = [&](unsigned short* oh, size_t i0, size_t i1, bool ok0, bool ok1, float v0, float v1) {
-    unsigned h, l;
-    split2_pk(v0, v1, DIM_F16_ACT_SCALE, h, l);
-    if (ok0) { oh[i0] = (unsigned short)(h & 0xffffu); oh[plane_out + i0] = (unsigned short)(l & 0xffffu); }
-    if (ok1) { oh[i1] = (unsigned short)(h >> 16); oh[plane_out + i1] = (unsigned short)(l >> 16); }
+  // Epilogue.  Addresses are a 64-bit row base plus 32-bit element offsets; with POUT two neighbouring pixels are
+  // split together (split2_pk packs two values) and each 16-bit piece is stored to its pixel in the h / l plane.
+  auto put2 = [&](float* fp, unsigned short* hp, unsigned o0, unsigned o1, bool ok0, bool ok1, float v0, float v1) {
+    if (POUT) {
+      unsigned h, l;
+      split2_pk(v0, v1, DIM_F16_ACT_SCALE, h, l);
+      unsigned short* lp = hp + plane_out;
+      if (ok0) { hp[o0] = (unsigned short)(h & 0xffffu); lp[o0] = (unsigned short)(l & 0xffffu); }
+      if (ok1) { hp[o1] = (unsigned short)(h >> 16); lp[o1] = (unsigned short)(l >> 16); }
+    } else {
+      if (ok0) fp[o0] = v0;
+      if (ok1) fp[o1] = v1;
+    }
   };
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
@@ -208,9 +215,8 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
     const float bv = bias[co];
     if (POOL) {
       const int Ho = H >> 1, Wo = W >> 1;
-      const int py = (oy >> 1) + wv;
-      float* out_b = out + (size_t)b * Ho * Wo * cout;
-      unsigned short* oh = (unsigned short*)out + (size_t)b * Ho * Wo * cout;
+      const int py = (oy >> 1) + wv, pxb = ox >> 1;
+      const size_t base = (((size_t)b * Ho + py) * Wo + pxb) * cout + co;  // pooled pixel (py, pxb), channel co
       float pv[8];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
@@ -220,27 +226,22 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       }
 #pragma unroll
       for (int j = 0; j < 8; j += 2) {
-        const int px0 = (ox + mfma_row(2 * j, half)) >> 1, px1 = (ox + mfma_row(2 * j + 2, half)) >> 1;
-        const bool ok0 = py < Ho && px0 < Wo, ok1 = py < Ho && px1 < Wo;
-        const size_t i0 = ((size_t)py * Wo + px0) * cout + co, i1 = ((size_t)py * Wo + px1) * cout + co;
-        if (POUT) put_planes(oh, i0, i1, ok0, ok1, pv[j], pv[j + 1]);
-        else { if (ok0) out_b[i0] = pv[j]; if (ok1) out_b[i1] = pv[j + 1]; }
+        const int q0 = mfma_row(2 * j, half) >> 1, q1 = mfma_row(2 * j + 2, half) >> 1;  // pooled column offsets inside the tile
+        const bool ok0 = py < Ho && pxb + q0 < Wo, ok1 = py < Ho && pxb + q1 < Wo;
+        put2(out + base, (unsigned short*)out + base, (unsigned)(q0 * cout), (unsigned)(q1 * cout), ok0, ok1, pv[j], pv[j + 1]);
       }
     } else {
-      float* out_b = out + (size_t)b * H * W * cout;
-      unsigned short* oh = (unsigned short*)out + (size_t)b * H * W * cout;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int y = oy + 2 * wv + m;
+        const size_t base = (((size_t)b * H + y) * W + ox) * cout + co;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const int x0 = ox + mfma_row(r, half), x1 = ox + mfma_row(r + 1, half);
+          const int x0 = mfma_row(r, half);  // r even: the odd register is the next column
           float v0 = acc[m][n][r] * inv_scale + bv, v1 = acc[m][n][r + 1] * inv_scale + bv;
           if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
-          const bool ok0 = y < H && x0 < W, ok1 = y < H && x1 < W;
-          const size_t i0 = ((size_t)y * W + x0) * cout + co, i1 = ((size_t)y * W + x1) * cout + co;
-          if (POUT) put_planes(oh, i0, i1, ok0, ok1, v0, v1);
-          else { if (ok0) out_b[i0] = v0; if (ok1) out_b[i1] = v1; }
+          const bool ok0 = y < H && ox + x0 < W, ok1 = y < H && ox + x0 + 1 < W;
+          put2(out + base, (unsigned short*)out + base, (unsigned)(x0 * cout), (unsigned)((x0 + 1) * cout), ok0, ok1, v0, v1);
         }
       }
     }
