@@ -42,36 +42,40 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* __restric
 // thread one 16-long segment of one line, loads 16+2R values into registers once and emits 16
 // window maxima (1 LDS read + 1 write per element instead of 2R+1 reads).  Lane -> line
 // mapping keeps both passes bank-conflict free: the row pass strides lanes over y (odd TS),
-// the column pass over x.  Arrays: s (scores, -inf outside the image), t (row-pass scratch),
+// the column pass over x.  Every stage covers only the region its inputs are exact on (T shrinks by 2R per
+// pool: 62 -> 56 -> 50 -> 44 -> 38 -> 32 for R = 3, TILE = 32): a third less work than full-tile passes.  Arrays: s (scores, -inf outside the image), t (row-pass scratch),
 // rest (suppressed scores; sign bit marks "near a kept maximum"), kp / t8 (keep mask, bytes).
+constexpr int NMS_THREADS = 512;
 template <int R, typename T, bool ROW, typename Emit>
-__device__ __forceinline__ void nms_line_max(const T* src, int Tn, int TS, T lowest, Emit emit) {
-  constexpr int SEG = 16;
-  const int nseg = (Tn + SEG - 1) / SEG;
-  for (int item = threadIdx.x; item < Tn * nseg; item += 256) {
-    const int line = item % Tn, seg = item / Tn;
-    const int base = seg * SEG - R;
+__device__ __forceinline__ void nms_line_max(const T* src, int TS, int l0, int l1, int p0, int p1, Emit emit) {
+  // lines l0..l1-1, window maxima at positions p0..p1-1 (the window p-R..p+R always lies inside the array: every
+  // stage only covers the region its inputs are valid on, which shrinks by R per pool)
+  constexpr int SEG = 8;  // with 512 threads one pass of a 62-wide tile is a single, short item per thread
+  const int nl = l1 - l0, nseg = (p1 - p0 + SEG - 1) / SEG;
+  for (int item = threadIdx.x; item < nl * nseg; item += NMS_THREADS) {
+    const int line = l0 + item % nl, seg = item / nl;
+    const int base = p0 + seg * SEG - R;
     const int stride = ROW ? 1 : TS;
     const int off = ROW ? line * TS : line;
     T v[SEG + 2 * R];
 #pragma unroll
     for (int k = 0; k < SEG + 2 * R; ++k) {
-      const int q = base + k;
-      v[k] = (q >= 0 && q < Tn) ? src[off + q * stride] : lowest;
+      const int q = min(base + k, p1 - 1 + R);  // the last segment may be short: re-read the last needed element
+      v[k] = src[off + q * stride];
     }
 #pragma unroll
     for (int o = 0; o < SEG; ++o) {
       T m = v[o];
 #pragma unroll
       for (int k = 1; k <= 2 * R; ++k) m = v[o + k] > m ? v[o + k] : m;
-      const int q = seg * SEG + o;
-      if (q < Tn) emit(off + q * stride, m);
+      const int q = p0 + seg * SEG + o;
+      if (q < p1) emit(off + q * stride, m);
     }
   }
 }
 
 template <int R, int TILE>
-__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ smap, float* __restrict__ out, int H8, int W8,
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ smap, float* __restrict__ out, int H8, int W8,
                                                   int tiles_x) {
   constexpr int HALO = 5 * R, T = TILE + 2 * HALO, TS = T | 1, TT = T * TS;
   __shared__ float s[TT];
@@ -84,29 +88,35 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ smap
   const float* src = smap + (size_t)b * H8 * W8;
   const float NEG = -INFINITY;
 
-  for (int i = tid; i < T * T; i += 256) {
+  for (int i = tid; i < T * T; i += NMS_THREADS) {
     const int y = i / T, x = i - y * T, gy = ty0 + y, gx = tx0 + x;
     s[y * TS + x] = (gy >= 0 && gy < H8 && gx >= 0 && gx < W8) ? src[(size_t)gy * W8 + gx] : NEG;
   }
   __syncthreads();
+  // region k = [k R, T - k R)^2: what is still exact after k pools.  Row passes run on the rows of the previous
+  // region and the columns of the next one, column passes on the next region.
+  auto lo = [](int k) { return k * R; };
+  auto hi = [&](int k) { return T - k * R; };
   // round 0: keep = (s == P(s)); the column pass compares in its epilogue
-  nms_line_max<R, float, true>(s, T, TS, NEG, [&](int j, float m) { t[j] = m; });
+  nms_line_max<R, float, true>(s, TS, lo(0), hi(0), lo(1), hi(1), [&](int j, float m) { t[j] = m; });
   __syncthreads();
-  nms_line_max<R, float, false>(t, T, TS, NEG, [&](int j, float m) { kp[j] = (s[j] != NEG && s[j] == m) ? 1 : 0; });
+  nms_line_max<R, float, false>(t, TS, lo(1), hi(1), lo(1), hi(1), [&](int j, float m) { kp[j] = (s[j] != NEG && s[j] == m) ? 1 : 0; });
   __syncthreads();
   // two rounds of suppress-and-recover
+#pragma unroll
   for (int round = 0; round < 2; ++round) {
-    nms_line_max<R, unsigned char, true>(kp, T, TS, (unsigned char)0, [&](int j, unsigned char m) { t8[j] = m; });
+    const int k = 1 + 2 * round;  // kp is exact on region k
+    nms_line_max<R, unsigned char, true>(kp, TS, lo(k), hi(k), lo(k + 1), hi(k + 1), [&](int j, unsigned char m) { t8[j] = m; });
     __syncthreads();
     // near = dilate(keep); rest = near ? 0 : s, the sign bit of the 0 remembers "near"
-    nms_line_max<R, unsigned char, false>(t8, T, TS, (unsigned char)0, [&](int j, unsigned char m) {
+    nms_line_max<R, unsigned char, false>(t8, TS, lo(k + 1), hi(k + 1), lo(k + 1), hi(k + 1), [&](int j, unsigned char m) {
       const float sv = s[j];
       rest[j] = (sv == NEG) ? NEG : (m ? -0.0f : sv);
     });
     __syncthreads();
-    nms_line_max<R, float, true>(rest, T, TS, NEG, [&](int j, float m) { t[j] = m; });
+    nms_line_max<R, float, true>(rest, TS, lo(k + 1), hi(k + 1), lo(k + 2), hi(k + 2), [&](int j, float m) { t[j] = m; });
     __syncthreads();
-    nms_line_max<R, float, false>(t, T, TS, NEG, [&](int j, float m) {
+    nms_line_max<R, float, false>(t, TS, lo(k + 2), hi(k + 2), lo(k + 2), hi(k + 2), [&](int j, float m) {
       const float rv = rest[j];
       const bool near = __float_as_uint(rv) == 0x80000000u;
       if (rv != NEG && !near && rv == m) kp[j] = 1;
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ smap
     __syncthreads();
   }
   float* dst = out + (size_t)b * H8 * W8;
-  for (int i = tid; i < TILE * TILE; i += 256) {
+  for (int i = tid; i < TILE * TILE; i += NMS_THREADS) {
     const int y = i / TILE, x = i - y * TILE;
     const int gy = ty0 + HALO + y, gx = tx0 + HALO + x;
     if (gy < H8 && gx < W8) {
@@ -375,7 +385,7 @@ int launch_nms(const float* smap, float* out, int batch, int H8, int W8, int rad
 #define DIM_NMS(RR, TL)                                                                                              \
   {                                                                                                                  \
     const int tx = cdiv(W8, TL), ty = cdiv(H8, TL);                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_kernel<RR, TL>), dim3(tx * ty, 1, batch), dim3(256), 0, s, smap, out, H8, W8, tx); \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_kernel<RR, TL>), dim3(tx * ty, 1, batch), dim3(NMS_THREADS), 0, s, smap, out, H8, W8, tx); \
   }
   switch (radius) {
     case 0: DIM_NMS(0, 32) break;
