@@ -173,10 +173,8 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
 #pragma unroll
       for (int tm = 0; tm < S::NT; ++tm) sacc = S::mma(kf[S::ta(tm)], qf[s][S::tb(tm)], sacc);
     }
-    if (MODE == 2) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] *= inv_qk;
-    }
+    // fp16x3: sacc holds scale^2 x the scores; the exact power-of-two factor is applied inside the fused
+    // multiply-add of the exponent below (and once to the tile maximum) instead of to all 16 values
 
     // ---- online softmax (log2 domain, deferred rescale) ----
     if (kt + 32 > nk) {
@@ -188,7 +186,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
 #pragma unroll
     for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[r]), sacc[r + 1]);
     tmax = fmaxf(tmax, sacc[15]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * inv_qk;
     constexpr float RESCALE_LOG2 = 8.0f;
     if (__any(tmax > m_run + RESCALE_LOG2)) {
       const float m_new = fmaxf(m_run, tmax);
@@ -204,7 +202,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
     float psum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      p[r] = __builtin_amdgcn_exp2f(sacc[r] - m_run);
+      p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], inv_qk, -m_run));  // sacc * 2^-k is exact: one rounding, as sacc' - m_run
       psum += p[r];
     }
     l_run += psum;
