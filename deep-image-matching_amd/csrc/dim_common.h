@@ -73,6 +73,12 @@ __device__ __forceinline__ void split2_pk(float x0, float x1, float scale, unsig
   const f16x2 hv = __builtin_bit_cast(f16x2, h);
   l = cvt_pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
 }
+// the same split for a value that is already scaled and known to lie inside +-65504 (no multiply, no clamp)
+__device__ __forceinline__ void split2_pk_raw(float x0, float x1, unsigned& h, unsigned& l) {
+  h = cvt_pk_f16(x0, x1);
+  const f16x2 hv = __builtin_bit_cast(f16x2, h);
+  l = cvt_pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+}
 // Split policy shared by conv_x6 / gemm_x6 / lg_attn_x6: MODE 1 = three bf16 planes, six cross terms;
 // MODE 2 = two fp16 planes, three cross terms.  Cross terms are issued smallest first.
 template <int MODE> struct SplitMma;

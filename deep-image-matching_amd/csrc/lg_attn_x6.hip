@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, TILE_SLOTS = tile_slots(NPL), KSL = NPL * 256, NCP = TILE_SLOTS / 256;
   // K, Q, V and P are multiplied by the (power-of-two) activation scale before the split: exact factors
-  const float inv_qk = 1.0f / (S::act_scale() * S::act_scale()), inv_pv = inv_qk;
+  const float inv_qk = 1.0f / (S::act_scale() * S::act_scale());
   const int item = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
   if (a.done[item >> 1] != 0) return;
   const int kitem = a.cross ? (item ^ 1) : item;
@@ -198,11 +198,15 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
         for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
       m_run = m_new;
     }
+    const float p_shift = MODE == 2 ? 4.0f : 0.0f;  // log2(DIM_F16_ACT_SCALE)
     float p[16];
     float psum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], inv_qk, -m_run));  // sacc * 2^-k is exact: one rounding, as sacc' - m_run
+      // sacc * 2^-k is exact: one rounding, as sacc' - m_run.  fp16x3: the probabilities are produced already multiplied
+      // by the activation scale (2^4 added to the exponent), so their split needs neither a multiply nor a clamp
+      // (p <= 2^RESCALE_LOG2 * 16 = 4096); l_run then carries the same factor, undone once at the end
+      p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], inv_qk, p_shift - m_run));
       psum += p[r];
     }
     l_run += psum;
@@ -212,7 +216,10 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
     for (int u = 0; u < 2; ++u) {
       unsigned pc[4][NPL];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) S::split(p[8 * u + 2 * e], p[8 * u + 2 * e + 1], S::act_scale(), pc[e]);
+      for (int e = 0; e < 4; ++e) {
+        if (MODE == 2) split2_pk_raw(p[8 * u + 2 * e], p[8 * u + 2 * e + 1], pc[e][0], pc[e][1]);
+        else S::split(p[8 * u + 2 * e], p[8 * u + 2 * e + 1], S::act_scale(), pc[e]);
+      }
       u32x4 pf[NPL];
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) pf[pl] = u32x4{pc[0][pl], pc[1][pl], pc[2][pl], pc[3][pl]};
@@ -231,7 +238,8 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
     __syncthreads();
   }
 
-  const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (MODE == 2 ? 1.0f / inv_pv : 1.0f);  // the scaled V·P accumulator is divided by scale^2 * l
+  // fp16x3: the V·P accumulator holds scale^2 x the sum and l_run scale x the normaliser: divide by scale * l_run
+  const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (MODE == 2 ? S::act_scale() : 1.0f);
   if (qok) {
     float* op = a.o + (size_t)item * a.so + (size_t)qrow * a.ldo + head * 64;
 #pragma unroll
