@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
           continue;
         }
         unsigned p0[NPL], p1[NPL];
-        S::split(rin[i].x, rin[i].y, S::act_scale(), p0);
-        S::split(rin[i].z, rin[i].w, S::act_scale(), p1);
+        S::split(rin[i].x, rin[i].y, F1A ? 1.0f : S::act_scale(), p0);  // F1A: already scaled (see W1a)
+        S::split(rin[i].z, rin[i].w, F1A ? 1.0f : S::act_scale(), p1);
         // channels q*4..q*4+3 live in k-half q>>1, dwords (q&1)*2, +1 of that pixel's 16-B slot
         unsigned* d = (unsigned*)&Ip[(q >> 1) * NPIX + p] + (q & 1) * 2;
 #pragma unroll
@@ -119,6 +119,17 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
     }
   };
 
+  // chunk-invariant part of the fused conv1a: where each staged item sits in the image patch
+  int img_off[F1A ? NIN : 1];
+  if (F1A) {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = t + 256 * i, p = idx >> 2;
+      const int py = p / IW, px = p - py * IW;
+      const int gy = oy + py - 1, gx = ox + px - 1;
+      img_off[i] = (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? py * IMW + px : -1;
+    }
+  }
   // fused conv1a: this thread's quad of channels is fixed (q = t & 3); per chunk it needs 9 x 4 weights
   auto conv1a_in = [&](int c) {
     const int q = t & 3;
@@ -131,22 +142,17 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
     const float4 bv = *(const float4*)&W1a[9 * 64 + c * 16 + q * 4];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
-      const int idx = t + 256 * i;
-      const int p = idx >> 2;
-      const int py = p / IW, px = p - py * IW;
-      const int gy = oy + py - 1, gx = ox + px - 1;
+      const int io = img_off[i];  // -1: not a halo pixel of this tile, or outside the image (conv1b's zero padding)
+      const int o = io < 0 ? 0 : io;
       float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-      if (idx < NPIX * 4) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const float v = Img[(py + k / 3) * IMW + px + k % 3];
-          o0 = fmaf(v, wr[k][0], o0); o1 = fmaf(v, wr[k][1], o1);
-          o2 = fmaf(v, wr[k][2], o2); o3 = fmaf(v, wr[k][3], o3);
-        }
+      for (int k = 0; k < 9; ++k) {
+        const float v = Img[o + (k / 3) * IMW + k % 3];
+        o0 = fmaf(v, wr[k][0], o0); o1 = fmaf(v, wr[k][1], o1);
+        o2 = fmaf(v, wr[k][2], o2); o3 = fmaf(v, wr[k][3], o3);
       }
-      const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;  // outside the image conv1b sees its zero padding
-      rin[i] = inside ? make_float4(fmaxf(o0 + bv.x, 0.f), fmaxf(o1 + bv.y, 0.f), fmaxf(o2 + bv.z, 0.f), fmaxf(o3 + bv.w, 0.f))
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      rin[i] = io >= 0 ? make_float4(fmaxf(o0 + bv.x, 0.f), fmaxf(o1 + bv.y, 0.f), fmaxf(o2 + bv.z, 0.f), fmaxf(o3 + bv.w, 0.f))
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   if (F1A) {
@@ -155,7 +161,9 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       const int gy = oy + r - 2, gx = ox + cc - 2;
       Img[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in_b[(size_t)gy * W + gx] : 0.0f;
     }
-    for (int idx = t; idx < 9 * 64 + 64; idx += 256) W1a[idx] = idx < 9 * 64 ? w1a[idx] : b1a[idx - 9 * 64];
+    // weights and bias pre-multiplied by the activation scale (a power of two: fmaf(v, s w, s acc) = s fmaf(v, w, acc)
+    // exactly), so the conv1a outputs come out scaled and their split skips the multiply
+    for (int idx = t; idx < 9 * 64 + 64; idx += 256) W1a[idx] = (idx < 9 * 64 ? w1a[idx] : b1a[idx - 9 * 64]) * S::act_scale();
   }
 
   if (PF >= 1) load_w(0, 0);
