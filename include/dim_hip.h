@@ -35,8 +35,10 @@ extern "C" {
 const char* dim_last_error(void);
 int dim_abi_version(void);
 int dim_device_synchronize(void);
-/* Tuning hook (experiments / A-B benchmarking): key 0 = fp32 conv3x3 kernel variant; key 1 = matrix
- * arithmetic: 1 (default) fp32-accurate products on the bf16 matrix cores ("bf16x6"), 0 = fp32 MFMA;
+/* Tuning hook (experiments / A-B benchmarking; process-wide): key 0 = fp32 conv3x3 kernel variant; key 1 = matrix
+ * arithmetic: 2 (default) fp32-accurate products on the fp16 matrix cores ("fp16x3": 2-way splits of the
+ * power-of-two-scaled operands x 3 terms; activations exact up to |x| = 4094, saturating beyond), 1 = "bf16x6" (exact
+ * 3-way bf16 splits x 6 terms, no range limit), 0 = plain fp32 MFMA;
  * key 2 = bf16x6 conv prefetch variant; key 3 = 1 (default) SuperPoint conv1a fused into conv1b, 0 = separate kernels;
  * key 4 = 1 (default) LightGlue out_proj folded into ffn.0 (split modes), 0 = separate GEMMs;
  * key 5 = 1 (default) SuperPoint conv-to-conv activations stored as pre-split fp16 planes (fp16x3), 0 = fp32. */
@@ -232,13 +234,13 @@ int dim_lg_debug_desc(dim_lg* h, const float** desc, const int32_t** n_cur, cons
 int dim_op_gemm_f32(const float* A, int lda, const float* B, int ldb, int b_is_nk, const float* bias,
                     const float* residual, int ldr, float* C, int ldc, int M, int N, int K, int relu, void* stream);
 
-/* fp32-accurate GEMM on the bf16 matrix cores (exact 3-way bf16 split, six cross terms; see
- * csrc/gemm_x6.hip).  dim_x3_create splits a host [K][N] fp32 operand into the device layout
- * [3][n_pad][K] bf16; dim_op_gemm_x6_f32 computes C = act(A*W + bias) (+ residual), act 0 none /
- * 1 ReLU / 2 SELU.  K % 32 == 0. */
-int dim_x3_create(const float* w_kn_host, int K, int N, void** out_dev, int* n_pad_out);
-void dim_x3_destroy(void* dev);
-int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3_dev, int n_pad, const float* bias, const float* residual, int ldr,
+/* fp32-accurate GEMM on the 16-bit matrix cores (csrc/gemm_x6.hip).  dim_x3_create pre-splits a host [K][N] fp32
+ * operand for the split mode that is active at the call (dim_tune_set key 1: fp16x3 or bf16x6) and returns an OPAQUE
+ * handle (host struct owning the device planes [planes][n_pad][K]); dim_op_gemm_x6_f32 computes
+ * C = act(A*W + bias) (+ residual), act 0 none / 1 ReLU / 2 SELU, in the handle's mode.  K % 32 == 0. */
+int dim_x3_create(const float* w_kn_host, int K, int N, void** out_handle, int* n_pad_out);
+void dim_x3_destroy(void* handle);
+int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3_handle, int n_pad, const float* bias, const float* residual, int ldr,
                        float* C, int ldc, int M, int N, int K, int act, void* stream);
 
 /* 3x3/s1/p1 conv, NHWC fp32, weights [9][cin][cout], bias+ReLU and optional
@@ -249,10 +251,11 @@ int dim_op_conv3x3_nhwc_f32(const float* in, const float* w_tap_cin_cout, const 
 /* simple_nms (SPN:47-63) on [batch][H][W] score maps, radius 0..6; non-maxima -> 0. */
 int dim_op_simple_nms_f32(const float* score_map, float* out, int batch, int H, int W, int radius, void* stream);
 
-/* The same convolution on the bf16 matrix cores at fp32 accuracy (csrc/conv_x6.hip): weights are
- * pre-split from the reference's OIHW fp32 layout by dim_convx6_create (free with dim_x3_destroy). */
-int dim_convx6_create(const float* w_oihw_host, int cin, int cout, void** out_dev);
-int dim_op_conv3x3_x6_nhwc_f32(const float* in, const void* w_x6_dev, const float* bias, float* out, int batch, int H, int W,
+/* The same convolution on the 16-bit matrix cores at fp32 accuracy (csrc/conv_x6.hip): weights are pre-split from
+ * the reference's OIHW fp32 layout by dim_convx6_create for the active split mode (opaque handle, free with
+ * dim_x3_destroy). */
+int dim_convx6_create(const float* w_oihw_host, int cin, int cout, void** out_handle);
+int dim_op_conv3x3_x6_nhwc_f32(const float* in, const void* w_x6_handle, const float* bias, float* out, int batch, int H, int W,
                                int cin, int cout, int pool2x2, int relu, void* stream);
 
 /* conv1a: [batch][H][W] -> [batch][H][W][64], weights [9][64], bias, ReLU. */
