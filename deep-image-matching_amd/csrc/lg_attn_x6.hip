@@ -31,7 +31,10 @@ struct AttnArgs6 {
   const float* enc;      // [items][nmax][64] cos|sin; rotary is applied to q (and k) iff !cross
   u32x4* kv_img;         // [items][4 heads][tiles][1536] pre-split K|V tile images (kv_prep_kernel)
   int nmax, tiles;
+  int splits;            // key range cut into `splits` parts per (query block, head, item): small batches only
+  float* part;           // [items][4][nmax][splits][PART] partial (unnormalised O, running max, running sum)
 };
+constexpr int PART = 68;   // 64 output dims + m + l, padded to a 16-byte multiple
 
 constexpr int TILE_STRIDE = 3 * 8 * 32 + 3 * 2 * 2 * 64;  // slots of 16 B reserved per tile image in HBM (mode 1 fills all 1536)
 constexpr int tile_slots(int npl) { return npl * 512; }    // npl * 256 K slots + npl * 256 V slots
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
   constexpr int NPL = S::NPL, TILE_SLOTS = tile_slots(NPL), KSL = NPL * 256, NCP = TILE_SLOTS / 256;
   // K, Q, V and P are multiplied by the (power-of-two) activation scale before the split: exact factors
   const float inv_qk = 1.0f / (S::act_scale() * S::act_scale());
-  const int item = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+  const int item = blockIdx.z, head = blockIdx.y, qb = blockIdx.x / a.splits, sp = blockIdx.x - qb * a.splits, q0 = qb * 128;
   if (a.done[item >> 1] != 0) return;
   const int kitem = a.cross ? (item ^ 1) : item;
   const int nq = a.n[item], nk = a.n[kitem];
@@ -154,12 +157,15 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
 #pragma unroll
     for (int i = 0; i < NCP; ++i) rt[i] = p[t + 256 * i];
   };
-  load_tile(0);
-  for (int kt = 0; kt < nk; kt += 32) {
+  // this workgroup's share of the key tiles (all of them unless the launcher split the key range)
+  const int per = ((nk + 31) / 32 + a.splits - 1) / a.splits * 32;
+  const int kt0 = sp * per, kt1 = min(nk, kt0 + per);
+  if (kt0 < kt1) load_tile(kt0);
+  for (int kt = kt0; kt < kt1; kt += 32) {
 #pragma unroll
     for (int i = 0; i < NCP; ++i) img[t + 256 * i] = rt[i];
     __syncthreads();
-    if (kt + 32 < nk) load_tile(kt + 32);
+    if (kt + 32 < kt1) load_tile(kt + 32);
 
     // ---- S^T = K · Q^T : 4 steps x 6 cross terms ----
     f32x16 sacc;
@@ -239,7 +245,20 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
   }
 
   // fp16x3: the V·P accumulator holds scale^2 x the sum and l_run scale x the normaliser: divide by scale * l_run
-  const float l_tot = (l_run + __shfl_xor(l_run, 32)) * (MODE == 2 ? S::act_scale() : 1.0f);
+  const float l_both = l_run + __shfl_xor(l_run, 32);
+  if (a.splits > 1) {  // partial result for attn_combine_kernel
+    if (qok) {
+      float* pp = a.part + ((((size_t)item * 4 + head) * a.nmax + qrow) * a.splits + sp) * PART;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(pp + n * 32 + 8 * g + 4 * half) = make_float4(oacc[n][4 * g], oacc[n][4 * g + 1], oacc[n][4 * g + 2], oacc[n][4 * g + 3]);
+      if (half == 0) { pp[64] = m_run; pp[65] = l_both; }
+    }
+    return;
+  }
+  const float l_tot = l_both * (MODE == 2 ? S::act_scale() : 1.0f);
   if (qok) {
     float* op = a.o + (size_t)item * a.so + (size_t)qrow * a.ldo + head * 64;
 #pragma unroll
@@ -251,6 +270,22 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
         *(float4*)(op + n * 32 + 8 * g + 4 * half) = o;
       }
   }
+}
+// merges the partial results of a split key range: one wave per (query row, head), lane = output dim
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs6 a, float out_scale) {
+  const int item = blockIdx.z, head = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), d = threadIdx.x & 63;
+  if (a.done[item >> 1] != 0 || row >= a.n[item]) return;
+  const float* pp = a.part + (((size_t)item * 4 + head) * a.nmax + row) * a.splits * PART;
+  float M = -INFINITY;
+  for (int s = 0; s < a.splits; ++s) M = fmaxf(M, pp[s * PART + 64]);
+  float L = 0.f, O = 0.f;
+  for (int s = 0; s < a.splits; ++s) {
+    const float m = pp[s * PART + 64];
+    const float w = (m == -INFINITY) ? 0.f : exp2f(m - M);
+    L += w * pp[s * PART + 65];
+    O += w * pp[s * PART + d];
+  }
+  a.o[(size_t)item * a.so + (size_t)row * a.ldo + head * 64 + d] = (L > 0.f) ? O / (L * out_scale) : 0.f;  // no keys -> zeros (LGN:103-104)
 }
 }  // namespace
 
@@ -264,7 +299,11 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s) {
   a.n = st.n_cur; a.done = st.done; a.cross = cross;
   a.scale = 0.125f;
   a.enc = st.enc; a.kv_img = (u32x4*)st.kv_img; a.nmax = st.nmax; a.tiles = cdiv(st.nmax, 32);
-  dim3 grid(cdiv(st.nmax, 128), 4, st.n_items);
+  // small batches leave most CUs idle and make every workgroup walk all key tiles alone: cut the key range
+  const int wgs = cdiv(st.nmax, 128) * 4 * st.n_items;
+  a.part = st.attn_part;
+  a.splits = (st.attn_part && st.n_items <= st.attn_part_items) ? (wgs <= 128 ? 4 : (wgs <= 256 ? 2 : 1)) : 1;
+  dim3 grid(cdiv(st.nmax, 128) * a.splits, 4, st.n_items);
   if (dim_precision_mode() == 2) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<2>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2>), grid, dim3(256), 0, s, a);
@@ -272,6 +311,8 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<1>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<1>), grid, dim3(256), 0, s, a);
   }
+  if (a.splits > 1)
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(cdiv(st.nmax, 4), 4, st.n_items), dim3(256), 0, s, a, dim_precision_mode() == 2 ? DIM_F16_ACT_SCALE : 1.0f);
   DIM_LAUNCH_CHECK();
   return 0;
 }

@@ -31,7 +31,8 @@ struct LgState {  // device pointers owned by the handle
   int* done;      // [pairs]
   int* cnt_lt;    // [pairs]
   float* tdesc; float* tenc; int* tind;  // compaction scratch
-  void* kv_img;   // [items][4][ceil(nmax/32)][1536 x 16 B] pre-split K|V tile images (bf16x6 attention)
+  void* kv_img;   // [items][4][ceil(nmax/32)][1536 x 16 B] pre-split K|V tile images (split-precision attention)
+  float* attn_part; int attn_part_items;  // scratch of the key-split attention used for small batches ([items][4][nmax][4][68])
 };
 
 int launch_lg_init(const LgState& st, const float* kpts_tab, const float* desc_tab, const int* n_tab, const float* size_tab,
