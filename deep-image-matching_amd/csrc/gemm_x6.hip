@@ -17,12 +17,14 @@
 #include "dim_kernels.h"
 
 namespace {
-constexpr int BM = 128, BN = 128, KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
+constexpr int BN = 128, KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
+// BM = 128 (each wave 64 x 64) or, for small problems that would leave most CUs idle, 64 (each wave 32 x 64: twice the
+// workgroups, half the MFMA / split work per barrier-to-barrier step of the serial K loop)
 
-template <int MODE>
+template <int MODE, int BM>
 __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
   using S = SplitMma<MODE>;
-  constexpr int NPL = S::NPL;
+  constexpr int NPL = S::NPL, MT = BM / 64, NLD = BM / 32;  // 32-row MFMA tiles per wave, float4 loads per thread and chunk
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
@@ -40,21 +42,21 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
   const u32x4* Bf = (const u32x4*)a.Bx3;
   const size_t nb0 = (size_t)(n0 + wn * 64) / 32;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  float4 ra[4];
+  float4 ra[NLD];
   auto load_chunk = [&](int k0) {
     const float* src; int ld, kk0;
     if (A1 == nullptr || k0 < a.ksplit) { src = A0; ld = a.lda0; kk0 = k0; }
     else { src = A1; ld = a.lda1; kk0 = k0 - a.ksplit; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
       // rows past the ragged end re-read the last valid row (always mapped): GEMM rows are independent and the
       // epilogue never stores them, so they need no zeroing — no branch, and no VALU touching the prefetch
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
       unsigned p0[NPL], p1[NPL];
       S::split(ra[i].x, ra[i].y, S::act_scale(), p0);
@@ -96,16 +98,16 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 fa[2][NPL];
+      u32x4 fa[MT][NPL];
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * 64 + m * 32 + lx) * RS + ks * 8 + half * 4];
+        for (int m = 0; m < MT; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * (32 * MT) + m * 32 + lx) * RS + ks * 8 + half * 4];
       // cross terms smallest first; the four accumulators interleave so no MFMA waits on its predecessor
 #pragma unroll
       for (int tm = 0; tm < S::NT; ++tm)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[ks][n][S::tb(tm)], acc[m][n]);
     }
@@ -124,8 +126,8 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
     const int colc = colok ? col : a.N - 1;
     const float bv = a.bias ? a.bias[colc] : 0.0f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int rbase = m0 + wm * 64 + m * 32;
+    for (int m = 0; m < MT; ++m) {
+      const int rbase = m0 + wm * (32 * MT) + m * 32;
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[m][n][r] * inv + bv;
@@ -160,9 +162,16 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
   DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
   if (batch <= 0 || a.M <= 0 || a.N <= 0) return 0;
-  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch);
-  if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<1>), grid, dim3(256), 0, s, a);
+  const bool small = (long)cdiv(a.M, 128) * cdiv(a.N, BN) * batch < 256;  // fewer 128-row workgroups than CUs
+  if (small) {
+    dim3 grid(cdiv(a.M, 64), cdiv(a.N, BN), batch);
+    if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<1, 64>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid(cdiv(a.M, 128), cdiv(a.N, BN), batch);
+    if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<1, 128>), grid, dim3(256), 0, s, a);
+  }
   DIM_LAUNCH_CHECK();
   return 0;
 }
