@@ -20,15 +20,21 @@ scripts/probe/mfma_f16_probe.hip: 0.7-1.7e-7 of sum|a*b| where an fp32 fmaf chai
 3 fp16 MFMAs per product step instead of 8 fp32 MFMAs.  `dim_tune_set(1, 1)` selects the exact 3-way
 bf16 split with six terms ("bf16x6"), `dim_tune_set(1, 0)` plain fp32 MFMA.
 
+Default workload = BASELINE configs[2]: 50 pairs per step, so the 20 steps the driver asks for cover the 1000 pairs
+that config names (a timed region of ~2 s: sustained clocks, not a burst).  `python bench.py --gpus N` without a
+torchrun wrapper re-executes itself under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL).
+
 Rank 0 prints one JSON line carrying the contract fields plus
   roofline     — the dominant kernel (conv3x3_x6_kernel<64,1,1,true,2>: conv1a fused into conv1b, 44 % of
                  SuperPoint's FLOPs) timed live with HIP events on the launch stream over the timed
-                 region; `achieved` counts ALGORITHMIC fp32 FLOPs; `peak` is the dense fp16 MFMA peak
-                 of MI355X_MICROARCH.md divided by the three passes the fp32-accurate product needs
-                 (2500 / 3 = 833.3 TFLOP/s); the fraction of the plain fp32-MFMA peak (157.3) is
-                 reported beside it;
-  cpu_baseline — the oracle (CPU restatement of the reference path) timed on this box's host
-                 cores on a bounded sample of the same workload.
+                 region; `achieved` counts ALGORITHMIC fp32 FLOPs; `peak` is the dense fp16 MFMA peak of
+                 MI355X_MICROARCH.md (2500 TFLOP/s: the precision actually issued, SURVEY §8(d) — the three
+                 split-precision passes are NOT credited), so `frac` <= 1/3 by construction;
+                 `mfma_pipe_util` = achieved x 3 passes / 2500 is the matrix-pipe utilisation the PMC counters
+                 show (profiles/*_pmc_mfma_summary.txt) and `frac_of_fp32_mfma_peak` compares with plain fp32 MFMA;
+  sustained_clock_mhz — average shader clock over the timed region (s_memtime / s_memrealtime probes);
+  cpu_baseline — the reference modules (kind "reference", when /root/reference exists) or the oracle (kind
+                 "port", on the GPU box) timed on this box's host cores on a bounded sample of the same workload.
 """
 from __future__ import annotations
 
@@ -59,9 +65,9 @@ X6_PASSES = 3                     # fp16 MFMA terms per fp32-accurate product st
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=16, help="pairs per step per GPU")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=50, help="pairs per step per GPU (50 x 20 steps = the 1000 pairs of configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="time the two-stream schedule (extraction of batch i+1 overlapping matching "
                     "of batch i) as the main region; by default it is measured after it and reported as two_stream_overlap")
@@ -71,11 +77,46 @@ def parse():
     return ap.parse_args()
 
 
+def respawn_under_torchrun(a):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _reference_modules():
+    """The reference's own network files (SPN, LGN: torch/numpy only), imported by path when /root/reference exists
+    (the build container); None on the GPU box."""
+    ref = Path("/root/reference/src/deep_image_matching/thirdparty")
+    spn, lgn = ref / "SuperGluePretrainedNetwork/models/superpoint.py", ref / "LightGlue/lightglue/lightglue.py"
+    if not (spn.exists() and lgn.exists()):
+        return None
+    import importlib.util
+
+    mods = []
+    for path, name in ((spn, "ref_spn_bench"), (lgn, "ref_lgn_bench")):
+        spec = importlib.util.spec_from_file_location(name, str(path))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mods.append(mod)
+    return mods
+
+
 def cpu_baseline(n_pairs: int):
-    """Oracle (kind 'port') on the host cores: same synthetic inputs, same configuration."""
+    """The reference modules (kind 'reference') when /root/reference is present, else the oracle (kind 'port'), on the host
+    cores: same synthetic inputs, same configuration (SURVEY §8(d) "CPU reference timing")."""
     from oracle import lightglue_ref, superpoint_ref
 
     weights = importlib.import_module(PKG + ".weights")
+    ref_mods = _reference_modules()
     # torch CPU peaks at 16-32 threads on this path (measured on the GPU box's 256-CPU host: 8 thr 0.25, 16 thr 0.28,
     # 32 thr 0.28, 64 thr 0.19, 128 thr 0.08 pairs/s), so the baseline runs at its best setting
     cores = min(16, os.cpu_count() or 16)
@@ -85,12 +126,31 @@ def cpu_baseline(n_pairs: int):
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
     conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
     size = torch.tensor([1024.0, 1024.0])
+    if ref_mods is not None:
+        spn, lgn = ref_mods
+        orig = torch.hub.load_state_dict_from_url
+        torch.hub.load_state_dict_from_url = lambda *a_, **k_: sp_sd  # SPN:149 downloads; feed the same synthetic weights
+        try:
+            ref_sp = spn.SuperPoint(dict(cfg)).eval()
+        finally:
+            torch.hub.load_state_dict_from_url = orig
+        ref_lg = lgn.LightGlue(features=None, input_dim=256, **conf).eval()
+        ref_lg.load_state_dict(lg_sd, strict=False)
 
+    @torch.no_grad()
     def one_pair(seed):
         f = []
         for s in (2 * seed, 2 * seed + 1):
             img = torch.rand(1, 1, 1024, 1024, generator=torch.Generator().manual_seed(s))
-            f.append(superpoint_ref.superpoint_forward(img, sp_sd, cfg))
+            if ref_mods is not None:
+                o = ref_sp({"image": img})
+                f.append({"keypoints": o["keypoints"][0], "descriptors": o["descriptors"][0]})
+            else:
+                f.append(superpoint_ref.superpoint_forward(img, sp_sd, cfg))
+        if ref_mods is not None:
+            ref_lg({"image0": {"keypoints": f[0]["keypoints"][None], "descriptors": f[0]["descriptors"].t()[None], "image_size": size[None]},
+                    "image1": {"keypoints": f[1]["keypoints"][None], "descriptors": f[1]["descriptors"].t()[None], "image_size": size[None]}})
+            return
         lightglue_ref.lightglue_forward(f[0]["keypoints"], f[0]["descriptors"].t().contiguous(), size,
                                         f[1]["keypoints"], f[1]["descriptors"].t().contiguous(), size, lg_sd, conf)
 
@@ -99,15 +159,19 @@ def cpu_baseline(n_pairs: int):
     for i in range(n_pairs):
         one_pair(i)
     dt = time.perf_counter() - t0
-    return {"value": n_pairs / dt, "unit": "image-pairs/s", "cores": cores, "kind": "port",
+    kind = "reference" if ref_mods is not None else "port"
+    what = "the reference's SuperPoint / LightGlue modules (imported from /root/reference)" if ref_mods is not None else "oracle/*.py"
+    return {"value": n_pairs / dt, "unit": "image-pairs/s", "cores": cores, "kind": kind,
             "sample": f"{n_pairs} pairs (= {2 * n_pairs} SuperPoint 1024x1024 forwards + {n_pairs} LightGlue 2048x2048 "
-                      f"9-layer forwards) after 1 warm-up pair, oracle/*.py on torch CPU, {cores} threads"}
+                      f"9-layer forwards) after 1 warm-up pair, {what} on torch CPU, {cores} threads"}
 
 
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     if not torch.cuda.is_available():
@@ -199,8 +263,12 @@ def main():
     barrier()
     # time every launch of conv3x3_x6_kernel<64,1,1,true> (conv1a fused into conv1b) with HIP events on the launch stream
     capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong(1 << 1)))  # DIM_PROF_SP_CONV1B: the fused conv1a+conv1b kernel
+    clk = torch.zeros(4, dtype=torch.int64, device=dev)  # {shader cycles, 100 MHz ticks} before / after the timed region
+    stream_ptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    capi.check(lib, lib.dim_op_read_clocks(ctypes.c_void_p(clk.data_ptr()), stream_ptr))
     t0 = time.perf_counter()
     n_last = run(K, W, overlap)
+    capi.check(lib, lib.dim_op_read_clocks(ctypes.c_void_p(clk.data_ptr() + 16), stream_ptr))
     if dist is not None:  # one collective for the whole job: per-rank match tables -> every rank
         cnt_all = torch.empty(world * T * P, dtype=torch.int32, device=dev)
         m_all = torch.empty(world * T * P * NK * 2, dtype=torch.int64, device=dev)
@@ -236,6 +304,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt, dt2 = float(tmax[0].item()), float(tmax[1].item())
     n_kpts_ok = bool((n_last == 2048).all().item())
+    ck = clk.cpu().tolist()
+    clock_mhz = (ck[2] - ck[0]) / max(1, ck[3] - ck[1]) * 100.0
+    sat_total, sat_sites = capi.saturation(lib, stream_ptr, reset=True)  # fp16x3 range guard over the whole run: must be 0
 
     if rank == 0:
         pairs_total = world * K * P
@@ -266,18 +337,22 @@ def main():
                 "value": pairs_total / dt2, "unit": "image-pairs/s", "ms_per_step": dt2 / K * 1e3,
                 "note": "the same K steps under the other schedule, timed right after the main region (barrier + synchronize on both sides)"},
             "end_to_end_tflops_per_gpu": (2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR) * value / world / 1e3,
+            "timed_region_s": dt, "pairs_total": pairs_total, "sustained_clock_mhz": clock_mhz,
+            "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
             "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1,true,2> (SuperPoint conv1a 1->64 evaluated in the halo staging + conv1b 64->64 3x3 "
                                    "+ bias + ReLU + 2x2 max-pool, fp32-accurate on the fp16 MFMA (fp16x3); 1024^2 images)", "bound": "mfma",
-                         "achieved": conv_tflops, "peak": PEAK_BF16_MFMA_TFLOPS / X6_PASSES, "unit": "TFLOP/s",
-                         "frac": conv_tflops / (PEAK_BF16_MFMA_TFLOPS / X6_PASSES),
-                         "peak_note": "dense fp16 MFMA peak 2500 TFLOP/s / 3 fp16 MFMA passes per fp32-accurate product; "
-                                      "clock and MFMA-busy fraction per kernel: profiles/r01_pmc_mfma_summary.txt",
+                         "achieved": conv_tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": conv_tflops / PEAK_BF16_MFMA_TFLOPS,
+                         "mfma_pipe_util": conv_tflops * X6_PASSES / PEAK_BF16_MFMA_TFLOPS,
+                         "peak_note": "frac = ALGORITHMIC fp32 FLOP/s / dense fp16 MFMA peak (2500 TFLOP/s, the precision issued; the 3 "
+                                      "split-precision passes are not credited, so frac <= 1/3); mfma_pipe_util = x 3 passes = what the "
+                                      "MFMA-busy counter shows (profiles/r02_pmc_mfma_summary.txt)",
                          "frac_of_fp32_mfma_peak": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "isolated": {"note": "same kernel, same launches, timed right after the timed region with no LightGlue work "
                                               "sharing the GPU (in the timed region the two streams overlap, so a launch is stretched)",
                                       "avg_launch_ms": iso_ms.value / max(1, iso_n.value),
                                       "achieved": gflop_per_launch / (iso_ms.value / max(1, iso_n.value)),
-                                      "frac": gflop_per_launch / (iso_ms.value / max(1, iso_n.value)) / (PEAK_BF16_MFMA_TFLOPS / X6_PASSES)},
+                                      "frac": gflop_per_launch / (iso_ms.value / max(1, iso_n.value)) / PEAK_BF16_MFMA_TFLOPS},
                          "avg_launch_ms": conv_ms, "launches": launches.value,
                          "algorithmic_gflop_per_launch": gflop_per_launch},
         }

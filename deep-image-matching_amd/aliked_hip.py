@@ -75,8 +75,9 @@ class AlikedHIP:
         c = _AlConfig(*geo, mk, float(self.cfg["detection_threshold"]), int(self.cfg["nms_radius"]))
         self.max_batch, self.max_hw = int(max_batch), (int(max_hw[0]), int(max_hw[1]))
         self._h = ctypes.c_void_p()
-        capi.check(self.lib, self.lib.dim_aliked_create(ctypes.byref(w), ctypes.byref(c), self.max_batch, self.max_hw[0], self.max_hw[1],
-                                                        self.capacity, ctypes.byref(self._h)))
+        with self._ctx():
+            capi.check(self.lib, self.lib.dim_aliked_create(ctypes.byref(w), ctypes.byref(c), self.max_batch, self.max_hw[0], self.max_hw[1],
+                                                            self.capacity, ctypes.byref(self._h)))
         del keep
 
     def __del__(self):
@@ -90,6 +91,11 @@ class AlikedHIP:
             return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         return None
 
+    def _ctx(self):
+        """The library launches on the CURRENT HIP device: make it the handle's."""
+        import contextlib
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
+
     @torch.no_grad()
     def extract_batch(self, images: torch.Tensor):
         """images [B,H,W,C] float32 in [0,1] (HWC, C = 3 or 1) on self.device -> device tensors
@@ -101,8 +107,9 @@ class AlikedHIP:
         sc = torch.empty(B, self.capacity, dtype=torch.float32, device=dev)
         de = torch.empty(B, self.capacity, 128, dtype=torch.float32, device=dev)
         n = torch.zeros(B, dtype=torch.int32, device=dev)
-        capi.check(self.lib, self.lib.dim_aliked_extract(self._h, capi.ptr(images), B, H, W, C, capi.ptr(kp), capi.ptr(sc), capi.ptr(de),
-                                                         capi.ptr(n), self._stream()))
+        with self._ctx():
+            capi.check(self.lib, self.lib.dim_aliked_extract(self._h, capi.ptr(images), B, H, W, C, capi.ptr(kp), capi.ptr(sc), capi.ptr(de),
+                                                             capi.ptr(n), self._stream()))
         return kp, sc, de, n
 
     @torch.no_grad()

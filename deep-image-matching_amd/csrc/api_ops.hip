@@ -22,6 +22,35 @@ std::vector<hipEvent_t> g_prof_ev;  // begin/end pairs
 size_t g_prof_used = 0;
 }  // namespace
 
+// ---- fp16x3 range guard: one block of sticky counters per device, allocated on first use ----
+namespace {
+constexpr int kMaxDev = 16;
+unsigned* g_sat_dev[kMaxDev] = {nullptr};
+bool g_sat_failed[kMaxDev] = {false};
+unsigned g_sat_host[DIM_SAT_SITES] = {0};
+__global__ void read_clocks_kernel(unsigned long long* out) {
+  out[0] = (unsigned long long)__builtin_readcyclecounter();
+  out[1] = (unsigned long long)wall_clock64();
+}
+unsigned* sat_block() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDev) return nullptr;
+  if (!g_sat_dev[d] && !g_sat_failed[d]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, DIM_SAT_SITES * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, DIM_SAT_SITES * sizeof(unsigned)) != hipSuccess) g_sat_failed[d] = true;
+    else g_sat_dev[d] = (unsigned*)p;
+  }
+  return g_sat_dev[d];
+}
+}  // namespace
+unsigned* dim_sat_counter(int site) {
+  unsigned* b = sat_block();
+  return (b && site >= 0 && site < DIM_SAT_SITES) ? b + site : nullptr;
+}
+void dim_sat_host_bump(int site) {
+  if (site >= 0 && site < DIM_SAT_SITES) g_sat_host[site]++;
+}
+
 static int g_precision_mode = 2;
 int dim_precision_mode() { return g_precision_mode; }
 static int g_fuse_conv1a = 1;
@@ -70,6 +99,32 @@ int dim_profile_stop(double* total_ms, int* launches) {
   return 0;
 }
 
+int dim_saturation_read(unsigned* counts_host, unsigned long long* total, int reset, void* stream) {
+  unsigned c[DIM_SAT_SITES] = {0};
+  unsigned* b = sat_block();
+  if (b) {
+    DIM_HIP(hipMemcpyAsync(c, b, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (reset) DIM_HIP(hipMemsetAsync(b, 0, sizeof(c), (hipStream_t)stream));
+    DIM_HIP(hipStreamSynchronize((hipStream_t)stream));
+  }
+  unsigned long long tot = 0;
+  for (int i = 0; i < DIM_SAT_SITES; ++i) {
+    c[i] += g_sat_host[i];
+    if (reset) g_sat_host[i] = 0;
+    tot += c[i];
+    if (counts_host) counts_host[i] = c[i];
+  }
+  if (total) *total = tot;
+  return 0;
+}
+
+int dim_op_read_clocks(unsigned long long* out_dev, void* stream) {
+  DIM_REQUIRE(out_dev, "dim_op_read_clocks: null argument");
+  hipLaunchKernelGGL(read_clocks_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out_dev);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
 const char* dim_last_error(void) { return g_err; }
 
 int dim_abi_version(void) { return DIM_HIP_ABI_VERSION; }
@@ -104,7 +159,7 @@ int dim_x3_create(const float* w_kn_host, int K, int N, void** out_dev, int* n_p
   const int n_pad = (N + 127) / 128 * 128;
   std::vector<unsigned short> host(gemm_split_weight_elems(K, n_pad, mode));
   SplitWeights* w = new SplitWeights();
-  split_weights(w_kn_host, K, N, n_pad, mode, host.data(), &w->inv_scale);
+  split_weights(w_kn_host, K, N, n_pad, mode, host.data(), w);
   void* d = nullptr;
   if (hipMalloc(&d, host.size() * 2) != hipSuccess || hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
     delete w;
@@ -127,6 +182,7 @@ int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3, int n_pad, con
   GemmArgs g;
   g.A0 = A; g.lda0 = lda; g.set_split(*(const SplitWeights*)w_x3); g.bias = bias;
   g.R = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = act;
+  g.sat = dim_sat_counter(DIM_SAT_OP);
   return launch_gemm_x6(g, 1, (hipStream_t)stream);
 }
 
@@ -135,7 +191,7 @@ int dim_convx6_create(const float* w_oihw_host, int cin, int cout, void** out_de
   const int mode = g_precision_mode == 1 ? 1 : 2;
   std::vector<unsigned short> host(conv_split_weight_elems(cin, cout, mode));
   SplitWeights* w = new SplitWeights();
-  prepare_conv_weights_split(w_oihw_host, cin, cout, mode, host.data(), &w->inv_scale);
+  prepare_conv_weights_split(w_oihw_host, cin, cout, mode, host.data(), w);
   void* d = nullptr;
   if (hipMalloc(&d, host.size() * 2) != hipSuccess || hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
     delete w;
@@ -149,7 +205,7 @@ int dim_convx6_create(const float* w_oihw_host, int cin, int cout, void** out_de
 int dim_op_conv3x3_x6_nhwc_f32(const float* in, const void* w_x6, const float* bias, float* out, int batch, int H, int W,
                                int cin, int cout, int pool2x2, int relu, void* stream) {
   DIM_REQUIRE(w_x6, "dim_op_conv3x3_x6_nhwc_f32: null weight handle");
-  return launch_conv3x3_x6(in, *(const SplitWeights*)w_x6, bias, out, batch, H, W, cin, cout, pool2x2, relu, (hipStream_t)stream);
+  return launch_conv3x3_x6(in, *(const SplitWeights*)w_x6, bias, out, batch, H, W, cin, cout, pool2x2, relu, (hipStream_t)stream, dim_sat_counter(DIM_SAT_OP));
 }
 
 int dim_tune_set(int key, int value) {

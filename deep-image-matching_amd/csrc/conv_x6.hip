@@ -12,6 +12,7 @@
 // consecutive lanes read consecutive 16-B slots in both images: conflict-free without padding.
 // The pre-split weight buffer is laid out so that each (cout block, chunk, kernel row) slice is one
 // contiguous 18,432-B run (a straight 16-B-per-lane copy).
+#include <math.h>
 #include <string.h>
 
 #include "dim_kernels.h"
@@ -37,8 +38,8 @@ template <int CIN, int POOL, int PF, bool F1A, int MODE, bool PIN, bool POUT>
 __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                             int cout, int relu, int tiles_x, const float* __restrict__ w1a,
-                                                            const float* __restrict__ b1a, float inv_scale, size_t plane_in,
-                                                            size_t plane_out) {
+                                                            const float* __restrict__ b1a, const float* __restrict__ inv_ch, size_t plane_in,
+                                                            size_t plane_out, unsigned* sat, unsigned* sat_image) {
   static_assert(!(PIN || POUT) || MODE == 2, "pre-split planes exist for the fp16x3 mode only");
   static_assert(!(PIN && F1A), "the fused conv1a computes its own input");
   using S = SplitMma<MODE>;
@@ -156,11 +157,15 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
     }
   };
   if (F1A) {
+    float imax = 0.0f;  // range guard: the host bound on conv1a's outputs assumes |image| <= 1 (image / 255)
     for (int idx = t; idx < IMH * IMW; idx += 256) {
       const int r = idx / IMW, cc = idx - r * IMW;
       const int gy = oy + r - 2, gx = ox + cc - 2;
-      Img[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in_b[(size_t)gy * W + gx] : 0.0f;
+      const float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in_b[(size_t)gy * W + gx] : 0.0f;
+      Img[idx] = v;
+      imax = fmaxf(imax, fabsf(v));
     }
+    if (sat_image != nullptr && !(imax <= 1.0f)) atomicAdd(sat_image, 1u);
     // weights and bias pre-multiplied by the activation scale (a power of two: fmaf(v, s w, s acc) = s fmaf(v, w, acc)
     // exactly), so the conv1a outputs come out scaled and their split skips the multiply
     for (int idx = t; idx < 9 * 64 + 64; idx += 256) W1a[idx] = (idx < 9 * 64 ? w1a[idx] : b1a[idx - 9 * 64]) * S::act_scale();
@@ -217,10 +222,12 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       if (ok1) fp[o1] = v1;
     }
   };
+  float vmax = 0.0f;  // fp16x3 range guard on everything this thread writes (dim_common.h)
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int co = cb * 64 + n * 32 + lx;
     const float bv = bias[co];
+    const float inv_scale = inv_ch[co];
     if (POOL) {
       const int Ho = H >> 1, Wo = W >> 1;
       const int py = (oy >> 1) + wv, pxb = ox >> 1;
@@ -236,6 +243,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       for (int j = 0; j < 8; j += 2) {
         const int q0 = mfma_row(2 * j, half) >> 1, q1 = mfma_row(2 * j + 2, half) >> 1;  // pooled column offsets inside the tile
         const bool ok0 = py < Ho && pxb + q0 < Wo, ok1 = py < Ho && pxb + q1 < Wo;
+        vmax = sat_track(vmax, pv[j], pv[j + 1]);
         put2(out + base, (unsigned short*)out + base, (unsigned)(q0 * cout), (unsigned)(q1 * cout), ok0, ok1, pv[j], pv[j + 1]);
       }
     } else {
@@ -249,11 +257,13 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
           float v0 = acc[m][n][r] * inv_scale + bv, v1 = acc[m][n][r + 1] * inv_scale + bv;
           if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
           const bool ok0 = y < H && ox + x0 < W, ok1 = y < H && ox + x0 + 1 < W;
+          vmax = sat_track(vmax, v0, v1);
           put2(out + base, (unsigned short*)out + base, (unsigned)(x0 * cout), (unsigned)((x0 + 1) * cout), ok0, ok1, v0, v1);
         }
       }
     }
   }
+  if (MODE == 2) sat_report(sat, vmax);
 }
 
 // debug / inspection: pre-split planes back to fp32 (h + l is exact in fp32; / 16 undoes the activation scale)
@@ -273,23 +283,28 @@ unsigned short host_bf16_rne(float x) {
 }
 }  // namespace
 
-// Host: OIHW fp32 3x3 weights -> [cout/64][cin/16][dy][plane][dx][k-half][64 co][8 ci] 16-bit pieces.
-// mode 1: three bf16 planes (RNE pieces, inv_scale 1); mode 2: two fp16 planes of w * 2^sw with 2^sw chosen so
-// that max|w| lands in [8192, 16384) — inv_scale = 1 / (2^sw * DIM_F16_ACT_SCALE), exact.
-size_t conv_split_weight_elems(int cin, int cout, int mode) { return (size_t)(cout / 64) * (cin / 16) * 3 * w_slice(mode == 2 ? 2 : 3); }
-void prepare_conv_weights_split(const float* w_oihw, int cin, int cout, int mode, unsigned short* out, float* inv_scale) {
+// Host: OIHW fp32 3x3 weights -> [cout/64][cin/16][dy][plane][dx][k-half][64 co][8 ci] 16-bit pieces, followed by
+// the fp32 per-output-channel inverse scales [cout] (SplitWeights::scale_off).
+// mode 1: three bf16 planes (RNE pieces, scales 1); mode 2: two fp16 planes of w * 2^s_co with 2^s_co chosen per output
+// channel so that max|w[co]| lands in [8192, 16384) — inverse scale 1 / (2^s_co * DIM_F16_ACT_SCALE), exact.
+static size_t conv_split_piece_elems(int cin, int cout, int mode) { return (size_t)(cout / 64) * (cin / 16) * 3 * w_slice(mode == 2 ? 2 : 3); }
+size_t conv_split_weight_elems(int cin, int cout, int mode) { return conv_split_piece_elems(cin, cout, mode) + 2 * (size_t)cout; }
+void prepare_conv_weights_split(const float* w_oihw, int cin, int cout, int mode, unsigned short* out, SplitWeights* sw) {
   const int nchunk = cin / 16, npl = mode == 2 ? 2 : 3;
-  float wscale = 1.0f;
-  if (mode == 2) {
-    float mx = 0.f;
-    for (size_t i = 0; i < (size_t)cout * cin * 9; ++i) mx = fmaxf(mx, fabsf(w_oihw[i]));
-    int e = 0;
-    if (mx > 0.f) { frexpf(mx, &e); wscale = ldexpf(1.0f, 14 - e); }  // mx = f * 2^e, f in [0.5, 1) -> mx * wscale in [8192, 16384)
-    *inv_scale = 1.0f / (wscale * DIM_F16_ACT_SCALE);
-  } else {
-    *inv_scale = 1.0f;
-  }
-  for (int co = 0; co < cout; ++co)
+  sw->mode = mode;
+  sw->scale_off = conv_split_piece_elems(cin, cout, mode);
+  float* inv = (float*)(out + sw->scale_off);
+  for (int co = 0; co < cout; ++co) {
+    float wscale = 1.0f;
+    float inv_co = 1.0f;
+    if (mode == 2) {
+      float mx = 0.f;
+      for (size_t i = 0; i < (size_t)cin * 9; ++i) mx = fmaxf(mx, fabsf(w_oihw[(size_t)co * cin * 9 + i]));
+      int e = 0;
+      if (mx > 0.f && mx < INFINITY) { frexpf(mx, &e); wscale = ldexpf(1.0f, 14 - e); }  // mx = f * 2^e, f in [0.5, 1) -> mx * wscale in [8192, 16384)
+      inv_co = 1.0f / (wscale * DIM_F16_ACT_SCALE);
+    }
+    memcpy(&inv[co], &inv_co, 4);
     for (int ci = 0; ci < cin; ++ci)
       for (int dy = 0; dy < 3; ++dy)
         for (int dx = 0; dx < 3; ++dx) {
@@ -312,6 +327,7 @@ void prepare_conv_weights_split(const float* w_oihw, int cin, int cout, int mode
             x = x - piece;
           }
         }
+  }
 }
 
 static int g_conv_x6_variant = 1;
@@ -319,7 +335,7 @@ int dim_conv_x6_variant() { return g_conv_x6_variant; }
 void dim_conv_x6_set_variant(int v) { g_conv_x6_variant = v; }
 
 int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
-                      int cout, int pool, int relu, hipStream_t s) {
+                      int cout, int pool, int relu, hipStream_t s, unsigned* sat) {
   DIM_REQUIRE(cout % 64 == 0, "conv3x3_x6: cout=%d must be a multiple of 64", cout);
   DIM_REQUIRE(cin == 64 || cin == 128, "conv3x3_x6: cin=%d unsupported (64 or 128)", cin);
   DIM_REQUIRE(wt.dev && (wt.mode == 1 || wt.mode == 2), "conv3x3_x6: weights not prepared (mode %d)", wt.mode);
@@ -327,8 +343,8 @@ int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
   const unsigned short* wx = wt.dev;
-  const float inv = wt.inv_scale;
-#define DIM_CONV6(CI, P, PFV, MD) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV, false, MD, false, false>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, inv, (size_t)0, (size_t)0)
+  const float* inv = wt.inv_ch();
+#define DIM_CONV6(CI, P, PFV, MD) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV, false, MD, false, false>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, inv, (size_t)0, (size_t)0, sat, (unsigned*)nullptr)
 #define DIM_CONV6_V(PFV, MD)                              \
   {                                                       \
     if (cin == 64 && pool) DIM_CONV6(64, 1, PFV, MD);     \
@@ -353,7 +369,8 @@ int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias
 
 // conv1a (1 -> 64) fused into the 64 -> cout convolution that consumes it (SuperPoint conv1a + conv1b, SPN:161-162).
 int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
-                              float* out, int batch, int H, int W, int cout, int pool, int relu, int planes_out, hipStream_t s) {
+                              float* out, int batch, int H, int W, int cout, int pool, int relu, int planes_out, hipStream_t s,
+                              unsigned* sat, unsigned* sat_image) {
   DIM_REQUIRE(cout % 64 == 0, "conv3x3_x6 fused conv1a: cout=%d must be a multiple of 64", cout);
   DIM_REQUIRE(wt.dev && (wt.mode == 1 || wt.mode == 2), "conv3x3_x6: weights not prepared (mode %d)", wt.mode);
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
@@ -361,7 +378,7 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
   const size_t plane_out = (size_t)batch * (pool ? (H / 2) * (W / 2) : H * W) * cout;
   DIM_REQUIRE(!planes_out || wt.mode == 2, "conv3x3_x6: pre-split output planes exist for the fp16x3 mode only");
-#define DIM_CONV6F(P, MD, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD, false, PO>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_scale, (size_t)0, plane_out)
+#define DIM_CONV6F(P, MD, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD, false, PO>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), (size_t)0, plane_out, sat, sat_image)
   if (wt.mode == 2 && planes_out) { if (pool) DIM_CONV6F(1, 2, true); else DIM_CONV6F(0, 2, true); }
   else if (wt.mode == 2) { if (pool) DIM_CONV6F(1, 2, false); else DIM_CONV6F(0, 2, false); }
   else { if (pool) DIM_CONV6F(1, 1, false); else DIM_CONV6F(0, 1, false); }
@@ -372,14 +389,14 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
 
 // fp16x3 convolution whose input and / or output are pre-split fp16 planes (see PIN / POUT above)
 int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
-                             int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s) {
+                             int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s, unsigned* sat) {
   DIM_REQUIRE(cout % 64 == 0 && (cin == 64 || cin == 128), "conv3x3_x6 planes: cin=%d cout=%d", cin, cout);
   DIM_REQUIRE(wt.dev && wt.mode == 2, "conv3x3_x6 planes: fp16x3 weights required (mode %d)", wt.mode);
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
   const size_t plane_in = (size_t)batch * H * W * cin, plane_out = (size_t)batch * (pool ? (H / 2) * (W / 2) : H * W) * cout;
-#define DIM_CONV6P(CI, P, PI, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, 1, false, 2, PI, PO>), grid, dim3(256), 0, s, in, wt.dev, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, wt.inv_scale, plane_in, plane_out)
+#define DIM_CONV6P(CI, P, PI, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, 1, false, 2, PI, PO>), grid, dim3(256), 0, s, in, wt.dev, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, wt.inv_ch(), plane_in, plane_out, sat, (unsigned*)nullptr)
 #define DIM_CONV6P_IO(CI, P)                                   \
   {                                                            \
     if (planes_in && planes_out) DIM_CONV6P(CI, P, true, true); \

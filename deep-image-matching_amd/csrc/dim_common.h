@@ -118,8 +118,24 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 
+// ---- fp16x3 range guard ---------------------------------------------------------------------------
+// Every kernel that PRODUCES a value a later fp16x3 split will consume (conv / GEMM epilogues, LayerNorm+GELU,
+// the rotated q / k, the external inputs) tracks max|x| of what it writes and bumps a sticky per-site device
+// counter when that exceeds the exact range of the split (65504 / DIM_F16_ACT_SCALE = 4094): one v_max3 per two
+// outputs in an epilogue and one (never taken) branch per thread.  The host reads the counters through
+// dim_saturation_read() and re-runs the call in bf16x6 (no range limit) when any is non-zero.
+#define DIM_F16_ACT_LIMIT (65504.0f / DIM_F16_ACT_SCALE)
+__device__ __forceinline__ float sat_track(float m, float a, float b) { return fmaxf(m, fmaxf(fabsf(a), fabsf(b))); }
+__device__ __forceinline__ void sat_report(unsigned* ctr, float m) {
+  if (ctr != nullptr && !(m <= DIM_F16_ACT_LIMIT)) atomicAdd(ctr, 1u);  // NaN counts as out of range
+}
+
 // ---- host side -------------------------------------------------------------
 void dim_set_error(const char* fmt, ...);
+// device pointer to the saturation counter of `site` (DIM_SAT_* in include/dim_hip.h) on the current device; the
+// block of counters is allocated and zeroed on first use.  nullptr if the allocation failed (guard disabled).
+unsigned* dim_sat_counter(int site);
+void dim_sat_host_bump(int site);  // a range violation established on the host (e.g. a weight bound at create time)
 #define DIM_HIP(expr)                                                                 \
   do {                                                                                \
     hipError_t e__ = (expr);                                                          \

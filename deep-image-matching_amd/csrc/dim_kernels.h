@@ -14,13 +14,17 @@
 // rows != nullptr, else M; same for cols (bt mode only).  flag gating: the item
 // is skipped unless flag[z >> flag_shift] == flag_eq (flag == nullptr: always run).
 // A matrix-core operand pre-split on the host into 16-bit planes (SplitMma policy, dim_common.h):
-// mode 1 = three bf16 planes, mode 2 = two fp16 planes of the power-of-two-scaled weights; inv_scale is the
-// exact factor the accumulator is multiplied by in the epilogue (1 for mode 1).
+// mode 1 = three bf16 planes, mode 2 = two fp16 planes of the power-of-two-scaled weights.  The scale is chosen PER
+// OUTPUT CHANNEL (max|w[:, co]| lands in [8192, 16384): one outlier weight cannot push the other channels' weights
+// towards the subnormal low piece); the exact per-channel factors the accumulator is multiplied by in the epilogue
+// (1 / (2^s_co * activation scale); all 1 for mode 1) are fp32 values stored in the tail of the same device buffer,
+// `scale_off` 16-bit elements from its start.
 struct SplitWeights {
   const unsigned short* dev = nullptr;
   int mode = 0;
-  float inv_scale = 1.0f;
+  size_t scale_off = 0;
   int n_pad = 0;  // GEMM operands: padded column count
+  const float* inv_ch() const { return (const float*)(dev + scale_off); }
 };
 struct GemmArgs {
   const float* A0 = nullptr; const float* A1 = nullptr;
@@ -29,8 +33,9 @@ struct GemmArgs {
   const int* a_idx = nullptr;  // optional indirection: A0 of item z starts at A0 + a_idx[z]*strideA0
   const float* B = nullptr; int ldb = 0; long long strideB = 0; int bt = 0;
   const unsigned short* Bx3 = nullptr; int n_pad = 0;  // split path: weights pre-split into [planes][n_pad][K] 16-bit pieces
-  int split_mode = 1; float inv_scale = 1.0f;           //   (SplitWeights::mode / inv_scale)
-  void set_split(const SplitWeights& w) { Bx3 = w.dev; n_pad = w.n_pad; split_mode = w.mode; inv_scale = w.inv_scale; }
+  int split_mode = 1; const float* inv_ch = nullptr;    //   (SplitWeights::mode / per-column inverse scales [n_pad])
+  void set_split(const SplitWeights& w) { Bx3 = w.dev; n_pad = w.n_pad; split_mode = w.mode; inv_ch = w.inv_ch(); }
+  unsigned* sat = nullptr;  // fp16x3 range guard: counter bumped when max|C| > DIM_F16_ACT_LIMIT (dim_common.h); nullptr = unchecked
   const float* bias = nullptr;
   const float* R = nullptr; int ldr = 0; long long strideR = 0;
   float* C = nullptr; int ldc = 0; long long strideC = 0;
@@ -43,9 +48,10 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, int batch, hipStream_t s);
 // fp32-accurate GEMM on the 16-bit matrix cores (gemm_x6.hip); needs a.set_split(...).
 int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s);
-// host: [K][N] fp32 -> the pre-split device layout; elems = planes * n_pad * K 16-bit values
+// host: [K][N] fp32 -> the pre-split device layout; elems = planes * n_pad * K 16-bit values + 2 * n_pad for the fp32
+// per-column inverse scales in the tail (sw->scale_off); fills sw->mode / n_pad / scale_off (not sw->dev)
 size_t gemm_split_weight_elems(int K, int n_pad, int mode);
-void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, float* inv_scale);
+void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, SplitWeights* sw);
 
 // ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution over NHWC fp32 images as an implicit GEMM
@@ -55,15 +61,17 @@ int launch_conv3x3(const float* in, const float* w, const float* bias, float* ou
                    int cin, int cout, int pool, int relu, hipStream_t s);
 // fp32-accurate 3x3 conv on the 16-bit matrix cores (conv_x6.hip); weights pre-split by prepare_conv_weights_split.
 size_t conv_split_weight_elems(int cin, int cout, int mode);
-void prepare_conv_weights_split(const float* w_oihw, int cin, int cout, int mode, unsigned short* out, float* inv_scale);
+void prepare_conv_weights_split(const float* w_oihw, int cin, int cout, int mode, unsigned short* out, SplitWeights* sw);
+// `sat` (all x6 conv launchers): fp16x3 range-guard counter for the outputs (dim_common.h), nullptr = unchecked
 int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
-                      int cout, int pool, int relu, hipStream_t s);
+                      int cout, int pool, int relu, hipStream_t s, unsigned* sat = nullptr);
 // conv1a (image -> 64 channels, weights [9][64]) computed on the fly inside the following 64 -> cout conv
 int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
-                              float* out, int batch, int H, int W, int cout, int pool, int relu, int planes_out, hipStream_t s);
+                              float* out, int batch, int H, int W, int cout, int pool, int relu, int planes_out, hipStream_t s,
+                              unsigned* sat = nullptr, unsigned* sat_image = nullptr);
 // fp16x3 only: input and / or output as pre-split fp16 planes (two NHWC fp16 tensors, h then l, in the bytes of the fp32 tensor)
 int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
-                             int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s);
+                             int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s, unsigned* sat = nullptr);
 int launch_planes_to_f32(const void* planes, size_t n, float* out, hipStream_t s);  // n = elements per plane
 int dim_presplit_activations();  // 1 (default): SuperPoint's conv-to-conv activations are stored pre-split (dim_tune_set key 5)
 int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)

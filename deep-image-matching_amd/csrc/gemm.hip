@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_kernel(GemmArgs a) {
   // ---- epilogue: bias, residual, ReLU; lanes 0..31 write 32 consecutive floats ----
   float* C = a.C + (size_t)z * a.strideC;
   const float* R = a.R ? a.R + (size_t)z * a.strideR : nullptr;
+  float vmax = 0.0f;  // fp16x3 range guard (dim_common.h) when the output feeds a split-precision kernel (a.sat != nullptr)
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = n0 + wn * 64 + n * 32 + lx;
@@ -151,9 +152,11 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_kernel(GemmArgs a) {
         if (a.relu == 1) v = fmaxf(v, 0.0f);
         else if (a.relu == 2) v = v <= 0.0f ? (expf(v) - 1.0f) * 1.7580993408473768599402175208123f : v * 1.0507009873554804934193349852946f;
         C[(size_t)row * a.ldc + col] = v;
+        vmax = fmaxf(vmax, fabsf(v));
       }
     }
   }
+  sat_report(a.sat, vmax);
 }
 }  // namespace
 

@@ -14,6 +14,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <vector>
+
 #include "dim_kernels.h"
 
 namespace {
@@ -118,13 +120,14 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
   // (residual? activation?) are hoisted, out-of-range lanes are masked at the store only.
   float* C = a.C + (size_t)z * a.strideC;
   const float* R = a.R ? a.R + (size_t)z * a.strideR : nullptr;
-  const float inv = a.inv_scale;
+  float vmax = 0.0f;  // fp16x3 range guard on what this thread stores (dim_common.h)
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int col = n0 + wn * 64 + n * 32 + lx;
     const bool colok = col < a.N;
     const int colc = colok ? col : a.N - 1;
     const float bv = a.bias ? a.bias[colc] : 0.0f;
+    const float inv = a.inv_ch[colc];  // per-column inverse weight scale (x activation scale)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int rbase = m0 + wm * (32 * MT) + m * 32;
@@ -148,10 +151,11 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + mfma_row(r, half);
-        if (colok && row < rows) C[(size_t)row * a.ldc + col] = v[r];
+        if (colok && row < rows) { C[(size_t)row * a.ldc + col] = v[r]; vmax = fmaxf(vmax, fabsf(v[r])); }
       }
     }
   }
+  if (MODE == 2) sat_report(a.sat, vmax);
 }
 }  // namespace
 
@@ -186,22 +190,30 @@ static unsigned short host_bf16_rne(float x) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
-size_t gemm_split_weight_elems(int K, int n_pad, int mode) { return (size_t)(mode == 2 ? 2 : 3) * n_pad * K; }
-void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, float* inv_scale) {
+static size_t gemm_split_piece_elems(int K, int n_pad, int mode) { return (size_t)(mode == 2 ? 2 : 3) * n_pad * K; }
+size_t gemm_split_weight_elems(int K, int n_pad, int mode) { return gemm_split_piece_elems(K, n_pad, mode) + 2 * (size_t)n_pad; }
+void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, SplitWeights* sw) {
   const int NB = n_pad / 32, KS = K / 16, npl = mode == 2 ? 2 : 3;
-  float wscale = 1.0f;
-  *inv_scale = 1.0f;
-  if (mode == 2) {
-    float mx = 0.f;
-    for (size_t i = 0; i < (size_t)K * N; ++i) mx = fmaxf(mx, fabsf(w_kn[i]));
-    int e = 0;
-    if (mx > 0.f) { frexpf(mx, &e); wscale = ldexpf(1.0f, 14 - e); }
-    *inv_scale = 1.0f / (wscale * DIM_F16_ACT_SCALE);
-  }
+  sw->mode = mode; sw->n_pad = n_pad; sw->scale_off = gemm_split_piece_elems(K, n_pad, mode);
   for (size_t i = 0; i < gemm_split_weight_elems(K, n_pad, mode); ++i) out[i] = 0;
+  // per-column (= output feature) power-of-two scale: max|w[:, n]| lands in [8192, 16384); inverse scales in the tail
+  std::vector<float> wsc(n_pad, 1.0f);
+  float* inv = (float*)(out + sw->scale_off);
+  for (int n = 0; n < n_pad; ++n) {
+    float inv_n = 1.0f;
+    if (mode == 2) {
+      float mx = 0.f;
+      if (n < N)
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, fabsf(w_kn[(size_t)k * N + n]));
+      int e = 0;
+      if (mx > 0.f && mx < INFINITY) { frexpf(mx, &e); wsc[n] = ldexpf(1.0f, 14 - e); }
+      inv_n = 1.0f / (wsc[n] * DIM_F16_ACT_SCALE);
+    }
+    memcpy(&inv[n], &inv_n, 4);
+  }
   for (int k = 0; k < K; ++k)
     for (int n = 0; n < N; ++n) {
-      float x = w_kn[(size_t)k * N + n] * wscale;
+      float x = w_kn[(size_t)k * N + n] * wsc[n];
       const int nb = n / 32, j = n % 32, ks = k / 16, hf = (k % 16) / 8, e = k % 8;
       for (int p = 0; p < npl; ++p) {
         unsigned short bits;

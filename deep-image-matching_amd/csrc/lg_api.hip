@@ -59,7 +59,7 @@ int upload_x3(dim_lg* h, SplitWeights* dst, const std::vector<float>& w_kn, int 
   const int n_pad = (N + 127) / 128 * 128;
   for (int mode = 1; mode <= 2; ++mode) {
     std::vector<unsigned short> host(gemm_split_weight_elems(K, n_pad, mode));
-    split_weights(w_kn.data(), K, N, n_pad, mode, host.data(), &dst[mode].inv_scale);
+    split_weights(w_kn.data(), K, N, n_pad, mode, host.data(), &dst[mode]);
     unsigned short* d = nullptr;
     if (dev_alloc(h, &d, host.size()) != 0) return -1;
     if (hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
@@ -211,18 +211,22 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
   const long long s256 = (long long)N * 256, s512 = (long long)N * 512, s768 = (long long)N * 768;
   const bool early = h->cfg.depth_confidence > 0, prune = h->cfg.width_confidence > 0;  // LGN:480-481
 #define LG_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
-  LG_RUN(launch_lg_init(st, kpts_tab_dev, desc_tab_dev, n_tab_dev, size_tab_dev, pair_idx_dev, cap, h->input_dim, h->Wr,
-                        h->input_dim == 256 ? 1 : 0, s));
   const int pmode = dim_precision_mode();  // 2 fp16x3 (default) / 1 bf16x6: fp32-accurate products on the 16-bit matrix cores; 0 fp32 MFMA
   const bool x6 = pmode != 0;
+  // fp16x3 range guard (dim_common.h): every producer of a value that a later split consumes reports max|x| > 4094
+  auto sat = [&](int site) -> unsigned* { return pmode == 2 ? dim_sat_counter(site) : nullptr; };
+  st.sat_qkv = sat(DIM_SAT_LG_QKV); st.sat_ffn = sat(DIM_SAT_LG_FFN);
+  LG_RUN(launch_lg_init(st, kpts_tab_dev, desc_tab_dev, n_tab_dev, size_tab_dev, pair_idx_dev, cap, h->input_dim, h->Wr,
+                        h->input_dim == 256 ? 1 : 0, sat(DIM_SAT_LG_INPUT), s));
   const bool fold = x6 && dim_fold_out_proj();  // split modes: out_proj folded into ffn.0 (one GEMM less per block)
   auto gemm_items = [&](const float* A, int lda, long long sA, const float* A1, int lda1, long long sA1, int ksplit,
                         const float* B, const SplitWeights* Bx, int ldb, const float* bias, const float* R, float* C, int ldc,
-                        long long sC, int Nn, int K, int flag_eq) -> int {
+                        long long sC, int Nn, int K, int flag_eq, unsigned* sat_ctr = nullptr) -> int {
     GemmArgs g;
     g.A0 = A; g.lda0 = lda; g.strideA0 = sA; g.A1 = A1; g.lda1 = lda1; g.strideA1 = sA1; g.ksplit = ksplit;
     g.B = B; g.ldb = ldb; g.bias = bias; g.R = R; g.ldr = ldc; g.strideR = sC; g.C = C; g.ldc = ldc; g.strideC = sC;
     g.M = N; g.N = Nn; g.K = K; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = flag_eq;
+    g.sat = sat_ctr;
     if (x6) { g.set_split(Bx[pmode]); return launch_gemm_x6(g, I, s); }
     return launch_gemm(g, I, s);
   };
@@ -230,13 +234,13 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     GemmArgs g;
     g.A0 = desc_tab_dev; g.lda0 = h->input_dim; g.strideA0 = (long long)cap * h->input_dim; g.a_idx = pair_idx_dev;
     g.B = h->inproj_w; g.ldb = 256; g.bias = h->inproj_b; g.C = st.desc; g.ldc = 256; g.strideC = s256;
-    g.M = N; g.N = 256; g.K = h->input_dim; g.rows = st.n_cur;
+    g.M = N; g.N = 256; g.K = h->input_dim; g.rows = st.n_cur; g.sat = sat(DIM_SAT_LG_INPUT);
     LG_RUN(launch_gemm(g, I, s));
   }
   for (int i = 0; i < Lr; ++i) {
     const LayerW& w = h->L[i];
     // ---- self block (LGN:146-159) ----
-    LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.qkv_w, w.qkv_x, 768, w.qkv_b, nullptr, st.qkv, 768, s768, 768, 256, 0));
+    LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.qkv_w, w.qkv_x, 768, w.qkv_b, nullptr, st.qkv, 768, s768, 768, 256, 0, st.sat_qkv));
     if (!x6) LG_RUN(launch_lg_rotary(st, s));  // the bf16x6 attention applies the rotary embedding while it loads q / pre-splits k
     dim_prof_begin(DIM_PROF_LG_SELF_ATTN, s);
     LG_RUN(launch_lg_attention(st, 0, s));
@@ -248,9 +252,9 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
       LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.sffn0_w, w.sffn0_x, 512, w.sffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
     }
     LG_RUN(launch_lg_ln_gelu(st, w.sln_w, w.sln_b, s));
-    LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.sffn3_w, w.sffn3_x, 256, w.sffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0));
+    LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.sffn3_w, w.sffn3_x, 256, w.sffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0, sat(DIM_SAT_LG_DESC)));
     // ---- cross block (LGN:186-211) ----
-    LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.cqkv_w, w.cqkv_x, 512, w.cqkv_b, nullptr, st.qkv, 768, s768, 512, 256, 0));
+    LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.cqkv_w, w.cqkv_x, 512, w.cqkv_b, nullptr, st.qkv, 768, s768, 512, 256, 0, st.sat_qkv));
     dim_prof_begin(DIM_PROF_LG_CROSS_ATTN, s);
     LG_RUN(launch_lg_attention(st, 1, s));
     dim_prof_end(DIM_PROF_LG_CROSS_ATTN, s);
@@ -261,7 +265,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
       LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.cffn0_w, w.cffn0_x, 512, w.cffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
     }
     LG_RUN(launch_lg_ln_gelu(st, w.cln_w, w.cln_b, s));
-    LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.cffn3_w, w.cffn3_x, 256, w.cffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0));
+    LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.cffn3_w, w.cffn3_x, 256, w.cffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0, sat(DIM_SAT_LG_DESC)));
     // ---- adaptive depth / width (LGN:494-516) ----
     const bool last = (i == Lr - 1);
     if (!last && (early || prune))

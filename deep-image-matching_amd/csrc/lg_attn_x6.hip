@@ -33,6 +33,7 @@ struct AttnArgs6 {
   int nmax, tiles;
   int splits;            // key range cut into `splits` parts per (query block, head, item): small batches only
   float* part;           // [items][4][nmax][splits][PART] partial (unnormalised O, running max, running sum)
+  unsigned* sat;         // fp16x3 range guard on the rotated K (the rotation can grow |k| by sqrt 2) and on V
 };
 constexpr int PART = 68;   // 64 output dims + m + l, padded to a 16-byte multiple
 
@@ -71,8 +72,10 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
       }
     }
     unsigned pc[4][NPL];
+    float vmax = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) S::split(x[2 * i], x[2 * i + 1], S::act_scale(), pc[i]);
+    for (int i = 0; i < 4; ++i) { S::split(x[2 * i], x[2 * i + 1], S::act_scale(), pc[i]); vmax = sat_track(vmax, x[2 * i], x[2 * i + 1]); }
+    if (MODE == 2) sat_report(a.sat, vmax);
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) img[(pl * 8 + blk) * 32 + key] = u32x4{pc[0][pl], pc[1][pl], pc[2][pl], pc[3][pl]};
   }
@@ -298,6 +301,7 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s) {
   a.o = st.ctx; a.ldo = 256; a.so = (long long)st.nmax * 256;
   a.n = st.n_cur; a.done = st.done; a.cross = cross;
   a.scale = 0.125f;
+  a.sat = st.sat_qkv;
   a.enc = st.enc; a.kv_img = (u32x4*)st.kv_img; a.nmax = st.nmax; a.tiles = cdiv(st.nmax, 32);
   // small batches leave most CUs idle and make every workgroup walk all key tiles alone: cut the key range
   const int wgs = cdiv(st.nmax, 128) * 4 * st.n_items;

@@ -32,11 +32,12 @@ struct LgState {  // device pointers owned by the handle
   int* cnt_lt;    // [pairs]
   float* tdesc; float* tenc; int* tind;  // compaction scratch
   void* kv_img;   // [items][4][ceil(nmax/32)][1536 x 16 B] pre-split K|V tile images (split-precision attention)
+  unsigned* sat_qkv = nullptr; unsigned* sat_ffn = nullptr;  // fp16x3 range-guard counters (dim_common.h), set per call
   float* attn_part; int attn_part_items;  // scratch of the key-split attention used for small batches ([items][4][nmax][4][68])
 };
 
 int launch_lg_init(const LgState& st, const float* kpts_tab, const float* desc_tab, const int* n_tab, const float* size_tab,
-                   const int* pair_idx, int cap, int in_dim, const float* Wr, int copy_desc, hipStream_t s);
+                   const int* pair_idx, int cap, int in_dim, const float* Wr, int copy_desc, unsigned* sat, hipStream_t s);
 int launch_lg_rotary(const LgState& st, hipStream_t s);
 int launch_lg_attention(const LgState& st, int cross, hipStream_t s);      // dispatches on dim_precision_mode()
 int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s);   // bf16x6 variant (lg_attn_x6.hip)

@@ -19,7 +19,7 @@ __device__ __forceinline__ float logsigmoidf_(float x) { return fminf(x, 0.0f) -
 __global__ __launch_bounds__(256) void lg_init_kernel(LgState st, const float* __restrict__ kpts_tab,
                                                       const float* __restrict__ desc_tab, const int* __restrict__ n_tab,
                                                       const float* __restrict__ size_tab, const int* __restrict__ pair_idx,
-                                                      int cap, int in_dim, const float* __restrict__ Wr, int copy_desc) {
+                                                      int cap, int in_dim, const float* __restrict__ Wr, int copy_desc, unsigned* sat) {
   const int item = blockIdx.y;
   const int img = pair_idx ? pair_idx[item] : item;
   const int n = min(n_tab[img], st.nmax);
@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void lg_init_kernel(LgState st, const float* _
   if (copy_desc) {  // input_dim == 256: Identity input_proj (LGN:363-364)
     const float4* src = (const float4*)(desc_tab + ((size_t)img * cap + pt) * in_dim);
     float4* dst = (float4*)(st.desc + row * 256);
-    dst[j] = src[j];
-    dst[j + 32] = src[j + 32];
+    const float4 a = src[j], b = src[j + 32];
+    dst[j] = a;
+    dst[j + 32] = b;
+    sat_report(sat, fmaxf(sat_track(sat_track(0.0f, a.x, a.y), a.z, a.w), sat_track(sat_track(0.0f, b.x, b.y), b.z, b.w)));
   }
 }
 
@@ -98,6 +100,10 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_kernel(LgState st, const float
   }
   *(float4*)(p + lane * 4) = make_float4(x[0], x[1], x[2], x[3]);
   *(float4*)(p + 256 + lane * 4) = make_float4(x[4], x[5], x[6], x[7]);
+  float vmax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) vmax = sat_track(vmax, x[i], x[i + 1]);
+  sat_report(st.sat_ffn, vmax);
 }
 
 // ---------------------------------------------------------------------------
@@ -423,9 +429,9 @@ __global__ __launch_bounds__(1024) void lg_finalize_kernel(LgState st, int n_lay
 
 // ---------------------------------------------------------------------------
 int launch_lg_init(const LgState& st, const float* kpts_tab, const float* desc_tab, const int* n_tab, const float* size_tab,
-                   const int* pair_idx, int cap, int in_dim, const float* Wr, int copy_desc, hipStream_t s) {
+                   const int* pair_idx, int cap, int in_dim, const float* Wr, int copy_desc, unsigned* sat, hipStream_t s) {
   hipLaunchKernelGGL(lg_init_kernel, dim3(cdiv(st.nmax, 8), st.n_items), dim3(256), 0, s, st, kpts_tab, desc_tab, n_tab,
-                     size_tab, pair_idx, cap, in_dim, Wr, copy_desc);
+                     size_tab, pair_idx, cap, in_dim, Wr, copy_desc, sat);
   DIM_LAUNCH_CHECK();
   return 0;
 }

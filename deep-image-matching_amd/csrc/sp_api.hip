@@ -7,6 +7,7 @@
 // un-normalised in HBM and is normalised only at the <= 4 cells each keypoint
 // touches (sample_desc_kernel), which is algebraically the reference's
 // normalise-then-sample (SPN:215,218-221).
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -25,6 +26,7 @@ struct dim_sp {
   float *a1, *b1, *a2, *b2, *a3, *b3, *a4, *x, *pa, *logits, *da, *dd, *smap, *nms, *cand_score;
   int *cand_idx, *rowcount, *rowoff, *ncand;
   int last_h, last_w, last_batch;
+  float conv1a_bound; // max over channels of sum|w1a| + |b1a|: bound on conv1a's outputs for |image| <= 1 (fp16x3 range guard)
   bool x_is_planes;   // the last extract stored the encoder output as pre-split planes
   float* x_dbg;       // fp32 copy of it, built on request by dim_sp_debug_buffers
   std::vector<void*> allocs;
@@ -82,7 +84,7 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
       for (int mode = 1; mode <= 2; ++mode) {
         std::vector<unsigned short> hx(conv_split_weight_elems(ci, co, mode));
         SplitWeights& sw = h->wsp[mode][l];
-        prepare_conv_weights_split(w->conv_w[l], ci, co, mode, hx.data(), &sw.inv_scale);
+        prepare_conv_weights_split(w->conv_w[l], ci, co, mode, hx.data(), &sw);
         unsigned short* d = nullptr;
         SP_TRY(dev_alloc(h, &d, hx.size()));
         if (hipMemcpy(d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
@@ -97,7 +99,7 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
       for (int mode = 1; mode <= 2; ++mode) {
         std::vector<unsigned short> hx(gemm_split_weight_elems(ci, n_pad, mode));
         SplitWeights& sw = h->wsp[mode][l];
-        split_weights(kn.data(), ci, co, n_pad, mode, hx.data(), &sw.inv_scale);
+        split_weights(kn.data(), ci, co, n_pad, mode, hx.data(), &sw);
         unsigned short* d = nullptr;
         SP_TRY(dev_alloc(h, &d, hx.size()));
         if (hipMemcpy(d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
@@ -110,6 +112,12 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
     memcpy(hb.data(), w->conv_b[l], co * sizeof(float));
     SP_TRY(dev_alloc(h, &h->bias[l], hb.size()));
     if (hipMemcpy(h->bias[l], hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("bias upload failed"); dim_sp_destroy(h); return -1; }
+  }
+  h->conv1a_bound = 0.0f;
+  for (int o = 0; o < 64; ++o) {
+    float sum = fabsf(w->conv_b[0][o]);
+    for (int t = 0; t < 9; ++t) sum += fabsf(w->conv_w[0][o * 9 + t]);
+    h->conv1a_bound = fmaxf(h->conv1a_bound, sum);
   }
   // ---- activations ----
   const size_t B = max_batch, H = max_h, W = max_w;
@@ -151,8 +159,13 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
 #define SP_SITE(id, x) do { dim_prof_begin(id, s); SP_RUN(x); dim_prof_end(id, s); } while (0)
   const int pmode = dim_precision_mode();  // 2 (default) fp16x3 / 1 bf16x6: fp32-accurate products on the 16-bit matrix cores; 0: fp32 MFMA
   const bool x6 = pmode != 0;
+  // fp16x3 range guard (dim_common.h): producers of values that a later split consumes report max|x| > 4094
+  unsigned* sat_enc = pmode == 2 ? dim_sat_counter(DIM_SAT_SP_ENCODER) : nullptr;
+  unsigned* sat_head = pmode == 2 ? dim_sat_counter(DIM_SAT_SP_HEADS) : nullptr;
+  unsigned* sat_img = pmode == 2 ? dim_sat_counter(DIM_SAT_SP_IMAGE) : nullptr;
+  if (pmode == 2 && !(h->conv1a_bound <= DIM_F16_ACT_LIMIT)) dim_sat_host_bump(DIM_SAT_SP_IMAGE);  // conv1a's outputs may leave the range
   auto conv = [&](int l, const float* in, float* out, int Hh, int Ww, int ci, int co, int pool) -> int {
-    return x6 ? launch_conv3x3_x6(in, h->wsp[pmode][l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s)
+    return x6 ? launch_conv3x3_x6(in, h->wsp[pmode][l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s, l >= 8 ? sat_head : sat_enc)
               : launch_conv3x3(in, h->wk[l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, s);
   };
   // encoder (SPN:161-171)
@@ -160,10 +173,10 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   // each value is split once by its producer instead of ~1.3 x (cout / 64) times by its consumers
   const bool planes = pmode == 2 && dim_fuse_conv1a() && dim_presplit_activations();
   auto convp = [&](int l, const float* in, float* out, int Hh, int Ww, int ci, int co, int pool, int pin, int pout) -> int {
-    return launch_conv3x3_x6_planes(in, h->wsp[2][l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, pin, pout, s);
+    return launch_conv3x3_x6_planes(in, h->wsp[2][l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, pin, pout, s, l >= 8 ? sat_head : sat_enc);
   };
   if (x6 && dim_fuse_conv1a()) {  // conv1a evaluated inside conv1b's halo staging: its 64-channel full-resolution map never exists
-    SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_x6_fused1a(images_dev, h->wk[0], h->bias[0], h->wsp[pmode][1], h->bias[1], h->b1, batch, H, W, 64, 1, 1, planes ? 1 : 0, s));
+    SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_x6_fused1a(images_dev, h->wk[0], h->bias[0], h->wsp[pmode][1], h->bias[1], h->b1, batch, H, W, 64, 1, 1, planes ? 1 : 0, s, sat_enc, sat_img));
   } else {
     if (!h->a1) SP_RUN(dev_alloc(h, &h->a1, (size_t)h->max_batch * h->max_h * h->max_w * 64));
     SP_SITE(DIM_PROF_SP_CONV1A, launch_conv1a(images_dev, h->wk[0], h->bias[0], h->a1, batch, H, W, s));

@@ -54,8 +54,9 @@ class LightGlueHIP:
                     "pruning_min_kpts": -1}
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], conf: Optional[dict] = None, max_pairs: int = 1,
-                 max_kpts: int = 2048, device="cuda", lib=None):
+                 max_kpts: int = 2048, device="cuda", lib=None, on_saturation: str = "fallback"):
         self.conf = {**self.default_conf, **(conf or {})}
+        self.on_saturation = on_saturation  # fp16x3 range guard policy of __call__: "fallback" (bf16x6 re-run) | "raise" | "off"
         self.lib = lib if lib is not None else capi.load()
         self.device = torch.device(device)
         if lib is None and self.device.type != "cuda":
@@ -85,7 +86,8 @@ class LightGlueHIP:
                       float(self.conf["filter_threshold"]), int(self.conf["pruning_min_kpts"]))
         self.max_pairs = int(max_pairs)
         self._h = ctypes.c_void_p()
-        capi.check(self.lib, self.lib.dim_lg_create(ctypes.byref(w), ctypes.byref(c), self.max_pairs, int(max_kpts), ctypes.byref(self._h)))
+        with self._ctx():
+            capi.check(self.lib, self.lib.dim_lg_create(ctypes.byref(w), ctypes.byref(c), self.max_pairs, int(max_kpts), ctypes.byref(self._h)))
         self.nk = self.lib.dim_lg_max_kpts(self._h)
         del keep
 
@@ -99,6 +101,16 @@ class LightGlueHIP:
         if self.device.type == "cuda":
             return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         return None
+
+    def _ctx(self):
+        """The library launches on the CURRENT HIP device: make it the handle's."""
+        import contextlib
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
+
+    def match_batch_guarded(self, *a, logger=None, **k):
+        """match_batch under the fp16x3 range guard (capi.run_guarded): synchronises."""
+        with self._ctx():
+            return capi.run_guarded(self.lib, self._stream(), lambda: self.match_batch(*a, **k), "LightGlue", self.on_saturation, logger)
 
     @torch.no_grad()
     def match_batch(self, kpts_tab, desc_tab, n_tab, size_tab, pair_idx=None, n_pairs=None, dense=False, out=None):
@@ -125,11 +137,12 @@ class LightGlueHIP:
             }
         if dense:
             out["dense"] = torch.zeros(P, NK + 1, NK + 1, dtype=torch.float32, device=dev)
-        capi.check(self.lib, self.lib.dim_lg_match(
-            self._h, capi.ptr(kpts_tab), capi.ptr(desc_tab), capi.ptr(n_tab), capi.ptr(size_tab), int(cap),
-            capi.ptr(pair_idx), int(P), capi.ptr(out["matches"]), capi.ptr(out["scores"]), capi.ptr(out["n_matches"]),
-            capi.ptr(out["matches01"]), capi.ptr(out["mscores01"]), capi.ptr(out["stop"]), capi.ptr(out["prune01"]),
-            capi.ptr(out.get("dense")), self._stream()))
+        with self._ctx():
+            capi.check(self.lib, self.lib.dim_lg_match(
+                self._h, capi.ptr(kpts_tab), capi.ptr(desc_tab), capi.ptr(n_tab), capi.ptr(size_tab), int(cap),
+                capi.ptr(pair_idx), int(P), capi.ptr(out["matches"]), capi.ptr(out["scores"]), capi.ptr(out["n_matches"]),
+                capi.ptr(out["matches01"]), capi.ptr(out["mscores01"]), capi.ptr(out["stop"]), capi.ptr(out["prune01"]),
+                capi.ptr(out.get("dense")), self._stream()))
         return out
 
     @torch.no_grad()
@@ -148,7 +161,7 @@ class LightGlueHIP:
         dt[0, :m], dt[1, :n] = d0["descriptors"][0].to(dev, torch.float32), d1["descriptors"][0].to(dev, torch.float32)
         nt = torch.tensor([m, n], dtype=torch.int32, device=dev)
         st = torch.stack([d0["image_size"][0].float(), d1["image_size"][0].float()]).to(dev).contiguous()
-        o = self.match_batch(kt, dt, nt, st, n_pairs=1, dense=dense)
+        o = self.match_batch_guarded(kt, dt, nt, st, n_pairs=1, dense=dense)
         S = int(o["n_matches"][0].item())
         res = {
             "matches0": o["matches01"][0, 0, :m].long()[None], "matches1": o["matches01"][0, 1, :n].long()[None],

@@ -93,7 +93,7 @@ class LowresPairSelector:
                 self._sp_hw = (max(h, self._sp_hw[0], self.resize_max), max(w, self._sp_hw[1], self.resize_max))
                 self._sp = SuperPointHIP(self._sp_sd, LOWRES_SP_CONF, max_batch=1, max_hw=self._sp_hw, capacity=cap,
                                          device=self.device, lib=self.lib)
-            kp, _, de, nk = self._sp.extract_batch(small[None].contiguous())
+            kp, _, de, nk = self._sp.extract_batch_guarded(small[None].contiguous())
             kt[i], dt[i], nt[i] = kp[0], de[0], nk[0]
             k = kp[0, : int(nk[0].item())]
             if k.numel():  # no image_size in the reference's call: LightGlue uses the keypoint extent (LGN:26-27)
@@ -108,12 +108,17 @@ class LowresPairSelector:
         P = len(pairs)
         mine = list(range(self.rank, P, self.world))
         counts = torch.zeros(P, dtype=torch.int32, device=self.device)
-        out = None
-        for s in range(0, len(mine), self.pair_batch):
-            chunk = mine[s:s + self.pair_batch]
-            pidx = torch.tensor([pairs[c] for c in chunk], dtype=torch.int32, device=self.device).contiguous()
-            out = self._lg.match_batch(kt, dt, nt, st, pair_idx=pidx, n_pairs=len(chunk), out=out)  # the first chunk is the largest
-            counts[torch.tensor(chunk, device=self.device)] = out["n_matches"][: len(chunk)]
+
+        def run():  # all chunks are enqueued back to back; the fp16x3 range guard is read once for the whole shard
+            out = None
+            for s in range(0, len(mine), self.pair_batch):
+                chunk = mine[s:s + self.pair_batch]
+                pidx = torch.tensor([pairs[c] for c in chunk], dtype=torch.int32, device=self.device).contiguous()
+                out = self._lg.match_batch(kt, dt, nt, st, pair_idx=pidx, n_pairs=len(chunk), out=out)  # the first chunk is the largest
+                counts[torch.tensor(chunk, device=self.device)] = out["n_matches"][: len(chunk)]
+
+        with self._lg._ctx():
+            capi.run_guarded(self.lib, self._stream(), run, "matching_lowres", self._lg.on_saturation)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)  # shards are disjoint: the sum is the gather

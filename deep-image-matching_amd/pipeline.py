@@ -54,6 +54,15 @@ def _all_gather_cat(t: torch.Tensor, world: int) -> torch.Tensor:
     return out
 
 
+def _guarded(net, fn, what: str):
+    """fn() under the fp16x3 range guard of ``net`` (capi.run_guarded): one counter read-back per phase; a phase that
+    left the exact range of the fp16 split is repeated in bf16x6."""
+    from . import capi
+
+    with net._ctx():
+        return capi.run_guarded(net.lib, net._stream(), fn, what, getattr(net, "on_saturation", "fallback"))
+
+
 class PairMatchingPipeline:
     """extractor: SuperPointHIP, matcher: LightGlueHIP (both resident on this rank's device)."""
 
@@ -75,10 +84,14 @@ class PairMatchingPipeline:
         de = torch.zeros(per, cap, 256, dtype=torch.float32, device=dev)
         n = torch.zeros(per, dtype=torch.int32, device=dev)
         B = self.ext.max_batch
-        for s in range(0, len(mine), B):
-            idx = mine[s:s + B]
-            k_, s_, d_, n_ = self.ext.extract_batch(images[idx.to(dev)].contiguous())
-            kp[s:s + len(idx)], sc[s:s + len(idx)], de[s:s + len(idx)], n[s:s + len(idx)] = k_, s_, d_, n_
+
+        def run():  # every batch of the shard is enqueued back to back; the fp16x3 range guard is read once per phase
+            for s in range(0, len(mine), B):
+                idx = mine[s:s + B]
+                k_, s_, d_, n_ = self.ext.extract_batch(images[idx.to(dev)].contiguous())
+                kp[s:s + len(idx)], sc[s:s + len(idx)], de[s:s + len(idx)], n[s:s + len(idx)] = k_, s_, d_, n_
+
+        _guarded(self.ext, run, "pipeline extraction")
         # phase 2: one all-gather per table; slot (r, j) holds image j*world + r
         kp_g, sc_g, de_g, n_g = (_all_gather_cat(t, self.world) for t in (kp, sc, de, n))
         if self.world > 1:
@@ -106,14 +119,18 @@ class PairMatchingPipeline:
         mt = torch.zeros(per, NK, 2, dtype=torch.int64, device=dev)
         ms = torch.zeros(per, NK, dtype=torch.float32, device=dev)
         my_pairs = pairs[mine].to(dev, torch.int32).contiguous()
-        for s in range(0, len(mine), B):
-            pp = my_pairs[s:s + B].contiguous()
-            o = self.mat.match_batch(kp, de, n, size, pair_idx=pp)
-            b = pp.shape[0]
-            live = torch.arange(NK, device=dev)[None, :] < o["n_matches"][:, None]  # rows beyond n_matches are unspecified
-            cnt[s:s + b] = o["n_matches"]
-            mt[s:s + b] = torch.where(live[..., None], o["matches"], torch.zeros_like(o["matches"]))
-            ms[s:s + b] = torch.where(live, o["scores"], torch.zeros_like(o["scores"]))
+
+        def run():
+            for s in range(0, len(mine), B):
+                pp = my_pairs[s:s + B].contiguous()
+                o = self.mat.match_batch(kp, de, n, size, pair_idx=pp)
+                b = pp.shape[0]
+                live = torch.arange(NK, device=dev)[None, :] < o["n_matches"][:, None]  # rows beyond n_matches are unspecified
+                cnt[s:s + b] = o["n_matches"]
+                mt[s:s + b] = torch.where(live[..., None], o["matches"], torch.zeros_like(o["matches"]))
+                ms[s:s + b] = torch.where(live, o["scores"], torch.zeros_like(o["scores"]))
+
+        _guarded(self.mat, run, "pipeline matching")
         cnt_g, mt_g, ms_g = (_all_gather_cat(t, self.world) for t in (cnt, mt, ms))
         if self.world > 1:
             order = torch.arange(self.world * per, device=dev).reshape(self.world, per).t().reshape(-1)[:P]

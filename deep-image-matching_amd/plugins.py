@@ -20,6 +20,7 @@ from typing import Optional
 import numpy as np
 import torch
 
+from . import capi
 from . import weights as _weights
 from .aliked_hip import AlikedHIP
 from .lightglue_hip import LightGlueHIP
@@ -60,26 +61,37 @@ except Exception:  # noqa: BLE001
         _role = "matcher"
 
 
-_ARITHMETIC = {"fp16x3": 2, "bf16x6": 1, "fp32": 0}
-
-
 def _apply_arithmetic(conf: dict, lib) -> None:
     """Optional plugin option ``arithmetic``: "fp16x3" (library default: 2-way fp16 splits x 3 MFMA terms; activations
-    exact up to |x| = 4094), "bf16x6" (exact 3-way bf16 splits x 6 terms, no range limit) or "fp32" (plain fp32 MFMA).
+    exact up to |x| = 4094 — guarded: a call that leaves the range is repeated in bf16x6, option ``on_saturation``),
+    "bf16x6" (exact 3-way bf16 splits x 6 terms, no range limit) or "fp32" (plain fp32 MFMA).
     The switch is process-wide (dim_tune_set key 1), like the reference's module-global sampler patch (Q3)."""
     name = (conf or {}).get("arithmetic")
     if name is None:
         return
-    if name not in _ARITHMETIC:
-        raise ValueError(f"arithmetic must be one of {sorted(_ARITHMETIC)}, got {name!r}")
-    from . import capi
-    (lib if lib is not None else capi.load()).dim_tune_set(1, _ARITHMETIC[name])
+    if name not in capi.ARITHMETIC:
+        raise ValueError(f"arithmetic must be one of {sorted(capi.ARITHMETIC)}, got {name!r}")
+    capi.set_arithmetic(lib, name)
 
 
-def _require_gpu(device: str, what: str):
-    if str(device) != "cuda" and not str(device).startswith("cuda"):
+def _saturation_policy(conf: dict) -> str:
+    pol = (conf or {}).get("on_saturation", "fallback")
+    if pol not in ("fallback", "raise", "off"):
+        raise ValueError(f"on_saturation must be 'fallback', 'raise' or 'off', got {pol!r}")
+    return pol
+
+
+def _resolve_device(device, what: str):
+    """The plugin's device: the reference's ``self._device`` ("cuda" unless general.force_cpu).  There is no CPU
+    path; the CPU tests install the emulator build through capi.install(), which also names the device."""
+    forced = capi.installed_device()
+    if forced is not None:
+        return forced
+    kind = getattr(device, "type", str(device))
+    if not str(kind).startswith("cuda"):
         raise RuntimeError(f"{what}: the MI355X plugin has no CPU path (device={device!r}); "
                            "use the reference's own plugin when general.force_cpu is set")
+    return device
 
 
 class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
@@ -100,43 +112,59 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
     features_as_half = True
     detection_noise = 2.0
 
-    def __init__(self, config, _lib=None, _device=None):
+    def __init__(self, config):
         super().__init__(config)
-        self._lib = _lib
-        if _device is not None:
-            self._device = _device
-        if _lib is None:
-            _require_gpu(self._device, "SuperPointExtractor")
+        self._lib = capi.load()
+        self._device = _resolve_device(self._device, "SuperPointExtractor")
         cfg = self.config.get("extractor")
-        _apply_arithmetic(cfg, _lib)
+        _apply_arithmetic(cfg, self._lib)
+        self._on_sat = _saturation_policy(cfg)
         path = cfg.get("weights_path") or os.environ.get("DIM_SUPERPOINT_WEIGHTS")
-        if path is None:
-            logger.warning("SuperPoint: no weights_path / DIM_SUPERPOINT_WEIGHTS given - using seeded SYNTHETIC weights "
-                           "(the official superpoint_v1.pth is a download, SPN:110)")
-        self._sd = _weights.load_superpoint_state_dict(path)
+        if path is None and cfg.get("allow_synthetic_weights"):
+            logger.warning("SuperPoint: running on seeded SYNTHETIC weights (allow_synthetic_weights) - test / benchmark use only")
+        self._sd = _weights.load_superpoint_state_dict(path, allow_synthetic=bool(cfg.get("allow_synthetic_weights", False)))
         self._net_cfg = {k: cfg[k] for k in ("nms_radius", "keypoint_threshold", "max_keypoints", "remove_borders", "fix_sampling")}
         self._net: Optional[SuperPointHIP] = None
         self._net_hw = (0, 0)
+        self._min_capacity = 0  # raised when a keep-all extraction overflowed the slot (see _regrow)
+
+    def _capacity(self, H: int, W: int) -> int:
+        """Slot size per image.  max_keypoints > 0: exactly that.  Keep-all mode (-1, the plugin default): a first
+        guess of 4 keypoints per 8x8 cell; a call that yields more candidates is repeated with a larger slot
+        (_regrow), so nothing is ever dropped — the reference returns every keypoint (SPN:183-207)."""
+        mk = self._net_cfg["max_keypoints"]
+        return mk if mk > 0 else max(self._min_capacity, min(4096 * 4, max(1024, (H // 8) * (W // 8) * 4)))
 
     def _ensure(self, H: int, W: int):
-        if self._net is None or H > self._net_hw[0] or W > self._net_hw[1]:
+        cap = self._capacity(H, W)
+        if self._net is None or H > self._net_hw[0] or W > self._net_hw[1] or cap > self._net.capacity:
             hw = (max(H, self._net_hw[0]), max(W, self._net_hw[1]))
-            mk = self._net_cfg["max_keypoints"]
-            cap = mk if mk > 0 else min(4096 * 4, max(1024, (H // 8) * (W // 8) * 4))
             self._net = SuperPointHIP(self._sd, self._net_cfg, max_batch=1, max_hw=hw, capacity=cap,
-                                      device=self._device, lib=self._lib)
+                                      device=self._device, lib=self._lib, on_saturation=self._on_sat)
             self._net_hw = hw
 
     def _ensure_batch(self, H: int, W: int, batch: int):
         """Separate resident handle for batched tile extraction (tiling.BatchedTilingMixin)."""
         key = getattr(self, "_tile_key", None)
-        if key is None or H > key[0] or W > key[1] or batch > key[2]:
-            mk = self._net_cfg["max_keypoints"]
-            cap = mk if mk > 0 else min(4096 * 4, max(1024, (H // 8) * (W // 8) * 4))
+        cap = self._capacity(H, W)
+        if key is None or H > key[0] or W > key[1] or batch > key[2] or cap > self._tile_net.capacity:
             self._tile_net = SuperPointHIP(self._sd, self._net_cfg, max_batch=batch, max_hw=(H, W), capacity=cap,
-                                           device=self._device, lib=self._lib)
+                                           device=self._device, lib=self._lib, on_saturation=self._on_sat)
             self._tile_key = (H, W, batch)
         return self._tile_net
+
+    def _regrow(self, net: SuperPointHIP, batch: int) -> bool:
+        """Keep-all mode: True when the last call produced more candidates than the slot holds (the library then kept
+        only the first `capacity` in row-major order).  The next _ensure / _ensure_batch builds a larger handle."""
+        if self._net_cfg["max_keypoints"] > 0:
+            return False
+        worst = int(net.candidate_counts(batch).max())
+        if worst <= net.capacity:
+            return False
+        self._min_capacity = 1 << (worst - 1).bit_length()
+        logger.warning("SuperPoint: %d keypoints exceed the slot of %d - repeating the extraction with %d", worst, net.capacity,
+                       self._min_capacity)
+        return True
 
     @torch.no_grad()
     def _extract(self, image: np.ndarray) -> dict:
@@ -147,6 +175,9 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
             raise ValueError("SuperPoint expects a single-channel image")
         self._ensure(image_.shape[-2], image_.shape[-1])
         feats = self._net(image_)
+        if self._regrow(self._net, 1):
+            self._ensure(image_.shape[-2], image_.shape[-1])
+            feats = self._net(image_)
         return {k: v.cpu().numpy() for k, v in feats.items()}
 
     def _frame2tensor(self, image: np.ndarray, device: str = "cuda"):
@@ -176,22 +207,19 @@ class AlikedExtractor(BatchedTilingMixin, _ExtractorBase):
     descriptor_size = 128
     features_as_half = True
 
-    def __init__(self, config, _lib=None, _device=None):
+    def __init__(self, config):
         super().__init__(config)
-        self._lib = _lib
-        if _device is not None:
-            self._device = _device
-        if _lib is None:
-            _require_gpu(self._device, "AlikedExtractor")
+        self._lib = capi.load()
+        self._device = _resolve_device(self._device, "AlikedExtractor")
         cfg = self.config.get("extractor")
         # ALIKED(**cfg) reads conf.model_name (default "aliked-n16", ALN:562-567); DIM's "model" key is ignored by the net
         self._net_cfg = {"model_name": cfg.get("model_name", "aliked-n16"), "max_num_keypoints": cfg["max_num_keypoints"],
                          "detection_threshold": cfg["detection_threshold"], "nms_radius": cfg["nms_radius"]}
         path = cfg.get("weights_path") or os.environ.get("DIM_ALIKED_WEIGHTS")
-        if path is None:
-            logger.warning("ALIKED: no weights_path / DIM_ALIKED_WEIGHTS given - using seeded SYNTHETIC weights "
-                           "(the real files are thirdparty/ALIKED/models/aliked-*.pth in the reference tree)")
-        self._sd = _weights.load_aliked_state_dict(path, model_name=self._net_cfg["model_name"])
+        if path is None and cfg.get("allow_synthetic_weights"):
+            logger.warning("ALIKED: running on seeded SYNTHETIC weights (allow_synthetic_weights) - test / benchmark use only")
+        self._sd = _weights.load_aliked_state_dict(path, model_name=self._net_cfg["model_name"],
+                                                   allow_synthetic=bool(cfg.get("allow_synthetic_weights", False)))
         self._net: Optional[AlikedHIP] = None
         self._net_hw = (0, 0)
 
@@ -265,32 +293,36 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
         "width_confidence": 0.99,
         "filter_threshold": 0.1,
         "weights": None,
+        # LGN:318-323,606-610: below this many keypoints the reference does not prune.  "auto" = what the reference
+        # uses on a GPU (1536 with flash attention, 1024 without); -1 = its CPU behaviour (always prune), which is
+        # what the CPU-generated parity goldens need.
+        "pruning_min_kpts": "auto",
     }
     required_inputs = []
     min_matches = 20
     max_feat_no_tiling = 200000
     _input_dims = {"superpoint": 256, "disk": 128, "aliked": 128, "sift": 128}  # LGN:331-349
 
-    def __init__(self, config, local_features="superpoint", _lib=None, _device=None) -> None:
+    def __init__(self, config, local_features="superpoint") -> None:
         self._localfeatures = local_features
         super().__init__(config)
-        self._lib = _lib
-        if _device is not None:
-            self._device = _device
-        if _lib is None:
-            _require_gpu(getattr(self._device, "type", self._device), "LightGlueMatcher")
+        self._lib = capi.load()
+        self._device = _resolve_device(self._device, "LightGlueMatcher")
         cfg = {**self._default_conf, **self.config.get("matcher", {})}
-        _apply_arithmetic(cfg, _lib)
+        _apply_arithmetic(cfg, self._lib)
+        self._on_sat = _saturation_policy(cfg)
         if cfg.get("mp"):
             logger.warning("LightGlue: mixed precision ('mp') is not implemented on the MI355X path; running fp32")
         self._conf = {k: cfg[k] for k in ("depth_confidence", "width_confidence", "filter_threshold")}
         self._conf["n_layers"] = int(cfg.get("n_layers", 9))
+        pm = cfg.get("pruning_min_kpts", "auto")
+        self._conf["pruning_min_kpts"] = (1536 if cfg.get("flash", True) else 1024) if pm == "auto" else int(pm)
         path = cfg.get("weights_path") or os.environ.get("DIM_LIGHTGLUE_WEIGHTS")
         in_dim = self._input_dims.get(local_features, 256)
-        if path is None:
-            logger.warning("LightGlue: no weights_path / DIM_LIGHTGLUE_WEIGHTS given - using seeded SYNTHETIC weights "
-                           "(the official %s_lightglue.pth is a download, LGN:327-328)", local_features)
-        self._sd = _weights.load_lightglue_state_dict(path, input_dim=in_dim, n_layers=self._conf["n_layers"])
+        if path is None and cfg.get("allow_synthetic_weights"):
+            logger.warning("LightGlue: running on seeded SYNTHETIC weights (allow_synthetic_weights) - test / benchmark use only")
+        self._sd = _weights.load_lightglue_state_dict(path, input_dim=in_dim, n_layers=self._conf["n_layers"],
+                                                      allow_synthetic=bool(cfg.get("allow_synthetic_weights", False)))
         self._net: Optional[LightGlueHIP] = None
         self._net_n = 0
         if self._localfeatures == "disk":
@@ -300,7 +332,8 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
         if self._net is None or n > self._net_n:
             self._net_n = max(256, 1 << (max(n, 1) - 1).bit_length())
             dev = self._device if isinstance(self._device, (str, torch.device)) else "cuda"
-            self._net = LightGlueHIP(self._sd, self._conf, max_pairs=1, max_kpts=self._net_n, device=dev, lib=self._lib)
+            self._net = LightGlueHIP(self._sd, self._conf, max_pairs=1, max_kpts=self._net_n, device=dev, lib=self._lib,
+                                     on_saturation=self._on_sat)
 
     def _ensure_pairs(self, n: int, pairs: int):
         """Batched instance for tile-pair matching (tile_matching.BatchedTileMatchingMixin)."""
@@ -309,7 +342,8 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
             self._net_b_n = max(256, 1 << (max(n, 1) - 1).bit_length(), getattr(self, "_net_b_n", 0))
             self._net_b_p = max(pairs, getattr(self, "_net_b_p", 0))
             dev = self._device if isinstance(self._device, (str, torch.device)) else "cuda"
-            self._net_b = LightGlueHIP(self._sd, self._conf, max_pairs=self._net_b_p, max_kpts=self._net_b_n, device=dev, lib=self._lib)
+            self._net_b = LightGlueHIP(self._sd, self._conf, max_pairs=self._net_b_p, max_kpts=self._net_b_n, device=dev, lib=self._lib,
+                                       on_saturation=self._on_sat)
         return self._net_b
 
     @torch.no_grad()

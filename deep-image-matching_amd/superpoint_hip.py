@@ -37,8 +37,9 @@ class SuperPointHIP:
                       "fix_sampling": False}
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[dict] = None, max_batch: int = 1,
-                 max_hw=(1024, 1024), capacity: Optional[int] = None, device="cuda", lib=None):
+                 max_hw=(1024, 1024), capacity: Optional[int] = None, device="cuda", lib=None, on_saturation: str = "fallback"):
         self.cfg = {**self.default_config, **(cfg or {})}
+        self.on_saturation = on_saturation  # fp16x3 range guard policy of __call__: "fallback" (bf16x6 re-run) | "raise" | "off"
         mk = self.cfg["max_keypoints"]
         if mk == 0 or mk < -1:
             raise ValueError('"max_keypoints" must be positive or "-1"')  # SPN:152-154
@@ -59,7 +60,7 @@ class SuperPointHIP:
         c = _SpConfig(int(self.cfg["nms_radius"]), float(self.cfg["keypoint_threshold"]), int(mk),
                       int(self.cfg["remove_borders"]), int(bool(self.cfg["fix_sampling"])))
         self._h = ctypes.c_void_p()
-        with torch.cuda.device(self.device) if self.device.type == "cuda" else _null():
+        with self._ctx():
             capi.check(self.lib, self.lib.dim_sp_create(ctypes.byref(w), ctypes.byref(c), self.max_batch, self.max_hw[0],
                                                         self.max_hw[1], self.capacity, ctypes.byref(self._h)))
         del keep
@@ -74,6 +75,25 @@ class SuperPointHIP:
         if self.device.type == "cuda":
             return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         return None
+
+    def _ctx(self):
+        """The library launches on the CURRENT HIP device: make it the handle's."""
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else _null()
+
+    def candidate_counts(self, batch: int) -> torch.Tensor:
+        """NMS survivors above threshold / border per image of the last call, BEFORE top-k / the capacity
+        cut (host int32 tensor; synchronises).  > capacity in keep-all mode (max_keypoints = -1) means the call
+        dropped keypoints the reference would return: re-create the handle with a larger capacity."""
+        p = ctypes.c_void_p()
+        capi.check(self.lib, self.lib.dim_sp_candidate_counts(self._h, ctypes.byref(p)))
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+            out = torch.empty(batch, dtype=torch.int32, device=self.device)
+            rc = ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(out.data_ptr()), p, ctypes.c_size_t(batch * 4), 3)
+            if rc != 0:
+                raise capi.DimHipError(f"hipMemcpy failed: {rc}")
+            return out.cpu()
+        return torch.frombuffer((ctypes.c_int32 * batch).from_address(p.value), dtype=torch.int32).clone()
 
     @torch.no_grad()
     def extract_batch(self, images: torch.Tensor, out=None):
@@ -91,16 +111,23 @@ class SuperPointHIP:
             sc = torch.empty(B, self.capacity, dtype=torch.float32, device=dev)
             de = torch.empty(B, self.capacity, 256, dtype=torch.float32, device=dev)
             n = torch.zeros(B, dtype=torch.int32, device=dev)
-        capi.check(self.lib, self.lib.dim_sp_extract(self._h, capi.ptr(images), B, H, W, capi.ptr(kp), capi.ptr(sc),
-                                                     capi.ptr(de), capi.ptr(n), self._stream()))
+        with self._ctx():
+            capi.check(self.lib, self.lib.dim_sp_extract(self._h, capi.ptr(images), B, H, W, capi.ptr(kp), capi.ptr(sc),
+                                                         capi.ptr(de), capi.ptr(n), self._stream()))
         return kp, sc, de, n
+
+    def extract_batch_guarded(self, images: torch.Tensor, out=None, logger=None):
+        """extract_batch under the fp16x3 range guard (capi.run_guarded): synchronises."""
+        with self._ctx():
+            return capi.run_guarded(self.lib, self._stream(), lambda: self.extract_batch(images, out=out), "SuperPoint",
+                                    self.on_saturation, logger)
 
     @torch.no_grad()
     def __call__(self, image: torch.Tensor) -> dict:
         """image [1,1,H,W] (the reference's input, SPN:158).  Returns the reference's dict
         for one image with tensors on the device: keypoints (N,2), scores (N,), descriptors (256,N)."""
         img = image.reshape(image.shape[-2], image.shape[-1])[None].contiguous().to(self.device, torch.float32)
-        kp, sc, de, n = self.extract_batch(img)
+        kp, sc, de, n = self.extract_batch_guarded(img)
         k = int(n[0].item())
         return {"keypoints": kp[0, :k], "scores": sc[0, :k], "descriptors": de[0, :k].t()}
 

@@ -119,7 +119,7 @@ class TilePreselector:
             self._sp_hw = (max(h, self._sp_hw[0], self.size), max(w, self._sp_hw[1], self.size))
             self._sp = SuperPointHIP(self._sp_sd, PRESELECTION_SP_CONF, max_batch=1, max_hw=self._sp_hw, capacity=4096,
                                      device=self.device, lib=self.lib)
-        kp, _, de, n = self._sp.extract_batch(small[None].contiguous())
+        kp, _, de, n = self._sp.extract_batch_guarded(small[None].contiguous(), logger=logger)
         ent = (kp, de, n, scale)
         self._cache[key] = ent
         while len(self._cache) > self._cache_size:
@@ -139,7 +139,7 @@ class TilePreselector:
             k = kp[: int(n.item())]
             sizes.append(1 + k.max(0).values - k.min(0).values if k.numel() else torch.ones(2, device=self.device))
         st = torch.stack(sizes).to(torch.float32).contiguous()
-        return self._lg.match_batch(kt, dt, nt, st, n_pairs=1)
+        return self._lg.match_batch_guarded(kt, dt, nt, st, n_pairs=1, logger=logger)
 
     def votes(self, key0: str, image0: np.ndarray, key1: str, image1: np.ndarray, origins0: Dict[int, Tuple[int, int]],
               origins1: Dict[int, Tuple[int, int]], tile_size) -> np.ndarray:
@@ -201,7 +201,7 @@ def match_tile_pairs_batched(net_for, features0: dict, features1: dict, tile_pai
     for s in range(0, len(tile_pairs), pair_batch):
         chunk = tile_pairs[s:s + pair_batch]
         pidx = torch.tensor([[row0[a], row1[b]] for a, b in chunk], dtype=torch.int32, device=dev).contiguous()
-        o = net.match_batch(kt_d, dt_d, nt_d, st_d, pair_idx=pidx, n_pairs=len(chunk))
+        o = net.match_batch_guarded(kt_d, dt_d, nt_d, st_d, pair_idx=pidx, n_pairs=len(chunk), logger=logger)
         cnt = o["n_matches"].cpu().numpy()
         m = o["matches"].cpu().numpy()
         for j, (a, b) in enumerate(chunk):
@@ -241,10 +241,10 @@ class BatchedTileMatchingMixin:
             import os
             sp_path = self.config["general"].get("preselection_superpoint_weights") or os.environ.get("DIM_SUPERPOINT_WEIGHTS")
             lg_path = self.config["general"].get("preselection_lightglue_weights") or os.environ.get("DIM_LIGHTGLUE_WEIGHTS")
-            if sp_path is None or lg_path is None:
-                logger.warning("tile preselection: no SuperPoint/LightGlue weights given - using seeded SYNTHETIC weights")
+            synth = bool(self.config["general"].get("allow_synthetic_weights", False) or self.config.get("matcher", {}).get("allow_synthetic_weights", False))
             self._tile_preselector = TilePreselector(
-                _weights.load_superpoint_state_dict(sp_path), _weights.load_lightglue_state_dict(lg_path, input_dim=256, n_layers=9),
+                _weights.load_superpoint_state_dict(sp_path, allow_synthetic=synth),
+                _weights.load_lightglue_state_dict(lg_path, input_dim=256, n_layers=9, allow_synthetic=synth),
                 tile_preselection_size=int(self.config["general"].get("tile_preselection_size", 1024)),
                 device=self._device if isinstance(self._device, (str, torch.device)) else "cuda", lib=self._lib)
         return self._tile_preselector

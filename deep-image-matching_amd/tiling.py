@@ -127,7 +127,12 @@ class BatchedTilingMixin:
             stack = torch.stack([padded[(i // n_cols) * stride[0]:(i // n_cols) * stride[0] + th,
                                         (i % n_cols) * stride[1]:(i % n_cols) * stride[1] + tw] for i in chunk]) / 255.0
             t = stack[..., 0].contiguous() if self.grayscale else stack.contiguous()  # [B,H,W] or [B,H,W,C]
-            kp, sc, de, n = net.extract_batch(t)
+            # under the fp16x3 range guard; SuperPoint in keep-all mode also repeats a batch that overflowed its slots
+            run = getattr(net, "extract_batch_guarded", net.extract_batch)
+            kp, sc, de, n = run(t)
+            if hasattr(self, "_regrow") and self._regrow(net, len(chunk)):
+                net = self._ensure_batch(th, tw, self.tile_batch)
+                kp, sc, de, n = getattr(net, "extract_batch_guarded", net.extract_batch)(t)
             kp, sc, de, n = kp.cpu().numpy(), sc.cpu().numpy(), de.cpu().numpy(), n.cpu().numpy()
             for j, i in enumerate(chunk):
                 k = int(n[j])

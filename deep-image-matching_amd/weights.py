@@ -42,8 +42,22 @@ def synthetic_superpoint_state_dict(seed: int = 1234) -> Dict[str, torch.Tensor]
     return sd
 
 
-def load_superpoint_state_dict(path: str | None = None, seed: int = 1234) -> Dict[str, torch.Tensor]:
+class MissingWeightsError(RuntimeError):
+    """No checkpoint was given.  The reference downloads the official files (SPN:149, LGN:383); this container and the
+    GPU boxes have no network, so a path is required — seeded synthetic weights are an explicit opt-in for tests and
+    benchmarks (``allow_synthetic_weights``), never a silent default: features from random weights are garbage."""
+
+
+def _no_weights(what: str, env: str, allow_synthetic: bool) -> None:
+    if not allow_synthetic:
+        raise MissingWeightsError(
+            f"{what}: no checkpoint given - set '<section>.weights_path' (or the {env} environment variable) to the official file; "
+            "pass 'allow_synthetic_weights: True' only for tests / synthetic benchmarks")
+
+
+def load_superpoint_state_dict(path: str | None = None, seed: int = 1234, allow_synthetic: bool = False) -> Dict[str, torch.Tensor]:
     if path is None:
+        _no_weights("SuperPoint (superpoint_v1.pth, SPN:149)", "DIM_SUPERPOINT_WEIGHTS", allow_synthetic)
         return synthetic_superpoint_state_dict(seed)
     sd = torch.load(str(Path(path)), map_location="cpu")
     missing = [f"{n}.{s}" for n, *_ in SP_LAYERS for s in ("weight", "bias") if f"{n}.{s}" not in sd]
@@ -98,8 +112,9 @@ def synthetic_lightglue_state_dict(seed: int = 0, input_dim: int = 256, n_layers
 
 
 def load_lightglue_state_dict(path: str | None = None, seed: int = 0, input_dim: int = 256, n_layers: int = 9,
-                              gain: float = 1.0) -> Dict[str, torch.Tensor]:
+                              gain: float = 1.0, allow_synthetic: bool = False) -> Dict[str, torch.Tensor]:
     if path is None:
+        _no_weights("LightGlue (<features>_lightglue.pth, LGN:383)", "DIM_LIGHTGLUE_WEIGHTS", allow_synthetic)
         return synthetic_lightglue_state_dict(seed, input_dim, n_layers, gain=gain)
     sd = torch.load(str(Path(path)), map_location="cpu")
     for i in range(n_layers):  # legacy names (LGN:389-396)
@@ -159,8 +174,10 @@ def synthetic_aliked_state_dict(seed: int = 7, model_name: str = "aliked-n16rot"
     return sd
 
 
-def load_aliked_state_dict(path: str | None = None, seed: int = 7, model_name: str = "aliked-n16rot") -> Dict[str, torch.Tensor]:
+def load_aliked_state_dict(path: str | None = None, seed: int = 7, model_name: str = "aliked-n16rot",
+                           allow_synthetic: bool = False) -> Dict[str, torch.Tensor]:
     if path is None:
+        _no_weights("ALIKED (thirdparty/ALIKED/models/aliked-*.pth in the reference tree)", "DIM_ALIKED_WEIGHTS", allow_synthetic)
         return synthetic_aliked_state_dict(seed, model_name)
     sd = torch.load(str(Path(path)), map_location="cpu")
     return {k: (v.float().contiguous() if v.is_floating_point() else v) for k, v in sd.items()}

@@ -57,6 +57,29 @@ enum {
 int dim_profile_start(unsigned long long site_mask);
 int dim_profile_stop(double* total_ms, int* launches);
 
+/* fp16x3 range guard.  The default arithmetic represents every activation as two fp16 pieces of 16*x, exact for
+ * |x| <= 4094 and saturating beyond.  Every kernel that produces a value a later split consumes checks max|x| of
+ * what it writes and bumps a sticky device counter per launch site when the range is exceeded (the results of that
+ * call are then NOT fp32-accurate).  dim_saturation_read synchronises `stream`, copies the DIM_SAT_SITES counters to
+ * counts_host (may be NULL), returns their sum in *total and zeroes them when reset != 0.  The Python plugins call it
+ * after every extract / match and re-run the call in bf16x6 (no range limit) when the sum is non-zero. */
+enum {
+  DIM_SAT_SP_IMAGE = 0,   /* |image| > 1 or conv1a's weight bound exceeds the range (fused conv1a+conv1b input) */
+  DIM_SAT_SP_ENCODER,     /* outputs of conv1b .. conv4b */
+  DIM_SAT_SP_HEADS,       /* outputs of convPa / convDa (inputs of the 1x1 head GEMMs) */
+  DIM_SAT_LG_INPUT,       /* descriptors handed to dim_lg_match / input_proj output */
+  DIM_SAT_LG_QKV,         /* Wqkv / to_qk|to_v outputs incl. the rotated q, k */
+  DIM_SAT_LG_FFN,         /* ffn.0 output after LayerNorm+GELU */
+  DIM_SAT_LG_DESC,        /* residual stream after ffn.3 */
+  DIM_SAT_OP,             /* operator-level entry points (dim_op_*_x6) */
+  DIM_SAT_SITES = 16
+};
+int dim_saturation_read(unsigned* counts_host, unsigned long long* total, int reset, void* stream);
+
+/* Shader-clock probe: writes {s_memtime (shader cycles), s_memrealtime (100 MHz)} to out_dev[2] on `stream`;
+ * two probes around a region give its average shader clock = d(cycles) / d(realtime) * 100 MHz (bench.py). */
+int dim_op_read_clocks(unsigned long long* out_dev, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* SuperPoint (reference SPN:101-227)                                       */
 /* ------------------------------------------------------------------------ */

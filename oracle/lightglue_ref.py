@@ -139,9 +139,12 @@ def lightglue_forward(kpts0, desc0, size0, kpts1, desc1, size1, sd: Dict[str, to
     c = {**DEFAULT_CONF, **(conf or {})}
     L, heads = c["n_layers"], c["num_heads"]
     m, n = kpts0.shape[0], kpts1.shape[0]
-    k0 = normalize_keypoints(kpts0.float(), size0)
-    k1 = normalize_keypoints(kpts1.float(), size1)
-    d0, d1 = desc0.float().contiguous(), desc1.float().contiguous()
+    # conf["dtype"] = torch.float64 (with a float64 state dict) evaluates the same network in double precision: the
+    # yardstick the fp32 paths are measured against (tests/test_saturation_gpu.py); the default is the reference's fp32
+    dt = c.get("dtype", torch.float32)
+    k0 = normalize_keypoints(kpts0.to(dt), size0)
+    k1 = normalize_keypoints(kpts1.to(dt), size1)
+    d0, d1 = desc0.to(dt).contiguous(), desc1.to(dt).contiguous()
     if "input_proj.weight" in sd:  # LGN:361-364,473-474
         d0, d1 = _lin(d0, sd, "input_proj"), _lin(d1, sd, "input_proj")
     e0 = positional_encoding(k0, sd["posenc.Wr.weight"])

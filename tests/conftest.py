@@ -33,3 +33,19 @@ def hip_lib():
 
     capi = importlib.import_module("deep-image-matching_amd.capi")
     return capi.load()
+
+
+@pytest.fixture
+def emu_install(emu_lib):
+    """Routes the package loader to the emulator build (capi.install test hook) for the duration of one test, so the
+    plugin classes are constructed exactly as in production — no library / device arguments."""
+    import importlib
+
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    capi.install(emu_lib, "cpu")
+    try:
+        yield emu_lib
+    finally:
+        emu_lib.dim_tune_set(1, 2)
+        capi.set_arithmetic(emu_lib, 2)
+        capi.install(None)

@@ -58,18 +58,24 @@ LG_CASES = {
     "adaptive": {"seed": 12, "m": 150, "n": 110, "input_dim": 256, "wseed": 2, "gain": 2.0, "heads_gain": 30.0,
                  "size0": (768.0, 1024.0), "size1": (1024.0, 768.0),
                  "conf": {"depth_confidence": 0.5, "width_confidence": 0.99, "filter_threshold": 0.0}},
-    # matchability head sharpened only: pruning removes points over several layers, all 9 layers run
-    "prune_only": {"seed": 12, "m": 150, "n": 110, "input_dim": 256, "wseed": 6, "gain": 2.0, "match_gain": 2.5,
+    # pruning removes points over several layers (prune counters 3..9), all 9 layers run, 19 matches survive
+    # (r1's wseed 6 / match_gain 2.5 pruned so hard that the match list was empty: vacuous for matches / scores)
+    "prune_only": {"seed": 12, "m": 150, "n": 110, "input_dim": 256, "wseed": 14, "gain": 2.0, "match_gain": 1.0,
                    "size0": (768.0, 1024.0), "size1": (1024.0, 768.0),
                    "conf": {"depth_confidence": -1, "width_confidence": 0.99, "filter_threshold": 0.0}},
     # everything gets pruned away: the reference's "no keypoints" exit (LGN:518-540)
     "prune_to_empty": {"seed": 12, "m": 150, "n": 110, "input_dim": 256, "wseed": 4, "gain": 2.0, "match_gain": 30.0,
                        "size0": (768.0, 1024.0), "size1": (1024.0, 768.0),
                        "conf": {"depth_confidence": -1, "width_confidence": 0.99, "filter_threshold": 0.0}},
-    # ALIKED-style 128-d descriptors through input_proj, default threshold 0.1
-    "aliked_dim": {"seed": 13, "m": 64, "n": 64, "input_dim": 128, "wseed": 3, "gain": 2.0, "heads_gain": 5.0,
+    # ALIKED-style 128-d descriptors through input_proj, the reference's default threshold 0.1: early stop at layer 4,
+    # 12 matches above the threshold (r1's wseed 3 / heads_gain 5 gave none)
+    "aliked_dim": {"seed": 13, "m": 64, "n": 64, "input_dim": 128, "wseed": 6, "gain": 2.0, "heads_gain": 2.0,
                    "size0": (512.0, 768.0), "size1": (512.0, 768.0),
                    "conf": {"depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.1}},
+    # 128-d inputs with pruning AND early stop AND surviving matches (prune counters 2..6, stop 6, 4 matches)
+    "aliked_prune": {"seed": 13, "m": 64, "n": 64, "input_dim": 128, "wseed": 13, "gain": 2.0, "heads_gain": 2.0,
+                     "size0": (512.0, 768.0), "size1": (512.0, 768.0),
+                     "conf": {"depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.1}},
 }
 
 

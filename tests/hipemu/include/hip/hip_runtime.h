@@ -271,6 +271,7 @@ template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 
+static inline unsigned long long wall_clock64() { return (unsigned long long)__builtin_readcyclecounter() / 30; }
 #define __expf(x) expf(x)
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 // only ever applied to wave-uniform values in this code base

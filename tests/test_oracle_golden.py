@@ -34,6 +34,8 @@ def test_lightglue_oracle_matches_reference_golden(name):
     out = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"],
                                           gc.lg_weights(case), case["conf"], taps=True)
     assert out["stop"] == int(g["stop"])
+    # no vacuous goldens: every case except the "no keypoints" exit holds matches (and so exercises matches / scores)
+    assert name == "prune_to_empty" or g["matches"].shape[0] > 0
     assert np.array_equal(out["matches0"].numpy(), g["matches0"])
     assert np.array_equal(out["matches1"].numpy(), g["matches1"])
     assert np.array_equal(out["matches"].numpy(), g["matches"])

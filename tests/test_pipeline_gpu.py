@@ -24,8 +24,8 @@ def test_pipeline_equals_plugin_hooks(hip_lib):
     table = pipe.extract_all(imgs.cuda())
     pairs = pl.exhaustive_pairs(6)
     lists = pipe.to_match_lists(*pipe.match_all(table, pairs))
-    ex = plugins.SuperPointExtractor({"general": {}, "extractor": dict(cfg)})
-    ma = plugins.LightGlueMatcher({"general": {}, "matcher": dict(conf)})
+    ex = plugins.SuperPointExtractor({"general": {}, "extractor": dict(cfg, allow_synthetic_weights=True)})
+    ma = plugins.LightGlueMatcher({"general": {}, "matcher": dict(conf, allow_synthetic_weights=True, pruning_min_kpts=-1)})
     feats = []
     for i in range(6):
         f = ex._extract((imgs[i] * 255).numpy().astype(np.float32))

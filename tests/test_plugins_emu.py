@@ -10,11 +10,12 @@ from oracle import lightglue_ref, superpoint_ref
 
 plugins = importlib.import_module("deep-image-matching_amd.plugins")
 weights = importlib.import_module("deep-image-matching_amd.weights")
+capi = importlib.import_module("deep-image-matching_amd.capi")
 
 
-def test_superpoint_extractor_hook_contract(emu_lib):
-    cfg = {"general": {}, "extractor": {"name": "superpoint", "nms_radius": 2, "keypoint_threshold": 0.001, "max_keypoints": 40}}
-    ex = plugins.SuperPointExtractor(cfg, _lib=emu_lib, _device="cpu")
+def test_superpoint_extractor_hook_contract(emu_install):
+    cfg = {"general": {}, "extractor": {"name": "superpoint", "nms_radius": 2, "keypoint_threshold": 0.001, "max_keypoints": 40, "allow_synthetic_weights": True}}
+    ex = plugins.SuperPointExtractor(cfg)
     assert ex.grayscale and ex.descriptor_size == 256 and ex.required_inputs == ["image"]
     img = (torch.rand(48, 64, generator=torch.Generator().manual_seed(4)) * 255).numpy().astype(np.float32)  # 0..255 as EB feeds it
     f = ex._extract(img)
@@ -28,9 +29,10 @@ def test_superpoint_extractor_hook_contract(emu_lib):
     assert f2["keypoints"].shape[1] == 2
 
 
-def test_lightglue_matcher_hook_contract(emu_lib):
-    cfg = {"general": {}, "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0}}
-    m = plugins.LightGlueMatcher(cfg, local_features="superpoint", _lib=emu_lib, _device="cpu")
+def test_lightglue_matcher_hook_contract(emu_install):
+    cfg = {"general": {}, "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0,
+                                      "allow_synthetic_weights": True, "pruning_min_kpts": -1}}
+    m = plugins.LightGlueMatcher(cfg, local_features="superpoint")
     assert m.min_matches == 20 and m.max_feat_no_tiling == 200000
     g = torch.Generator().manual_seed(1)
     k0, k1 = torch.rand(20, 2, generator=g) * 100, torch.rand(28, 2, generator=g) * 100
@@ -53,11 +55,11 @@ def test_lightglue_matcher_hook_contract(emu_lib):
     assert m._match_pairs(e, f1).shape == (0, 2)
 
 
-def test_aliked_extractor_hook_contract(emu_lib):
+def test_aliked_extractor_hook_contract(emu_install):
     from oracle import aliked_ref
 
-    cfg = {"general": {}, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 50, "nms_radius": 2}}
-    ex = plugins.AlikedExtractor(cfg, _lib=emu_lib, _device="cpu")
+    cfg = {"general": {}, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 50, "nms_radius": 2, "allow_synthetic_weights": True}}
+    ex = plugins.AlikedExtractor(cfg)
     assert not ex.grayscale and ex.descriptor_size == 128
     img = (torch.rand(48, 64, 3, generator=torch.Generator().manual_seed(6)) * 255).numpy().astype(np.float32)  # HxWx3 RGB 0..255
     f = ex._extract(img)
@@ -69,11 +71,11 @@ def test_aliked_extractor_hook_contract(emu_lib):
     assert len(a ^ b) <= 2
 
 
-def test_plugin_arithmetic_option_switches_the_library_mode(emu_lib):
+def test_plugin_arithmetic_option_switches_the_library_mode(emu_install):
     cfg = {"general": {}, "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1,
-                                      "filter_threshold": 0.0, "arithmetic": "bf16x6"}}
+                                      "filter_threshold": 0.0, "arithmetic": "bf16x6", "allow_synthetic_weights": True}}
     try:
-        m = plugins.LightGlueMatcher(cfg, _lib=emu_lib, _device="cpu")
+        m = plugins.LightGlueMatcher(cfg)
         g = torch.Generator().manual_seed(1)
         k0, k1 = torch.rand(20, 2, generator=g) * 100, torch.rand(28, 2, generator=g) * 100
         d0 = torch.nn.functional.normalize(torch.randn(20, 256, generator=g), dim=-1)
@@ -82,10 +84,55 @@ def test_plugin_arithmetic_option_switches_the_library_mode(emu_lib):
         f0 = {"keypoints": k0.numpy(), "descriptors": d0.t().numpy(), "image_size": size}
         f1 = {"keypoints": k1.numpy(), "descriptors": d1.t().numpy(), "image_size": size}
         a = m._match_pairs(f0, f1)
-        emu_lib.dim_tune_set(1, 2)
+        capi.set_arithmetic(emu_install, "fp16x3")
         b = m._match_pairs(f0, f1)
         assert np.array_equal(a, b)  # both modes are fp32-class: same matches
         with pytest.raises(ValueError):
-            plugins.LightGlueMatcher({"general": {}, "matcher": {"name": "lightglue", "arithmetic": "fp8"}}, _lib=emu_lib, _device="cpu")
+            plugins.LightGlueMatcher({"general": {}, "matcher": {"name": "lightglue", "arithmetic": "fp8"}})
     finally:
-        emu_lib.dim_tune_set(1, 2)
+        capi.set_arithmetic(emu_install, "fp16x3")
+
+
+def test_plugins_refuse_to_run_without_weights(emu_install, monkeypatch):
+    """The reference downloads its checkpoints (SPN:149, LGN:383); without a path the plugins raise instead of
+    silently producing features from random weights (synthetic weights are an explicit opt-in)."""
+    for var in ("DIM_SUPERPOINT_WEIGHTS", "DIM_LIGHTGLUE_WEIGHTS", "DIM_ALIKED_WEIGHTS"):
+        monkeypatch.delenv(var, raising=False)
+    with pytest.raises(weights.MissingWeightsError):
+        plugins.SuperPointExtractor({"general": {}, "extractor": {"name": "superpoint"}})
+    with pytest.raises(weights.MissingWeightsError):
+        plugins.LightGlueMatcher({"general": {}, "matcher": {"name": "lightglue"}})
+    with pytest.raises(weights.MissingWeightsError):
+        plugins.AlikedExtractor({"general": {}, "extractor": {"name": "aliked"}})
+
+
+def test_plugins_load_checkpoint_files(emu_install, tmp_path):
+    """weights_path: the official key layout saved with torch.save loads unchanged (incl. the legacy LightGlue names)."""
+    sp_sd = weights.synthetic_superpoint_state_dict(5)
+    torch.save(sp_sd, tmp_path / "sp.pth")
+    ex = plugins.SuperPointExtractor({"general": {}, "extractor": {"name": "superpoint", "weights_path": str(tmp_path / "sp.pth"), "max_keypoints": 30}})
+    assert all(torch.equal(ex._sd[k], sp_sd[k]) for k in sp_sd)
+    lg_sd = weights.synthetic_lightglue_state_dict(3, 256, n_layers=2)
+    legacy = {k.replace("transformers.0.self_attn", "self_attn.0").replace("transformers.1.cross_attn", "cross_attn.1"): v for k, v in lg_sd.items()}
+    legacy.pop("confidence_thresholds")
+    torch.save(legacy, tmp_path / "lg.pth")
+    m = plugins.LightGlueMatcher({"general": {}, "matcher": {"name": "lightglue", "n_layers": 2, "weights_path": str(tmp_path / "lg.pth")}})
+    assert set(m._sd) == set(lg_sd) and all(torch.equal(m._sd[k], lg_sd[k]) for k in lg_sd)
+    assert m._conf["pruning_min_kpts"] == 1536  # the reference's GPU value with flash attention (LGN:318-323)
+
+
+def test_keep_all_mode_never_drops_keypoints(emu_install):
+    """with max_keypoints = -1 an image with more candidates than the slot is re-extracted with a larger
+    slot, so every keypoint the reference returns is returned."""
+    cfg = {"general": {}, "extractor": {"name": "superpoint", "nms_radius": 1, "keypoint_threshold": 0.0, "max_keypoints": -1,
+                                        "remove_borders": 1, "allow_synthetic_weights": True}}
+    ex = plugins.SuperPointExtractor(cfg)
+    img = (torch.rand(48, 64, generator=torch.Generator().manual_seed(9)) * 255).numpy().astype(np.float32)
+    ex._ensure(48, 64)
+    ex._net = None
+    ex._capacity = lambda H, W: max(ex._min_capacity, 64)   # force a slot that is too small for the first call
+    f = ex._extract(img)
+    ref = superpoint_ref.superpoint_forward(torch.tensor(img / 255.0, dtype=torch.float)[None, None], ex._sd, ex._net_cfg)
+    assert ref["keypoints"].shape[0] > 64
+    assert f["keypoints"].shape[0] == ref["keypoints"].shape[0]
+    assert np.array_equal(f["keypoints"], ref["keypoints"].numpy())  # row-major order, like torch.nonzero

@@ -1,0 +1,91 @@
+"""CPU (emulator): the fp16x3 range guard and the per-output-channel weight scales on adversarial inputs
+(tests/adversarial.py).  A call that leaves the exact range of the fp16 split must (a) bump the device counters and
+(b) come back correct through the bf16x6 re-run of the guarded entry points; everything inside the range must be
+fp32-accurate WITHOUT a re-run."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lightglue_ref, superpoint_ref
+from tests import adversarial as adv
+from tests.parity import compare_lightglue, compare_superpoint
+
+capi = importlib.import_module("deep-image-matching_amd.capi")
+sp_mod = importlib.import_module("deep-image-matching_amd.superpoint_hip")
+lg_mod = importlib.import_module("deep-image-matching_amd.lightglue_hip")
+
+CFG = {"nms_radius": 2, "keypoint_threshold": 0.001, "max_keypoints": 60, "remove_borders": 2}
+
+
+@pytest.mark.parametrize("name", adv.SP_CASES)
+def test_superpoint_adversarial_ranges(emu_lib, name):
+    sd, img, expect_guard = adv.sp_case(name, 40, 56)
+    net = sp_mod.SuperPointHIP(sd, CFG, max_batch=1, max_hw=(40, 56), capacity=256, device="cpu", lib=emu_lib)
+    capi.saturation(emu_lib, None, reset=True)
+    net.extract_batch(img[0].contiguous())            # raw call in the default arithmetic
+    total, sites = capi.saturation(emu_lib, None, reset=True)
+    assert (total > 0) == expect_guard, (name, sites)
+    if name == "bright":
+        assert "sp_image" in sites
+    out = net(img)                                      # guarded call: re-runs in bf16x6 when the guard fired
+    assert capi.get_arithmetic(emu_lib) == 2            # the fallback restores the default arithmetic
+    taps = net.debug_taps()
+    ref = superpoint_ref.superpoint_forward(img, sd, CFG, taps=True)
+    assert (taps["score_map"][0] - ref["score_map"][0]).abs().max().item() <= 2e-5, name
+    compare_superpoint({k: v.cpu() for k, v in out.items()}, ref)
+    with pytest.raises(capi.SaturationError) if expect_guard else _noraise():
+        strict = sp_mod.SuperPointHIP(sd, CFG, max_batch=1, max_hw=(40, 56), capacity=256, device="cpu", lib=emu_lib, on_saturation="raise")
+        strict(img)
+
+
+@pytest.mark.parametrize("name", adv.LG_CASES)
+def test_lightglue_adversarial_ranges(emu_lib, name):
+    sd, f0, f1, conf, expect_guard = adv.lg_case(name, m=40, n=36, n_layers=2)
+    net = lg_mod.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=64, device="cpu", lib=emu_lib)
+    data = {"image0": {"keypoints": f0["kpts"][None], "descriptors": f0["desc"][None], "image_size": f0["size"][None]},
+            "image1": {"keypoints": f1["kpts"][None], "descriptors": f1["desc"][None], "image_size": f1["size"][None]}}
+    net.on_saturation = "off"
+    capi.saturation(emu_lib, None, reset=True)
+    net(data)
+    total, sites = capi.saturation(emu_lib, None, reset=True)
+    assert (total > 0) == expect_guard, (name, sites)
+    net.on_saturation = "fallback"
+    res = net(data, dense=True)
+    ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, conf, taps=True)
+    la = ref["log_assignment"]
+    m, n = la.shape[0] - 1, la.shape[1] - 1
+    # 1e-3 absolute on the dense log-assignment, or (descriptors x 1e5: entries of order 1e9) the same relative to its range
+    tol = 1e-3 * max(1.0, la[:m, :n].abs().max().item() * 1e-3)
+    info = compare_lightglue(res, ref, score_tol=1e-3, dense_ref=la, dense_out=res["dense"], dense_tol=tol)
+    assert info["max_log_assignment_diff"] <= tol
+
+
+class _noraise:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def test_weight_scales_are_per_output_channel(emu_lib):
+    """One 1e4 x outlier COLUMN must not cost the other columns any accuracy (dim_x3_create scales per column)."""
+    import ctypes
+
+    g = torch.Generator().manual_seed(0)
+    K, N, M = 64, 128, 64
+    A = torch.randn(M, K, generator=g)
+    Wt = torch.randn(K, N, generator=g) * 0.05
+    Wt[:, 7] *= 1e4
+    Wt[:, 9] *= 1e-4
+    h, npad = ctypes.c_void_p(), ctypes.c_int()
+    assert emu_lib.dim_x3_create(ctypes.c_void_p(Wt.contiguous().data_ptr()), K, N, ctypes.byref(h), ctypes.byref(npad)) == 0
+    C = torch.zeros(M, N)
+    assert emu_lib.dim_op_gemm_x6_f32(ctypes.c_void_p(A.data_ptr()), K, h, npad.value, None, None, 0, ctypes.c_void_p(C.data_ptr()), N, M, N, K, 0, None) == 0
+    emu_lib.dim_x3_destroy(h)
+    ref = (A.double() @ Wt.double())
+    scale = (A.double().abs() @ Wt.double().abs())
+    rel = ((C.double() - ref).abs() / scale).max().item()
+    assert rel < 4e-7, rel

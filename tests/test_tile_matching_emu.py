@@ -96,10 +96,11 @@ def _tiled_features(seed, n, n_tiles, hw):
     return {"keypoints": k, "descriptors": d, "scores": np.ones(n, np.float32), "tile_idx": t, "image_size": np.array(hw, np.int32)}
 
 
-def test_batched_match_by_tile_equals_the_sequential_reference_loop(emu_lib):
+def test_batched_match_by_tile_equals_the_sequential_reference_loop(emu_install):
     cfg = {"general": {"tile_size": (60, 50), "tile_overlap": 0},
-           "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0}}
-    m = plugins.LightGlueMatcher(cfg, _lib=emu_lib, _device="cpu")
+           "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0,
+                       "allow_synthetic_weights": True, "pruning_min_kpts": -1}}
+    m = plugins.LightGlueMatcher(cfg)
     m.tile_pair_batch = 3
     f0, f1 = _tiled_features(0, 90, 4, (100, 120)), _tiled_features(1, 70, 3, (100, 120))
     f1["tile_idx"][f1["tile_idx"] == 2] = 1  # tile 2 of image 1 is empty

@@ -54,7 +54,8 @@ def test_batched_tile_pairs_equal_one_call_per_pair(hip_lib):
     """16 x 16 tiles with 1000 ALIKED-sized keypoints each; the batched table path must give exactly the
     list the reference's loop builds from one _match_pairs call per tile pair (same kernels, batch 1)."""
     cfg = {"general": {"tile_size": (1500, 1000), "tile_overlap": 0},
-           "matcher": {"name": "lightglue", "depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.0}}
+           "matcher": {"name": "lightglue", "depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.0,
+                       "allow_synthetic_weights": True, "pruning_min_kpts": -1}}
     m = plugins.LightGlueMatcher(cfg, local_features="aliked")
     f0, f1 = _tiled_features(0, 1000, 16, (4000, 6000)), _tiled_features(1, 900, 16, (4000, 6000))
     pairs = tm.select_tile_pairs("GRID", range(16), range(16)) + [(0, 5), (7, 2), (15, 0)]

@@ -28,10 +28,10 @@ def test_reference_known_answers():
     assert pad == (0, 0, 0, 0)
 
 
-def test_batched_tile_extraction_equals_sequential(emu_lib):
+def test_batched_tile_extraction_equals_sequential(emu_install):
     cfg = {"general": {"tile_size": (40, 32), "tile_overlap": 8},
-           "extractor": {"name": "superpoint", "nms_radius": 2, "keypoint_threshold": 0.001, "max_keypoints": 20, "remove_borders": 2}}
-    ex = plugins.SuperPointExtractor(cfg, _lib=emu_lib, _device="cpu")
+           "extractor": {"name": "superpoint", "nms_radius": 2, "keypoint_threshold": 0.001, "max_keypoints": 20, "remove_borders": 2, "allow_synthetic_weights": True}}
+    ex = plugins.SuperPointExtractor(cfg)
     ex.tile_batch = 4
     img = (torch.rand(60, 70, generator=torch.Generator().manual_seed(2)) * 255).round().numpy().astype(np.float32)
     feats = ex._extract_by_tile(img)
