@@ -105,10 +105,11 @@ class PairMatchingPipeline:
 
     # ---- phases 3+4 ------------------------------------------------------------------------
     @torch.no_grad()
-    def match_all(self, table, pairs: torch.Tensor):
+    def match_all(self, table, pairs: torch.Tensor, aux: bool = False):
         """table from extract_all (or any device feature table); pairs [P,2] int32 (image slots).
         Returns, on every rank, (n_matches [P], matches [P,NK,2] int64, scores [P,NK]) in the
-        order of ``pairs``."""
+        order of ``pairs``; with ``aux`` additionally (stop [P] int32, prune01 [P,2,NK] int32) — the reference's
+        "stop" / "prune0" / "prune1" outputs (LGN:570-577), gathered the same way (parity tests)."""
         kp, sc, de, n, size = table
         dev = kp.device
         P = pairs.shape[0]
@@ -118,6 +119,8 @@ class PairMatchingPipeline:
         cnt = torch.zeros(per, dtype=torch.int32, device=dev)
         mt = torch.zeros(per, NK, 2, dtype=torch.int64, device=dev)
         ms = torch.zeros(per, NK, dtype=torch.float32, device=dev)
+        stp = torch.zeros(per, dtype=torch.int32, device=dev)
+        prn = torch.zeros(per, 2, NK, dtype=torch.int32, device=dev) if aux else None
         my_pairs = pairs[mine].to(dev, torch.int32).contiguous()
 
         def run():
@@ -129,6 +132,9 @@ class PairMatchingPipeline:
                 cnt[s:s + b] = o["n_matches"]
                 mt[s:s + b] = torch.where(live[..., None], o["matches"], torch.zeros_like(o["matches"]))
                 ms[s:s + b] = torch.where(live, o["scores"], torch.zeros_like(o["scores"]))
+                stp[s:s + b] = o["stop"]
+                if aux:
+                    prn[s:s + b] = o["prune01"]
 
         _guarded(self.mat, run, "pipeline matching")
         cnt_g, mt_g, ms_g = (_all_gather_cat(t, self.world) for t in (cnt, mt, ms))
@@ -137,6 +143,11 @@ class PairMatchingPipeline:
             cnt_g, mt_g, ms_g = cnt_g[order], mt_g[order], ms_g[order]
         else:
             cnt_g, mt_g, ms_g = cnt_g[:P], mt_g[:P], ms_g[:P]
+        if aux:
+            stp_g, prn_g = _all_gather_cat(stp, self.world), _all_gather_cat(prn, self.world)
+            if self.world > 1:
+                stp_g, prn_g = stp_g[order], prn_g[order]
+            return cnt_g, mt_g, ms_g, stp_g[:P], prn_g[:P]
         return cnt_g, mt_g, ms_g
 
     @staticmethod
