@@ -1,8 +1,10 @@
 // Tile preselection on device (tile_selection, PRESELECTION branch, matchers/matcher_base.py:1054-1133):
 // the down-sampling of both images and the per-tile-pair vote count, so that the whole preselection
 // (resize -> SuperPoint -> LightGlue -> votes) runs without leaving HBM.
+#include <math.h>
+
 #include "../../include/dim_hip.h"
-#include "dim_common.h"
+#include "dim_kernels.h"
 
 namespace {
 
@@ -64,6 +66,39 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const float* __restric
   dst[i] = div255 ? out / 255.0f : out;
 }
 
+// cv2.resize(..., INTER_AREA) when the image is NOT decimated on both axes (OpenCV 4.11 imgproc/resize.cpp: "true area
+// interpolation is only implemented for the case (scale_x >= 1 && scale_y >= 1); in other cases it is emulated using some
+// variant of bilinear"): per destination index d the source index is s = floor(d * scale) and the weight of s + 1 is
+// f = (d + 1) - (s + 1) / scale, clamped to 0 when negative, fractional part otherwise; at the last source pixel f = 0.
+// Rows are interpolated along x first (S[s] * (1 - f) + S[s + 1] * f in fp32), then along y, like HResizeLinear /
+// VResizeLinear<float>.  pairs_from_lowres and the tile preselection up-sample every image whose long side is below
+// resize_max / tile_preselection_size this way (pairs_generator.py:141-146, matcher_base.py:1062-1069).
+struct LinTap { int s; float f; };
+__device__ __forceinline__ LinTap area_linear_tap(int d, int ssize, int dsize) {
+  const double scale = (double)ssize / (double)dsize, inv_scale = (double)dsize / (double)ssize;
+  LinTap t;
+  t.s = (int)floor(d * scale);
+  float f = (float)((double)(d + 1) - (double)(t.s + 1) * inv_scale);
+  t.f = f <= 0.f ? 0.f : f - floorf(f);
+  if (t.s >= ssize - 1) { t.f = 0.f; t.s = ssize - 1; }
+  return t;
+}
+__global__ __launch_bounds__(256) void resize_area_linear_kernel(const float* __restrict__ src, int H, int W, float* __restrict__ dst,
+                                                                 int h, int w, int div255) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= h * w) return;
+  const int dy = i / w, dx = i - dy * w;
+  const LinTap tx = area_linear_tap(dx, W, w), ty = area_linear_tap(dy, H, h);
+  const int y0 = ty.s, y1 = min(ty.s + 1, H - 1);
+  auto hrow = [&](int y) -> float {
+    const float* r = src + (size_t)y * W;
+    if (tx.s >= W - 1) return r[W - 1];                       // the "dx >= xmax" tail of HResizeLinear: a plain copy
+    return r[tx.s] * (1.0f - tx.f) + r[tx.s + 1] * tx.f;
+  };
+  const float out = hrow(y0) * (1.0f - ty.f) + hrow(y1) * ty.f;
+  dst[i] = div255 ? out / 255.0f : out;
+}
+
 // thread = match.  Both keypoints are scaled back to full resolution (kp / scale, fp32 like numpy) and
 // tested against every tile rectangle with the strict inequalities of points_in_rect (MB:1410-1412).
 __global__ __launch_bounds__(256) void tile_votes_kernel(const float* __restrict__ k0, const float* __restrict__ k1,
@@ -85,13 +120,65 @@ __global__ __launch_bounds__(256) void tile_votes_kernel(const float* __restrict
     }
   }
 }
+// Retrieval pair selection (thirdparty/hloc/pairs_from_retrieval.py:49-70): per query row mask the invalid entries
+// (self matches, score < min_score) to -inf and take the top-k — k passes of a workgroup arg-max (ties: lowest index),
+// the winner is knocked out in place.  sim is the scratch similarity matrix written by the GEMM that precedes it.
+__global__ __launch_bounds__(256) void retrieval_topk_kernel(float* __restrict__ sim, const unsigned char* __restrict__ invalid, int nd, int k,
+                                                             float min_score, int use_min, int* __restrict__ idx_out, float* __restrict__ val_out) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int row = blockIdx.x, t = threadIdx.x;
+  float* r = sim + (size_t)row * nd;
+  const unsigned char* inv = invalid ? invalid + (size_t)row * nd : nullptr;
+  for (int j = t; j < nd; j += 256) {
+    const float v = r[j];
+    if ((inv && inv[j]) || (use_min && v < min_score)) r[j] = -INFINITY;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < k; ++pass) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int j = t; j < nd; j += 256) { const float v = r[j]; if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; } }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((t & 63) == 0) { sv[t >> 6] = bv; si[t >> 6] = bi; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < 4; ++w) if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+      const bool ok = bv > -INFINITY && bi < nd;
+      idx_out[(size_t)row * k + pass] = ok ? bi : -1;
+      val_out[(size_t)row * k + pass] = ok ? bv : -INFINITY;
+      if (ok) r[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
 }  // namespace
 
 extern "C" {
 
+int dim_op_retrieval_topk(const float* query_dev, int nq, const float* db_dev, int nd, int dim, const unsigned char* invalid_dev, int num_select,
+                          float min_score, int use_min_score, float* sim_scratch_dev, int* indices_dev, float* values_dev, void* stream) {
+  DIM_REQUIRE(query_dev && db_dev && sim_scratch_dev && indices_dev && values_dev, "dim_op_retrieval_topk: null argument");
+  DIM_REQUIRE(nq > 0 && nd > 0 && dim > 0 && dim % 32 == 0 && num_select > 0, "dim_op_retrieval_topk: bad sizes (dim must be a multiple of 32)");
+  GemmArgs g;  // sim = query * db^T on the exact fp32 MFMA path (einsum("id,jd->ij"), pairs_from_retrieval.py:108)
+  g.A0 = query_dev; g.lda0 = dim; g.B = db_dev; g.ldb = dim; g.bt = 1; g.C = sim_scratch_dev; g.ldc = nd; g.M = nq; g.N = nd; g.K = dim;
+  const int rc = launch_gemm(g, 1, (hipStream_t)stream);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(retrieval_topk_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, sim_scratch_dev, invalid_dev, nd, num_select, min_score,
+                     use_min_score, indices_dev, values_dev);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
 int dim_op_resize_area_f32(const float* src, int H, int W, float* dst, int h, int w, int div255, void* stream) {
   DIM_REQUIRE(src && dst && H > 0 && W > 0 && h > 0 && w > 0, "dim_op_resize_area_f32: bad arguments");
-  DIM_REQUIRE(h <= H && w <= W, "dim_op_resize_area_f32: %dx%d -> %dx%d is not a decimation (INTER_AREA enlargement is not built)", H, W, h, w);
+  if (h > H || w > W) {  // not a decimation on both axes: OpenCV's bilinear emulation of INTER_AREA
+    hipLaunchKernelGGL(resize_area_linear_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, (hipStream_t)stream, src, H, W, dst, h, w, div255);
+    DIM_LAUNCH_CHECK();
+    return 0;
+  }
   const int fast = (H % h == 0) && (W % w == 0);
   hipLaunchKernelGGL(resize_area_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, (hipStream_t)stream, src, H, W, dst, h, w, fast, div255);
   DIM_LAUNCH_CHECK();

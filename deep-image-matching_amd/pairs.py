@@ -49,6 +49,35 @@ def pairs_from_bruteforce(img_list: Sequence) -> List[tuple]:
     return list(combinations(img_list, 2))
 
 
+def pairs_from_retrieval(query_names: Sequence[str], db_names: Sequence[str], query_desc, db_desc, num_matched: int,
+                         min_score: Optional[float] = 0.0, device="cuda", lib=None) -> List[tuple]:
+    """thirdparty/hloc/pairs_from_retrieval.py:49-70,108-112 on the device: global descriptors (N, D) -> similarity GEMM
+    -> self / low-score masking -> top-``num_matched`` per query; returns (query, db) name pairs in the reference's order
+    (query by query, best first).  Only the (nq, k) index table leaves the device."""
+    lib = lib if lib is not None else capi.load()
+    dev = torch.device(device)
+    q = torch.as_tensor(np.asarray(query_desc), dtype=torch.float32)
+    d = torch.as_tensor(np.asarray(db_desc), dtype=torch.float32)
+    nq, nd, D = q.shape[0], d.shape[0], q.shape[1]
+    if nq == 0 or nd == 0:
+        return []
+    pad = (-D) % 32
+    if pad:
+        q, d = torch.nn.functional.pad(q, (0, pad)), torch.nn.functional.pad(d, (0, pad))
+    k = min(int(num_matched), nd)   # torch.topk raises for k > nd; hloc callers keep num_matched <= number of images
+    q, d = q.contiguous().to(dev), d.contiguous().to(dev)
+    invalid = torch.from_numpy(np.array(query_names)[:, None] == np.array(db_names)[None]).to(torch.uint8).contiguous().to(dev)
+    sim = torch.empty(nq, nd, dtype=torch.float32, device=dev)
+    idx = torch.empty(nq, k, dtype=torch.int32, device=dev)
+    val = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+    capi.check(lib, lib.dim_op_retrieval_topk(capi.ptr(q), nq, capi.ptr(d), nd, D + pad, capi.ptr(invalid), k,
+                                              ctypes.c_float(0.0 if min_score is None else float(min_score)), int(min_score is not None),
+                                              capi.ptr(sim), capi.ptr(idx), capi.ptr(val), stream))
+    idx = idx.cpu().numpy()
+    return [(query_names[i], db_names[j]) for i in range(nq) for j in idx[i] if j >= 0]
+
+
 class LowresPairSelector:
     """``pairs_from_lowres`` with resident networks.  ``images``: grey float32 arrays (0..255) in list order."""
 

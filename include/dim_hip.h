@@ -24,6 +24,7 @@
 #ifndef DIM_HIP_H
 #define DIM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -298,6 +299,34 @@ int dim_op_resize_area_f32(const float* src, int H, int W, float* dst, int h, in
 int dim_op_tile_pair_votes(const float* kpts0_xy, const float* kpts1_xy, const long long* matches, const int* n_matches_dev,
                            int max_matches, float scale0, float scale1, const int* origins0_xy, int T0, const int* origins1_xy, int T1,
                            int tile_w, int tile_h, int* votes, void* stream);
+
+/* ---- retrieval pair selection (csrc/tile_ops.hip) --------------------------------------------------------------
+ * thirdparty/hloc/pairs_from_retrieval.py:49-70,108-112: sim = einsum("id,jd->ij", query, db) (global descriptors,
+ * fp32 MFMA), invalid entries (self matches; score < min_score when use_min_score) -> -inf, torch.topk(num_select) per
+ * query row.  indices [nq][num_select] int32 in descending score order (ties: lowest index), -1 where fewer finite
+ * entries exist; values likewise.  sim_scratch: nq * nd floats.  dim must be a multiple of 32 (zero-pad otherwise). */
+int dim_op_retrieval_topk(const float* query_dev, int nq, const float* db_dev, int nd, int dim, const unsigned char* invalid_dev, int num_select,
+                          float min_score, int use_min_score, float* sim_scratch_dev, int* indices_dev, float* values_dev, void* stream);
+
+/* ---- geometric verification on device (csrc/geom_verify.hip) ----------------------------------------------
+ * Replaces the per-pair host call geometric_verification(kpts0[matches[:,0]], kpts1[matches[:,1]], method, threshold,
+ * confidence) that follows _match_pairs in the reference (utils/geometric_verification.py:45-179, called at
+ * matchers/matcher_base.py:311): a batched fundamental-matrix RANSAC straight on dim_lg_match's device outputs.
+ * Inputs: the feature table's keypoints [n_img][cap][2], pair_idx [n_pairs][2] (NULL = slots 2p, 2p+1), matches
+ * [n_pairs][nk][2] int64 + n_matches [n_pairs] exactly as dim_lg_match wrote them (nk <= 4096).
+ * threshold_px as the reference passes it (gv_threshold x quality scale); iters = number of 7-point hypotheses (the
+ * reference's max_iters is 10000); error_type 0 = Sampson distance (USAC / pydegensac family), 1 = symmetric
+ * epipolar distance (max of the two point-line distances, cv2.RANSAC); seed makes the sampling reproducible.
+ * Outputs: inlier_mask [n_pairs][nk] uint8 (0 beyond n_matches), n_inliers [n_pairs], F [n_pairs][9] fp64 row-major
+ * acting on pixel coordinates (x1^T F x0 = 0, scaled to F33 = 1 when possible; zeros when the pair has < 8 matches, in
+ * which case every match is an inlier as in geometric_verification.py:107-110).
+ * scratch: dim_gv_scratch_bytes(n_pairs) bytes of device memory.  The estimator is deterministic and restated in
+ * numpy by oracle/geom_ref.py; it is NOT result-identical to cv2's MAGSAC (no two RANSACs are). */
+size_t dim_gv_scratch_bytes(int n_pairs);
+int dim_gv_fundamental(const float* kpts_tab_dev, int cap, const int32_t* pair_idx_dev, const int64_t* matches_dev,
+                       const int32_t* n_matches_dev, int nk, int n_pairs, double threshold_px, int iters, int error_type, unsigned seed,
+                       void* scratch_dev, size_t scratch_bytes, unsigned char* inlier_mask_dev, int32_t* n_inliers_dev, double* F_dev,
+                       void* stream);
 
 #ifdef __cplusplus
 }

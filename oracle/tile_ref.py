@@ -109,12 +109,29 @@ def _area_table(ssize: int, dsize: int):
 
 
 def resize_area(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
-    """cv2.resize(img, (w, h), interpolation=cv2.INTER_AREA) for a 2-D float32 image, decimation only."""
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_AREA) for a 2-D float32 image.  Decimation on both axes: the
+    area tables; otherwise OpenCV's bilinear emulation of INTER_AREA (resize.cpp: sx = floor(dx * scale),
+    fx = (dx + 1) - (sx + 1) * inv_scale, <= 0 -> 0 else fractional part; fx = 0 at the last source pixel)."""
     img = np.ascontiguousarray(img, dtype=np.float32)
     H, W = img.shape
     w, h = int(size_wh[0]), int(size_wh[1])
     if h > H or w > W:
-        raise ValueError("decimation only")
+        def taps(ssize, dsize):
+            scale, inv = ssize / dsize, dsize / ssize
+            d = np.arange(dsize)
+            s = np.floor(d * scale).astype(np.int64)
+            f = ((d + 1) - (s + 1) * inv).astype(np.float32)
+            f = np.where(f <= 0, np.float32(0), f - np.floor(f)).astype(np.float32)
+            last = s >= ssize - 1
+            return np.where(last, ssize - 1, s), np.where(last, np.float32(0), f).astype(np.float32), last
+        sx, fx, lastx = taps(W, w)
+        sy, fy, _ = taps(H, h)
+        one = np.float32(1)
+        sx1 = np.minimum(sx + 1, W - 1)
+        rows = (img[:, sx] * (one - fx)).astype(np.float32) + (img[:, sx1] * fx).astype(np.float32)
+        rows = np.where(lastx[None, :], img[:, [W - 1]], rows).astype(np.float32)
+        sy1 = np.minimum(sy + 1, H - 1)
+        return ((rows[sy] * (one - fy)[:, None]).astype(np.float32) + (rows[sy1] * fy[:, None]).astype(np.float32)).astype(np.float32)
     if H % h == 0 and W % w == 0:  # ResizeAreaFast: row-major block sum, times 1/area
         sy, sx = H // h, W // w
         acc = np.zeros((h, w), dtype=np.float32)

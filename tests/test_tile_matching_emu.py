@@ -36,11 +36,16 @@ def test_resize_area_matches_oracle_bit_exact(emu_lib, shape, out):
     assert np.array_equal(got255, ref / np.float32(255.0))
 
 
-def test_resize_area_refuses_enlargement(emu_lib):
-    src = torch.zeros(8, 8)
-    dst = torch.zeros(16, 16)
-    assert emu_lib.dim_op_resize_area_f32(ctypes.c_void_p(src.data_ptr()), 8, 8, ctypes.c_void_p(dst.data_ptr()), 16, 16, 0, None) != 0
-    assert b"decimation" in emu_lib.dim_last_error()
+@pytest.mark.parametrize("shape,out", [((48, 64), (100, 75)), ((30, 41), (97, 71)), ((64, 48), (48, 100))])
+def test_resize_area_enlargement_matches_oracle_bit_exact(emu_lib, shape, out):
+    """pairs_from_lowres / tile preselection up-sample images smaller than resize_max (a 640x480 input):
+    OpenCV's bilinear emulation of INTER_AREA, device == oracle bit for bit (third case: one axis up, one down)."""
+    img = (np.random.default_rng(5).random(shape) * 255).astype(np.float32)
+    ref = tile_ref.resize_area(img, (out[1], out[0]))
+    got = _resize(emu_lib, img, out[0], out[1])
+    assert got.shape == ref.shape == (out[0], out[1]) and np.array_equal(got, ref)
+    assert abs(float(got.mean()) - float(img.mean())) < 3.0 and got.min() >= img.min() - 1e-3 and got.max() <= img.max() + 1e-3
+
 
 
 def _votes(lib, g):
