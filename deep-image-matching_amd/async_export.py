@@ -31,11 +31,17 @@ from . import export
 class AsyncExporter:
     """Background writer of features / raw matches / verified matches (+ the COLMAP database at close)."""
 
-    def __init__(self, out_dir: Path, device="cuda", max_pending: int = 8, write_database: bool = True, camera_model: str = "simple-radial"):
+    def __init__(self, out_dir: Path, device="cuda", max_pending: int = 8, write_database: bool = True, camera_model: str = "simple-radial",
+                 feature_workers: int = 4):
         self.out_dir = Path(out_dir)
         self.out_dir.mkdir(parents=True, exist_ok=True)
         self.device = torch.device(device)
+        # The fp16 + gzip feature groups are the expensive part (~1 MB deflated per 2048-keypoint image).  h5py serialises
+        # all access behind one lock, so with the real container there is one feature writer; the .npz mirror lets
+        # `feature_workers` threads deflate into their own shard files in parallel (zlib releases the GIL).
         self.features = export.FeatureStore(self.out_dir / "features.h5")
+        n_fw = 1 if self.features.use_h5 else max(1, int(feature_workers))
+        self._fstores = [self.features] + [export.FeatureStore(self.out_dir / "features.h5", shard=i) for i in range(1, n_fw)]
         self.raw = export.MatchStore(self.out_dir / "raw_matches.h5")
         self.verified = export.MatchStore(self.out_dir / "matches.h5")
         self._write_db, self._camera_model = write_database, camera_model
@@ -43,13 +49,18 @@ class AsyncExporter:
         self._wh: Dict[str, Tuple[int, int]] = {}
         self._raw: Dict[Tuple[str, str], np.ndarray] = {}
         self._ver: Dict[Tuple[str, str], np.ndarray] = {}
-        self._q: "queue.Queue" = queue.Queue(maxsize=max_pending)
+        self._q: "queue.Queue" = queue.Queue(maxsize=max_pending)      # match batches -> one writer (ordered appends + database)
+        self._fq: "queue.Queue" = queue.Queue(maxsize=max_pending)     # feature batches -> the feature writers
+        self._lock = threading.Lock()
         self._err: Optional[BaseException] = None
         self._copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self.busy_s = 0.0            # time the writer thread spent working (hidden behind the GPU when it keeps up)
         self.n_images = self.n_pairs = 0
-        self._thread = threading.Thread(target=self._run, name="dim-writer", daemon=True)
-        self._thread.start()
+        self._threads = [threading.Thread(target=self._run, args=(self._q, None), name="dim-writer-matches", daemon=True)]
+        self._threads += [threading.Thread(target=self._run, args=(self._fq, st), name=f"dim-writer-features{i}", daemon=True)
+                          for i, st in enumerate(self._fstores)]
+        for th in self._threads:
+            th.start()
 
     # ---- producer side (GPU thread) --------------------------------------------------------------------------------
     def _stage(self, tensors: Sequence[torch.Tensor]):
@@ -74,39 +85,41 @@ class AsyncExporter:
     def put_features(self, names: Sequence[str], kpts, scores, desc, n, image_hw: Sequence[Tuple[int, int]], tile_idx=None):
         """One extracted batch: kpts [B,cap,2], scores [B,cap], desc [B,cap,D], n [B] (device) -> features.h5 groups."""
         ev, host = self._stage([kpts, scores, desc, n] + ([tile_idx] if tile_idx is not None else []))
-        self._put(("features", ev, host, list(names), [tuple(hw) for hw in image_hw]))
+        self._put(("features", ev, host, list(names), [tuple(hw) for hw in image_hw]), self._fq)
 
     def put_matches(self, pair_names: Sequence[Tuple[str, str]], matches, n_matches, mask=None):
         """One matched (and optionally verified) batch: matches [P,NK,2] int64, n_matches [P], mask [P,NK] uint8 or None."""
         ev, host = self._stage([matches, n_matches] + ([mask] if mask is not None else []))
-        self._put(("matches", ev, host, list(pair_names), mask is not None))
+        self._put(("matches", ev, host, list(pair_names), mask is not None), self._q)
 
-    def _put(self, item):
+    def _put(self, item, q):
         if self._err is not None:
             raise RuntimeError("the writer thread failed") from self._err
-        self._q.put(item)
+        q.put(item)
 
     # ---- writer thread ------------------------------------------------------------------------------------------
-    def _run(self):
+    def _run(self, q, store):
         while True:
-            item = self._q.get()
+            item = q.get()
             if item is None:
+                q.task_done()
                 return
             try:
                 t0 = time.perf_counter()
                 if item[1] is not None:
                     item[1].synchronize()       # the D2H copy of THIS batch; the GPU is already on the next one
                 if item[0] == "features":
-                    self._write_features(*item[2:])
+                    self._write_features(store, *item[2:])
                 else:
                     self._write_matches(*item[2:])
-                self.busy_s += time.perf_counter() - t0
+                with self._lock:
+                    self.busy_s += time.perf_counter() - t0
             except BaseException as e:  # noqa: BLE001 - surfaced on the producer side
                 self._err = e
             finally:
-                self._q.task_done()
+                q.task_done()
 
-    def _write_features(self, host, names, image_hw):
+    def _write_features(self, store, host, names, image_hw):
         kp, sc, de, n = (h.numpy() for h in host[:4])
         ti = host[4].numpy() if len(host) > 4 else None
         for b, name in enumerate(names):
@@ -114,10 +127,11 @@ class AsyncExporter:
             feats = {"keypoints": kp[b, :k], "descriptors": np.ascontiguousarray(de[b, :k].T), "scores": sc[b, :k],
                      "tile_idx": ti[b, :k].astype(np.float32) if ti is not None else np.zeros(k, np.float32),
                      "image_size": np.array(image_hw[b])}     # (H, W), extractor_base.py:227 (Q4)
-            self.features.add(name, feats)
-            self._kpts[name] = feats["keypoints"].astype(np.float32).copy()
-            self._wh[name] = (int(image_hw[b][1]), int(image_hw[b][0]))
-            self.n_images += 1
+            store.add(name, feats)
+            with self._lock:
+                self._kpts[name] = feats["keypoints"].astype(np.float32).copy()
+                self._wh[name] = (int(image_hw[b][1]), int(image_hw[b][0]))
+                self.n_images += 1
 
     def _write_matches(self, host, pair_names, verified):
         m, n = host[0].numpy(), host[1].numpy()
@@ -136,13 +150,18 @@ class AsyncExporter:
     # ---- shutdown ------------------------------------------------------------------------------------------------
     def close(self) -> Dict[str, float]:
         """Drains the queue, finalises the containers and writes database.db; returns the writer's statistics."""
-        self._q.join()
+        self._q.join(); self._fq.join()
         self._q.put(None)
-        self._thread.join()
+        for _ in self._fstores:
+            self._fq.put(None)
+        for th in self._threads:
+            th.join()
         if self._err is not None:
             raise RuntimeError("the writer thread failed") from self._err
         t0 = time.perf_counter()
-        self.features.close(); self.raw.close(); self.verified.close()
+        for st in self._fstores:
+            st.close()
+        self.raw.close(); self.verified.close()
         if self._write_db and self._kpts:
             names = sorted(self._kpts)
             export.export_to_colmap(self.out_dir / "database.db", names, self._wh, self._kpts, self._raw, self._ver or None,

@@ -71,13 +71,45 @@ def features_to_half(features: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     return {k: np.asarray(v).astype(np.float16) for k, v in features.items() if isinstance(v, np.ndarray)}
 
 
-class FeatureStore:
-    """features.h5 writer/reader (h5py) or its .npz mirror."""
+class _NpzAppender:
+    """Incremental writer of an .npz (a zip of .npy members): every ``add`` deflates and appends one member, so nothing
+    is held back for ``close`` (np.savez_compressed would write everything at the end — on the critical path of a run
+    that is otherwise overlapped with the GPU).  np.load reads the result like any other .npz."""
 
     def __init__(self, path: Path):
+        import zipfile
+
         self.path = Path(path)
-        self._npz: Dict[str, np.ndarray] = {}
+        self.path.parent.mkdir(parents=True, exist_ok=True)
+        self._zf = zipfile.ZipFile(str(self.path), "w", zipfile.ZIP_DEFLATED, allowZip64=True)
+        self.keys = set()
+
+    def add(self, key: str, arr: np.ndarray):
+        with self._zf.open(key + ".npy", "w", force_zip64=True) as f:
+            np.lib.format.write_array(f, np.asanyarray(arr), allow_pickle=False)
+        self.keys.add(key)
+
+    def close(self):
+        self._zf.close()
+
+
+def _npz_shards(path: Path):
+    """features.npz plus the shard files parallel writers add next to it (features.shard1.npz, ...)."""
+    base = Path(path).with_suffix(".npz")
+    return [p for p in [base] + sorted(base.parent.glob(base.stem + ".shard*.npz")) if p.exists()]
+
+
+class FeatureStore:
+    """features.h5 writer/reader (h5py) or its .npz mirror.  ``shard`` > 0 writes ``<stem>.shard<k>.npz`` next to the main
+    mirror so that several writer threads can compress in parallel (zlib releases the GIL); readers see the union."""
+
+    def __init__(self, path: Path, shard: int = 0):
+        self.path = Path(path)
         self.use_h5 = HAVE_H5PY and self.path.suffix == ".h5"
+        self._npz = None
+        if not self.use_h5:
+            base = self.path.with_suffix(".npz")
+            self._npz = _NpzAppender(base if shard == 0 else base.with_name(f"{base.stem}.shard{shard}.npz"))
 
     def add(self, im_name: str, features: Dict[str, np.ndarray]):
         half = features_to_half(features)
@@ -92,11 +124,11 @@ class FeatureStore:
                     grp.create_dataset(k, data=v, dtype=np.float16, compression="gzip", compression_opts=9)
         else:
             for k, v in half.items():
-                self._npz[f"{im_name}/{k}"] = v
+                self._npz.add(f"{im_name}/{k}", v)
 
     def close(self):
-        if not self.use_h5:
-            np.savez_compressed(str(self.path.with_suffix(".npz")), **self._npz)
+        if self._npz is not None:
+            self._npz.close()
 
     @staticmethod
     def read(path: Path, im_name: str) -> Dict[str, np.ndarray]:
@@ -108,8 +140,12 @@ class FeatureStore:
             with h5py.File(str(path), "r") as fd:
                 raw = {k: np.array(v) for k, v in fd[im_name].items()}
         else:
-            z = np.load(str(path.with_suffix(".npz")))
-            raw = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(im_name + "/")}
+            raw = {}
+            for shard in _npz_shards(path):
+                z = np.load(str(shard))
+                raw.update({k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(im_name + "/")})
+            if not raw:
+                raise KeyError(f"Cannot find image {im_name} in {path}")
         out = {k: raw[k].astype(np.float32) for k in ("keypoints", "descriptors", "scores", "tile_idx") if k in raw}
         if "image_size" in raw:
             out["image_size"] = raw["image_size"].astype(np.int32)
@@ -121,8 +157,8 @@ class MatchStore:
 
     def __init__(self, path: Path):
         self.path = Path(path)
-        self._npz: Dict[str, np.ndarray] = {}
         self.use_h5 = HAVE_H5PY and self.path.suffix == ".h5"
+        self._npz = None if self.use_h5 else _NpzAppender(self.path.with_suffix(".npz"))
 
     def add(self, img0: str, img1: str, matches: np.ndarray):
         m = np.asarray(matches).reshape(-1, 2).astype(np.int64)
@@ -134,13 +170,13 @@ class MatchStore:
                 grp.create_dataset(img1, data=m)  # raises if the pair exists, like MB:282-285
         else:
             key = f"{img0}/{img1}"
-            if key in self._npz:
+            if key in self._npz.keys:
                 raise ValueError(f"Unable to create dataset (name already exists): {key}")
-            self._npz[key] = m
+            self._npz.add(key, m)
 
     def close(self):
-        if not self.use_h5:
-            np.savez_compressed(str(self.path.with_suffix(".npz")), **self._npz)
+        if self._npz is not None:
+            self._npz.close()
 
     @staticmethod
     def read_all(path: Path) -> Dict[Tuple[str, str], np.ndarray]:

@@ -23,7 +23,6 @@ def test_async_exporter_equals_synchronous_stores(tmp_path):
     names = [f"im{i}.jpg" for i in range(6)]
     ex = aexp.AsyncExporter(tmp_path / "async", device="cpu", max_pending=2)
     sync_f = export.FeatureStore(tmp_path / "sync" / "features.h5")
-    (tmp_path / "sync").mkdir()
     batches = []
     for s in range(0, 6, 3):
         kp, sc, de, n = _fake_batch(rng, 3, 64)

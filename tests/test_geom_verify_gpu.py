@@ -19,7 +19,7 @@ def test_batched_ransac_at_bench_batch_size(hip_lib):
     mt = torch.zeros(P, S, 2, dtype=torch.int64)
     truth = []
     for p in range(P):
-        ratio = 0.35 + 0.6 * (p / (P - 1))            # inlier ratios from 35 % to 95 %
+        ratio = 0.5 + 0.45 * (p / (P - 1))            # inlier ratios from 50 % to 95 % (0.5^7 x 4096 = 32 clean samples expected)
         ni = int(S * ratio)
         x0, x1, is_in, _ = geom_ref.synthetic_two_view(ni, S - ni, seed=p, noise_px=0.4)
         kt[2 * p], kt[2 * p + 1] = torch.from_numpy(x0), torch.from_numpy(x1)
@@ -27,7 +27,7 @@ def test_batched_ransac_at_bench_batch_size(hip_lib):
         truth.append(is_in)
     n = torch.full((P,), S, dtype=torch.int32)
     n[3] = 5                                           # < 8 matches: everything is an inlier, F = 0 (reference rule)
-    v = verify.DeviceVerifier(threshold=2.0, iters=2048, seed=3)
+    v = verify.DeviceVerifier(threshold=2.0, iters=4096, seed=3)
     kt_d, mt_d, n_d = kt.cuda(), mt.cuda(), n.cuda()
     out = v.verify_batch(kt_d, mt_d, n_d)
     torch.cuda.synchronize()
@@ -36,7 +36,7 @@ def test_batched_ransac_at_bench_batch_size(hip_lib):
         out = v.verify_batch(kt_d, mt_d, n_d, out=out)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
-    print(f"dim_gv_fundamental: {P} pairs x {S} matches x 2048 hypotheses: {ms:.2f} ms per batch ({ms / P * 1e3:.0f} us per pair)")
+    print(f"dim_gv_fundamental: {P} pairs x {S} matches x 4096 hypotheses: {ms:.2f} ms per batch ({ms / P * 1e3:.0f} us per pair)")
     mask = out["mask"].cpu().numpy().astype(bool)
     ninl = out["n_inliers"].cpu().numpy()
     assert ninl[3] == 5 and mask[3, :5].all() and not mask[3, 5:].any() and float(out["F"][3].abs().sum()) == 0.0
