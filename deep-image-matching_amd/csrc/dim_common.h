@@ -118,6 +118,32 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 
+// ---- buffer (SRD) addressing for epilogues --------------------------------------------------------------------------
+// A masked `if (ok) p[i] = v` store costs a branch (s_and_saveexec / s_cbranch_execz) plus 64-bit address arithmetic PER
+// ELEMENT: the epilogues of the matrix-core kernels were 30-45 % of their instruction stream that way.  With a buffer
+// resource descriptor (wave-uniform base + byte size) the address is a 32-bit byte offset, and anything at or beyond the
+// size is dropped (stores) or reads as zero (loads) by the hardware: rows past a ragged end need no test at all, and any
+// other mask is one v_cndmask selecting the out-of-range offset DIM_BUF_OOB (cdna_hip_programming.md T8 / T20).
+// The base must be wave-uniform (blockIdx-derived); sizes above 4 GiB are avoided by taking the base per image / item.
+typedef __amdgpu_buffer_rsrc_t dim_rsrc;
+#define DIM_BUF_OOB 0x80000000u   // beyond every descriptor used here (< 2 GiB) and still out of range after adding a tile's offsets
+__device__ __forceinline__ dim_rsrc buf_rsrc(const void* base, size_t bytes) {
+  // readfirstlane makes the (already uniform) base provably uniform to the compiler: no waterfall loop around each access
+  const unsigned long long p = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)p), hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+  void* q = (void*)(((unsigned long long)hi << 32) | lo);
+  const unsigned n = bytes > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)__builtin_amdgcn_readfirstlane((int)n), 0x00020000);
+}
+__device__ __forceinline__ void buf_store_f32(dim_rsrc r, unsigned byte_off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, 0); }
+__device__ __forceinline__ void buf_store_u32(dim_rsrc r, unsigned byte_off, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)byte_off, 0, 0); }
+__device__ __forceinline__ void buf_store_u16(dim_rsrc r, unsigned byte_off, unsigned short v) { __builtin_amdgcn_raw_buffer_store_b16(v, r, (int)byte_off, 0, 0); }
+// neighbouring-lane exchange (lane ^ 1) as a DPP quad permute: no LDS traffic, one VALU
+__device__ __forceinline__ unsigned lane_swap1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
+// byte select from {hi, lo} (v_perm_b32): selector byte k in 0..3 picks lo byte k, 4..7 picks hi byte k - 4
+__device__ __forceinline__ unsigned byte_perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ float buf_load_f32(dim_rsrc r, unsigned byte_off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0)); }
+
 // ---- fp16x3 range guard ---------------------------------------------------------------------------
 // Every kernel that PRODUCES a value a later fp16x3 split will consume (conv / GEMM epilogues, LayerNorm+GELU,
 // the rotated q / k, the external inputs) tracks max|x| of what it writes and bumps a sticky per-site device

@@ -116,10 +116,14 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
     __syncthreads();
   }
 
-  // Epilogue: per (m, n) tile all 16 residual values are requested before any is used, the uniform decisions
-  // (residual? activation?) are hoisted, out-of-range lanes are masked at the store only.
-  float* C = a.C + (size_t)z * a.strideC;
-  const float* R = a.R ? a.R + (size_t)z * a.strideR : nullptr;
+  // Epilogue through buffer descriptors (dim_common.h): 32-bit offsets, no per-element branches.  The descriptor of C / R
+  // ends after the item's last valid row, so rows past the ragged end are dropped (stores) / read as zero (loads) by the
+  // hardware; a column past N selects the out-of-range offset.  Per (m, n) tile all 16 residual values are requested
+  // before any is used; the uniform decisions (residual? activation?) are hoisted.
+  const dim_rsrc Cr = buf_rsrc(a.C + (size_t)z * a.strideC, ((size_t)(rows - 1) * a.ldc + a.N) * sizeof(float));
+  const dim_rsrc Rr = buf_rsrc(a.R ? a.R + (size_t)z * a.strideR : a.C, a.R ? ((size_t)(rows - 1) * a.ldr + a.N) * sizeof(float) : 0);
+  const bool has_r = a.R != nullptr;
+  const unsigned ldc4 = (unsigned)a.ldc * 4u, ldr4 = (unsigned)a.ldr * 4u;
   float vmax = 0.0f;  // fp16x3 range guard on what this thread stores (dim_common.h)
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
@@ -130,14 +134,16 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
     const float inv = a.inv_ch[colc];  // per-column inverse weight scale (x activation scale)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const int rbase = m0 + wm * (32 * MT) + m * 32;
+      const unsigned row0 = (unsigned)(m0 + wm * (32 * MT) + m * 32 + 4 * half);  // row of register r: row0 + (r & 3) + 8 * (r >> 2)
+      const unsigned cbase = colok ? row0 * ldc4 + (unsigned)col * 4u : DIM_BUF_OOB;
+      const unsigned rbase = colok ? row0 * ldr4 + (unsigned)col * 4u : DIM_BUF_OOB;
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[m][n][r] * inv + bv;
-      if (R) {
+      if (has_r) {
         float rv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = R[(size_t)min(rbase + mfma_row(r, half), rows - 1) * a.ldr + colc];
+        for (int r = 0; r < 16; ++r) rv[r] = buf_load_f32(Rr, rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * ldr4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] += rv[r];
       }
@@ -148,11 +154,12 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = v[r] <= 0.0f ? (expf(v[r]) - 1.0f) * 1.7580993408473768599402175208123f : v[r] * 1.0507009873554804934193349852946f;
       }
+      // range guard over all 16 values, unconditionally: rows past the ragged end are duplicates of the last valid row
+      // (load_chunk clamps) plus a zero residual, padded columns hold the bias of the last valid column
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + mfma_row(r, half);
-        if (colok && row < rows) { C[(size_t)row * a.ldc + col] = v[r]; vmax = fmaxf(vmax, fabsf(v[r])); }
-      }
+      for (int r = 0; r < 16; r += 2) vmax = sat_track(vmax, v[r], v[r + 1]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) buf_store_f32(Cr, cbase + (unsigned)((r & 3) + 8 * (r >> 2)) * ldc4, v[r]);
     }
   }
   if (MODE == 2) sat_report(a.sat, vmax);

@@ -263,6 +263,38 @@ static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return 
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4((a), (b), (c))
 
+// buffer resource descriptors: (base, bytes); accesses at or beyond `bytes` are dropped / read as zero, like the hardware's
+struct hipemu_rsrc { unsigned char* base; unsigned bytes; };
+typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
+static inline hipemu_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int n, int) { return hipemu_rsrc{(unsigned char*)p, (unsigned)n}; }
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, hipemu_rsrc r, int off, int soff, int) {
+  const unsigned o = (unsigned)off + (unsigned)soff; if ((unsigned long long)o + 4 <= r.bytes) memcpy(r.base + o, &v, 4);
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b16(unsigned short v, hipemu_rsrc r, int off, int soff, int) {
+  const unsigned o = (unsigned)off + (unsigned)soff; if ((unsigned long long)o + 2 <= r.bytes) memcpy(r.base + o, &v, 2);
+}
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(hipemu_rsrc r, int off, int soff, int) {
+  const unsigned o = (unsigned)off + (unsigned)soff; unsigned v = 0; if ((unsigned long long)o + 4 <= r.bytes) memcpy(&v, r.base + o, 4); return v;
+}
+
+// DPP quad permutes used by the kernels: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+  (void)old;
+  const int x = ctrl == 0xB1 ? 1 : (ctrl == 0x4E ? 2 : -1);
+  if (x < 0) { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+  return hipemu_shfl_from(src, (int)hipemu::cur->lane ^ x);
+}
+static inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel) {
+  const unsigned long long both = ((unsigned long long)hi << 32) | lo;
+  unsigned out = 0;
+  for (int k = 0; k < 4; ++k) {
+    const unsigned s = (sel >> (8 * k)) & 0xff;
+    const unsigned b = s < 8 ? (unsigned)((both >> (8 * s)) & 0xff) : (s == 0x0c ? 0u : 0xffu);
+    out |= b << (8 * k);
+  }
+  return out;
+}
+
 // atomics: one fiber runs at a time, so plain read-modify-write is atomic.
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; *p = o > v ? o : v; return o; }
