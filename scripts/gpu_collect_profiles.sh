@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd $R && python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err
 tail -c 600 $OUT/bench_$TAG.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${TAG}_$C -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
 done

@@ -46,3 +46,30 @@ def test_aliked_emulated_vs_oracle_and_golden(emu_lib, name):
     g = np.load(GOLD / f"al_{name}.npz")
     gold = {k: torch.from_numpy(g[k]) for k in ("keypoints", "scores", "descriptors")}
     compare_aliked(out, gold)
+
+
+REAL_ALIKED = Path("/root/reference/src/deep_image_matching/thirdparty/ALIKED/models/aliked-n16rot.pth")
+
+
+@pytest.mark.skipif(not REAL_ALIKED.exists(), reason="the reference tree (with its aliked-n16rot.pth) is not present")
+def test_aliked_real_checkpoint_through_the_hip_sources(emu_lib):
+    """The REAL aliked-n16rot.pth that ships inside the reference tree (read in place, never copied — so this runs in the
+    build container only; the checkpoint cannot travel to the GPU box) through the HIP sources on the emulator, vs the
+    oracle that oracle/make_golden.py pins bit-exact against the reference's aliked.py with the same file.  Real weights
+    have the trained dynamic range (BatchNorm scales, score head) that the seeded synthetic ones lack."""
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.load_aliked_state_dict(str(REAL_ALIKED), model_name="aliked-n16rot")
+    cfg = {"model_name": "aliked-n16rot", "max_num_keypoints": 200, "detection_threshold": 0.2, "nms_radius": 2}
+    yy, xx = torch.meshgrid(torch.arange(64.0), torch.arange(96.0), indexing="ij")
+    img = (0.5 + 0.25 * torch.sin(xx / 5.0) * torch.cos(yy / 7.0))[None, None].repeat(1, 3, 1, 1) \
+        + 0.2 * torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(3))
+    img = img.clamp(0, 1)
+    net = al_mod.AlikedHIP(sd, cfg, max_batch=1, max_hw=(64, 96), capacity=4096, device="cpu", lib=emu_lib)
+    out = {k: v.cpu() for k, v in net(img).items()}
+    ref = aliked_ref.aliked_forward(img, sd, cfg, taps=True)
+    taps = net.debug_taps()
+    pt, pl = taps["pad"]
+    fm = torch.nn.functional.normalize(taps["x1234"][0, pt:pt + 64, pl:pl + 96].permute(2, 0, 1), dim=0)
+    assert (fm - ref["feature_map"][0]).abs().max().item() < 1e-3
+    res = compare_aliked(out, ref)
+    assert res["n_out"] > 10
