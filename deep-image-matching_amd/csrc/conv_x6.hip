@@ -29,11 +29,15 @@ constexpr int w_slice(int npl) { return npl * 3 * 2 * 64 * 8; }              // 
 //      image is neither written nor read back.  CIN must be 64.
 // MODE: SplitMma policy (dim_common.h) — 1: three bf16 planes x six cross terms, 2: two fp16 planes x three
 //       cross terms (activations scaled by act_scale(), weights pre-scaled; inv_scale undoes both exactly).
-// PIN / POUT (mode 2 only): the input / output lives in HBM as two NHWC fp16 planes (h then l, `plane_in` /
-//      `plane_out` elements apart; together exactly the bytes of the fp32 tensor they replace) holding the 2-way
-//      split of 16 x the activation, clamped to +-65504.  A producer splits each value ONCE in its epilogue; a
+// PIN / POUT (mode 2 only): the input / output lives in HBM pre-split, in the bytes of the fp32 NHWC tensor it replaces:
+//      per pixel, every group of 16 channels holds its 16 h pieces followed by its 16 l pieces (fp16 of 16 x the
+//      activation, clamped to +-65504): element (pixel, channel c, plane) sits at 16-bit index
+//      pixel * 2C + (c / 16) * 32 + plane * 16 + c % 16.  A producer splits each value ONCE in its epilogue; a
 //      consumer stages its halo tile with straight 16-byte copies — no per-consumer split VALU (every element
-//      used to be split (cout / 64) x 1.33 times, ~5 VALU each).
+//      used to be split (cout / 64) x 1.33 times, ~5 VALU each) — and the 16 channels of one K chunk are ONE
+//      contiguous 64-byte run per pixel.  (Round 1 kept two separate planes: a chunk then read 32 bytes per pixel and
+//      plane, half of every 64-byte HBM burst was wasted, and conv2a .. conv4b ran at 4.2-5.3 TB/s of FETCH — HBM-bound
+//      on 2.6-6x their input — instead of matrix-core-bound.)
 template <int CIN, int POOL, int PF, bool F1A, int MODE, bool PIN, bool POUT>
 __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
@@ -93,9 +97,9 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       const int py = p / IW, px = p - py * IW;
       const int gy = oy + py - 1, gx = ox + px - 1;
       rin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (PIN) {  // q = plane * 2 + k-half: 8 consecutive channels of one plane = one 16-byte item
-        const unsigned short* pl = (const unsigned short*)in + (size_t)(q >> 1) * plane_in + (size_t)b * H * W * CIN;
-        if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(pl + ((size_t)gy * W + gx) * CIN + c * 16 + (q & 1) * 8);
+      if (PIN) {  // q = plane * 2 + k-half: 8 consecutive channels of one plane = one 16-byte item; the 4 items of a pixel are contiguous
+        const unsigned short* pl = (const unsigned short*)in + (size_t)b * H * W * CIN * 2;
+        if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(pl + ((size_t)gy * W + gx) * (2 * CIN) + c * 32 + q * 8);
       } else if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(in_b + ((size_t)gy * W + gx) * CIN + c * 16 + q * 4);
     }
   };
@@ -219,17 +223,17 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
   const int par = lx & 1;
   const unsigned psel = par ? 0x03020706u : 0x05040100u;   // odd lanes keep the high halves (second pixel), even lanes the low halves
   const dim_rsrc rs_f = buf_rsrc(out + (size_t)b * img_elems, POUT ? 0 : img_elems * 4);
-  const dim_rsrc rs_h = buf_rsrc((unsigned short*)out + (size_t)b * img_elems, POUT ? img_elems * 2 : 0);
-  const dim_rsrc rs_l = buf_rsrc((unsigned short*)out + plane_out + (size_t)b * img_elems, POUT ? img_elems * 2 : 0);
+  const dim_rsrc rs_p = buf_rsrc(out + (size_t)b * img_elems, POUT ? img_elems * 4 : 0);  // h and l pieces interleaved per 16 channels
   // pix0 / pix1: pixel indices inside the image (may lie past its end: dropped); okc0 / okc1: their columns are inside
   auto put2 = [&](unsigned pix0, unsigned pix1, bool okc0, bool okc1, int co, float v0, float v1) {
     if (POUT) {
       unsigned h, l;
       split2_pk(v0, v1, DIM_F16_ACT_SCALE, h, l);
       const unsigned ho = byte_perm(lane_swap1(h), h, psel), lo = byte_perm(lane_swap1(l), l, psel);
-      const unsigned off = (par ? okc1 : okc0) ? ((par ? pix1 : pix0) * (unsigned)cout + (unsigned)(co - par)) * 2u : DIM_BUF_OOB;
-      buf_store_u32(rs_h, off, ho);
-      buf_store_u32(rs_l, off, lo);
+      const unsigned c2 = (unsigned)(co - par);  // the even channel of this lane pair
+      const unsigned off = (par ? okc1 : okc0) ? ((par ? pix1 : pix0) * (unsigned)cout * 2u + (c2 >> 4) * 32u + (c2 & 15u)) * 2u : DIM_BUF_OOB;
+      buf_store_u32(rs_p, off, ho);
+      buf_store_u32(rs_p, off + 32u, lo);   // the l pieces of the group follow its 16 h pieces
     } else {
       buf_store_f32(rs_f, okc0 ? (pix0 * (unsigned)cout + (unsigned)co) * 4u : DIM_BUF_OOB, v0);
       buf_store_f32(rs_f, okc1 ? (pix1 * (unsigned)cout + (unsigned)co) * 4u : DIM_BUF_OOB, v1);
@@ -275,10 +279,11 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
 }
 
 // debug / inspection: pre-split planes back to fp32 (h + l is exact in fp32; / 16 undoes the activation scale)
-__global__ __launch_bounds__(256) void planes_to_f32_kernel(const unsigned short* __restrict__ planes, size_t plane, float* __restrict__ out, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const unsigned short* __restrict__ planes, int C, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // i = pixel * C + channel
   if (i >= n) return;
-  const _Float16 hv = __builtin_bit_cast(_Float16, planes[i]), lv = __builtin_bit_cast(_Float16, planes[plane + i]);
+  const size_t pix = i / C, c = i - pix * C, o = pix * 2 * C + (c >> 4) * 32 + (c & 15);
+  const _Float16 hv = __builtin_bit_cast(_Float16, planes[o]), lv = __builtin_bit_cast(_Float16, planes[o + 16]);
   out[i] = ((float)hv + (float)lv) / DIM_F16_ACT_SCALE;
 }
 
@@ -422,9 +427,9 @@ int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const floa
   return 0;
 }
 
-int launch_planes_to_f32(const void* planes, size_t n, float* out, hipStream_t s) {
+int launch_planes_to_f32(const void* planes, size_t n, int channels, float* out, hipStream_t s) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned short*)planes, n, out, n);
+  hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned short*)planes, channels, out, n);
   DIM_LAUNCH_CHECK();
   return 0;
 }

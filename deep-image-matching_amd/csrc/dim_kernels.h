@@ -69,10 +69,10 @@ int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias
 int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
                               float* out, int batch, int H, int W, int cout, int pool, int relu, int planes_out, hipStream_t s,
                               unsigned* sat = nullptr, unsigned* sat_image = nullptr);
-// fp16x3 only: input and / or output as pre-split fp16 planes (two NHWC fp16 tensors, h then l, in the bytes of the fp32 tensor)
+// fp16x3 only: input and / or output pre-split in the bytes of the fp32 NHWC tensor: per pixel and 16-channel group, 16 h then 16 l fp16 pieces (conv_x6.hip)
 int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
                              int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s, unsigned* sat = nullptr);
-int launch_planes_to_f32(const void* planes, size_t n, float* out, hipStream_t s);  // n = elements per plane
+int launch_planes_to_f32(const void* planes, size_t n, int channels, float* out, hipStream_t s);  // n = pixels x channels
 int dim_presplit_activations();  // 1 (default): SuperPoint's conv-to-conv activations are stored pre-split (dim_tune_set key 5)
 int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)

@@ -240,7 +240,7 @@ int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits,
     if (h->x_is_planes) {  // rebuild fp32 from the planes of the last batch
       const size_t n = (size_t)h->last_batch * h->last_h * h->last_w * 128;
       if (!h->x_dbg && dev_alloc(h, &h->x_dbg, (size_t)h->max_batch * (h->max_h / 8) * (h->max_w / 8) * 128) != 0) return -1;
-      if (launch_planes_to_f32(h->x, n, h->x_dbg, nullptr) != 0) return -1;
+      if (launch_planes_to_f32(h->x, n, 128, h->x_dbg, nullptr) != 0) return -1;
       DIM_HIP(hipDeviceSynchronize());
       *encoder = h->x_dbg;
     }
