@@ -57,7 +57,15 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
 
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6, lx = lane & 31, half = lane >> 5;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+  // XCD-aware tile order (cdna_hip_programming.md T1): the hardware sends workgroup L to XCD L % 8; giving every XCD a
+  // contiguous BAND of the image's tiles (bijective for any tile count) lets neighbouring tiles find each other's halo
+  // rows / columns in that XCD's L2 instead of fetching them again.  Speed only.
+  int tile;
+  {
+    const int nt = gridDim.x, xcd = blockIdx.x & 7, j = blockIdx.x >> 3, q = nt >> 3, r = nt & 7;
+    tile = xcd * q + min(xcd, r) + j;
+  }
+  const int ty = tile / tiles_x, tx = tile % tiles_x;
   const int cb = blockIdx.y, b = blockIdx.z;
   const int oy = ty * TH, ox = tx * TW;
   const float* in_b = in + (size_t)b * H * W * (F1A ? 1 : CIN);
