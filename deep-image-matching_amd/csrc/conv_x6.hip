@@ -42,8 +42,8 @@ template <int CIN, int POOL, int PF, bool F1A, int MODE, bool PIN, bool POUT>
 __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                             int cout, int relu, int tiles_x, const float* __restrict__ w1a,
-                                                            const float* __restrict__ b1a, const float* __restrict__ inv_ch, size_t plane_in,
-                                                            size_t plane_out, unsigned* sat, unsigned* sat_image) {
+                                                            const float* __restrict__ b1a, const float* __restrict__ inv_ch, unsigned* sat,
+                                                            unsigned* sat_image) {
   static_assert(!(PIN || POUT) || MODE == 2, "pre-split planes exist for the fp16x3 mode only");
   static_assert(!(PIN && F1A), "the fused conv1a computes its own input");
   using S = SplitMma<MODE>;
@@ -365,7 +365,7 @@ int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
   const unsigned short* wx = wt.dev;
   const float* inv = wt.inv_ch();
-#define DIM_CONV6(CI, P, PFV, MD) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV, false, MD, false, false>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, inv, (size_t)0, (size_t)0, sat, (unsigned*)nullptr)
+#define DIM_CONV6(CI, P, PFV, MD) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, PFV, false, MD, false, false>), grid, dim3(256), 0, s, in, wx, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, inv, sat, (unsigned*)nullptr)
 #define DIM_CONV6_V(PFV, MD)                              \
   {                                                       \
     if (cin == 64 && pool) DIM_CONV6(64, 1, PFV, MD);     \
@@ -397,9 +397,8 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-  const size_t plane_out = (size_t)batch * (pool ? (H / 2) * (W / 2) : H * W) * cout;
   DIM_REQUIRE(!planes_out || wt.mode == 2, "conv3x3_x6: pre-split output planes exist for the fp16x3 mode only");
-#define DIM_CONV6F(P, MD, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD, false, PO>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), (size_t)0, plane_out, sat, sat_image)
+#define DIM_CONV6F(P, MD, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD, false, PO>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image)
   if (wt.mode == 2 && planes_out) { if (pool) DIM_CONV6F(1, 2, true); else DIM_CONV6F(0, 2, true); }
   else if (wt.mode == 2) { if (pool) DIM_CONV6F(1, 2, false); else DIM_CONV6F(0, 2, false); }
   else { if (pool) DIM_CONV6F(1, 1, false); else DIM_CONV6F(0, 1, false); }
@@ -416,8 +415,7 @@ int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const floa
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-  const size_t plane_in = (size_t)batch * H * W * cin, plane_out = (size_t)batch * (pool ? (H / 2) * (W / 2) : H * W) * cout;
-#define DIM_CONV6P(CI, P, PI, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, 1, false, 2, PI, PO>), grid, dim3(256), 0, s, in, wt.dev, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, wt.inv_ch(), plane_in, plane_out, sat, (unsigned*)nullptr)
+#define DIM_CONV6P(CI, P, PI, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, 1, false, 2, PI, PO>), grid, dim3(256), 0, s, in, wt.dev, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, wt.inv_ch(), sat, (unsigned*)nullptr)
 #define DIM_CONV6P_IO(CI, P)                                   \
   {                                                            \
     if (planes_in && planes_out) DIM_CONV6P(CI, P, true, true); \
