@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
         else if (c + 1 < NCHUNK) load_w(c + 1, 0);
       }
       if (PF == 2 && !F1A && dy == 2 && c + 1 < NCHUNK) load_in(c + 1);
+      __builtin_amdgcn_s_setprio(1);  // a wave in its matrix phase outranks the co-resident waves that are staging (T5)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         u32x4 fa[2][NPL], fb[2][NPL];
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
 #pragma unroll
             for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[n][S::tb(tm)], acc[m][n]);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 
