@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=50, help="pairs per step per GPU (50 x 20 steps = the 1000 pairs of configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="developer knob: dim_tune_set(KEY, VALUE) before the "
+                    "networks are created (A/B runs of kernel variants; the default line uses none)")
     ap.add_argument("--overlap", action="store_true", help="time the two-stream schedule (extraction of batch i+1 overlapping matching "
                     "of batch i) as the main region; by default it is measured after it and reported as two_stream_overlap")
     ap.add_argument("--no-overlap", action="store_true", help="(default since round 1) kept for compatibility")
@@ -189,6 +191,9 @@ def main():
     weights = importlib.import_module(PKG + ".weights")
     capi = importlib.import_module(PKG + ".capi")
     lib = capi.load()
+    for kv in a.tune:
+        k, v = kv.split("=")
+        lib.dim_tune_set(int(k), int(v))
 
     P, K, W = a.pairs, a.steps, a.warmup
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}

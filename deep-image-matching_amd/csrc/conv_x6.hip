@@ -18,7 +18,8 @@
 #include "dim_kernels.h"
 
 namespace {
-constexpr int TH = 8, TW = 32, IW = TW + 2, IH = TH + 2, NPIX = IH * IW;  // 340 halo pixels
+constexpr int TW = 32, IW = TW + 2;
+constexpr int tile_rows(int mr) { return 4 * mr; }   // output rows per workgroup: 4 waves x MR rows
 constexpr int w_slice(int npl) { return npl * 3 * 2 * 64 * 8; }              // 16-bit elements per (cb, chunk, dy) slice
 
 // PF: 0 = no software prefetch, 1 = next weight slice fetched into registers behind the MFMAs,
@@ -38,8 +39,12 @@ constexpr int w_slice(int npl) { return npl * 3 * 2 * 64 * 8; }              // 
 //      contiguous 64-byte run per pixel.  (Round 1 kept two separate planes: a chunk then read 32 bytes per pixel and
 //      plane, half of every 64-byte HBM burst was wasted, and conv2a .. conv4b ran at 4.2-5.3 TB/s of FETCH — HBM-bound
 //      on 2.6-6x their input — instead of matrix-core-bound.)
-template <int CIN, int POOL, int PF, bool F1A, int MODE, bool PIN, bool POUT>
-__global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
+// MR: output rows per wave.  2: tile 8 x 32, 4 accumulators per wave, 3 workgroups per CU.  4: tile 16 x 32, 8 accumulators,
+//     2 workgroups per CU — 12 instead of 16 LDS operand reads per 24 MFMAs, half the weight staging per MFMA, 1.20 x
+//     instead of 1.33 x halo overhead: the production shapes run it (measured 522 -> 531 pairs/s at a power-limited clock;
+//     staging all three kernel rows of weights per barrier pair on top of it was +-0 at MR 4 and 3 % slower at MR 2).
+template <int CIN, int POOL, int PF, bool F1A, int MODE, bool PIN, bool POUT, int MR = 2>
+__global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                             int cout, int relu, int tiles_x, const float* __restrict__ w1a,
                                                             const float* __restrict__ b1a, const float* __restrict__ inv_ch, unsigned* sat,
@@ -48,6 +53,7 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
   static_assert(!(PIN && F1A), "the fused conv1a computes its own input");
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, W_SLICE = w_slice(NPL);
+  constexpr int TH = tile_rows(MR), IH = TH + 2, NPIX = IH * IW;  // MR 2: 340 halo pixels, MR 4: 612
   __shared__ u32x4 Ip[NPL * 2 * NPIX];
   __shared__ u32x4 Wp[NPL * 3 * 2 * 64];
   constexpr int IMW = IW + 2, IMH = IH + 2;  // image tile of the fused conv1a: halo of the halo
@@ -70,15 +76,16 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
   const int oy = ty * TH, ox = tx * TW;
   const float* in_b = in + (size_t)b * H * W * (F1A ? 1 : CIN);
 
-  f32x16 acc[2][2];
+  f32x16 acc[MR][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  constexpr int NWV = (W_SLICE / 8 + 255) / 256;   // 16-B weight items per thread per slice (4.5 -> 5)
+  constexpr int W_ITEMS = W_SLICE / 8;              // 16-B weight items per staging step
+  constexpr int NWV = (W_ITEMS + 255) / 256;        // per thread (bf16x6: 4.5 -> 5; fp16x3: 3)
   constexpr int NIN = (NPIX * 4 + 255) / 256;       // float4 halo items per thread per chunk (5.3 -> 6)
   u32x4 rw[NWV];
   float4 rin[NIN];
@@ -87,14 +94,14 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
       const int idx = t + 256 * i;
-      if (idx < W_SLICE / 8) rw[i] = src[idx];
+      if (idx < W_ITEMS) rw[i] = src[idx];
     }
   };
   auto store_w = [&]() {
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
       const int idx = t + 256 * i;
-      if (idx < W_SLICE / 8) Wp[idx] = rw[i];
+      if (idx < W_ITEMS) Wp[idx] = rw[i];
     }
   };
   auto load_in = [&](int c) {
@@ -203,18 +210,18 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
       __builtin_amdgcn_s_setprio(1);  // a wave in its matrix phase outranks the co-resident waves that are staging (T5)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        u32x4 fa[2][NPL], fb[2][NPL];
+        u32x4 fa[MR][NPL], fb[2][NPL];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-          for (int m = 0; m < 2; ++m) fa[m][p] = Ip[(p * 2 + half) * NPIX + (2 * wv + m + dy) * IW + lx + dx];
+          for (int m = 0; m < MR; ++m) fa[m][p] = Ip[(p * 2 + half) * NPIX + (MR * wv + m + dy) * IW + lx + dx];
 #pragma unroll
           for (int n = 0; n < 2; ++n) fb[n][p] = Wp[((p * 3 + dx) * 2 + half) * 64 + n * 32 + lx];
         }
 #pragma unroll
         for (int tm = 0; tm < S::NT; ++tm)  // smallest cross terms first
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+          for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[n][S::tb(tm)], acc[m][n]);
       }
@@ -256,24 +263,27 @@ __global__ __launch_bounds__(256, (PF == 2 ? 2 : 3)) void conv3x3_x6_kernel(cons
     const float bv = bias[co];
     const float inv_scale = inv_ch[co];
     if (POOL) {
-      const int py = (oy >> 1) + wv, pxb = ox >> 1;
-      float pv[8];
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        float v = fmaxf(fmaxf(acc[0][n][r], acc[0][n][r + 1]), fmaxf(acc[1][n][r], acc[1][n][r + 1])) * inv_scale + bv;
-        if (relu) v = fmaxf(v, 0.0f);
-        pv[r >> 1] = v;
-      }
+      for (int mp = 0; mp < MR / 2; ++mp) {
+        const int py = (oy >> 1) + (MR / 2) * wv + mp, pxb = ox >> 1;
+        float pv[8];
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        const int q0 = mfma_row(2 * j, half) >> 1, q1 = mfma_row(2 * j + 2, half) >> 1;  // pooled column offsets inside the tile
-        vmax = sat_track(vmax, pv[j], pv[j + 1]);
-        put2((unsigned)(py * Wo + pxb + q0), (unsigned)(py * Wo + pxb + q1), pxb + q0 < Wo, pxb + q1 < Wo, co, pv[j], pv[j + 1]);
+        for (int r = 0; r < 16; r += 2) {
+          float v = fmaxf(fmaxf(acc[2 * mp][n][r], acc[2 * mp][n][r + 1]), fmaxf(acc[2 * mp + 1][n][r], acc[2 * mp + 1][n][r + 1])) * inv_scale + bv;
+          if (relu) v = fmaxf(v, 0.0f);
+          pv[r >> 1] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const int q0 = mfma_row(2 * j, half) >> 1, q1 = mfma_row(2 * j + 2, half) >> 1;  // pooled column offsets inside the tile
+          vmax = sat_track(vmax, pv[j], pv[j + 1]);
+          put2((unsigned)(py * Wo + pxb + q0), (unsigned)(py * Wo + pxb + q1), pxb + q0 < Wo, pxb + q1 < Wo, co, pv[j], pv[j + 1]);
+        }
       }
     } else {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int y = oy + 2 * wv + m;
+      for (int m = 0; m < MR; ++m) {
+        const int y = oy + MR * wv + m;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const int x0 = ox + mfma_row(r, half);  // r even: the odd register is the next column
@@ -353,7 +363,7 @@ void prepare_conv_weights_split(const float* w_oihw, int cin, int cout, int mode
   }
 }
 
-static int g_conv_x6_variant = 1;
+static int g_conv_x6_variant = 1 | 16;  // bits 0-1: prefetch variant of the bf16x6 kernels; bit 4: 16-row tiles for the production fp16x3 shapes
 int dim_conv_x6_variant() { return g_conv_x6_variant; }
 void dim_conv_x6_set_variant(int v) { g_conv_x6_variant = v; }
 
@@ -363,7 +373,7 @@ int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias
   DIM_REQUIRE(cin == 64 || cin == 128, "conv3x3_x6: cin=%d unsupported (64 or 128)", cin);
   DIM_REQUIRE(wt.dev && (wt.mode == 1 || wt.mode == 2), "conv3x3_x6: weights not prepared (mode %d)", wt.mode);
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
-  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
+  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, tile_rows(2));
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
   const unsigned short* wx = wt.dev;
   const float* inv = wt.inv_ch();
@@ -378,7 +388,7 @@ int launch_conv3x3_x6(const float* in, const SplitWeights& wt, const float* bias
   if (wt.mode == 2) {
     DIM_CONV6_V(1, 2)
   } else {
-    switch (dim_conv_x6_variant()) {
+    switch (dim_conv_x6_variant() & 3) {
       case 0: DIM_CONV6_V(0, 1) break;
       case 2: DIM_CONV6_V(2, 1) break;
       default: DIM_CONV6_V(1, 1) break;
@@ -397,11 +407,15 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
   DIM_REQUIRE(cout % 64 == 0, "conv3x3_x6 fused conv1a: cout=%d must be a multiple of 64", cout);
   DIM_REQUIRE(wt.dev && (wt.mode == 1 || wt.mode == 2), "conv3x3_x6: weights not prepared (mode %d)", wt.mode);
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
-  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
+  const int var = dim_conv_x6_variant();
+  const bool big = wt.mode == 2 && planes_out && pool && (var & 16);   // the production shape has the 16-row tile variant
+  const int mr = big ? 4 : 2;
+  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, tile_rows(mr));
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
   DIM_REQUIRE(!planes_out || wt.mode == 2, "conv3x3_x6: pre-split output planes exist for the fp16x3 mode only");
-#define DIM_CONV6F(P, MD, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD, false, PO>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image)
-  if (wt.mode == 2 && planes_out) { if (pool) DIM_CONV6F(1, 2, true); else DIM_CONV6F(0, 2, true); }
+#define DIM_CONV6F(P, MD, PO, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD, false, PO, ##__VA_ARGS__>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image)
+  if (big) DIM_CONV6F(1, 2, true, 4);
+  else if (wt.mode == 2 && planes_out) { if (pool) DIM_CONV6F(1, 2, true); else DIM_CONV6F(0, 2, true); }
   else if (wt.mode == 2) { if (pool) DIM_CONV6F(1, 2, false); else DIM_CONV6F(0, 2, false); }
   else { if (pool) DIM_CONV6F(1, 1, false); else DIM_CONV6F(0, 1, false); }
 #undef DIM_CONV6F
@@ -415,12 +429,17 @@ int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const floa
   DIM_REQUIRE(cout % 64 == 0 && (cin == 64 || cin == 128), "conv3x3_x6 planes: cin=%d cout=%d", cin, cout);
   DIM_REQUIRE(wt.dev && wt.mode == 2, "conv3x3_x6 planes: fp16x3 weights required (mode %d)", wt.mode);
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
-  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
+  const int var = dim_conv_x6_variant();
+  const bool big = planes_in && (var & 16);
+  const int mr = big ? 4 : 2;
+  const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, tile_rows(mr));
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-#define DIM_CONV6P(CI, P, PI, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, 1, false, 2, PI, PO>), grid, dim3(256), 0, s, in, wt.dev, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, wt.inv_ch(), sat, (unsigned*)nullptr)
+#define DIM_CONV6P(CI, P, PI, PO, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, 1, false, 2, PI, PO, ##__VA_ARGS__>), grid, dim3(256), 0, s, in, wt.dev, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, wt.inv_ch(), sat, (unsigned*)nullptr)
 #define DIM_CONV6P_IO(CI, P)                                   \
   {                                                            \
-    if (planes_in && planes_out) DIM_CONV6P(CI, P, true, true); \
+    if (big && planes_out) DIM_CONV6P(CI, P, true, true, 4);   \
+    else if (big) DIM_CONV6P(CI, P, true, false, 4);           \
+    else if (planes_in && planes_out) DIM_CONV6P(CI, P, true, true); \
     else if (planes_in) DIM_CONV6P(CI, P, true, false);        \
     else if (planes_out) DIM_CONV6P(CI, P, false, true);       \
     else DIM_CONV6P(CI, P, false, false);                      \

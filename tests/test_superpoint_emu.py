@@ -99,3 +99,23 @@ def test_presplit_activation_planes_are_bit_identical_to_consumer_side_splits(em
     np.testing.assert_allclose(ta["encoder"].numpy(), tb["encoder"].numpy(), rtol=3e-7, atol=4e-9)  # small values: the low piece is an fp16 subnormal (absolute step 2^-24 / 16)
     assert torch.equal(ta["score_map"], tb["score_map"]) and torch.equal(ta["logits"], tb["logits"])
     assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
+
+
+def test_conv_16_row_tiles_are_bit_identical_to_8_row_tiles(emu_lib):
+    """conv_x6.hip's 16-row workgroup tile (bit 4 of dim_tune_set key 2, the default for the production shapes) accumulates
+    every output in the same order as the 8-row tile: nothing may change."""
+    name = next(iter(gc.SP_CASES))
+    case = gc.SP_CASES[name]
+    sd = gc.sp_weights(case)
+    img = torch.rand(1, 1, 52, 70, generator=torch.Generator().manual_seed(11))  # ragged tiles at every scale
+    net = sp_mod.SuperPointHIP(sd, case["cfg"], max_batch=1, max_hw=(52, 70), capacity=512, device="cpu", lib=emu_lib)
+    try:
+        emu_lib.dim_tune_set(2, 1)
+        a = net(img); ta = net.debug_taps()
+        emu_lib.dim_tune_set(2, 1 | 16)
+        b = net(img); tb = net.debug_taps()
+    finally:
+        emu_lib.dim_tune_set(2, 1 | 16)
+    for k in ("encoder", "score_map", "logits"):
+        assert torch.equal(ta[k], tb[k]), k
+    assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
