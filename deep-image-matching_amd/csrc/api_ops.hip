@@ -215,6 +215,7 @@ int dim_tune_set(int key, int value) {
   if (key == 3) g_fuse_conv1a = value;
   if (key == 4) g_fold_out_proj = value;
   if (key == 5) g_presplit = value;
+  if (key == 6) dim_gemm_x6_set_wide(value);
   return 0;
 }
 

@@ -77,6 +77,8 @@ int dim_presplit_activations();  // 1 (default): SuperPoint's conv-to-conv activ
 int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
 int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)
+int dim_gemm_x6_wide();      // 1 (default): 128 x 256 workgroup blocks where n_pad allows (dim_tune_set key 6)
+void dim_gemm_x6_set_wide(int v);
 void dim_conv_x6_set_variant(int v);  // tuning hook: prefetch variant of conv3x3_x6 (dim_tune_set key 2)
 void dim_conv_set_variant(int v);  // tuning hook: selects the conv3x3 kernel variant (see conv.hip)
 // conv1a: 1 -> 64 channels, direct (VALU) convolution; in: [B][H][W], w: [9][64].

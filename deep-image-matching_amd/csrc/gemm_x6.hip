@@ -19,14 +19,18 @@
 #include "dim_kernels.h"
 
 namespace {
-constexpr int BN = 128, KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
+constexpr int KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
 // BM = 128 (each wave 64 x 64) or, for small problems that would leave most CUs idle, 64 (each wave 32 x 64: twice the
 // workgroups, half the MFMA / split work per barrier-to-barrier step of the serial K loop)
 
-template <int MODE, int BM>
-__global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
+// NT: 32-column MFMA tiles per wave.  2: block 128 x 128 (3 workgroups per CU); 4: block 128 x 256, each wave 64 x 128 =
+//     8 accumulators (2 per CU) — the activation tile is loaded, split and staged once for twice the MFMAs, and the K loop's
+//     two barriers and its exposed prefetch latency are paid per 48 instead of per 24 MFMAs.
+template <int MODE, int BM, int NT = 2>
+__global__ __launch_bounds__(256, (NT == 4 ? 2 : 3)) void gemm_x6_kernel(GemmArgs a) {
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, MT = BM / 64, NLD = BM / 32;  // 32-row MFMA tiles per wave, float4 loads per thread and chunk
+  constexpr int BN = 64 * NT;
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
@@ -42,13 +46,13 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
   const int NB = a.n_pad / 32, KS = a.K / 16;
   // this lane's slot inside a [k-half][32 cols] fragment block, for its two 32-column groups
   const u32x4* Bf = (const u32x4*)a.Bx3;
-  const size_t nb0 = (size_t)(n0 + wn * 64) / 32;
+  const size_t nb0 = (size_t)(n0 + wn * (32 * NT)) / 32;
 
-  f32x16 acc[MT][2];
+  f32x16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -86,13 +90,13 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
     // Issue order matters: vector-memory loads retire in order, so the weight fragments this chunk's MFMAs
     // need are requested BEFORE the next chunk's activation prefetch — the wait in front of the first MFMA
     // then covers the (L2-resident) fragments only and the HBM latency of the prefetch hides behind the MFMAs.
-    u32x4 fb[2][2][NPL];
+    u32x4 fb[2][NT][NPL];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) fb[ks][n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + (k0 >> 4) + ks) * 2 + half) * 32 + lx];
+        for (int n = 0; n < NT; ++n) fb[ks][n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + (k0 >> 4) + ks) * 2 + half) * 32 + lx];
     // unconditional (the last iteration harmlessly re-reads its own chunk): a branch here would make the compiler
     // size every wait in the MFMA phase for the path WITHOUT the prefetch, i.e. wait for the prefetch on the other
     __builtin_amdgcn_sched_barrier(0);
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[ks][n][S::tb(tm)], acc[m][n]);
+          for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[ks][n][S::tb(tm)], acc[m][n]);
     }
     __syncthreads();
   }
@@ -126,8 +130,8 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
   const unsigned ldc4 = (unsigned)a.ldc * 4u, ldr4 = (unsigned)a.ldr * 4u;
   float vmax = 0.0f;  // fp16x3 range guard on what this thread stores (dim_common.h)
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int col = n0 + wn * 64 + n * 32 + lx;
+  for (int n = 0; n < NT; ++n) {
+    const int col = n0 + wn * (32 * NT) + n * 32 + lx;
     const bool colok = col < a.N;
     const int colc = colok ? col : a.N - 1;
     const float bv = a.bias ? a.bias[colc] : 0.0f;
@@ -166,10 +170,15 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_kernel(GemmArgs a) {
 }
 }  // namespace
 
+static int g_gemm_x6_wide = 1;
+int dim_gemm_x6_wide() { return g_gemm_x6_wide; }
+void dim_gemm_x6_set_wide(int v) { g_gemm_x6_wide = v; }
+
 int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.Bx3 != nullptr && !a.bt && (a.split_mode == 1 || a.split_mode == 2), "gemm_x6: needs pre-split [planes][n_pad][K] weights");
   DIM_REQUIRE(a.K % 16 == 0, "gemm_x6: K");
   DIM_REQUIRE(a.K % KC == 0 && (a.A1 == nullptr || a.ksplit % KC == 0), "gemm_x6: K=%d / ksplit=%d must be multiples of %d", a.K, a.ksplit, KC);
+  constexpr int BN = 128;
   DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
   DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
   if (batch <= 0 || a.M <= 0 || a.N <= 0) return 0;
@@ -178,6 +187,10 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     dim3 grid(cdiv(a.M, 64), cdiv(a.N, BN), batch);
     if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<1, 64>), grid, dim3(256), 0, s, a);
+  } else if (a.split_mode == 2 && dim_gemm_x6_wide() && a.n_pad % 256 == 0 &&
+             (dim_gemm_x6_wide() == 2 || (long)cdiv(a.M, 128) * (a.n_pad / 256) * batch >= 512)) {  // 2: forced (tests); 1: when it still fills 2 workgroups per CU
+    dim3 grid(cdiv(a.M, 128), cdiv(a.N, 256), batch);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid(cdiv(a.M, 128), cdiv(a.N, BN), batch);
     if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128>), grid, dim3(256), 0, s, a);

@@ -79,6 +79,28 @@ def test_gemm_split_precision_is_fp32_accurate(emu_lib, split_mode, M, N, K):
     assert ((C.double() - ref).abs() / mag).max().item() < 4e-7
 
 
+@pytest.mark.parametrize("M,N,K", [(130, 256, 512), (200, 500, 64)])
+def test_gemm_wide_blocks_are_bit_identical(emu_lib, M, N, K):
+    """The 128 x 256 workgroup block of gemm_x6.hip (dim_tune_set key 6; 2 = forced whatever the problem size) accumulates
+    every output in the same order as the 128 x 128 block."""
+    g = torch.Generator().manual_seed(K + M)
+    A, W = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g).contiguous()
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    dev, npad = ctypes.c_void_p(), ctypes.c_int()
+    assert emu_lib.dim_x3_create(p(W), K, N, ctypes.byref(dev), ctypes.byref(npad)) == 0
+    outs = []
+    try:
+        for wide in (0, 2):
+            emu_lib.dim_tune_set(6, wide)
+            C = torch.full((M, N), -3.0)
+            assert emu_lib.dim_op_gemm_x6_f32(p(A), K, dev, npad.value, p(bias), p(R), N, p(C), N, M, N, K, 1, None) == 0, emu_lib.dim_last_error()
+            outs.append(C)
+    finally:
+        emu_lib.dim_tune_set(6, 1)
+        emu_lib.dim_x3_destroy(dev)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("cin,cout,H,W,pool", [(64, 64, 20, 37, 1), (64, 128, 9, 33, 0), (128, 128, 16, 34, 1)])
 def test_conv3x3_split_precision_is_fp32_accurate(emu_lib, split_mode, cin, cout, H, W, pool):
     g = torch.Generator().manual_seed(cin + H)
