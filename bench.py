@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=50, help="pairs per step per GPU (50 x 20 steps = the 1000 pairs of configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lib", default=None, help="developer knob: path of an alternative libdim_hip build to load")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="developer knob: dim_tune_set(KEY, VALUE) before the "
                     "networks are created (A/B runs of kernel variants; the default line uses none)")
     ap.add_argument("--overlap", action="store_true", help="time the two-stream schedule (extraction of batch i+1 overlapping matching "
@@ -190,6 +191,8 @@ def main():
     lg = importlib.import_module(PKG + ".lightglue_hip")
     weights = importlib.import_module(PKG + ".weights")
     capi = importlib.import_module(PKG + ".capi")
+    if a.lib:  # developer knob: A/B a differently built library in the same GPU call
+        capi.install(capi.load(a.lib), None)
     lib = capi.load()
     for kv in a.tune:
         k, v = kv.split("=")

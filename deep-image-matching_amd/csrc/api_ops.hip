@@ -216,6 +216,7 @@ int dim_tune_set(int key, int value) {
   if (key == 4) g_fold_out_proj = value;
   if (key == 5) g_presplit = value;
   if (key == 6) dim_gemm_x6_set_wide(value);
+  if (key == 7) dim_nms_set_big_tiles(value);
   return 0;
 }
 

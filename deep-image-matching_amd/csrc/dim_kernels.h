@@ -77,6 +77,8 @@ int dim_presplit_activations();  // 1 (default): SuperPoint's conv-to-conv activ
 int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
 int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)
+int dim_nms_big_tiles();     // 1 (default): 64 x 64 NMS tiles on large score maps (dim_tune_set key 7; 2 = forced)
+void dim_nms_set_big_tiles(int v);
 int dim_gemm_x6_wide();      // 1 (default): 128 x 256 workgroup blocks where n_pad allows (dim_tune_set key 6)
 void dim_gemm_x6_set_wide(int v);
 void dim_conv_x6_set_variant(int v);  // tuning hook: prefetch variant of conv3x3_x6 (dim_tune_set key 2)

@@ -25,6 +25,23 @@ def test_simple_nms_bit_exact_with_ties_and_plateaus(emu_lib, radius):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("radius", [1, 3, 4])
+def test_simple_nms_64_tiles_bit_exact(emu_lib, radius):
+    """The 64 x 64-tile variant (dim_tune_set key 7 = 2 forces it on any map size) on a map with partial tiles on both axes."""
+    g = torch.Generator().manual_seed(40 + radius)
+    H, W = 75, 130
+    s = torch.rand(1, H, W, generator=g)
+    s[0, :40] = (s[0, :40] * 5).round() / 5 + 0.01
+    s[0, 50:70, 60:100] = 0.5
+    out = torch.full_like(s, -1.0)
+    try:
+        emu_lib.dim_tune_set(7, 2)
+        assert emu_lib.dim_op_simple_nms_f32(p(s), p(out), 1, H, W, radius, None) == 0, emu_lib.dim_last_error()
+    finally:
+        emu_lib.dim_tune_set(7, 1)
+    assert torch.equal(out, superpoint_ref.simple_nms(s, radius))
+
+
 @pytest.mark.parametrize("M,N,K,bt", [(200, 65, 64, 0), (130, 256, 256, 0), (150, 140, 64, 1), (1, 4, 32, 0)])
 def test_gemm_mfma(emu_lib, M, N, K, bt):
     g = torch.Generator().manual_seed(M)
