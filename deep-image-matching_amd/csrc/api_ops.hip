@@ -57,6 +57,8 @@ static int g_fuse_conv1a = 1;
 int dim_fuse_conv1a() { return g_fuse_conv1a; }
 static int g_fold_out_proj = 1;
 int dim_fold_out_proj() { return g_fold_out_proj; }
+static int g_fuse_kv = 1;
+int dim_fuse_kv() { return g_fuse_kv; }
 static int g_presplit = 1;
 int dim_presplit_activations() { return g_presplit; }
 
@@ -217,6 +219,7 @@ int dim_tune_set(int key, int value) {
   if (key == 5) g_presplit = value;
   if (key == 6) dim_gemm_x6_set_wide(value);
   if (key == 7) dim_nms_set_big_tiles(value);
+  if (key == 8) g_fuse_kv = value;
   return 0;
 }
 

@@ -44,7 +44,14 @@ struct GemmArgs {
   const int* cols = nullptr; int cols_mul = 1, cols_off = 0;
   const int* flag = nullptr; int flag_shift = 0, flag_eq = 0;
   int relu = 0;  // epilogue activation: 0 none, 1 ReLU, 2 SELU
+  // LightGlue q|k|v projections (fp16x3, 128 x 256 blocks only; gemm_x6_fuses_kv()): the 256-column blocks kv_kblock / kv_vblock
+  // are not stored as fp32 but written pre-split, in the tile-image layout lg_attn_x6.hip's attention kernel stages from
+  // (kv_img: [item][4 heads][kv_tiles][KV_TILE_STRIDE x 16 B]), K with the rotary embedding applied when kv_enc != nullptr
+  // ([item][kv_nmax][64] cos | sin) — what kv_prep_kernel did in a separate pass over the fp32 projections.
+  void* kv_img = nullptr; int kv_tiles = 0, kv_kblock = -1, kv_vblock = -1, kv_nmax = 0; const float* kv_enc = nullptr;
 };
+constexpr int KV_TILE_STRIDE = 3 * 8 * 32 + 3 * 2 * 2 * 64;  // 16-byte slots reserved per (item, head, 32-key tile) image (bf16x6 fills all 1536)
+bool gemm_x6_fuses_kv(int M, int n_pad, int batch, int split_mode);  // true when launch_gemm_x6 will honour kv_img for this shape
 int launch_gemm(const GemmArgs& a, int batch, hipStream_t s);
 // fp32-accurate GEMM on the 16-bit matrix cores (gemm_x6.hip); needs a.set_split(...).
 int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s);
@@ -77,6 +84,7 @@ int dim_presplit_activations();  // 1 (default): SuperPoint's conv-to-conv activ
 int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
 int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)
+int dim_fuse_kv();           // 1 (default): LightGlue's K | V tile images written by the projection GEMM's epilogue (dim_tune_set key 8)
 int dim_nms_big_tiles();     // 1 (default): 64 x 64 NMS tiles on large score maps (dim_tune_set key 7; 2 = forced)
 void dim_nms_set_big_tiles(int v);
 int dim_gemm_x6_wide();      // 1 (default): 128 x 256 workgroup blocks where n_pad allows (dim_tune_set key 6)

@@ -26,16 +26,27 @@ constexpr int KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
 // NT: 32-column MFMA tiles per wave.  2: block 128 x 128 (3 workgroups per CU); 4: block 128 x 256, each wave 64 x 128 =
 //     8 accumulators (2 per CU) — the activation tile is loaded, split and staged once for twice the MFMAs, and the K loop's
 //     two barriers and its exposed prefetch latency are paid per 48 instead of per 24 MFMAs.
-template <int MODE, int BM, int NT = 2>
+// KV (fp16x3, NT 4 only): the q|k|v projection of LightGlue.  The workgroups of column block a.kv_kblock issue their MFMAs with
+//     the operands SWAPPED (C^T = W^T X^T: lane = key, registers = 16 output dims), apply the rotary embedding to adjacent
+//     dims, split, and store each lane's registers 8j .. 8j+7 as one 16-byte slot of the attention kernel's K tile image;
+//     the workgroups of block a.kv_vblock keep the normal orientation — the MFMA C layout of a 32-key tile IS the key
+//     order of the V image — and store registers 8u .. 8u+7 of every (dim, step u) as one slot.  No fp32 k / v, no
+//     separate pre-split pass (kv_prep_kernel: 155 us per launch, 0.85 GB of traffic).
+// KV 1 / 2: the launch (grid.y = 1) that computes column block kv_kblock / kv_vblock only; the fp32 blocks in front of them
+// are a plain launch (separate kernels: both MFMA orientations, or two epilogues, in one kernel spill 30 .. 800 registers).
+template <int MODE, int BM, int NT = 2, int KV = 0>
 __global__ __launch_bounds__(256, (NT == 4 ? 2 : 3)) void gemm_x6_kernel(GemmArgs a) {
+  static_assert(KV == 0 || (MODE == 2 && NT == 4 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, MT = BM / 64, NLD = BM / 32;  // 32-row MFMA tiles per wave, float4 loads per thread and chunk
   constexpr int BN = 64 * NT;
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int by = KV == 1 ? a.kv_kblock : (KV == 2 ? a.kv_vblock : (int)blockIdx.y);
+  const int m0 = blockIdx.x * BM, n0 = by * BN;
   if (m0 >= rows || n0 >= a.N) return;
+  constexpr bool kblk = KV == 1, vblk = KV == 2;
 
   __shared__ unsigned Ap[NPL * BM * RS];
 
@@ -110,14 +121,91 @@ __global__ __launch_bounds__(256, (NT == 4 ? 2 : 3)) void gemm_x6_kernel(GemmArg
 #pragma unroll
         for (int m = 0; m < MT; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * (32 * MT) + m * 32 + lx) * RS + ks * 8 + half * 4];
       // cross terms smallest first; the four accumulators interleave so no MFMA waits on its predecessor
+      if (kblk) {  // transposed tiles: the weights are the A operand
 #pragma unroll
-      for (int tm = 0; tm < S::NT; ++tm)
+        for (int tm = 0; tm < S::NT; ++tm)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[ks][n][S::tb(tm)], acc[m][n]);
+            for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fb[ks][n][S::tb(tm)], fa[m][S::ta(tm)], acc[m][n]);
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < S::NT; ++tm)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[ks][n][S::tb(tm)], acc[m][n]);
+      }
     }
     __syncthreads();
+  }
+
+  if (kblk || vblk) {
+    // ---- K | V tile images (layout: lg_attn_x6.hip).  Rows past the ragged end are copies of the last valid row (finite;
+    // the attention kernel masks their scores), tiles past the image capacity are skipped. ----
+    u32x4* const img_item = (u32x4*)a.kv_img + (size_t)z * 4 * a.kv_tiles * KV_TILE_STRIDE;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int tile = (m0 + wm * (32 * MT) + m * 32) >> 5;
+      if (tile >= a.kv_tiles) continue;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int head = wn * 2 + (n >> 1), np = n & 1;   // this wave's 128 columns = 2 heads x 2 tiles of 32 dims
+        u32x4* const img = img_item + ((size_t)head * a.kv_tiles + tile) * KV_TILE_STRIDE;
+        const int cbase = n0 + wn * 128 + n * 32;          // first column of the 32-column tile
+        if (kblk) {
+          // lane = key lx (+ 32-key tile m), register r = output dim cbase + 8 (r >> 2) + 4 half + (r & 3)
+          const int key = m0 + wm * (32 * MT) + m * 32 + lx;
+          const float* e = a.kv_enc ? a.kv_enc + ((size_t)z * a.kv_nmax + min(key, a.kv_nmax - 1)) * 64 : nullptr;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {   // registers 8j .. 8j+7 = one slot: dims 16 (2 np + j) + 4 half + {0..3, 8..11} of the head
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int c0 = cbase + 8 * (2 * j + g) + 4 * half;
+              const float4 bv = *(const float4*)(a.bias + c0), iv = *(const float4*)(a.inv_ch + c0);
+              v[4 * g + 0] = acc[m][n][8 * j + 4 * g + 0] * iv.x + bv.x;
+              v[4 * g + 1] = acc[m][n][8 * j + 4 * g + 1] * iv.y + bv.y;
+              v[4 * g + 2] = acc[m][n][8 * j + 4 * g + 2] * iv.z + bv.z;
+              v[4 * g + 3] = acc[m][n][8 * j + 4 * g + 3] * iv.w + bv.w;
+              if (e != nullptr) {  // rotary (LGN:41-54,155-156): pair (d, d+1) <-> frequency d / 2 of the head
+                const int f0 = (np * 32 + 8 * (2 * j + g) + 4 * half) >> 1;
+                const float2 cs = *(const float2*)(e + f0), sn = *(const float2*)(e + 32 + f0);
+                const float t0 = v[4 * g], t1 = v[4 * g + 1], t2 = v[4 * g + 2], t3 = v[4 * g + 3];
+                v[4 * g + 0] = t0 * cs.x + (-t1) * sn.x;
+                v[4 * g + 1] = t1 * cs.x + t0 * sn.x;
+                v[4 * g + 2] = t2 * cs.y + (-t3) * sn.y;
+                v[4 * g + 3] = t3 * cs.y + t2 * sn.y;
+              }
+            }
+            unsigned pc[4][NPL];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { S::split(v[2 * i], v[2 * i + 1], S::act_scale(), pc[i]); vmax = sat_track(vmax, v[2 * i], v[2 * i + 1]); }
+            const int blk = 2 * (2 * np + j) + half;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) img[(pl * 8 + blk) * 32 + lx] = u32x4{pc[0][pl], pc[1][pl], pc[2][pl], pc[3][pl]};
+          }
+        } else {
+          // lane = dim lx of the tile, register r = key (r & 3) + 8 (r >> 2) + 4 half: registers 8u .. 8u+7 = slot (u, half, dim)
+          const float bv = a.bias[cbase + lx], iv = a.inv_ch[cbase + lx];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            unsigned pc[4][NPL];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float v0 = acc[m][n][8 * u + 2 * i] * iv + bv, v1 = acc[m][n][8 * u + 2 * i + 1] * iv + bv;
+              S::split(v0, v1, S::act_scale(), pc[i]);
+              vmax = sat_track(vmax, v0, v1);
+            }
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) img[NPL * 256 + ((pl * 2 + u) * 2 + half) * 64 + np * 32 + lx] = u32x4{pc[0][pl], pc[1][pl], pc[2][pl], pc[3][pl]};
+          }
+        }
+      }
+    }
+    sat_report(a.sat, vmax);
+    return;
   }
 
   // Epilogue through buffer descriptors (dim_common.h): 32-bit offsets, no per-element branches.  The descriptor of C / R
@@ -174,6 +262,15 @@ static int g_gemm_x6_wide = 1;
 int dim_gemm_x6_wide() { return g_gemm_x6_wide; }
 void dim_gemm_x6_set_wide(int v) { g_gemm_x6_wide = v; }
 
+static bool small_problem(int M, int N, int batch) {  // fewer 128-row workgroups than CUs (never when the wide block is forced: tests)
+  return dim_gemm_x6_wide() != 2 && (long)cdiv(M, 128) * cdiv(N, 128) * batch < 256;
+}
+static bool wide_block(int M, int n_pad, int batch, int split_mode) {
+  // dim_gemm_x6_wide(): 2 = forced (tests); 1 = when the launch still fills 2 workgroups per CU
+  return split_mode == 2 && dim_gemm_x6_wide() && n_pad % 256 == 0 && (dim_gemm_x6_wide() == 2 || (long)cdiv(M, 128) * (n_pad / 256) * batch >= 512);
+}
+bool gemm_x6_fuses_kv(int M, int n_pad, int batch, int split_mode) { return !small_problem(M, n_pad, batch) && wide_block(M, n_pad, batch, split_mode); }
+
 int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.Bx3 != nullptr && !a.bt && (a.split_mode == 1 || a.split_mode == 2), "gemm_x6: needs pre-split [planes][n_pad][K] weights");
   DIM_REQUIRE(a.K % 16 == 0, "gemm_x6: K");
@@ -182,15 +279,25 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
   DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
   if (batch <= 0 || a.M <= 0 || a.N <= 0) return 0;
-  const bool small = (long)cdiv(a.M, 128) * cdiv(a.N, BN) * batch < 256;  // fewer 128-row workgroups than CUs
+  const bool small = small_problem(a.M, a.N, batch);
+  DIM_REQUIRE(a.kv_img == nullptr || (!small && wide_block(a.M, a.n_pad, batch, a.split_mode)), "gemm_x6: K|V images need the 128 x 256 block (gemm_x6_fuses_kv)");
   if (small) {
     dim3 grid(cdiv(a.M, 64), cdiv(a.N, BN), batch);
     if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<1, 64>), grid, dim3(256), 0, s, a);
-  } else if (a.split_mode == 2 && dim_gemm_x6_wide() && a.n_pad % 256 == 0 &&
-             (dim_gemm_x6_wide() == 2 || (long)cdiv(a.M, 128) * (a.n_pad / 256) * batch >= 512)) {  // 2: forced (tests); 1: when it still fills 2 workgroups per CU
+  } else if (wide_block(a.M, a.n_pad, batch, a.split_mode)) {
     dim3 grid(cdiv(a.M, 128), cdiv(a.N, 256), batch);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4>), grid, dim3(256), 0, s, a);
+    if (a.kv_img != nullptr) {
+      DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
+      DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == (int)grid.y - 1, "gemm_x6: the K and V blocks must be the last two");
+      if (a.kv_kblock > 0) {  // the fp32 column blocks in front (q)
+        GemmArgs q = a;
+        q.N = a.kv_kblock * 256; q.kv_img = nullptr;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4>), dim3(grid.x, a.kv_kblock, batch), dim3(256), 0, s, q);
+      }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4, 1>), dim3(grid.x, 1, batch), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4, 2>), dim3(grid.x, 1, batch), dim3(256), 0, s, a);
+    } else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid(cdiv(a.M, 128), cdiv(a.N, BN), batch);
     if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128>), grid, dim3(256), 0, s, a);

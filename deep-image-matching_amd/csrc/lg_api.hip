@@ -230,6 +230,20 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     if (x6) { g.set_split(Bx[pmode]); return launch_gemm_x6(g, I, s); }
     return launch_gemm(g, I, s);
   };
+  // fp16x3 at batch sizes that run the 128 x 256 GEMM block: the q|k|v projections write the attention kernel's K | V tile
+  // images themselves (rotary + pre-split in the epilogue; dim_tune_set key 8 = 0 keeps the separate kv_prep pass)
+  const bool fuse_kv = pmode == 2 && dim_fuse_kv() && gemm_x6_fuses_kv(N, 512, I, 2);
+  auto gemm_qkv = [&](const SplitWeights* Bx, const float* bias, int Nn, int kblock, bool rotary) -> int {
+    GemmArgs g;
+    g.A0 = st.desc; g.lda0 = 256; g.strideA0 = s256;
+    g.bias = bias; g.C = st.qkv; g.ldc = 768; g.strideC = s768;
+    g.M = N; g.N = Nn; g.K = 256; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = 0;
+    g.sat = st.sat_qkv;
+    g.kv_img = st.kv_img; g.kv_tiles = (N + 31) / 32; g.kv_kblock = kblock; g.kv_vblock = kblock + 1; g.kv_nmax = N;
+    g.kv_enc = rotary ? st.enc : nullptr;
+    g.set_split(Bx[2]);
+    return launch_gemm_x6(g, I, s);
+  };
   if (h->input_dim != 256) {  // input_proj (LGN:473-474) straight from the feature table
     GemmArgs g;
     g.A0 = desc_tab_dev; g.lda0 = h->input_dim; g.strideA0 = (long long)cap * h->input_dim; g.a_idx = pair_idx_dev;
@@ -240,10 +254,11 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
   for (int i = 0; i < Lr; ++i) {
     const LayerW& w = h->L[i];
     // ---- self block (LGN:146-159) ----
-    LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.qkv_w, w.qkv_x, 768, w.qkv_b, nullptr, st.qkv, 768, s768, 768, 256, 0, st.sat_qkv));
+    if (fuse_kv) LG_RUN(gemm_qkv(w.qkv_x, w.qkv_b, 768, 1, true));
+    else LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.qkv_w, w.qkv_x, 768, w.qkv_b, nullptr, st.qkv, 768, s768, 768, 256, 0, st.sat_qkv));
     if (!x6) LG_RUN(launch_lg_rotary(st, s));  // the bf16x6 attention applies the rotary embedding while it loads q / pre-splits k
     dim_prof_begin(DIM_PROF_LG_SELF_ATTN, s);
-    LG_RUN(launch_lg_attention(st, 0, s));
+    LG_RUN(launch_lg_attention(st, 0, s, fuse_kv ? 1 : 0));
     dim_prof_end(DIM_PROF_LG_SELF_ATTN, s);
     if (fold) {  // out_proj folded into ffn.0: A = [desc | ctx]
       LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.sffn0f_x, 512, w.sffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0));
@@ -254,9 +269,10 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     LG_RUN(launch_lg_ln_gelu(st, w.sln_w, w.sln_b, s));
     LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.sffn3_w, w.sffn3_x, 256, w.sffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0, sat(DIM_SAT_LG_DESC)));
     // ---- cross block (LGN:186-211) ----
-    LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.cqkv_w, w.cqkv_x, 512, w.cqkv_b, nullptr, st.qkv, 768, s768, 512, 256, 0, st.sat_qkv));
+    if (fuse_kv) LG_RUN(gemm_qkv(w.cqkv_x, w.cqkv_b, 512, 0, false));
+    else LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.cqkv_w, w.cqkv_x, 512, w.cqkv_b, nullptr, st.qkv, 768, s768, 512, 256, 0, st.sat_qkv));
     dim_prof_begin(DIM_PROF_LG_CROSS_ATTN, s);
-    LG_RUN(launch_lg_attention(st, 1, s));
+    LG_RUN(launch_lg_attention(st, 1, s, fuse_kv ? 1 : 0));
     dim_prof_end(DIM_PROF_LG_CROSS_ATTN, s);
     if (fold) {
       LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.cffn0f_x, 512, w.cffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0));

@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnArgs a) {
 }
 }  // namespace
 
-int launch_lg_attention(const LgState& st, int cross, hipStream_t s) {
-  if (dim_precision_mode() != 0) return launch_lg_attention_x6(st, cross, s);
+int launch_lg_attention(const LgState& st, int cross, hipStream_t s, int kv_ready) {
+  if (dim_precision_mode() != 0) return launch_lg_attention_x6(st, cross, s, kv_ready);
   AttnArgs a;
   const long long is = (long long)st.nmax * 768;
   if (!cross) {  // qkv = [q(256) | k(256) | v(256)] after the Wqkv row permutation done at load time

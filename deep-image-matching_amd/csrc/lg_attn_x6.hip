@@ -6,7 +6,9 @@
 // eight v_mfma_f32_32x32x2_f32 (512 cycles).
 //
 // Operand images (one 16-B ds_read_b128 = one MFMA operand, consecutive lanes -> consecutive slots):
-//   Kp[plane][d-block 8][key 32][8 bf16]          A operand of K·Q^T   (k = d)
+//   Kp[plane][d-block 8][key 32][8 bf16]          A operand of K·Q^T   (k = d); d-block 2s + h holds the head dims
+//       16s + 4h + {0,1,2,3, 8,9,10,11} — the 8 registers a lane of gemm_x6.hip's transposed K block owns — and Q uses the
+//       same assignment (a dot product does not care in which order its dims are paired with MFMA k-slots)
 //   Vp[plane][step 2][k-half 2][d 64][8 keys]     A operand of V^T·P^T (k = key), keys stored in the
 //       order in which the MFMA C layout of S^T holds them: register 8u+e of lane-half h holds key
 //       (e&3) + 8*(2u + (e>>2)) + 4h, so registers 8u..8u+7 of P ARE the B operand of step u.
@@ -35,10 +37,12 @@ struct AttnArgs6 {
   int qblocks, groups;   // workgroups per (item, head) group = qblocks (incl. splits); groups = 4 * items (XCD-aware 1-D grid)
   float* part;           // [items][4][nmax][splits][PART] partial (unnormalised O, running max, running sum)
   unsigned* sat;         // fp16x3 range guard on the rotated K (the rotation can grow |k| by sqrt 2) and on V
+  int q_img;             // cross attention with images written by the projection GEMM (gemm_x6.hip KV): there is no fp32 qk —
+                         // the Q operand is this item's own K image, and the softmax scale is applied to the scores instead
 };
 constexpr int PART = 68;   // 64 output dims + m + l, padded to a 16-byte multiple
 
-constexpr int TILE_STRIDE = 3 * 8 * 32 + 3 * 2 * 2 * 64;  // slots of 16 B reserved per tile image in HBM (mode 1 fills all 1536)
+constexpr int TILE_STRIDE = KV_TILE_STRIDE;  // slots of 16 B reserved per tile image in HBM (mode 1 fills all 1536)
 constexpr int tile_slots(int npl) { return npl * 512; }    // npl * 256 K slots + npl * 256 V slots
 
 // One workgroup per (key tile, head, item): rotary on K (self-attention only, LGN:41-54,155-156), exact
@@ -55,18 +59,19 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
   const float* kb = a.k + (size_t)item * a.sk + head * 64;
   const float* vb = a.v + (size_t)item * a.sv + head * 64;
   u32x4* img = a.kv_img + (((size_t)item * 4 + head) * a.tiles + tile) * TILE_STRIDE;
-  {  // K: thread (key = t>>3, d-block = t&7)
-    const int key = t >> 3, blk = t & 7;
+  {  // K: thread (key = t>>3, d-block = t&7 = 2s + h: dims 16s + 4h + {0..3, 8..11})
+    const int key = t >> 3, blk = t & 7, d0 = 16 * (blk >> 1) + 4 * (blk & 1);
     float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (kt + key < nk) {
-      const float* p = kb + (size_t)(kt + key) * a.ldk + blk * 8;
-      const float4 x0 = *(const float4*)p, x1 = *(const float4*)(p + 4);
+      const float* p = kb + (size_t)(kt + key) * a.ldk + d0;
+      const float4 x0 = *(const float4*)p, x1 = *(const float4*)(p + 8);
       x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
       if (!a.cross) {
-        const float* e = a.enc + ((size_t)item * a.nmax + kt + key) * 64 + blk * 4;  // pairs 4*blk .. 4*blk+3
+        const float* e = a.enc + ((size_t)item * a.nmax + kt + key) * 64 + (d0 >> 1);  // pairs d0/2, d0/2 + 1, d0/2 + 4, d0/2 + 5
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float c = e[i], sn = e[32 + i], t0 = x[2 * i], t1 = x[2 * i + 1];
+          const int f = (i & 1) + 4 * (i >> 1);
+          const float c = e[f], sn = e[32 + f], t0 = x[2 * i], t1 = x[2 * i + 1];
           x[2 * i] = t0 * c + (-t1) * sn;
           x[2 * i + 1] = t1 * c + t0 * sn;
         }
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, TILE_SLOTS = tile_slots(NPL), KSL = NPL * 256, NCP = TILE_SLOTS / 256;
   // K, Q, V and P are multiplied by the (power-of-two) activation scale before the split: exact factors
-  const float inv_qk = 1.0f / (S::act_scale() * S::act_scale());
+  const float inv_qk = (1.0f / (S::act_scale() * S::act_scale())) * (a.q_img ? a.scale * 1.44269504088896340736f : 1.0f);
   // XCD-aware mapping of a 1-D grid (cdna_hip_programming.md T1): the hardware sends workgroup L to XCD L % 8, and all the
   // query blocks of one (item, head) group stream the SAME K | V tile images.  Giving every group to ONE XCD (group =
   // (L / 8 / qblocks) * 8 + L % 8) makes 15 of its 16 workgroups hit that XCD's L2 instead of each XCD fetching its own
@@ -125,22 +130,30 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
   const int qrow = q0 + wv * 32 + lx;
   const bool qok = qrow < nq;
 
-  // Q^T operand: lane (query lx, half) holds d = 16s + 8*half + 0..7 for s = 0..3, three planes each
+  // Q^T operand: lane (query lx, half) holds d = 16s + 4*half + {0..3, 8..11} for s = 0..3 (the K image's assignment), NPL planes each
   u32x4 qf[4][NPL];
-  {
-    const float* qp = a.q + (size_t)item * a.sq + (size_t)(qok ? qrow : 0) * a.ldq + head * 64 + half * 8;
-    const float sc = a.scale * 1.44269504088896340736f;  // scores in the log2 domain
+  const float sc = a.scale * 1.44269504088896340736f;  // scores in the log2 domain
+  if (a.q_img) {  // the item's own K image IS the split Q operand (cross attention: q and k are the same projection)
+    // (a wave whose 32 queries all lie past the ragged end reads the last written tile: its results are never stored)
+    const u32x4* qi = a.kv_img + (((size_t)item * 4 + head) * a.tiles + min((q0 + wv * 32) >> 5, (nq - 1) >> 5)) * TILE_STRIDE;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) qf[s][pl] = qi[(pl * 8 + 2 * s + half) * 32 + lx];
+  } else {
+    const float* qp = a.q + (size_t)item * a.sq + (size_t)(qok ? qrow : 0) * a.ldq + head * 64 + half * 4;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (qok) {
-        const float4 x0 = *(const float4*)(qp + 16 * s), x1 = *(const float4*)(qp + 16 * s + 4);
+        const float4 x0 = *(const float4*)(qp + 16 * s), x1 = *(const float4*)(qp + 16 * s + 8);
         x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
-        if (!a.cross) {  // rotary (LGN:41-54,155): d = 16s + 8half + 2i, +1 <-> frequency 8s + 4half + i
-          const float* e = a.enc + ((size_t)item * a.nmax + qrow) * 64 + 8 * s + 4 * half;
+        if (!a.cross) {  // rotary (LGN:41-54,155): pair i of the lane <-> frequency 8s + 2half + (i & 1) + 4 (i >> 1)
+          const float* e = a.enc + ((size_t)item * a.nmax + qrow) * 64 + 8 * s + 2 * half;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float c = e[i], sn = e[32 + i], t0 = x[2 * i], t1 = x[2 * i + 1];
+            const int f = (i & 1) + 4 * (i >> 1);
+            const float c = e[f], sn = e[32 + f], t0 = x[2 * i], t1 = x[2 * i + 1];
             x[2 * i] = t0 * c + (-t1) * sn;
             x[2 * i + 1] = t1 * c + t0 * sn;
           }
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs6 a, float ou
 }
 }  // namespace
 
-int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s) {
+int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_ready) {
   AttnArgs6 a;
   const long long is = (long long)st.nmax * 768;
   if (!cross) { a.q = st.qkv; a.k = st.qkv + 256; a.v = st.qkv + 512; }
@@ -310,6 +323,7 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s) {
   a.n = st.n_cur; a.done = st.done; a.cross = cross;
   a.scale = 0.125f;
   a.sat = st.sat_qkv;
+  a.q_img = (kv_ready && cross) ? 1 : 0;
   a.enc = st.enc; a.kv_img = (u32x4*)st.kv_img; a.nmax = st.nmax; a.tiles = cdiv(st.nmax, 32);
   // small batches leave most CUs idle and make every workgroup walk all key tiles alone: cut the key range
   const int wgs = cdiv(st.nmax, 128) * 4 * st.n_items;
@@ -319,7 +333,7 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s) {
   a.groups = 4 * st.n_items;
   dim3 grid((unsigned)(cdiv(a.groups, 8) * 8 * a.qblocks));  // whole rounds of 8 groups, one per XCD (surplus workgroups exit)
   if (dim_precision_mode() == 2) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<2>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
+    if (!kv_ready) hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<2>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2>), grid, dim3(256), 0, s, a);
   } else {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<1>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);

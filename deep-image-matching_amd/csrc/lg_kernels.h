@@ -39,8 +39,10 @@ struct LgState {  // device pointers owned by the handle
 int launch_lg_init(const LgState& st, const float* kpts_tab, const float* desc_tab, const int* n_tab, const float* size_tab,
                    const int* pair_idx, int cap, int in_dim, const float* Wr, int copy_desc, unsigned* sat, hipStream_t s);
 int launch_lg_rotary(const LgState& st, hipStream_t s);
-int launch_lg_attention(const LgState& st, int cross, hipStream_t s);      // dispatches on dim_precision_mode()
-int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s);   // bf16x6 variant (lg_attn_x6.hip)
+// kv_ready: the K | V tile images were already written by the projection GEMM (gemm_x6.hip KV epilogue): no kv_prep pass, and
+// cross attention takes its Q operand from the item's own K image
+int launch_lg_attention(const LgState& st, int cross, hipStream_t s, int kv_ready = 0);      // dispatches on dim_precision_mode()
+int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_ready = 0);   // split-precision variant (lg_attn_x6.hip)
 int launch_lg_ln_gelu(const LgState& st, const float* gamma, const float* beta, hipStream_t s);
 int launch_lg_confidence(const LgState& st, const float* w_tok, const float* b_tok, const float* w_match,
                          const float* b_match, float thr, int use_token, hipStream_t s);

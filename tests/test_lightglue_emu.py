@@ -50,3 +50,22 @@ def test_lightglue_bf16x6_mode_still_matches_the_oracle(emu_lib):
             compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
     finally:
         emu_lib.dim_tune_set(1, 2)
+
+
+@pytest.mark.parametrize("name", list(gc.LG_CASES))
+def test_lightglue_kv_images_written_by_the_projection_gemm(emu_lib, name):
+    """Large batches run the 128 x 256 GEMM block, whose epilogue writes the attention kernel's K | V tile images itself
+    (rotary + pre-split; cross attention then takes Q from the item's own K image).  dim_tune_set(6, 2) forces that path at
+    the golden sizes (ragged key counts, pruning, early stop, 128-d inputs): same goldens, same oracle."""
+    case = gc.LG_CASES[name]
+    try:
+        emu_lib.dim_tune_set(6, 2)
+        out, ref = run_case(emu_lib, case)
+    finally:
+        emu_lib.dim_tune_set(6, 1)
+    compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+    g = np.load(GOLD / f"lg_{name}.npz")
+    gold = {k: torch.from_numpy(np.asarray(g[k])) for k in ("matches0", "matches1", "matching_scores0", "matching_scores1",
+                                                             "matches", "scores", "prune0", "prune1")}
+    gold["stop"] = int(g["stop"])
+    compare_lightglue(out, gold)

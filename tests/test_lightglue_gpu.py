@@ -63,6 +63,50 @@ def test_lightglue_gpu_full_size_vs_oracle(hip_lib, mode):
     print(mode, res, "stop", out["stop"], "S", out["matches"][0].shape[0])
 
 
+@pytest.mark.parametrize("mode", ["fixed", "default"])
+def test_lightglue_gpu_full_size_kv_images_from_the_projection_gemm(hip_lib, mode):
+    """The large-batch path (128 x 256 GEMM blocks whose epilogue writes the K | V tile images: rotary + pre-split fused,
+    cross-attention Q taken from the K image), forced at batch 1 with dim_tune_set(6, 2): same oracle, same tolerances; and
+    a real large batch (8 ragged pairs, which selects that path by itself) equals the pairs run one by one on it."""
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_lightglue_state_dict(0, 256, gain=2.0)
+    conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0} if mode == "fixed" else \
+           {"depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.0}
+    f0, f1 = _full_inputs(21, 2048, 2048)
+    lg = _lg()
+    try:
+        hip_lib.dim_tune_set(6, 2)
+        net = lg.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=2048)
+        out = _cpu(net(_data(f0, f1), dense=True))
+        ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, conf, taps=True)
+        res = compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+        print(mode, "fused", res, "stop", out["stop"], "S", out["matches"][0].shape[0])
+        # 8 ragged pairs of the same images: the batch picks the path itself (dim_tune_set(6, 1)); singles are forced onto it
+        g = torch.Generator().manual_seed(4)
+        counts = [2048, 1900, 1777, 2048, 1500, 2001, 1999, 1024, 2048]
+        kt = torch.rand(9, 2048, 2, generator=g) * 1024
+        dt = torch.nn.functional.normalize(torch.randn(9, 2048, 256, generator=g), dim=-1)
+        nt, st = torch.tensor(counts, dtype=torch.int32), torch.tensor([[1024.0, 1024.0]] * 9)
+        pairs = torch.tensor([[i, i + 1] for i in range(8)], dtype=torch.int32)
+        singles = []
+        for a, b in pairs.tolist():
+            data = {"image0": {"keypoints": kt[a, :counts[a]][None], "descriptors": dt[a, :counts[a]][None], "image_size": st[a][None]},
+                    "image1": {"keypoints": kt[b, :counts[b]][None], "descriptors": dt[b, :counts[b]][None], "image_size": st[b][None]}}
+            singles.append(_cpu(net(data)))
+        hip_lib.dim_tune_set(6, 1)
+        big = lg.LightGlueHIP(sd, conf, max_pairs=8, max_kpts=2048)
+        o = {k: v.cpu() for k, v in big.match_batch(kt.cuda(), dt.cuda(), nt.cuda(), st.cuda(), pair_idx=pairs.cuda()).items()}
+        for p, r in enumerate(singles):
+            S = int(o["n_matches"][p])
+            assert int(o["stop"][p]) == r["stop"]
+            assert torch.equal(o["matches"][p, :S], r["matches"][0])
+            # (not bit-equal: a 2-item launch cuts the key range of every attention workgroup in 4 and merges the partial
+            # softmaxes, a 16-item launch does not — fp32 reassociation)
+            torch.testing.assert_close(o["scores"][p, :S], r["scores"][0], rtol=1e-3, atol=1e-9)
+    finally:
+        hip_lib.dim_tune_set(6, 1)
+
+
 def test_lightglue_gpu_batch_equals_single_and_pair_index(hip_lib):
     """A batch of ragged pairs through pair_idx == the same pairs one by one."""
     weights = importlib.import_module("deep-image-matching_amd.weights")
