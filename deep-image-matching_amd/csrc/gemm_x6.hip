@@ -32,26 +32,29 @@ constexpr int KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
 //     the workgroups of block a.kv_vblock keep the normal orientation — the MFMA C layout of a 32-key tile IS the key
 //     order of the V image — and store registers 8u .. 8u+7 of every (dim, step u) as one slot.  No fp32 k / v, no
 //     separate pre-split pass (kv_prep_kernel: 155 us per launch, 0.85 GB of traffic).
-// KV 1 / 2: the launch (grid.y = 1) that computes column block kv_kblock / kv_vblock only; the fp32 blocks in front of them
-// are a plain launch (separate kernels: both MFMA orientations, or two epilogues, in one kernel spill 30 .. 800 registers).
-template <int MODE, int BM, int NT = 2, int KV = 0>
-__global__ __launch_bounds__(256, (NT == 4 ? 2 : 3)) void gemm_x6_kernel(GemmArgs a) {
-  static_assert(KV == 0 || (MODE == 2 && NT == 4 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
+// KV 1 / 2: the body for column block kv_kblock / kv_vblock (separate instantiations selected per workgroup by
+// gemm_x6_qkv_kernel: both MFMA orientations, or two epilogues, inside ONE loop body spill 30 .. 800 registers).
+// WN: waves along N.  2: waves 2 x 2, each (BM / 2) rows x 32 NT columns.  4 (the 128 x 256 block): waves 1 x 4, each ALL 128
+//     rows x 64 columns (MT 4 x NT 2 = 8 accumulators): a weight fragment is then fetched by exactly one wave — with 2 x 2
+//     waves of 64 x 128 every fragment was fetched twice per workgroup and the per-CU vector-memory path (64 B / clk), not
+//     the matrix pipe or HBM latency, was what the kernel ran at (an experiment that made every activation prefetch an L2
+//     hit changed nothing).  The activation fragments come from LDS, which has the bandwidth to feed 4 waves.
+template <int MODE, int BM, int NT, int KV, int WN>
+__device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, int by) {
   using S = SplitMma<MODE>;
-  constexpr int NPL = S::NPL, MT = BM / 64, NLD = BM / 32;  // 32-row MFMA tiles per wave, float4 loads per thread and chunk
-  constexpr int BN = 64 * NT;
+  constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
+  constexpr int NPL = S::NPL, NLD = BM / 32;        // float4 loads per thread and chunk
+  constexpr int BN = 32 * NT * WN;
+  static_assert(KV == 0 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
-  const int by = KV == 1 ? a.kv_kblock : (KV == 2 ? a.kv_vblock : (int)blockIdx.y);
   const int m0 = blockIdx.x * BM, n0 = by * BN;
   if (m0 >= rows || n0 >= a.N) return;
   constexpr bool kblk = KV == 1, vblk = KV == 2;
 
-  __shared__ unsigned Ap[NPL * BM * RS];
-
   const int t = threadIdx.x;
-  const int lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1, lx = lane & 31, half = lane >> 5;
+  const int lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN, lx = lane & 31, half = lane >> 5;
   const float* A0 = a.A0 + (size_t)(a.a_idx ? a.a_idx[z] : z) * a.strideA0;
   const float* A1 = a.A1 ? a.A1 + (size_t)z * a.strideA1 : nullptr;
   const int NB = a.n_pad / 32, KS = a.K / 16;
@@ -151,9 +154,10 @@ __global__ __launch_bounds__(256, (NT == 4 ? 2 : 3)) void gemm_x6_kernel(GemmArg
       if (tile >= a.kv_tiles) continue;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int head = wn * 2 + (n >> 1), np = n & 1;   // this wave's 128 columns = 2 heads x 2 tiles of 32 dims
+        const int colw = wn * (32 * NT) + n * 32;          // first column of the 32-column tile inside the 256-column block (4 heads x 2 tiles)
+        const int head = colw >> 6, np = (colw >> 5) & 1;
         u32x4* const img = img_item + ((size_t)head * a.kv_tiles + tile) * KV_TILE_STRIDE;
-        const int cbase = n0 + wn * 128 + n * 32;          // first column of the 32-column tile
+        const int cbase = n0 + colw;
         if (kblk) {
           // lane = key lx (+ 32-key tile m), register r = output dim cbase + 8 (r >> 2) + 4 half + (r & 3)
           const int key = m0 + wm * (32 * MT) + m * 32 + lx;
@@ -256,6 +260,23 @@ __global__ __launch_bounds__(256, (NT == 4 ? 2 : 3)) void gemm_x6_kernel(GemmArg
   }
   if (MODE == 2) sat_report(a.sat, vmax);
 }
+
+template <int MODE, int BM, int NT = 2, int WN = 2>
+__global__ __launch_bounds__(256, ((BM / (32 * (4 / WN))) * NT >= 8 ? 2 : 3)) void gemm_x6_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[SplitMma<MODE>::NPL * BM * RS];
+  gemm_x6_body<MODE, BM, NT, 0, WN>(a, Ap, (int)blockIdx.y);
+}
+// LightGlue's q|k|v projection in ONE launch: blockIdx.y selects the column block and with it the code path (plain fp32 /
+// transposed K image / V image — three inlined bodies, one register allocation each), so that the 2 or 3 column blocks of
+// a row block run next to each other on the same XCD and the activation rows come from HBM once (as separate launches
+// the three blocks each re-read them: 116 + 162 + 121 us where the traffic of one pass allows ~ 170).
+__global__ __launch_bounds__(256, 2) void gemm_x6_qkv_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 128 * RS];
+  const int by = (int)blockIdx.y;
+  if (by == a.kv_kblock) gemm_x6_body<2, 128, 2, 1, 4>(a, Ap, by);
+  else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4>(a, Ap, by);
+  else gemm_x6_body<2, 128, 2, 0, 4>(a, Ap, by);
+}
 }  // namespace
 
 static int g_gemm_x6_wide = 1;
@@ -290,14 +311,8 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     if (a.kv_img != nullptr) {
       DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
       DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == (int)grid.y - 1, "gemm_x6: the K and V blocks must be the last two");
-      if (a.kv_kblock > 0) {  // the fp32 column blocks in front (q)
-        GemmArgs q = a;
-        q.N = a.kv_kblock * 256; q.kv_img = nullptr;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4>), dim3(grid.x, a.kv_kblock, batch), dim3(256), 0, s, q);
-      }
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4, 1>), dim3(grid.x, 1, batch), dim3(256), 0, s, a);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4, 2>), dim3(grid.x, 1, batch), dim3(256), 0, s, a);
-    } else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 4>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(gemm_x6_qkv_kernel, grid, dim3(256), 0, s, a);
+    } else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid(cdiv(a.M, 128), cdiv(a.N, BN), batch);
     if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128>), grid, dim3(256), 0, s, a);
