@@ -20,6 +20,7 @@
 namespace {
 constexpr int TW = 32, IW = TW + 2;
 constexpr int tile_rows(int mr) { return 4 * mr; }   // output rows per workgroup: 4 waves x MR rows
+__host__ __device__ constexpr size_t planes_image_pixels(int h, int w) { return ((size_t)h * w + 1) & ~(size_t)1; }  // pixel slots of one pre-split image
 constexpr int w_slice(int npl) { return npl * 3 * 2 * 64 * 8; }              // 16-bit elements per (cb, chunk, dy) slice
 
 // PF: 0 = no software prefetch, 1 = next weight slice fetched into registers behind the MFMAs,
@@ -31,9 +32,13 @@ constexpr int w_slice(int npl) { return npl * 3 * 2 * 64 * 8; }              // 
 // MODE: SplitMma policy (dim_common.h) — 1: three bf16 planes x six cross terms, 2: two fp16 planes x three
 //       cross terms (activations scaled by act_scale(), weights pre-scaled; inv_scale undoes both exactly).
 // PIN / POUT (mode 2 only): the input / output lives in HBM pre-split, in the bytes of the fp32 NHWC tensor it replaces:
-//      per pixel, every group of 16 channels holds its 16 h pieces followed by its 16 l pieces (fp16 of 16 x the
-//      activation, clamped to +-65504): element (pixel, channel c, plane) sits at 16-bit index
-//      pixel * 2C + (c / 16) * 32 + plane * 16 + c % 16.  A producer splits each value ONCE in its epilogue; a
+//      per PAIR of pixels (linear index 2i, 2i+1 inside the image; an image occupies an even number of pixel slots) and
+//      group of 16 channels: pixel 2i's 16 h pieces, its 16 l pieces, then pixel 2i+1's (fp16 of 16 x the activation,
+//      clamped to +-65504): element (pixel, channel c, plane) sits at 16-bit index
+//      (pixel / 2) * 4C + (c / 16) * 64 + (pixel % 2) * 32 + plane * 16 + c % 16 — the 16 channels of one K chunk of two
+//      neighbouring pixels are ONE 128-byte L2 line (with the pixels' chunks laid out one pixel after the other, every line
+//      held chunks c and c + 1 of one pixel, the second half was usually evicted before the K loop came back for it, and
+//      the 512^2 x 64 layers fetched 1.66 x their input).  A producer splits each value ONCE in its epilogue; a
 //      consumer stages its halo tile with straight 16-byte copies — no per-consumer split VALU (every element
 //      used to be split (cout / 64) x 1.33 times, ~5 VALU each) — and the 16 channels of one K chunk are ONE
 //      contiguous 64-byte run per pixel.  (Round 1 kept two separate planes: a chunk then read 32 bytes per pixel and
@@ -113,8 +118,9 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
       const int gy = oy + py - 1, gx = ox + px - 1;
       rin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PIN) {  // q = plane * 2 + k-half: 8 consecutive channels of one plane = one 16-byte item; the 4 items of a pixel are contiguous
-        const unsigned short* pl = (const unsigned short*)in + (size_t)b * H * W * CIN * 2;
-        if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(pl + ((size_t)gy * W + gx) * (2 * CIN) + c * 32 + q * 8);
+        const unsigned short* pl = (const unsigned short*)in + (size_t)b * planes_image_pixels(H, W) * CIN * 2;
+        const int pix = gy * W + gx;
+        if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(pl + (size_t)(pix >> 1) * (4 * CIN) + c * 64 + (pix & 1) * 32 + q * 8);
       } else if (idx < NPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) rin[i] = *(const float4*)(in_b + ((size_t)gy * W + gx) * CIN + c * 16 + q * 4);
     }
   };
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
   // ONE 4-byte {channel pair} per plane: even lanes the first pixel, odd lanes the second (half the store instructions
   // of 2-byte stores, 4 instead of ~25 instructions per pair of values).
   const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
-  const size_t img_elems = (size_t)Ho * Wo * cout;
+  const size_t img_elems = (POUT ? planes_image_pixels(Ho, Wo) : (size_t)Ho * Wo) * cout;
   const int par = lx & 1;
   const unsigned psel = par ? 0x03020706u : 0x05040100u;   // odd lanes keep the high halves (second pixel), even lanes the low halves
   const dim_rsrc rs_f = buf_rsrc(out + (size_t)b * img_elems, POUT ? 0 : img_elems * 4);
@@ -248,7 +254,8 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
       split2_pk(v0, v1, DIM_F16_ACT_SCALE, h, l);
       const unsigned ho = byte_perm(lane_swap1(h), h, psel), lo = byte_perm(lane_swap1(l), l, psel);
       const unsigned c2 = (unsigned)(co - par);  // the even channel of this lane pair
-      const unsigned off = (par ? okc1 : okc0) ? ((par ? pix1 : pix0) * (unsigned)cout * 2u + (c2 >> 4) * 32u + (c2 & 15u)) * 2u : DIM_BUF_OOB;
+      const unsigned pix = par ? pix1 : pix0;
+      const unsigned off = (par ? okc1 : okc0) ? ((pix >> 1) * (unsigned)cout * 4u + (c2 >> 4) * 64u + (pix & 1u) * 32u + (c2 & 15u)) * 2u : DIM_BUF_OOB;
       buf_store_u32(rs_p, off, ho);
       buf_store_u32(rs_p, off + 32u, lo);   // the l pieces of the group follow its 16 h pieces
     } else {
@@ -299,10 +306,11 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
 }
 
 // debug / inspection: pre-split planes back to fp32 (h + l is exact in fp32; / 16 undoes the activation scale)
-__global__ __launch_bounds__(256) void planes_to_f32_kernel(const unsigned short* __restrict__ planes, int C, float* __restrict__ out, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // i = pixel * C + channel
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const unsigned short* __restrict__ planes, int C, int hw, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // i = (image * hw + pixel) * C + channel
   if (i >= n) return;
-  const size_t pix = i / C, c = i - pix * C, o = pix * 2 * C + (c >> 4) * 32 + (c & 15);
+  const size_t gp = i / C, c = i - gp * C, b = gp / hw, pix = gp - b * hw;
+  const size_t o = b * planes_image_pixels(hw, 1) * 2 * C + (pix >> 1) * 4 * C + (c >> 4) * 64 + (pix & 1) * 32 + (c & 15);
   const _Float16 hv = __builtin_bit_cast(_Float16, planes[o]), lv = __builtin_bit_cast(_Float16, planes[o + 16]);
   out[i] = ((float)hv + (float)lv) / DIM_F16_ACT_SCALE;
 }
@@ -454,9 +462,10 @@ int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const floa
   return 0;
 }
 
-int launch_planes_to_f32(const void* planes, size_t n, int channels, float* out, hipStream_t s) {
+int launch_planes_to_f32(const void* planes, int batch, int hw, int channels, float* out, hipStream_t s) {
+  const size_t n = (size_t)batch * hw * channels;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned short*)planes, channels, out, n);
+  hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned short*)planes, channels, hw, out, n);
   DIM_LAUNCH_CHECK();
   return 0;
 }

@@ -79,7 +79,9 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
 // fp16x3 only: input and / or output pre-split in the bytes of the fp32 NHWC tensor: per pixel and 16-channel group, 16 h then 16 l fp16 pieces (conv_x6.hip)
 int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
                              int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s, unsigned* sat = nullptr);
-int launch_planes_to_f32(const void* planes, size_t n, int channels, float* out, hipStream_t s);  // n = pixels x channels
+int launch_planes_to_f32(const void* planes, int batch, int hw, int channels, float* out, hipStream_t s);  // [batch][hw pixels][channels]
+// a pre-split image occupies an even number of pixel slots (pixels are stored in pairs): size buffers with this
+inline size_t dim_planes_image_pixels(int h, int w) { return ((size_t)h * w + 1) & ~(size_t)1; }
 int dim_presplit_activations();  // 1 (default): SuperPoint's conv-to-conv activations are stored pre-split (dim_tune_set key 5)
 int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)

@@ -123,13 +123,13 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
   const size_t B = max_batch, H = max_h, W = max_w;
   const size_t H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, hh = H4 / 2, ww = W4 / 2;
   h->a1 = nullptr;  // conv1a's 64-channel full-resolution map: only the unfused A/B path needs it, allocated on first use
-  SP_TRY(dev_alloc(h, &h->b1, B * H2 * W2 * 64));
-  SP_TRY(dev_alloc(h, &h->a2, B * H2 * W2 * 64));
-  SP_TRY(dev_alloc(h, &h->b2, B * H4 * W4 * 64));
-  SP_TRY(dev_alloc(h, &h->a3, B * H4 * W4 * 128));
-  SP_TRY(dev_alloc(h, &h->b3, B * hh * ww * 128));
-  SP_TRY(dev_alloc(h, &h->a4, B * hh * ww * 128));
-  SP_TRY(dev_alloc(h, &h->x, B * hh * ww * 128));
+  SP_TRY(dev_alloc(h, &h->b1, B * dim_planes_image_pixels(H2, W2) * 64));
+  SP_TRY(dev_alloc(h, &h->a2, B * dim_planes_image_pixels(H2, W2) * 64));
+  SP_TRY(dev_alloc(h, &h->b2, B * dim_planes_image_pixels(H4, W4) * 64));
+  SP_TRY(dev_alloc(h, &h->a3, B * dim_planes_image_pixels(H4, W4) * 128));
+  SP_TRY(dev_alloc(h, &h->b3, B * dim_planes_image_pixels(hh, ww) * 128));
+  SP_TRY(dev_alloc(h, &h->a4, B * dim_planes_image_pixels(hh, ww) * 128));
+  SP_TRY(dev_alloc(h, &h->x, B * dim_planes_image_pixels(hh, ww) * 128));
   SP_TRY(dev_alloc(h, &h->pa, B * hh * ww * 256));
   SP_TRY(dev_alloc(h, &h->logits, B * hh * ww * 65));
   SP_TRY(dev_alloc(h, &h->da, B * hh * ww * 256));
@@ -238,9 +238,8 @@ int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits,
   if (encoder) {
     *encoder = h->x;
     if (h->x_is_planes) {  // rebuild fp32 from the planes of the last batch
-      const size_t n = (size_t)h->last_batch * h->last_h * h->last_w * 128;
       if (!h->x_dbg && dev_alloc(h, &h->x_dbg, (size_t)h->max_batch * (h->max_h / 8) * (h->max_w / 8) * 128) != 0) return -1;
-      if (launch_planes_to_f32(h->x, n, 128, h->x_dbg, nullptr) != 0) return -1;
+      if (launch_planes_to_f32(h->x, h->last_batch, h->last_h * h->last_w, 128, h->x_dbg, nullptr) != 0) return -1;
       DIM_HIP(hipDeviceSynchronize());
       *encoder = h->x_dbg;
     }
