@@ -15,6 +15,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "dim_kernels.h"
 
 namespace {
@@ -247,62 +249,82 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
   const unsigned psel = par ? 0x03020706u : 0x05040100u;   // odd lanes keep the high halves (second pixel), even lanes the low halves
   const dim_rsrc rs_f = buf_rsrc(out + (size_t)b * img_elems, POUT ? 0 : img_elems * 4);
   const dim_rsrc rs_p = buf_rsrc(out + (size_t)b * img_elems, POUT ? img_elems * 4 : 0);  // h and l pieces interleaved per 16 channels
-  // pix0 / pix1: pixel indices inside the image (may lie past its end: dropped); okc0 / okc1: their columns are inside
-  auto put2 = [&](unsigned pix0, unsigned pix1, bool okc0, bool okc1, int co, float v0, float v1) {
-    if (POUT) {
-      unsigned h, l;
-      split2_pk(v0, v1, DIM_F16_ACT_SCALE, h, l);
-      const unsigned ho = byte_perm(lane_swap1(h), h, psel), lo = byte_perm(lane_swap1(l), l, psel);
-      const unsigned c2 = (unsigned)(co - par);  // the even channel of this lane pair
-      const unsigned pix = par ? pix1 : pix0;
-      const unsigned off = (par ? okc1 : okc0) ? ((pix >> 1) * (unsigned)cout * 4u + (c2 >> 4) * 64u + (pix & 1u) * 32u + (c2 & 15u)) * 2u : DIM_BUF_OOB;
-      buf_store_u32(rs_p, off, ho);
-      buf_store_u32(rs_p, off + 32u, lo);   // the l pieces of the group follow its 16 h pieces
-    } else {
-      buf_store_f32(rs_f, okc0 ? (pix0 * (unsigned)cout + (unsigned)co) * 4u : DIM_BUF_OOB, v0);
-      buf_store_f32(rs_f, okc1 ? (pix1 * (unsigned)cout + (unsigned)co) * 4u : DIM_BUF_OOB, v1);
-    }
-  };
-  float vmax = 0.0f;  // fp16x3 range guard on everything this thread writes (dim_common.h)
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int co = cb * 64 + n * 32 + lx;
-    const float bv = bias[co];
-    const float inv_scale = inv_ch[co];
-    if (POOL) {
-#pragma unroll
-      for (int mp = 0; mp < MR / 2; ++mp) {
-        const int py = (oy >> 1) + (MR / 2) * wv + mp, pxb = ox >> 1;
-        float pv[8];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          float v = fmaxf(fmaxf(acc[2 * mp][n][r], acc[2 * mp][n][r + 1]), fmaxf(acc[2 * mp + 1][n][r], acc[2 * mp + 1][n][r + 1])) * inv_scale + bv;
-          if (relu) v = fmaxf(v, 0.0f);
-          pv[r >> 1] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const int q0 = mfma_row(2 * j, half) >> 1, q1 = mfma_row(2 * j + 2, half) >> 1;  // pooled column offsets inside the tile
-          vmax = sat_track(vmax, pv[j], pv[j + 1]);
-          put2((unsigned)(py * Wo + pxb + q0), (unsigned)(py * Wo + pxb + q1), pxb + q0 < Wo, pxb + q1 < Wo, co, pv[j], pv[j + 1]);
-        }
+  // POUT: the values arrive already multiplied by the activation scale (folded into the per-channel factor and the bias: a
+  // power of two, exact), ReLU and the fp16 clamp are ONE v_med3 (0 .. 65504; the launchers require relu for pre-split
+  // outputs), the range guard tracks the scaled value before the clamp.  CHK = false (the tile lies inside the image's
+  // columns: every tile but the last of a ragged row) drops the per-element column test.
+  // pix0: pixel index of the first value inside the image (the second value is the next pixel); rows past the image end
+  // lie past the descriptor and are dropped by the hardware
+  constexpr float OSC = POUT ? DIM_F16_ACT_SCALE : 1.0f;
+  auto run_epilogue = [&](auto chk_t) {
+    constexpr bool CHK = decltype(chk_t)::value;
+    auto put2 = [&](unsigned pix0, int col0, int wlim, int co, unsigned cpart, float v0, float v1) {
+      if (POUT) {
+        unsigned h, l;
+        split2_pk_raw(v0, v1, h, l);
+        const unsigned ho = byte_perm(lane_swap1(h), h, psel), lo = byte_perm(lane_swap1(l), l, psel);
+        const unsigned pix = pix0 + (unsigned)par;   // even lanes store the first pixel's channel pair, odd lanes the second's
+        unsigned off = (pix >> 1) * ((unsigned)cout * 8u) + (pix & 1u) * 64u + cpart;
+        if (CHK) off = (col0 + par < wlim) ? off : DIM_BUF_OOB;
+        buf_store_u32(rs_p, off, ho);
+        buf_store_u32(rs_p, off + 32u, lo);   // the l pieces of the group follow its 16 h pieces
+      } else {
+        const unsigned o0 = (pix0 * (unsigned)cout + (unsigned)co) * 4u;
+        buf_store_f32(rs_f, (!CHK || col0 < wlim) ? o0 : DIM_BUF_OOB, v0);
+        buf_store_f32(rs_f, (!CHK || col0 + 1 < wlim) ? o0 + (unsigned)cout * 4u : DIM_BUF_OOB, v1);
       }
-    } else {
+    };
+    float vmax = 0.0f;  // fp16x3 range guard on everything this thread writes (dim_common.h), in units of OSC
 #pragma unroll
-      for (int m = 0; m < MR; ++m) {
-        const int y = oy + MR * wv + m;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int x0 = ox + mfma_row(r, half);  // r even: the odd register is the next column
-          float v0 = acc[m][n][r] * inv_scale + bv, v1 = acc[m][n][r + 1] * inv_scale + bv;
+    for (int n = 0; n < 2; ++n) {
+      const int co = cb * 64 + n * 32 + lx;
+      const float bv = bias[co] * OSC;
+      const float inv_scale = inv_ch[co] * OSC;
+      const unsigned c2 = (unsigned)(co - par);  // the even channel of this lane pair
+      const unsigned cpart = ((c2 >> 4) * 64u + (c2 & 15u)) * 2u;
+      auto finish = [&](float& v0, float& v1) {  // activation, range guard, clamp
+        if (POUT) {
+          vmax = fmaxf(vmax, fmaxf(v0, v1));
+          v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, 65504.0f);
+          v1 = __builtin_amdgcn_fmed3f(v1, 0.0f, 65504.0f);
+        } else {
           if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
           vmax = sat_track(vmax, v0, v1);
-          put2((unsigned)(y * W + x0), (unsigned)(y * W + x0 + 1), x0 < W, x0 + 1 < W, co, v0, v1);
+        }
+      };
+      if (POOL) {
+#pragma unroll
+        for (int mp = 0; mp < MR / 2; ++mp) {
+          const int py = (oy >> 1) + (MR / 2) * wv + mp, pxb = ox >> 1;
+          float pv[8];
+#pragma unroll
+          for (int r = 0; r < 16; r += 2)
+            pv[r >> 1] = fmaxf(fmaxf(acc[2 * mp][n][r], acc[2 * mp][n][r + 1]), fmaxf(acc[2 * mp + 1][n][r], acc[2 * mp + 1][n][r + 1])) * inv_scale + bv;
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const int q0 = mfma_row(2 * j, half) >> 1;  // pooled column offset inside the tile; the next value is the next column
+            finish(pv[j], pv[j + 1]);
+            put2((unsigned)(py * Wo + pxb + q0), pxb + q0, Wo, co, cpart, pv[j], pv[j + 1]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          const int y = oy + MR * wv + m;
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int x0 = ox + mfma_row(r, half);  // r even: the odd register is the next column
+            float v0 = acc[m][n][r] * inv_scale + bv, v1 = acc[m][n][r + 1] * inv_scale + bv;
+            finish(v0, v1);
+            put2((unsigned)(y * W + x0), x0, W, co, cpart, v0, v1);
+          }
         }
       }
     }
-  }
-  if (MODE == 2) sat_report(sat, vmax);
+    if (MODE == 2) sat_report(sat, vmax * (1.0f / OSC));
+  };
+  if (POOL ? ((ox >> 1) + TW / 2 <= Wo) : (ox + TW <= W)) run_epilogue(std::false_type{});
+  else run_epilogue(std::true_type{});
 }
 
 // debug / inspection: pre-split planes back to fp32 (h + l is exact in fp32; / 16 undoes the activation scale)
@@ -421,6 +443,7 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, tile_rows(mr));
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
   DIM_REQUIRE(!planes_out || wt.mode == 2, "conv3x3_x6: pre-split output planes exist for the fp16x3 mode only");
+  DIM_REQUIRE(!planes_out || relu, "conv3x3_x6: a pre-split output implies ReLU (its clamp starts at 0)");
 #define DIM_CONV6F(P, MD, PO, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD, false, PO, ##__VA_ARGS__>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image)
   if (big) DIM_CONV6F(1, 2, true, 4);
   else if (wt.mode == 2 && planes_out) { if (pool) DIM_CONV6F(1, 2, true); else DIM_CONV6F(0, 2, true); }
@@ -436,6 +459,7 @@ int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const floa
                              int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s, unsigned* sat) {
   DIM_REQUIRE(cout % 64 == 0 && (cin == 64 || cin == 128), "conv3x3_x6 planes: cin=%d cout=%d", cin, cout);
   DIM_REQUIRE(wt.dev && wt.mode == 2, "conv3x3_x6 planes: fp16x3 weights required (mode %d)", wt.mode);
+  DIM_REQUIRE(!planes_out || relu, "conv3x3_x6 planes: a pre-split output implies ReLU (its clamp starts at 0)");
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int var = dim_conv_x6_variant();
   const bool big = planes_in && (var & 16);
