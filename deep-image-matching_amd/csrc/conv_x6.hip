@@ -50,7 +50,11 @@ constexpr int w_slice(int npl) { return npl * 3 * 2 * 64 * 8; }              // 
 //     2 workgroups per CU — 12 instead of 16 LDS operand reads per 24 MFMAs, half the weight staging per MFMA, 1.20 x
 //     instead of 1.33 x halo overhead: the production shapes run it (measured 522 -> 531 pairs/s at a power-limited clock;
 //     staging all three kernel rows of weights per barrier pair on top of it was +-0 at MR 4 and 3 % slower at MR 2).
-template <int CIN, int POOL, int PF, bool F1A, int MODE, bool PIN, bool POUT, int MR = 2>
+// WDMA (the 16-row fp16x3 kernels): the weight slice of the NEXT kernel row travels L2 -> LDS by LDS-DMA into the other half of
+//     a double-buffered Wp while the MFMAs of the current row run: no staging registers, no ds_write pass, one barrier per
+//     kernel row instead of two (the slice copy through registers was the largest staging cost: +4 % of the step when
+//     switched off in the stage-ablation experiment).
+template <int CIN, int POOL, int PF, bool F1A, int MODE, bool PIN, bool POUT, int MR = 2, bool WDMA = false>
 __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x6_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wx,
                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                             int cout, int relu, int tiles_x, const float* __restrict__ w1a,
@@ -62,7 +66,8 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
   constexpr int NPL = S::NPL, W_SLICE = w_slice(NPL);
   constexpr int TH = tile_rows(MR), IH = TH + 2, NPIX = IH * IW;  // MR 2: 340 halo pixels, MR 4: 612
   __shared__ u32x4 Ip[NPL * 2 * NPIX];
-  __shared__ u32x4 Wp[NPL * 3 * 2 * 64];
+  constexpr int WSL = NPL * 3 * 2 * 64;   // 16-byte slots of one weight slice
+  __shared__ u32x4 Wp[(WDMA ? 2 : 1) * WSL];
   constexpr int IMW = IW + 2, IMH = IH + 2;  // image tile of the fused conv1a: halo of the halo
   __shared__ float Img[F1A ? IMH * IMW : 1];
   __shared__ float W1a[F1A ? 9 * 64 + 64 : 1];  // conv1a weights [tap][64] + bias[64]: read per chunk from LDS, not from L2
@@ -198,7 +203,16 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
     for (int idx = t; idx < 9 * 64 + 64; idx += 256) W1a[idx] = (idx < 9 * 64 ? w1a[idx] : b1a[idx - 9 * 64]) * S::act_scale();
   }
 
-  if (PF >= 1) load_w(0, 0);
+  // WDMA: slice `ph` = (chunk, kernel row) of this cout block, the slices are contiguous in HBM; wave w moves items
+  // w * 64 + 256 i + lane (the same item-to-thread mapping as the register path)
+  auto dma_w = [&](int ph) {
+    const u32x4* src = (const u32x4*)(wx + ((size_t)cb * NCHUNK * 3 + ph) * W_SLICE);
+#pragma unroll
+    for (int i = 0; i < W_ITEMS / 256; ++i) lds_dma16(src + wv * 64 + 256 * i + lane, &Wp[(ph & 1) * WSL + wv * 64 + 256 * i]);
+  };
+  static_assert(!WDMA || W_ITEMS % 256 == 0, "LDS-DMA weight staging moves whole 256-item rounds");
+  if (WDMA) dma_w(0);
+  else if (PF >= 1) load_w(0, 0);
   if (PF == 2 && !F1A) load_in(0);
   for (int c = 0; c < NCHUNK; ++c) {
     __syncthreads();  // every wave is done with the previous chunk's Ip / Wp (and Img is complete)
@@ -206,13 +220,22 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
     else if (PF != 2) load_in(c);
     store_in();
     for (int dy = 0; dy < 3; ++dy) {
-      if (dy > 0) __syncthreads();  // previous kernel row's weights consumed
-      if (PF == 0) load_w(c, dy);
-      store_w();
-      __syncthreads();
-      if (PF >= 1) {  // next slice (and, at the last kernel row, the next halo tile) behind the MFMAs
-        if (dy < 2) load_w(c, dy + 1);
-        else if (c + 1 < NCHUNK) load_w(c + 1, 0);
+      const int wbuf = WDMA ? ((c * 3 + dy) & 1) * WSL : 0;
+      if (WDMA) {
+        // slice (c, dy) was requested one kernel row ago: the barrier's vmcnt(0) retires it for every wave, and every
+        // wave has left the row that read the other buffer, which the next slice may now overwrite
+        lds_dma_wait_all();
+        __syncthreads();
+        if (c * 3 + dy + 1 < NCHUNK * 3) dma_w(c * 3 + dy + 1);
+      } else {
+        if (dy > 0) __syncthreads();  // previous kernel row's weights consumed
+        if (PF == 0) load_w(c, dy);
+        store_w();
+        __syncthreads();
+        if (PF >= 1) {  // next slice (and, at the last kernel row, the next halo tile) behind the MFMAs
+          if (dy < 2) load_w(c, dy + 1);
+          else if (c + 1 < NCHUNK) load_w(c + 1, 0);
+        }
       }
       if (PF == 2 && !F1A && dy == 2 && c + 1 < NCHUNK) load_in(c + 1);
       __builtin_amdgcn_s_setprio(1);  // a wave in its matrix phase outranks the co-resident waves that are staging (T5)
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
 #pragma unroll
           for (int m = 0; m < MR; ++m) fa[m][p] = Ip[(p * 2 + half) * NPIX + (MR * wv + m + dy) * IW + lx + dx];
 #pragma unroll
-          for (int n = 0; n < 2; ++n) fb[n][p] = Wp[((p * 3 + dx) * 2 + half) * 64 + n * 32 + lx];
+          for (int n = 0; n < 2; ++n) fb[n][p] = Wp[wbuf + ((p * 3 + dx) * 2 + half) * 64 + n * 32 + lx];
         }
 #pragma unroll
         for (int tm = 0; tm < S::NT; ++tm)  // smallest cross terms first
@@ -445,7 +468,7 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
   DIM_REQUIRE(!planes_out || wt.mode == 2, "conv3x3_x6: pre-split output planes exist for the fp16x3 mode only");
   DIM_REQUIRE(!planes_out || relu, "conv3x3_x6: a pre-split output implies ReLU (its clamp starts at 0)");
 #define DIM_CONV6F(P, MD, PO, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<64, P, 1, true, MD, false, PO, ##__VA_ARGS__>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, relu, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image)
-  if (big) DIM_CONV6F(1, 2, true, 4);
+  if (big) DIM_CONV6F(1, 2, true, 4, true);
   else if (wt.mode == 2 && planes_out) { if (pool) DIM_CONV6F(1, 2, true); else DIM_CONV6F(0, 2, true); }
   else if (wt.mode == 2) { if (pool) DIM_CONV6F(1, 2, false); else DIM_CONV6F(0, 2, false); }
   else { if (pool) DIM_CONV6F(1, 1, false); else DIM_CONV6F(0, 1, false); }
@@ -469,8 +492,8 @@ int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const floa
 #define DIM_CONV6P(CI, P, PI, PO, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_x6_kernel<CI, P, 1, false, 2, PI, PO, ##__VA_ARGS__>), grid, dim3(256), 0, s, in, wt.dev, bias, out, H, W, cout, relu, tiles_x, (const float*)nullptr, (const float*)nullptr, wt.inv_ch(), sat, (unsigned*)nullptr)
 #define DIM_CONV6P_IO(CI, P)                                   \
   {                                                            \
-    if (big && planes_out) DIM_CONV6P(CI, P, true, true, 4);   \
-    else if (big) DIM_CONV6P(CI, P, true, false, 4);           \
+    if (big && planes_out) DIM_CONV6P(CI, P, true, true, 4, true);   \
+    else if (big) DIM_CONV6P(CI, P, true, false, 4, true);           \
     else if (planes_in && planes_out) DIM_CONV6P(CI, P, true, true); \
     else if (planes_in) DIM_CONV6P(CI, P, true, false);        \
     else if (planes_out) DIM_CONV6P(CI, P, false, true);       \

@@ -144,6 +144,16 @@ __device__ __forceinline__ unsigned lane_swap1(unsigned v) { return (unsigned)__
 __device__ __forceinline__ unsigned byte_perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ float buf_load_f32(dim_rsrc r, unsigned byte_off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0)); }
 
+// LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane straight from global memory into LDS at the WAVE-UNIFORM base + lane * 16
+// — no staging registers, no ds_write pass.  The transfer is an outstanding vector-memory operation: it is complete after
+// s_waitcnt vmcnt(0) (which __syncthreads() emits when one is in flight), and may be read after the barrier that follows.
+__device__ __forceinline__ void lds_dma16(const void* gsrc_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(gsrc_lane, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// The compiler does NOT order a later LDS read (or the barrier in front of it) after an LDS-DMA by itself: retire this
+// wave's outstanding transfers explicitly before the barrier.  s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields left at "any").
+__device__ __forceinline__ void lds_dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // ---- fp16x3 range guard ---------------------------------------------------------------------------
 // Every kernel that PRODUCES a value a later fp16x3 split will consume (conv / GEMM epilogues, LayerNorm+GELU,
 // the rotated q / k, the external inputs) tracks max|x| of what it writes and bumps a sticky per-site device

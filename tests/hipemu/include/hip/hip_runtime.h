@@ -260,6 +260,7 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma_32x32x16_f16((a), (b), (c))
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(fmaxf(a, b), c), fminf(a, b)); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4((a), (b), (c))
@@ -276,6 +277,11 @@ static inline void __builtin_amdgcn_raw_buffer_store_b16(unsigned short v, hipem
 }
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(hipemu_rsrc r, int off, int soff, int) {
   const unsigned o = (unsigned)off + (unsigned)soff; unsigned v = 0; if ((unsigned long long)o + 4 <= r.bytes) memcpy(&v, r.base + o, 4); return v;
+}
+
+// LDS-DMA (global_load_lds_dwordx4 ...): every lane's `size` bytes go to LDS at the wave-uniform base + lane * size + offset
+static inline void __builtin_amdgcn_global_load_lds(const void* gptr, __attribute__((address_space(3))) void* lds, unsigned size, int offset, int) {
+  memcpy((char*)(unsigned long long)lds + (size_t)hipemu::cur->lane * size + offset, gptr, size);
 }
 
 // DPP quad permutes used by the kernels: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2)
