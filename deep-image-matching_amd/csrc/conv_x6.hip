@@ -1,17 +1,16 @@
-// 3x3 convolution on the bf16 matrix cores at fp32 accuracy ("bf16x6", see dim_common.h split3_pk and
-// gemm_x6.hip): the NHWC fp32 input tile is split EXACTLY into three bf16 planes while it is staged into
-// LDS, the weights are pre-split on the host, and every 32x32x16 MFMA step issues the six leading cross
-// terms (32 cycles each) instead of eight fp32 MFMAs (64 cycles each): 192 vs 512 cycles.
+// 3x3 convolution on the 16-bit matrix cores at fp32 accuracy: every fp32 operand is split into 16-bit pieces (SplitMma,
+// dim_common.h: fp16x3 = two fp16 pieces of the power-of-two-scaled value x three cross terms, the default; bf16x6 = three
+// bf16 pieces x six terms) and each 32x32x16 MFMA step issues the cross terms instead of eight fp32 MFMAs.
 //
-// Workgroup = 4 waves; output tile = 8 rows x 32 columns x 64 channels (wave w: rows 2w, 2w+1 x two
-// 32-channel slabs = 4 accumulators), as in conv.hip.  K loop: 16 input channels per chunk; inside a
-// chunk the weights are staged one kernel ROW (3 taps) at a time, which keeps LDS at 51 KB per
-// workgroup (3 workgroups per CU: the split/staging VALU work of one overlaps the MFMAs of the others):
-//   Ip[plane 3][k-half 2][pixel 10x34][8 bf16]   32,640 B   one 16-B ds_read_b128 = one A operand,
-//   Wp[plane 3][dx 3][k-half 2][cout 64][8 bf16] 18,432 B   one 16-B ds_read_b128 = one B operand;
+// Implicit GEMM, M = pixels, N = cout, K = 9 cin.  Workgroup = 4 waves; production shape (MR 4): output tile 16 rows x 32
+// columns x 64 channels, wave w owns rows 4w .. 4w+3 x two 32-channel slabs = 8 accumulators, 2 workgroups per CU.
+// K loop: 16 input channels per chunk; inside a chunk the weights are staged one kernel ROW (3 taps) at a time:
+//   Ip[plane][k-half 2][pixel (TH+2) x 34][8 x 16 bit]   one 16-B ds_read_b128 = one A operand,
+//   Wp[plane][dx 3][k-half 2][cout 64][8 x 16 bit]       one 16-B ds_read_b128 = one B operand (double-buffered with WDMA);
 // consecutive lanes read consecutive 16-B slots in both images: conflict-free without padding.
-// The pre-split weight buffer is laid out so that each (cout block, chunk, kernel row) slice is one
-// contiguous 18,432-B run (a straight 16-B-per-lane copy).
+// The pre-split weight buffer is laid out so that each (cout block, chunk, kernel row) slice is one contiguous run
+// (a straight 16-B-per-lane copy, or an LDS-DMA).  Template parameters below: fused conv1a (F1A), pre-split input / output
+// (PIN / POUT), tile height (MR), LDS-DMA weight staging (WDMA).
 #include <math.h>
 #include <string.h>
 
