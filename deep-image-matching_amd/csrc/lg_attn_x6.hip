@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
   const int nq = a.n[item], nk = a.n[kitem];
   if (q0 >= nq) return;
 
-  __shared__ u32x4 img[TILE_SLOTS];
-  u32x4* Kp = img;
-  u32x4* Vp = img + KSL;
+  // two tile images: the next key tile arrives by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass)
+  // in the other half while this one is consumed — one barrier per tile
+  __shared__ u32x4 img[2 * TILE_SLOTS];
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, lx = lane & 31, half = lane >> 5;
   const int qrow = q0 + wv * 32 + lx;
@@ -175,21 +175,24 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
 
   // staging: NCP (6 / 4) straight 16-byte copies per thread per tile (images pre-built by kv_prep_kernel)
   const u32x4* src = a.kv_img + ((size_t)kitem * 4 + head) * a.tiles * TILE_STRIDE;
-  u32x4 rt[NCP];
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, int buf) {  // wave w moves items w * 64 + 256 i + lane
     const u32x4* p = src + (size_t)(kt >> 5) * TILE_STRIDE;
 #pragma unroll
-    for (int i = 0; i < NCP; ++i) rt[i] = p[t + 256 * i];
+    for (int i = 0; i < NCP; ++i) lds_dma16(p + wv * 64 + 256 * i + lane, &img[buf * TILE_SLOTS + wv * 64 + 256 * i]);
   };
   // this workgroup's share of the key tiles (all of them unless the launcher split the key range)
   const int per = ((nk + 31) / 32 + a.splits - 1) / a.splits * 32;
   const int kt0 = sp * per, kt1 = min(nk, kt0 + per);
-  if (kt0 < kt1) load_tile(kt0);
-  for (int kt = kt0; kt < kt1; kt += 32) {
-#pragma unroll
-    for (int i = 0; i < NCP; ++i) img[t + 256 * i] = rt[i];
+  if (kt0 < kt1) load_tile(kt0, 0);
+  int buf = 0;
+  for (int kt = kt0; kt < kt1; kt += 32, buf ^= 1) {
+    // the compiler does not order the barrier after the DMA by itself; after it every wave has also left the tile that
+    // lived in the other half, which the next transfer may overwrite
+    lds_dma_wait_all();
     __syncthreads();
-    if (kt + 32 < kt1) load_tile(kt + 32);
+    if (kt + 32 < kt1) load_tile(kt + 32, buf ^ 1);
+    const u32x4* Kp = img + buf * TILE_SLOTS;
+    const u32x4* Vp = Kp + KSL;
 
     // ---- S^T = K · Q^T : 4 steps x 6 cross terms ----
     f32x16 sacc;
@@ -265,7 +268,6 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
         oacc[1] = S::mma(vf[1][S::ta(tm)], pf[S::tb(tm)], oacc[1]);
       }
     }
-    __syncthreads();
   }
 
   // fp16x3: the V·P accumulator holds scale^2 x the sum and l_run scale x the normaliser: divide by scale * l_run
