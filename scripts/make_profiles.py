@@ -21,10 +21,10 @@ L = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separa
      "# gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads -> 'fetch_x2' column.",
      "# conv / GEMM lines are per launch shape: g<workgroups>; at 100 images of 1024^2: conv1b g204800, conv2a / conv2b g51200, conv3a g25600 (<64,0>), conv3b g25600 (<128,1>),",
      "# conv4a / conv4b g6400, convPa / convDa g12800; GEMM g12800 = SuperPoint's 1x1 heads, g1600 / g3200 / g4800 = LightGlue's 256- / 512- / 768-column linears.",
-     "%-56s %6s %14s %14s %14s %6s %7s %5s" % ("kernel", "calls", "fetch_KiB_avg", "fetch_x2_KiB", "write_KiB_avg", "vgpr", "lds_B", "sgpr")]
+     "%-66s %6s %14s %14s %14s %6s %7s %5s" % ("kernel", "calls", "fetch_KiB_avg", "fetch_x2_KiB", "write_KiB_avg", "vgpr", "lds_B", "sgpr")]
 for n in names[:34]:
     f = out['FETCH_SIZE'][n]; w = out['WRITE_SIZE'].get(n, [1, 0.0])
-    L.append("%-56s %6d %14.1f %14.1f %14.1f %6s %7s %5s" % (n[:56], f[0], f[1] / f[0], 2 * f[1] / f[0], w[1] / max(1, w[0]), f[2], f[3], f[4]))
+    L.append("%-66s %6d %14.1f %14.1f %14.1f %6s %7s %5s" % (n[:66], f[0], f[1] / f[0], 2 * f[1] / f[0], w[1] / max(1, w[0]), f[2], f[3], f[4]))
 open(f'profiles/{tag}_pmc_hbm_summary.txt', 'w').write('\n'.join(L) + '\n')
 k = [n for n in names if n.startswith('conv3x3_x6_kernel<64,1,1,true,2')][0]
 f = out['FETCH_SIZE'][k]; w = out['WRITE_SIZE'][k]
@@ -40,10 +40,10 @@ for r in csv.DictReader(open(f'gpurun_out/pmc_{tag}_MFMA/pmc_counter_collection.
         seen.add(r['Dispatch_Id']); cnt[n] += 1; dur[n] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
 L = ["# rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES on `python bench.py --steps 2 --warmup 1`",
      "# clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / duration; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles); waves/SIMD = 4 x SQ_WAVE_CYCLES / (1024 x cycles)",
-     "%-56s %6s %10s %9s %9s %10s %12s" % ("kernel", "calls", "avg_us", "clock_GHz", "mfma_busy", "waves/SIMD", "VALU_per_MFMA")]
+     "%-66s %6s %10s %9s %9s %10s %12s" % ("kernel", "calls", "avg_us", "clock_GHz", "mfma_busy", "waves/SIMD", "VALU_per_MFMA")]
 for n in sorted(agg, key=lambda n: -dur[n])[:24]:
     a = agg[n]; c = cnt[n]; us = dur[n] / c / 1e3; cyc = a['GRBM_GUI_ACTIVE'] / c / 8
-    L.append("%-56s %6d %10.1f %9.2f %9.2f %10.2f %12s" % (n[:56], c, us, cyc / us / 1e3, a['SQ_VALU_MFMA_BUSY_CYCLES'] / c / (1024 * cyc) if cyc else 0,
+    L.append("%-66s %6d %10.1f %9.2f %9.2f %10.2f %12s" % (n[:66], c, us, cyc / us / 1e3, a['SQ_VALU_MFMA_BUSY_CYCLES'] / c / (1024 * cyc) if cyc else 0,
              4 * a['SQ_WAVE_CYCLES'] / c / (1024 * cyc) if cyc else 0, ("%.1f" % (a['SQ_INSTS_VALU'] / a['SQ_INSTS_MFMA'])) if a['SQ_INSTS_MFMA'] else "-"))
 open(f'profiles/{tag}_pmc_mfma_summary.txt', 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L)); print(hb / 1e9, 'GB/launch for', k)
