@@ -40,9 +40,13 @@ int dim_device_synchronize(void);
  * arithmetic: 2 (default) fp32-accurate products on the fp16 matrix cores ("fp16x3": 2-way splits of the
  * power-of-two-scaled operands x 3 terms; activations exact up to |x| = 4094, saturating beyond), 1 = "bf16x6" (exact
  * 3-way bf16 splits x 6 terms, no range limit), 0 = plain fp32 MFMA;
- * key 2 = bf16x6 conv prefetch variant; key 3 = 1 (default) SuperPoint conv1a fused into conv1b, 0 = separate kernels;
- * key 4 = 1 (default) LightGlue out_proj folded into ffn.0 (split modes), 0 = separate GEMMs;
- * key 5 = 1 (default) SuperPoint conv-to-conv activations stored as pre-split fp16 planes (fp16x3), 0 = fp32. */
+ * key 2 = split-precision conv variant: bits 0-1 prefetch variant of the bf16x6 kernels, bit 4 (default set) 16-row tiles
+ * with LDS-DMA weight staging for the production fp16x3 shapes; key 3 = 1 (default) SuperPoint conv1a fused into
+ * conv1b, 0 = separate kernels; key 4 = 1 (default) LightGlue out_proj folded into ffn.0 (split modes), 0 = separate GEMMs;
+ * key 5 = 1 (default) SuperPoint conv-to-conv activations stored pre-split (fp16x3), 0 = fp32;
+ * key 6 = split-precision GEMM block: 1 (default) 128 x 256 when the launch fills the GPU, 0 = always 128 x 128,
+ * 2 = always 128 x 256 (tests); key 7 = simple_nms tiles: 1 (default) 64 x 64 on large maps, 0 = 32 x 32, 2 = always 64 x 64;
+ * key 8 = 1 (default) LightGlue's K | V attention tile images written by the projection GEMM, 0 = separate pre-split pass. */
 int dim_tune_set(int key, int value);
 
 /* Per-launch-site timing with HIP events recorded on the launch stream (bench.py's
