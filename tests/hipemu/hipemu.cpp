@@ -62,8 +62,24 @@ static bool progress;
 
 static void yield() { hipemu_switch(&cur->sp, sched_sp); }
 
+// pending LDS-DMA transfers per thread of the running block (see hip_runtime.h: dma_issue / dma_retire)
+struct PendingDma { void* dst; unsigned size; unsigned char data[16]; };
+static std::vector<std::vector<PendingDma>> pending_dma;
+void dma_issue(void* lds_dst, const void* src, unsigned size) {
+  if (size > 16) { fprintf(stderr, "hipemu: LDS-DMA of %u bytes per lane\n", size); abort(); }
+  if (pending_dma.size() <= cur->flat) pending_dma.resize(cur->flat + 1);
+  PendingDma d; d.dst = lds_dst; d.size = size; memcpy(d.data, src, size);
+  pending_dma[cur->flat].push_back(d);
+}
+void dma_retire() {
+  if (pending_dma.size() <= cur->flat) return;
+  for (const PendingDma& d : pending_dma[cur->flat]) memcpy(d.dst, d.data, d.size);
+  pending_dma[cur->flat].clear();
+}
+
 static void fiber_main() {
   (*body_fn)();
+  dma_retire();  // a thread's outstanding transfers complete at the latest when it ends
   Fiber* f = cur;
   f->state = 2;
   waves[f->wave].alive--;

@@ -81,6 +81,11 @@ const unsigned char* wave_exchange(const void* in, unsigned bytes, unsigned* str
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void wave_collective(const void* in, unsigned bytes, void (*compute)(const unsigned char* tab, unsigned stride, unsigned char* out),
                      unsigned out_bytes, void* my_out);
+// LDS-DMA is ASYNCHRONOUS on the hardware and neither the compiler nor __syncthreads() orders later LDS reads after it:
+// the emulated transfer snapshots its source bytes at issue and lands only when the issuing thread executes
+// s_waitcnt vmcnt(0) (or exits) — a kernel that forgets the wait reads stale LDS here too and fails its parity test.
+void dma_issue(void* lds_dst, const void* src, unsigned size);
+void dma_retire();
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur->tid)
@@ -260,7 +265,6 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma_32x32x16_f16((a), (b), (c))
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
-#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(fmaxf(a, b), c), fminf(a, b)); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4((a), (b), (c))
@@ -281,7 +285,11 @@ static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(hipemu_rsrc r, int o
 
 // LDS-DMA (global_load_lds_dwordx4 ...): every lane's `size` bytes go to LDS at the wave-uniform base + lane * size + offset
 static inline void __builtin_amdgcn_global_load_lds(const void* gptr, __attribute__((address_space(3))) void* lds, unsigned size, int offset, int) {
-  memcpy((char*)(unsigned long long)lds + (size_t)hipemu::cur->lane * size + offset, gptr, size);
+  hipemu::dma_issue((char*)(unsigned long long)lds + (size_t)hipemu::cur->lane * size + offset, gptr, size);
+}
+// s_waitcnt simm16 (gfx9 encoding): vmcnt = bits 3:0 | bits 15:14 << 4.  vmcnt(0) retires this thread's LDS-DMA transfers.
+static inline void __builtin_amdgcn_s_waitcnt(int imm) {
+  if ((((unsigned)imm & 0xFu) | ((((unsigned)imm >> 14) & 3u) << 4)) == 0) hipemu::dma_retire();
 }
 
 // DPP quad permutes used by the kernels: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2)
