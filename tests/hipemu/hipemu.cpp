@@ -65,12 +65,17 @@ static void yield() { hipemu_switch(&cur->sp, sched_sp); }
 // pending LDS-DMA transfers per thread of the running block (see hip_runtime.h: dma_issue / dma_retire)
 struct PendingDma { void* dst; unsigned size; unsigned char data[16]; };
 static std::vector<std::vector<PendingDma>> pending_dma;
+static int wave_serial = 0;  // set_schedule(1): see the block runner
+void set_schedule(int mode) { wave_serial = mode; }
+static int dma_early = 0;  // 0: transfers land at the wait (exposes a missing wait: RAW); 1: at issue (exposes restaging a buffer that is still being read: WAR)
 void dma_issue(void* lds_dst, const void* src, unsigned size) {
   if (size > 16) { fprintf(stderr, "hipemu: LDS-DMA of %u bytes per lane\n", size); abort(); }
+  if (dma_early) { memcpy(lds_dst, src, size); return; }
   if (pending_dma.size() <= cur->flat) pending_dma.resize(cur->flat + 1);
   PendingDma d; d.dst = lds_dst; d.size = size; memcpy(d.data, src, size);
   pending_dma[cur->flat].push_back(d);
 }
+void set_dma_mode(int early) { dma_early = early; }
 void dma_retire() {
   if (pending_dma.size() <= cur->flat) return;
   for (const PendingDma& d : pending_dma[cur->flat]) memcpy(d.dst, d.data, d.size);
@@ -162,9 +167,30 @@ static void run_block(dim3 block) {
   }
   n_alive = T; n_at_barrier = 0;
   static int reverse = -1;
-  if (reverse < 0) { const char* e = getenv("HIPEMU_ORDER"); reverse = (e && !strcmp(e, "reverse")) ? 1 : 0; }
+  if (reverse < 0) {
+    const char* e = getenv("HIPEMU_ORDER");
+    reverse = (e && !strcmp(e, "reverse")) ? 1 : 0;
+    if (e && !strcmp(e, "wave_serial")) wave_serial = 1;   // HIPEMU_ORDER=wave_serial: the adversarial schedule for a whole test run
+  }
   while (n_alive) {
     progress = false;
+    if (wave_serial) {
+      // adversarial schedule: every wave runs as far as it can (to its next barrier or its end) before the next wave
+      // moves at all — the waves of a workgroup are maximally out of step between barriers, as they may be on hardware
+      for (unsigned w = 0; w < nw; ++w) {
+        bool moved = true;
+        while (moved) {
+          moved = false;
+          for (unsigned t = w * 64; t < std::min(T, (w + 1) * 64); ++t) {
+            Fiber& f = fibers[t];
+            if (f.state != 0) continue;
+            cur = &f;
+            hipemu_switch(&sched_sp, f.sp);
+            moved = true;
+          }
+        }
+      }
+    } else
     for (unsigned i = 0; i < T; ++i) {
       unsigned t = reverse ? T - 1 - i : i;
       Fiber& f = fibers[t];
@@ -226,3 +252,8 @@ hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 }
+
+// test switch (ctypes): when the emulated LDS-DMA transfers land — see dma_issue
+extern "C" void hipemu_set_dma_mode(int early) { hipemu::set_dma_mode(early); }
+// test switch: 0 = all threads advance one step per round (default), 1 = wave after wave between barriers
+extern "C" void hipemu_set_schedule(int mode) { hipemu::set_schedule(mode); }

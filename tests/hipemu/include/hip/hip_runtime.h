@@ -86,6 +86,7 @@ void wave_collective(const void* in, unsigned bytes, void (*compute)(const unsig
 // s_waitcnt vmcnt(0) (or exits) — a kernel that forgets the wait reads stale LDS here too and fails its parity test.
 void dma_issue(void* lds_dst, const void* src, unsigned size);
 void dma_retire();
+void set_dma_mode(int early);  // 1: land at issue instead (exposes restaging a buffer other threads still read)
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur->tid)

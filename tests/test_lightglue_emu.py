@@ -1,6 +1,7 @@
 """CPU: the HIP LightGlue sources, compiled against the test-only emulator, vs the oracle and the
 reference's golden vectors (early stop, pruning, the empty exit, 128-d input_proj)."""
 import importlib
+import os
 from pathlib import Path
 
 import numpy as np
@@ -69,3 +70,18 @@ def test_lightglue_kv_images_written_by_the_projection_gemm(emu_lib, name):
                                                              "matches", "scores", "prune0", "prune1")}
     gold["stop"] = int(g["stop"])
     compare_lightglue(out, gold)
+
+
+def test_attention_tile_dma_is_ordered_both_ways(emu_lib):
+    """As test_lds_dma_staging_is_ordered_both_ways (test_superpoint_emu.py), for the double-buffered key-tile image of the
+    attention kernel: transfers landing at the wait (default) and at issue must give the same result."""
+    name = next(iter(gc.LG_CASES))
+    out, _ = run_case(emu_lib, gc.LG_CASES[name])
+    try:
+        emu_lib.hipemu_set_dma_mode(1)
+        emu_lib.hipemu_set_schedule(1)   # wave after wave between barriers: the waves are maximally out of step
+        out2, _ = run_case(emu_lib, gc.LG_CASES[name])
+    finally:
+        emu_lib.hipemu_set_dma_mode(0)
+        emu_lib.hipemu_set_schedule(1 if os.environ.get("HIPEMU_ORDER") == "wave_serial" else 0)
+    assert torch.equal(out["dense"], out2["dense"]) and torch.equal(out["matches"][0], out2["matches"][0])

@@ -1,6 +1,7 @@
 """CPU: the HIP SuperPoint sources, compiled against the test-only emulator, vs the
 oracle and the reference's golden vectors on the small golden cases."""
 import importlib
+import os
 from pathlib import Path
 
 import numpy as np
@@ -116,6 +117,27 @@ def test_conv_16_row_tiles_are_bit_identical_to_8_row_tiles(emu_lib):
         b = net(img); tb = net.debug_taps()
     finally:
         emu_lib.dim_tune_set(2, 1 | 16)
+    for k in ("encoder", "score_map", "logits"):
+        assert torch.equal(ta[k], tb[k]), k
+    assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
+
+
+def test_lds_dma_staging_is_ordered_both_ways(emu_lib):
+    """The emulator lands an LDS-DMA transfer at the issuing thread's s_waitcnt vmcnt(0) by default (a missing wait reads
+    stale LDS: RAW).  hipemu_set_dma_mode(1) lands it at ISSUE instead, which exposes the opposite mistake — restaging a
+    buffer other threads still read (WAR).  The weight-slice double buffer of conv_x6.hip must be right in both."""
+    name = next(iter(gc.SP_CASES))
+    case = gc.SP_CASES[name]
+    sd, img = gc.sp_weights(case), gc.sp_image(case)
+    net = sp_mod.SuperPointHIP(sd, case["cfg"], max_batch=1, max_hw=(case["H"], case["W"]), capacity=512, device="cpu", lib=emu_lib)
+    a = net(img); ta = net.debug_taps()
+    try:
+        emu_lib.hipemu_set_dma_mode(1)
+        emu_lib.hipemu_set_schedule(1)   # wave after wave between barriers: the waves are maximally out of step
+        b = net(img); tb = net.debug_taps()
+    finally:
+        emu_lib.hipemu_set_dma_mode(0)
+        emu_lib.hipemu_set_schedule(1 if os.environ.get("HIPEMU_ORDER") == "wave_serial" else 0)
     for k in ("encoder", "score_map", "logits"):
         assert torch.equal(ta[k], tb[k]), k
     assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
