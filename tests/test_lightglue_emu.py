@@ -85,3 +85,37 @@ def test_attention_tile_dma_is_ordered_both_ways(emu_lib):
         emu_lib.hipemu_set_dma_mode(0)
         emu_lib.hipemu_set_schedule(1 if os.environ.get("HIPEMU_ORDER") == "wave_serial" else 0)
     assert torch.equal(out["dense"], out2["dense"]) and torch.equal(out["matches"][0], out2["matches"][0])
+
+
+def test_batch_with_ragged_and_empty_images_on_the_projection_written_images(emu_lib):
+    """A batch of ragged pairs (one image without keypoints) through pair_idx on the large-batch path (K | V tile images written
+    by the projection GEMM, forced with dim_tune_set(6, 2)), adaptive depth and width on: every pair equals the same pair
+    run alone."""
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_lightglue_state_dict(5, 256, n_layers=3, gain=2.0)
+    conf = {"n_layers": 3, "depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.0}
+    g = torch.Generator().manual_seed(3)
+    n_img, cap = 4, 70
+    counts = [70, 0, 33, 57]
+    kt = torch.rand(n_img, cap, 2, generator=g) * 640
+    dt = torch.nn.functional.normalize(torch.randn(n_img, cap, 256, generator=g), dim=-1)
+    nt = torch.tensor(counts, dtype=torch.int32)
+    st = torch.tensor([[480.0, 640.0]] * n_img)
+    pairs = torch.tensor([[0, 2], [2, 3], [0, 1], [3, 0]], dtype=torch.int32)
+    try:
+        emu_lib.dim_tune_set(6, 2)
+        net = lg_mod.LightGlueHIP(sd, conf, max_pairs=4, max_kpts=cap, device="cpu", lib=emu_lib)
+        o = net.match_batch(kt, dt, nt, st, pair_idx=pairs)
+        single = lg_mod.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=cap, device="cpu", lib=emu_lib)
+        for p, (a, b) in enumerate(pairs.tolist()):
+            data = {"image0": {"keypoints": kt[a, :counts[a]][None], "descriptors": dt[a, :counts[a]][None], "image_size": st[a][None]},
+                    "image1": {"keypoints": kt[b, :counts[b]][None], "descriptors": dt[b, :counts[b]][None], "image_size": st[b][None]}}
+            r = single(data)
+            S = int(o["n_matches"][p])
+            assert int(o["stop"][p]) == r["stop"]
+            assert torch.equal(o["matches"][p, :S], r["matches"][0]) and torch.equal(o["scores"][p, :S], r["scores"][0])
+            assert torch.equal(o["matches01"][p, 0, :counts[a]].long(), r["matches0"][0])
+            if counts[a] == 0 or counts[b] == 0:
+                assert S == 0 and r["stop"] == 1
+    finally:
+        emu_lib.dim_tune_set(6, 1)
