@@ -161,7 +161,9 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
         if (kblk) {
           // lane = key lx (+ 32-key tile m), register r = output dim cbase + 8 (r >> 2) + 4 half + (r & 3)
           const int key = m0 + wm * (32 * MT) + m * 32 + lx;
-          const float* e = a.kv_enc ? a.kv_enc + ((size_t)z * a.kv_nmax + min(key, a.kv_nmax - 1)) * 64 : nullptr;
+          // rows past the ragged end are copies of the last valid row (load_chunk clamps): rotate them with THAT row's table
+          // entry — the table is only initialised for live rows, and garbage here would trip the range guard
+          const float* e = a.kv_enc ? a.kv_enc + ((size_t)z * a.kv_nmax + min(key, rows - 1)) * 64 : nullptr;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {   // registers 8j .. 8j+7 = one slot: dims 16 (2 np + j) + 4 half + {0..3, 8..11} of the head
             float v[8];

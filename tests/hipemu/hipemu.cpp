@@ -229,7 +229,15 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 struct hipemu_event { std::chrono::steady_clock::time_point t; };
 
 extern "C" {
-hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// device memory is handed out POISONED (0x7F bytes: 3.4e38 as float — finite, so max-based range tracking sees it, unlike a NaN — and 2139062143 as int): a kernel that reads what nothing wrote — ragged
+// tails, scratch it assumes zeroed — produces NaNs / trips the range guard deterministically instead of depending on what
+// the allocator happened to return
+hipError_t hipMalloc(void** p, size_t n) {
+  const size_t bytes = (n + 255) & ~(size_t)255;
+  *p = aligned_alloc(256, bytes);
+  if (*p) memset(*p, 0x7F, bytes);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }

@@ -141,3 +141,20 @@ def test_lds_dma_staging_is_ordered_both_ways(emu_lib):
     for k in ("encoder", "score_map", "logits"):
         assert torch.equal(ta[k], tb[k]), k
     assert torch.equal(a["keypoints"], b["keypoints"]) and torch.equal(a["descriptors"], b["descriptors"])
+
+
+def test_range_guard_is_silent_on_ragged_odd_sized_batches(emu_lib):
+    """Benign images at sizes whose pooled maps have odd pixel counts (the pre-split layout pads every image to a pixel pair) and
+    partial tiles on both axes: no kernel may report a value outside the fp16 split's range — the emulator hands out device
+    memory poisoned with 3.4e38, so a read of anything that was never written (padding slots, rows past a ragged end) would."""
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    name = next(iter(gc.SP_CASES))
+    case = gc.SP_CASES[name]
+    sd = gc.sp_weights(case)
+    for hw in ((45, 70), (52, 38), (77, 102)):
+        imgs = torch.rand(2, hw[0], hw[1], generator=torch.Generator().manual_seed(hw[0]))
+        net = sp_mod.SuperPointHIP(sd, case["cfg"], max_batch=2, max_hw=hw, capacity=512, device="cpu", lib=emu_lib)
+        capi.saturation(emu_lib, None, reset=True)
+        net.extract_batch(imgs)
+        total, sites = capi.saturation(emu_lib, None, reset=True)
+        assert total == 0, (hw, sites)
