@@ -76,26 +76,36 @@ class BatchedImageMatcher:
     def extract_features(self, images: Sequence[Path]) -> Path:
         feature_path = self.out / "features.h5"
         store = export.FeatureStore(feature_path)
+        # Images are bucketed by shape and a bucket is extracted as soon as it holds ``image_batch`` images, so the host
+        # keeps at most image_batch decoded images per distinct shape (the reference holds one; decoding everything up
+        # front would be O(dataset) of float32 in host memory).
         by_shape: Dict[Tuple[int, ...], List[Tuple[Path, np.ndarray]]] = {}
+
+        def flush(shape, chunk):
+            H, W = shape[:2]
+            net = self.ext._ensure_batch(H, W, self.image_batch)
+            stack = torch.from_numpy(np.stack([im for _, im in chunk])).to(net.device) / 255.0      # _frame2tensor's /255
+            run = getattr(net, "extract_batch_guarded", net.extract_batch)
+            kp, sc, de, n = run(stack.contiguous())
+            if hasattr(self.ext, "_regrow") and self.ext._regrow(net, len(chunk)):
+                net = self.ext._ensure_batch(H, W, self.image_batch)
+                kp, sc, de, n = getattr(net, "extract_batch_guarded", net.extract_batch)(stack.contiguous())
+            kp, sc, de, n = kp.cpu().numpy(), sc.cpu().numpy(), de.cpu().numpy(), n.cpu().numpy()
+            for j, (p, _) in enumerate(chunk):
+                k = int(n[j])
+                store.add(p.name, {"keypoints": kp[j, :k], "descriptors": np.ascontiguousarray(de[j, :k].T), "scores": sc[j, :k],
+                                   "tile_idx": np.zeros(k, np.float32), "image_size": np.array((H, W))})
+
         for p in images:
             img = self.loader(Path(p))
-            by_shape.setdefault(img.shape, []).append((Path(p), img))
-        for shape, group in by_shape.items():
-            H, W = shape[:2]
-            for s in range(0, len(group), self.image_batch):
-                chunk = group[s:s + self.image_batch]
-                net = self.ext._ensure_batch(H, W, self.image_batch)
-                stack = torch.from_numpy(np.stack([im for _, im in chunk])).to(net.device) / 255.0      # _frame2tensor's /255
-                run = getattr(net, "extract_batch_guarded", net.extract_batch)
-                kp, sc, de, n = run(stack.contiguous())
-                if hasattr(self.ext, "_regrow") and self.ext._regrow(net, len(chunk)):
-                    net = self.ext._ensure_batch(H, W, self.image_batch)
-                    kp, sc, de, n = getattr(net, "extract_batch_guarded", net.extract_batch)(stack.contiguous())
-                kp, sc, de, n = kp.cpu().numpy(), sc.cpu().numpy(), de.cpu().numpy(), n.cpu().numpy()
-                for j, (p, _) in enumerate(chunk):
-                    k = int(n[j])
-                    store.add(p.name, {"keypoints": kp[j, :k], "descriptors": np.ascontiguousarray(de[j, :k].T), "scores": sc[j, :k],
-                                       "tile_idx": np.zeros(k, np.float32), "image_size": np.array((H, W))})
+            bucket = by_shape.setdefault(img.shape, [])
+            bucket.append((Path(p), img))
+            if len(bucket) >= self.image_batch:
+                flush(img.shape, bucket)
+                by_shape[img.shape] = []
+        for shape, bucket in by_shape.items():
+            if bucket:
+                flush(shape, bucket)
         store.close()
         return feature_path
 
@@ -118,6 +128,10 @@ class BatchedImageMatcher:
             kt[i, :k], dt[i, :k], nt[i], st[i] = f["keypoints"], f["descriptors"].T, k, f["image_size"].astype(np.float32)
         net = self.mat._ensure_pairs(cap, self.pair_batch)
         dev = net.device
+        if self._verifier is not None and net.nk > 4096:
+            # dim_gv_fundamental stages a pair's correspondences in LDS: at most 4096 matches per pair
+            raise ValueError(f"device verification handles at most 4096 keypoints per image (this run needs {net.nk}); lower "
+                             "max_keypoints, or construct BatchedImageMatcher(verify=False) and verify with verify.HostVerifierPool")
         kt_d, dt_d, nt_d, st_d = (torch.from_numpy(a).to(dev) for a in (kt, dt, nt, st))
         for s in range(0, len(pairs), self.pair_batch):
             chunk = [(Path(a).name, Path(b).name) for a, b in pairs[s:s + self.pair_batch]]

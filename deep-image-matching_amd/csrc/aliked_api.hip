@@ -44,6 +44,7 @@ int dev_alloc(dim_aliked* h, T** p, size_t count) {
   return 0;
 }
 int upload(dim_aliked* h, float** dst, const std::vector<float>& v) {
+  if (!dim_all_finite(v.data(), v.size())) { dim_set_error("non-finite value in the weights"); return -1; }
   if (dev_alloc(h, dst, v.size()) != 0) return -1;
   if (hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
     dim_set_error("weight upload failed");

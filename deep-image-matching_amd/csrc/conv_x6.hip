@@ -188,15 +188,17 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
     }
   };
   if (F1A) {
-    float imax = 0.0f;  // range guard: the host bound on conv1a's outputs assumes |image| <= 1 (image / 255)
+    // range guard: the host bound on conv1a's outputs assumes |image| <= 1 (image / 255).  Tracked on the bit patterns of |v|
+    // (ordered like the values for non-negative floats; NaN patterns sort above Inf, so a NaN pixel trips the guard too).
+    unsigned imax = 0u;
     for (int idx = t; idx < IMH * IMW; idx += 256) {
       const int r = idx / IMW, cc = idx - r * IMW;
       const int gy = oy + r - 2, gx = ox + cc - 2;
       const float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in_b[(size_t)gy * W + gx] : 0.0f;
       Img[idx] = v;
-      imax = fmaxf(imax, fabsf(v));
+      imax = max(imax, __float_as_uint(v) & 0x7fffffffu);
     }
-    if (sat_image != nullptr && !(imax <= 1.0f)) atomicAdd(sat_image, 1u);
+    if (sat_image != nullptr && imax > 0x3f800000u) atomicAdd(sat_image, 1u);
     // weights and bias pre-multiplied by the activation scale (a power of two: fmaf(v, s w, s acc) = s fmaf(v, w, acc)
     // exactly), so the conv1a outputs come out scaled and their split skips the multiply
     for (int idx = t; idx < 9 * 64 + 64; idx += 256) W1a[idx] = (idx < 9 * 64 ? w1a[idx] : b1a[idx - 9 * 64]) * S::act_scale();

@@ -309,6 +309,12 @@ __global__ __launch_bounds__(GV_T) void gv_refine_kernel(GvArgs a) {
     for (int j = 0; j < 9; ++j) Fcur[j] = bs >= 0 ? a.best_F[((size_t)pair * a.splits + bs) * 9 + j] : 0.0;
   }
   __syncthreads();
+  if (cur_cnt < 0) {  // every 7-point sample was degenerate (duplicate / collinear correspondences): the estimator has no
+    // model.  geometric_verification.py:150-172 keeps an all-ones mask when its estimator fails; so does this path.
+    for (int i = t; i < a.nk; i += GV_T) mask[i] = i < n ? 1 : 0;
+    if (t == 0) { a.n_inl[pair] = n; for (int j = 0; j < 9; ++j) a.F_out[(size_t)pair * 9 + j] = 0.0; }
+    return;
+  }
   for (int lo = 0; lo < 2 && cur_cnt >= 8; ++lo) {
     // normal matrix of the normalised 8-point system over the current inliers: 45 upper-triangle sums per thread
     double acc[45];

@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256) void lg_init_kernel(LgState st, const float* _
     const float4 a = src[j], b = src[j + 32];
     dst[j] = a;
     dst[j + 32] = b;
-    sat_report(sat, fmaxf(sat_track(sat_track(0.0f, a.x, a.y), a.z, a.w), sat_track(sat_track(0.0f, b.x, b.y), b.z, b.w)));
+    // external input: a NaN descriptor must trip the guard too, and fmaxf drops NaN — add the NaN marker explicitly
+    const float nanmark = (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w) * 0.0f;   // 0 for finite inputs, NaN for NaN / Inf
+    sat_report(sat, fmaxf(sat_track(sat_track(0.0f, a.x, a.y), a.z, a.w), sat_track(sat_track(0.0f, b.x, b.y), b.z, b.w)) + nanmark);
   }
 }
 

@@ -76,6 +76,7 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
   for (int l = 0; l < 12; ++l) {
     const int ci = kCin[l], co = kCout[l], k = kK[l];
     const int co_pad = (co + 3) & ~3;
+    if (!dim_all_finite(w->conv_w[l], (size_t)k * k * ci * co) || !dim_all_finite(w->conv_b[l], (size_t)co)) { dim_set_error("dim_sp_create: non-finite value in the weights of layer %d", l); dim_sp_destroy(h); return -1; }
     std::vector<float> host((size_t)k * k * ci * co_pad, 0.0f);
     for (int o = 0; o < co; ++o)
       for (int i = 0; i < ci; ++i)

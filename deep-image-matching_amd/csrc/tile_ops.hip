@@ -99,6 +99,39 @@ __global__ __launch_bounds__(256) void resize_area_linear_kernel(const float* __
   dst[i] = div255 ? out / 255.0f : out;
 }
 
+// cv2.resize(..., INTER_LINEAR) of a single-channel fp32 image (OpenCV 4.11 imgproc/resize.cpp, resizeGeneric_ with
+// HResizeLinear / VResizeLinear<float>): pixel centres, fx = (float)((dx + 0.5) * scale - 0.5), s = floor(fx), fx -= s;
+// s < 0 -> (0, 0); s >= ssize - 1 -> (ssize - 1, 0) and the horizontal pass copies S[s] there; rows are clamped instead
+// (the vertical weights keep their fraction).  This is what utils/image.py:52-57 resize_image switches to when the
+// requested size ENLARGES the image (quality HIGHEST, extractor_base.py:392-412 / matcher_base.py:1026-1034).
+__device__ __forceinline__ LinTap linear_tap(int d, int ssize, int dsize) {
+  const double scale = (double)ssize / (double)dsize;
+  float fx = (float)(((double)d + 0.5) * scale - 0.5);
+  LinTap t;
+  t.s = (int)floorf(fx);
+  t.f = fx - (float)t.s;
+  return t;
+}
+__global__ __launch_bounds__(256) void resize_linear_kernel(const float* __restrict__ src, int H, int W, float* __restrict__ dst, int h, int w,
+                                                            int div255) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= h * w) return;
+  const int dy = i / w, dx = i - dy * w;
+  LinTap tx = linear_tap(dx, W, w);
+  const LinTap ty = linear_tap(dy, H, h);
+  if (tx.s < 0) { tx.s = 0; tx.f = 0.f; }
+  const bool copy = tx.s + 1 >= W;   // dx >= xmax
+  if (tx.s >= W - 1) { tx.s = W - 1; tx.f = 0.f; }
+  const int y0 = min(max(ty.s, 0), H - 1), y1 = min(max(ty.s + 1, 0), H - 1);
+  auto hrow = [&](int y) -> float {
+    const float* r = src + (size_t)y * W;
+    if (copy) return r[tx.s];
+    return r[tx.s] * (1.0f - tx.f) + r[tx.s + 1] * tx.f;
+  };
+  const float out = hrow(y0) * (1.0f - ty.f) + hrow(y1) * ty.f;
+  dst[i] = div255 ? out / 255.0f : out;
+}
+
 // thread = match.  Both keypoints are scaled back to full resolution (kp / scale, fp32 like numpy) and
 // tested against every tile rectangle with the strict inequalities of points_in_rect (MB:1410-1412).
 __global__ __launch_bounds__(256) void tile_votes_kernel(const float* __restrict__ k0, const float* __restrict__ k1,
@@ -181,6 +214,13 @@ int dim_op_resize_area_f32(const float* src, int H, int W, float* dst, int h, in
   }
   const int fast = (H % h == 0) && (W % w == 0);
   hipLaunchKernelGGL(resize_area_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, (hipStream_t)stream, src, H, W, dst, h, w, fast, div255);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+int dim_op_resize_linear_f32(const float* src, int H, int W, float* dst, int h, int w, int div255, void* stream) {
+  DIM_REQUIRE(src && dst && H > 0 && W > 0 && h > 0 && w > 0, "dim_op_resize_linear_f32: bad arguments");
+  hipLaunchKernelGGL(resize_linear_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, (hipStream_t)stream, src, H, W, dst, h, w, div255);
   DIM_LAUNCH_CHECK();
   return 0;
 }

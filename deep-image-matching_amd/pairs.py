@@ -71,9 +71,11 @@ def pairs_from_retrieval(query_names: Sequence[str], db_names: Sequence[str], qu
     idx = torch.empty(nq, k, dtype=torch.int32, device=dev)
     val = torch.empty(nq, k, dtype=torch.float32, device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
-    capi.check(lib, lib.dim_op_retrieval_topk(capi.ptr(q), nq, capi.ptr(d), nd, D + pad, capi.ptr(invalid), k,
-                                              ctypes.c_float(0.0 if min_score is None else float(min_score)), int(min_score is not None),
-                                              capi.ptr(sim), capi.ptr(idx), capi.ptr(val), stream))
+    import contextlib
+    with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):   # launch on dev, not on the current device
+        capi.check(lib, lib.dim_op_retrieval_topk(capi.ptr(q), nq, capi.ptr(d), nd, D + pad, capi.ptr(invalid), k,
+                                                  ctypes.c_float(0.0 if min_score is None else float(min_score)), int(min_score is not None),
+                                                  capi.ptr(sim), capi.ptr(idx), capi.ptr(val), stream))
     idx = idx.cpu().numpy()
     return [(query_names[i], db_names[j]) for i in range(nq) for j in idx[i] if j >= 0]
 

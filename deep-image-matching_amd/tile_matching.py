@@ -1,8 +1,8 @@
 """Tile-wise matching for large-format images, batched on the GPU.
 
 Host-side restatement of ``MatcherBase._match_by_tile`` (matchers/matcher_base.py:362-460) and
-``tile_selection`` (matchers/matcher_base.py:989-1140: EXHAUSTIVE / GRID / PRESELECTION with the
-superpoint+lightglue pipeline) with two differences that do not change results:
+``tile_selection`` (matchers/matcher_base.py:989-1342: EXHAUSTIVE / GRID / PRESELECTION / PRESELECTION_AFFINE_TRANSFORM with
+the superpoint+lightglue pipeline, every quality level) with two differences that do not change results:
 
 * the reference calls ``_match_pairs`` once per tile pair, sequentially (MB:417-425); here the tiles of
   both images form ONE device feature table and all selected tile pairs go through
@@ -40,7 +40,13 @@ logger = logging.getLogger("dim_amd")
 # (MB:18), whose defaults add remove_borders 4 and fix_sampling True (thirdparty/hloc/extractors/superpoint.py:24-31, Q3).
 PRESELECTION_SP_CONF = {"nms_radius": 5, "max_keypoints": 4000, "keypoint_threshold": 0.005, "remove_borders": 4, "fix_sampling": True}
 PRESELECTION_LG_CONF = {"n_layers": 9, "depth_confidence": 0.9, "width_confidence": 0.95, "filter_threshold": 0.3}
-_QUALITY_FACTOR = {"HIGHEST": 2, "HIGH": 1, "MEDIUM": 1 / 2, "LOW": 1 / 4, "LOWEST": 1 / 8}  # constants.py:76-88
+_QUALITY_FACTOR = {"HIGHEST": 2, "HIGH": 1, "MEDIUM": 1 / 2, "LOW": 1 / 4, "LOWEST": 1 / 8}  # constants.py:80-86
+
+
+def get_size_by_quality(quality: str, size: Tuple[int, int]) -> Tuple[int, int]:
+    """constants.py:76-88 (pinned against the reference's function by oracle/make_golden.py)."""
+    f = _QUALITY_FACTOR[quality]
+    return (int(size[0] * f), int(size[1] * f))
 
 
 def get_features_by_tile(features: dict, tile_idx: int):
@@ -78,7 +84,145 @@ def select_tile_pairs(method: str, keys0: Sequence[int], keys1: Sequence[int], v
             raise ValueError("PRESELECTION needs the vote table")
         k0, k1 = sorted(keys0), sorted(keys1)
         return sorted((k0[a], k1[b]) for a in range(len(k0)) for b in range(len(k1)) if votes[a, b] > min_matches_per_tile)
-    raise ValueError(f"tile selection method {method} is not built on the MI355X path")
+    raise ValueError(f"Invalid tile selection method: {method}")   # MB:1335-1336
+
+
+def _affine_total_least_squares(kp0: np.ndarray, kp1: np.ndarray) -> np.ndarray:
+    """The reference's second-stage estimator, skimage.transform.estimate_transform('affine', kp0, kp1) (MB:1441-1445), restated
+    from scikit-image's published algorithm (AffineTransform.estimate: Hartley-normalised points, the 6 affine coefficients
+    + the homogeneous scale as the right singular vector of the smallest singular value).  skimage is absent here: unpinned."""
+    def normalise(p):
+        c = p.mean(axis=0)
+        rms = np.sqrt(np.mean(np.sum((p - c) ** 2, axis=1)))
+        if rms == 0:
+            raise ValueError("degenerate points")
+        k = np.sqrt(2.0) / rms
+        T = np.array([[k, 0, -k * c[0]], [0, k, -k * c[1]], [0, 0, 1.0]])
+        return T, (p - c) * k
+    T0, a = normalise(np.asarray(kp0, np.float64))
+    T1, b = normalise(np.asarray(kp1, np.float64))
+    n = len(a)
+    A = np.zeros((2 * n, 7))
+    A[:n, 0:2], A[:n, 2], A[:n, 6] = a, 1.0, b[:, 0]
+    A[n:, 3:5], A[n:, 5], A[n:, 6] = a, 1.0, b[:, 1]
+    V = np.linalg.svd(A)[2]
+    H = np.eye(3)
+    H.flat[:6] = -V[-1, :6] / V[-1, 6]
+    H = np.linalg.inv(T1) @ H @ T0
+    return (H / H[2, 2])[:2]
+
+
+def _similarity_ransac(kp0: np.ndarray, kp1: np.ndarray, threshold: float = 4.0, confidence: float = 0.999, max_iters: int = 10000,
+                       seed: int = 0) -> Optional[np.ndarray]:
+    """Stand-in for cv2.estimateAffinePartial2D(method=RANSAC, ransacReprojThreshold=4, confidence=0.999, maxIters=10000)
+    (MB:1436-1440) where OpenCV is absent: the same model class (4-DoF similarity from 2-point samples), threshold and
+    adaptive stopping rule, least-squares refit on the inliers.  Deterministic (seeded); NOT result-identical to OpenCV's RNG
+    and LM refinement — the transform only feeds rectangle-intersection tests with a >= 2 px margin (MB:1276-1310)."""
+    a, b = np.asarray(kp0, np.float64), np.asarray(kp1, np.float64)
+    n = len(a)
+    rng = np.random.default_rng(seed)
+
+    def fit(p, q):   # q ~ s R p + t, least squares (Umeyama without reflection handling: [a -b; b a] parametrisation)
+        pc, qc = p.mean(0), q.mean(0)
+        dp, dq = p - pc, q - qc
+        den = np.sum(dp * dp)
+        if den <= 0:
+            return None
+        ca = np.sum(dp[:, 0] * dq[:, 0] + dp[:, 1] * dq[:, 1]) / den
+        sa = np.sum(dp[:, 0] * dq[:, 1] - dp[:, 1] * dq[:, 0]) / den
+        R = np.array([[ca, -sa], [sa, ca]])
+        return np.c_[R, qc - R @ pc]
+
+    best, best_mask, iters, it = -1, None, int(max_iters), 0
+    thr2 = threshold * threshold
+    while it < iters:
+        batch = min(256, iters - it)
+        i0 = rng.integers(0, n, batch)
+        i1 = (i0 + 1 + rng.integers(0, n - 1, batch)) % n
+        for u, v in zip(i0, i1):
+            it += 1
+            M = fit(a[[u, v]], b[[u, v]])
+            if M is None:
+                continue
+            r = a @ M[:, :2].T + M[:, 2] - b
+            mask = np.sum(r * r, axis=1) <= thr2
+            c = int(mask.sum())
+            if c > best:
+                best, best_mask = c, mask
+                w = min(max(c / n, 1e-9), 1 - 1e-9)
+                need = np.log(1 - confidence) / np.log(1 - w * w)
+                iters = min(iters, int(np.ceil(need)) if np.isfinite(need) else iters)
+            if it >= iters:
+                break
+    if best < 2:
+        return None
+    return fit(a[best_mask], b[best_mask])
+
+
+def estimate_affine_from_matches(kp0: np.ndarray, kp1: np.ndarray) -> np.ndarray:
+    """MB:1431-1454: img0 -> img1 2x3 transform; identity when every estimator fails or returns non-finite values."""
+    M = None
+    try:
+        try:
+            import cv2  # type: ignore
+        except ImportError:
+            cv2 = None
+        if cv2 is not None:
+            M, _ = cv2.estimateAffinePartial2D(kp0, kp1, method=cv2.RANSAC, ransacReprojThreshold=4.0, confidence=0.999, maxIters=10000)
+        else:
+            M = _similarity_ransac(kp0, kp1)
+        if M is None:
+            M = _affine_total_least_squares(kp0, kp1)
+    except Exception:  # noqa: BLE001 - the reference swallows estimator failures the same way
+        logger.warning("Affine estimation failed")
+        M = None
+    if M is None or not np.isfinite(M).all():
+        M = np.array([[1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    return np.asarray(M).astype(np.float32)
+
+
+def _rects(origins: Dict[int, Tuple[int, int]], tile_size) -> Tuple[np.ndarray, np.ndarray]:
+    ids = np.array(list(origins.keys()), dtype=np.int64)
+    o = np.array([origins[int(t)] for t in ids], dtype=np.float32).reshape(-1, 2)
+    return ids, np.concatenate([o, o + np.array([tile_size[0], tile_size[1]], np.float32)], axis=1)   # get_tile_bounding_box, float32
+
+
+def select_tile_pairs_affine(kp0: np.ndarray, kp1: np.ndarray, origins0: Dict[int, Tuple[int, int]], origins1: Dict[int, Tuple[int, int]],
+                             tile_size, tile_overlap: int, size1_hw, min_matches_per_tile: int = 5, M: Optional[np.ndarray] = None,
+                             estimator=estimate_affine_from_matches) -> List[Tuple[int, int]]:
+    """PRESELECTION_AFFINE_TRANSFORM after the preselection match (MB:1244-1333), vectorised over the tiles of image 1 and, for
+    the match-count filter, over all candidate pairs.  kp0 / kp1: matched preselection keypoints in full-resolution
+    coordinates; fewer than 3 of them -> the PRESELECTION vote rule (strict inequalities, ``>`` threshold, MB:1244-1258)."""
+    kp0, kp1 = np.asarray(kp0, np.float32).reshape(-1, 2), np.asarray(kp1, np.float32).reshape(-1, 2)
+    ids0, box0 = _rects(origins0, tile_size)
+    ids1, box1 = _rects(origins1, tile_size)
+    if len(kp0) < 3:
+        logger.warning("Not enough matches (<3) to estimate affine transform. Falling back to standard PRESELECTION.")
+        in0 = np.all(kp0[None] > box0[:, None, :2], axis=2) & np.all(kp0[None] < box0[:, None, 2:], axis=2)     # [T0, n]
+        in1 = np.all(kp1[None] > box1[:, None, :2], axis=2) & np.all(kp1[None] < box1[:, None, 2:], axis=2)     # [T1, n]
+        votes = in0.astype(np.int64) @ in1.astype(np.int64).T
+        return sorted((int(ids0[a]), int(ids1[b])) for a, b in zip(*np.nonzero(votes > min_matches_per_tile)))
+    if M is None:
+        M = estimator(kp0, kp1)
+    M = np.asarray(M, np.float32)
+    margin = np.float32(max(2, tile_overlap))
+    exp = box0 + np.array([-margin, -margin, margin, margin], np.float32)
+    # transform_rectangle_with_affine (MB:1456-1470) for every tile of image 0 at once: corners in the reference's order
+    corners = np.stack([exp[:, [0, 1]], exp[:, [0, 3]], exp[:, [2, 3]], exp[:, [2, 1]]], axis=1)                  # [T0, 4, 2] float32
+    warped = np.stack([corners[..., 0] * M[0, 0] + corners[..., 1] * M[0, 1] + M[0, 2],
+                       corners[..., 0] * M[1, 0] + corners[..., 1] * M[1, 1] + M[1, 2]], axis=2)                     # corners_h @ M.T, [T0, 4, 2]
+    pred = np.concatenate([warped.min(axis=1), warped.max(axis=1)], axis=1).astype(np.float32)                     # [T0, 4]
+    pred[:, [0, 2]] = np.clip(pred[:, [0, 2]], 0, size1_hw[1])
+    pred[:, [1, 3]] = np.clip(pred[:, [1, 3]], 0, size1_hw[0])
+    ok = (np.minimum(pred[:, None, 2], box1[None, :, 2]) > np.maximum(pred[:, None, 0], box1[None, :, 0])) & \
+         (np.minimum(pred[:, None, 3], box1[None, :, 3]) > np.maximum(pred[:, None, 1], box1[None, :, 1]))          # [T0, T1]
+    if ok.any() and min_matches_per_tile > 0:
+        in0 = (kp0[None, :, 0] >= box0[:, None, 0]) & (kp0[None, :, 0] <= box0[:, None, 2]) & \
+              (kp0[None, :, 1] >= box0[:, None, 1]) & (kp0[None, :, 1] <= box0[:, None, 3])                          # inclusive: MB:1318-1321
+        in1 = (kp1[None, :, 0] >= box1[:, None, 0]) & (kp1[None, :, 0] <= box1[:, None, 2]) & \
+              (kp1[None, :, 1] >= box1[:, None, 1]) & (kp1[None, :, 1] <= box1[:, None, 3])
+        ok &= (in0.astype(np.int64) @ in1.astype(np.int64).T) >= min_matches_per_tile
+    return sorted({(int(ids0[a]), int(ids1[b])) for a, b in zip(*np.nonzero(ok))})
 
 
 class TilePreselector:
@@ -98,22 +242,36 @@ class TilePreselector:
     def _stream(self):
         return ctypes_stream(self.device)
 
-    def downsample(self, image: np.ndarray) -> Tuple[torch.Tensor, float]:
-        """cv2.resize(i, size_new, INTER_AREA) then frame2tensor's /255 (MB:1062-1073), on the device."""
-        H, W = image.shape[:2]
+    def _resize(self, src: torch.Tensor, h: int, w: int, linear: bool = False) -> torch.Tensor:
+        H, W = src.shape
+        dst = torch.empty(h, w, dtype=torch.float32, device=self.device)
+        fn = self.lib.dim_op_resize_linear_f32 if linear else self.lib.dim_op_resize_area_f32
+        capi.check(self.lib, fn(capi.ptr(src), H, W, capi.ptr(dst), h, w, 0, self._stream()))
+        return dst
+
+    def downsample(self, image: np.ndarray, quality: str = "HIGH") -> Tuple[torch.Tensor, float]:
+        """The image-side half of tile_selection on the device: ``resize_image`` to the extraction quality (MB:1026-1034;
+        utils/image.py:52-57: INTER_AREA, INTER_LINEAR when an axis is enlarged), then cv2.resize(i, size_new, INTER_AREA) to
+        the preselection size (MB:1062-1069); frame2tensor's /255 happens in the extractor call."""
+        src = torch.as_tensor(np.ascontiguousarray(image, dtype=np.float32)).to(self.device)
+        if quality != "HIGH":
+            H, W = src.shape
+            h, w = get_size_by_quality(quality, (H, W))
+            src = self._resize(src, h, w, linear=(W < w or H < h))
+        H, W = src.shape
         scale = self.size / max(W, H)
         w, h = int(round(W * scale)), int(round(H * scale))
-        src = torch.as_tensor(np.ascontiguousarray(image, dtype=np.float32)).to(self.device)
         dst = torch.empty(h, w, dtype=torch.float32, device=self.device)
         capi.check(self.lib, self.lib.dim_op_resize_area_f32(capi.ptr(src), H, W, capi.ptr(dst), h, w, 1, self._stream()))
         return dst, scale
 
-    def features(self, key: str, image: np.ndarray):
-        """(kpts [1,cap,2], desc [1,cap,256], n [1] int32, scale) of the down-sampled image, cached by key."""
+    def features(self, key: str, image: np.ndarray, quality: str = "HIGH"):
+        """(kpts [1,cap,2], desc [1,cap,256], n [1] int32, scale) of the down-sampled image, cached by (key, quality)."""
+        key = (key, quality)
         if key in self._cache:
             self._cache.move_to_end(key)
             return self._cache[key]
-        small, scale = self.downsample(image)
+        small, scale = self.downsample(image, quality)
         h, w = small.shape
         if self._sp is None or h > self._sp_hw[0] or w > self._sp_hw[1]:
             self._sp_hw = (max(h, self._sp_hw[0], self.size), max(w, self._sp_hw[1], self.size))
@@ -142,8 +300,8 @@ class TilePreselector:
         return self._lg.match_batch_guarded(kt, dt, nt, st, n_pairs=1, logger=logger)
 
     def votes(self, key0: str, image0: np.ndarray, key1: str, image1: np.ndarray, origins0: Dict[int, Tuple[int, int]],
-              origins1: Dict[int, Tuple[int, int]], tile_size) -> np.ndarray:
-        f0, f1 = self.features(key0, image0), self.features(key1, image1)
+              origins1: Dict[int, Tuple[int, int]], tile_size, quality: str = "HIGH") -> np.ndarray:
+        f0, f1 = self.features(key0, image0, quality), self.features(key1, image1, quality)
         o = self.match(f0, f1)
         k0, k1 = sorted(origins0), sorted(origins1)
         og0 = torch.tensor([origins0[k] for k in k0], dtype=torch.int32, device=self.device).contiguous()
@@ -154,6 +312,17 @@ class TilePreselector:
             ctypes_float(f0[3]), ctypes_float(f1[3]), capi.ptr(og0), len(k0), capi.ptr(og1), len(k1), int(tile_size[0]), int(tile_size[1]),
             capi.ptr(votes), self._stream()))
         return votes.cpu().numpy().astype(np.int64)
+
+    def matched_points(self, key0: str, image0: np.ndarray, key1: str, image1: np.ndarray, quality: str = "HIGH"):
+        """The matched preselection keypoints scaled back to the (quality-resized) image frames: kp / scale in fp32 like numpy
+        (MB:1192-1200).  The affine selection needs them on the host: 2 x (S, 2) floats leave the device."""
+        f0, f1 = self.features(key0, image0, quality), self.features(key1, image1, quality)
+        o = self.match(f0, f1)
+        s = int(o["n_matches"][0].item())
+        m = o["matches"][0, :s].cpu().numpy()
+        kp0 = f0[0][0].cpu().numpy()[m[:, 0]] / np.float32(f0[3])
+        kp1 = f1[0][0].cpu().numpy()[m[:, 1]] / np.float32(f1[3])
+        return kp0.astype(np.float32), kp1.astype(np.float32)
 
 
 def ctypes_stream(device):
@@ -253,23 +422,24 @@ class BatchedTileMatchingMixin:
         """tile_selection (MB:989-1140) -> sorted list of (tile0, tile1)."""
         general = self.config["general"]
         quality = getattr(general.get("quality", "HIGH"), "name", general.get("quality", "HIGH"))
+        method = getattr(method, "name", method)
         i0 = image0 if image0 is not None else _read_band1(Path(img0))
         i1 = image1 if image1 is not None else _read_band1(Path(img1))
-        if quality != "HIGH":
-            if method == "PRESELECTION":
-                raise NotImplementedError("tile preselection with quality != HIGH needs the reference's cv2 resize; not built")
-            f = _QUALITY_FACTOR[quality]
-            shape0, shape1 = (int(i0.shape[0] * f), int(i0.shape[1] * f)), (int(i1.shape[0] * f), int(i1.shape[1] * f))
-        else:
-            shape0, shape1 = i0.shape[:2], i1.shape[:2]
+        # the tiling of the quality-resized images (MB:1026-1041): only the shapes are needed for the grid
+        shape0, shape1 = get_size_by_quality(quality, i0.shape[:2]), get_size_by_quality(quality, i1.shape[:2])
         tile_size, overlap = general["tile_size"], general.get("tile_overlap", 0)
         origins0, origins1 = tile_grid(shape0, tile_size, overlap), tile_grid(shape1, tile_size, overlap)
-        votes = None
-        if method == "PRESELECTION":
+        min_matches = int(getattr(self, "min_matches_per_tile", general.get("min_matches_per_tile", 5)))
+        if method in ("PRESELECTION", "PRESELECTION_AFFINE_TRANSFORM"):
             if general.get("preselection_pipeline", "superpoint+lightglue") != "superpoint+lightglue":
                 raise ValueError("Only the superpoint+lightglue preselection pipeline is built on the MI355X path")
-            votes = self._preselector().votes(str(img0), i0, str(img1), i1, origins0, origins1, tile_size)
-        return select_tile_pairs(method, list(origins0), list(origins1), votes, int(getattr(self, "min_matches_per_tile", general.get("min_matches_per_tile", 5))))
+            if method == "PRESELECTION":
+                votes = self._preselector().votes(str(img0), i0, str(img1), i1, origins0, origins1, tile_size, quality)
+                return select_tile_pairs(method, list(origins0), list(origins1), votes, min_matches)
+            kp0, kp1 = self._preselector().matched_points(str(img0), i0, str(img1), i1, quality)
+            ov = overlap if isinstance(overlap, int) else max(overlap)
+            return select_tile_pairs_affine(kp0, kp1, origins0, origins1, tile_size, int(ov), shape1, min_matches)
+        return select_tile_pairs(method, list(origins0), list(origins1), None, min_matches)
 
     @torch.no_grad()
     def _match_by_tile(self, img0, img1, features0: dict, features1: dict, method="PRESELECTION", select_unique: bool = True) -> np.ndarray:

@@ -293,13 +293,18 @@ int dim_op_conv1a_f32(const float* in, const float* w_tap_cout, const float* bia
 /* ---- tile preselection on device (csrc/tile_ops.hip) ------------------------------------------------
  * Replaces the host steps of tile_selection's PRESELECTION branch (matchers/matcher_base.py:1054-1133):
  * cv2.resize(img, size, interpolation=cv2.INTER_AREA) of a single-channel fp32 image (MB:1068-1069; the
- * OpenCV 4.11 decimation table restated, enlargement is refused), optionally followed by frame2tensor's
+ * OpenCV 4.11 decimation table restated; an enlarging size takes OpenCV's bilinear emulation of INTER_AREA),
+ * optionally followed by frame2tensor's
  * /255 (MB:1393-1398); and the vote count "matches whose two end points fall into tile t0 of image 0 and
  * tile t1 of image 1" (points_in_rect / get_tile_bounding_box, MB:1124-1133, strict inequalities).
  * matches is dim_lg_match's (S,2) int64 list with its device-side count; keypoints are the down-sampled
  * images' (x,y) and are divided by scale0/scale1 in fp32 as numpy does; origins are (x,y) int32 pairs;
  * votes[T0*T1] is zeroed by the call. */
 int dim_op_resize_area_f32(const float* src, int H, int W, float* dst, int h, int w, int div255, void* stream);
+/* cv2.resize(img, size, interpolation=cv2.INTER_LINEAR) (pixel-centre bilinear, OpenCV 4.11 restated): what
+ * utils/image.py:52-57 resize_image uses when the target size enlarges the image — quality HIGHEST in
+ * extractor_base.py:392-412 and tile_selection (matcher_base.py:1026-1034). */
+int dim_op_resize_linear_f32(const float* src, int H, int W, float* dst, int h, int w, int div255, void* stream);
 int dim_op_tile_pair_votes(const float* kpts0_xy, const float* kpts1_xy, const long long* matches, const int* n_matches_dev,
                            int max_matches, float scale0, float scale1, const int* origins0_xy, int T0, const int* origins1_xy, int T1,
                            int tile_w, int tile_h, int* votes, void* stream);

@@ -244,10 +244,121 @@ def main_tile():
     print("tile_votes.npz: votes total", int(votes.sum()), "pinned against matcher_base.py helpers")
 
 
+def reference_affine_selection():
+    """tile_selection's PRESELECTION_AFFINE_TRANSFORM branch (matcher_base.py:1244-1333) is inline code of a function that cannot be
+    imported; its statements — the ``if len(kp0) < 3: <fallback> else: <affine selection>`` block — are cut out of the
+    reference's source through ``ast`` and executed as they stand, together with ``transform_rectangle_with_affine``,
+    ``get_tile_bounding_box``, ``points_in_rect`` and constants.py's ``get_size_by_quality``.  Only ``estimate_affine_from_matches``
+    (cv2.estimateAffinePartial2D, absent here) is supplied by the caller."""
+    import ast
+    import logging
+    from itertools import product
+    src = (REF.parent / "matchers" / "matcher_base.py").read_text()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "tile_selection")
+    block = None
+    for node in ast.walk(fn):
+        if isinstance(node, ast.If) and ast.unparse(node.test) == "method == TileSelection.PRESELECTION_AFFINE_TRANSFORM":
+            block = next(n for n in node.body if isinstance(n, ast.If) and ast.unparse(n.test) == "len(kp0) < 3")
+    assert block is not None, "the affine branch moved: re-read matcher_base.py"
+    helpers = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in
+               {"transform_rectangle_with_affine", "get_tile_bounding_box", "points_in_rect"}]
+    assert len(helpers) == 3
+    for n in helpers:
+        n.returns = None
+        for a in n.args.args:
+            a.annotation = None
+    ctree = ast.parse((REF.parent / "constants.py").read_text())
+    gq = next(n for n in ctree.body if isinstance(n, ast.FunctionDef) and n.name == "get_size_by_quality")
+    gq.returns = None
+    for a in gq.args.args:
+        a.annotation = None
+    qcls = next(n for n in ctree.body if isinstance(n, ast.ClassDef) and n.name == "Quality")
+
+    class _Timer:
+        def update(self, *_):
+            pass
+
+    def run(kp0, kp1, M, t_orig0, t_orig1, tile_size, tile_overlap, i1_new_size, min_matches_per_tile):
+        ns = {"np": np, "product": product, "logger": logging.getLogger("ref"), "timer": _Timer(), "kp0": kp0, "kp1": kp1,
+              "t_orig0": t_orig0, "t_orig1": t_orig1, "tiles0": t_orig0, "tiles1": t_orig1, "tile_size": tile_size,
+              "tile_overlap": tile_overlap, "i1_new_size": i1_new_size, "min_matches_per_tile": min_matches_per_tile,
+              "estimate_affine_from_matches": lambda a, b: M}
+        exec(compile(ast.Module(body=helpers, type_ignores=[]), "matcher_base_helpers", "exec"), ns)
+        exec(compile(ast.Module(body=[block], type_ignores=[]), "matcher_base_affine_branch", "exec"), ns)
+        return ns["tile_pairs"]
+
+    from enum import Enum
+    cns = {"Enum": Enum, "Tuple": tuple}
+    exec(compile(ast.Module(body=[qcls, gq], type_ignores=[]), "constants_quality", "exec"), cns)
+    return run, cns
+
+
+def main_affine():
+    """tests/golden/tile_affine.npz: tile pairs chosen by the reference's own affine-selection code for given matches and
+    transforms (identity, shift, rotation + scale, a mirror, < 3 matches -> fallback, min_matches_per_tile 0)."""
+    from oracle import tile_ref
+    run, cns = reference_affine_selection()
+    Q = cns["Quality"]
+    for q in ("HIGHEST", "HIGH", "MEDIUM", "LOW", "LOWEST"):
+        for size in ((4000, 6000), (4001, 5999), (777, 1023), (15, 9)):
+            assert tuple(cns["get_size_by_quality"](Q[q], size)) == tile_ref.get_size_by_quality(q, size), (q, size)
+    rng = np.random.default_rng(11)
+    tile_size, overlap = (300, 200), 10
+    org0 = {r * 4 + c: (-14 + c * 290, -9 + r * 190) for r in range(4) for c in range(4)}      # 1132 x 751 image, overlap 10
+    org1 = {r * 3 + c: (-5 + c * 290, -20 + r * 190) for r in range(5) for c in range(3)}      # 860 x 910 image
+    size1 = (910, 860)   # (H, W)
+    out = {}
+    cases = []
+    th = np.deg2rad(17.0)
+    mats = {"identity": np.array([[1, 0, 0], [0, 1, 0]], np.float32), "shift": np.array([[1, 0, -180.5], [0, 1, 240.25]], np.float32),
+            "rot_scale": np.array([[0.8 * np.cos(th), -0.8 * np.sin(th), 120.0], [0.8 * np.sin(th), 0.8 * np.cos(th), -60.0]], np.float32),
+            "mirror": np.array([[-1, 0, 860.0], [0, 1, 30.0]], np.float32)}
+    for name, M in mats.items():
+        n = 900
+        kp0 = (rng.random((n, 2)) * np.array([1132, 751])).astype(np.float32)
+        kp1 = (np.c_[kp0, np.ones(n, np.float32)] @ M.T + rng.normal(0, 1.5, (n, 2))).astype(np.float32)
+        kp0[:30] = np.round(kp0[:30] / 95) * 95      # points on tile borders: the inclusive tests of MB:1318-1321
+        for mm in (5, 0, 40):
+            cases.append((f"{name}_mm{mm}", kp0, kp1, M, mm))
+    few = (rng.random((2, 2)) * 500).astype(np.float32)
+    cases.append(("fallback_lt3", few, few.copy(), None, 5))
+    for name, kp0, kp1, M, mm in cases:
+        ref = run(kp0, kp1, M, org0, org1, tile_size, overlap, size1, mm)
+        mine = tile_ref.affine_tile_pairs(kp0, kp1, M, org0, org1, tile_size, overlap, size1, mm)
+        assert [tuple(map(int, p)) for p in ref] == mine, f"{name}: oracle != reference"
+        out[name + "/kp0"], out[name + "/kp1"] = kp0, kp1
+        out[name + "/M"] = M if M is not None else np.zeros((0, 3), np.float32)
+        out[name + "/mm"] = np.int64(mm)
+        out[name + "/pairs"] = np.array(ref, dtype=np.int64).reshape(-1, 2)
+        print(f"tile_affine {name}: {len(ref)} tile pairs (oracle == reference)")
+    for name, M in mats.items():
+        for rect in ([0.0, 0.0, 300.0, 200.0], [-14.0, 181.0, 286.0, 381.0]):
+            ns_rect = {}
+            assert np.array_equal(tile_ref.transform_rectangle_with_affine(M, rect), _ref_rect(M, rect))
+    np.savez_compressed(ROOT / "tests" / "golden" / "tile_affine.npz", origins0=np.array([org0[k] for k in sorted(org0)], np.int32),
+                        origins1=np.array([org1[k] for k in sorted(org1)], np.int32), tile_size=np.array(tile_size, np.int32),
+                        overlap=np.int64(overlap), size1=np.array(size1, np.int64), names=np.array([c[0] for c in cases]), **out)
+
+
+def _ref_rect(M, rect):
+    import ast
+    src = (REF.parent / "matchers" / "matcher_base.py").read_text()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "transform_rectangle_with_affine")
+    fn.returns = None
+    for a in fn.args.args:
+        a.annotation = None
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "trwa", "exec"), ns)
+    return ns["transform_rectangle_with_affine"](M, rect)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "tile":
         main_tile()
+        main_affine()
         sys.exit(0)
     main()
     main_aliked()
     main_tile()
+    main_affine()

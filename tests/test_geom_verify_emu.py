@@ -79,6 +79,17 @@ def test_edge_rules_of_the_reference(emu_lib):
     assert F0 is None and m0.all()
 
 
+def test_degenerate_correspondences_keep_every_match(emu_lib):
+    """All correspondences identical: every 7-point sample is rejected, the estimator has no model.  The reference keeps
+    an all-ones mask when its estimator fails (geometric_verification.py:150-172); n_inliers must never be negative."""
+    x = np.tile(np.array([[100.0, 50.0]], np.float32), (12, 1))
+    kt, mt, n = _tables([(x, x)], cap=32)
+    v = verify.DeviceVerifier(threshold=2.0, iters=128, seed=3, device="cpu", lib=emu_lib)
+    out = v.verify_batch(kt, mt, n)
+    assert int(out["n_inliers"][0]) == 12 and out["mask"][0, :12].all() and not out["mask"][0, 12:].any()
+    assert float(out["F"][0].abs().sum()) == 0.0
+
+
 def test_reference_accept_rules_and_host_pool():
     m = np.stack([np.arange(20), np.arange(20)], 1)
     mask = np.zeros(20, bool); mask[:16] = True

@@ -139,7 +139,7 @@ def test_device_preselection_matches_the_oracle_pipeline(emu_lib):
         pre = tm.TilePreselector(sp_sd, lg_sd, tile_preselection_size=64, device="cpu", lib=emu_lib)
         origins0, origins1 = tm.tile_grid(imgs[0].shape, (100, 75), 0), tm.tile_grid(imgs[1].shape, (100, 80), 0)
         votes = pre.votes("i0", imgs[0], "i1", imgs[1], origins0, origins1, (100, 75))
-        assert pre.features("i0", imgs[0]) is pre._cache["i0"]           # cached: no second extraction
+        assert pre.features("i0", imgs[0]) is pre._cache[("i0", "HIGH")]           # cached: no second extraction
 
         feats, scales = [], []
         for im in imgs:
@@ -157,6 +157,116 @@ def test_device_preselection_matches_the_oracle_pipeline(emu_lib):
         b = k1.numpy()[mm[:, 1]] / np.float32(scales[1])
         ref = tile_ref.tile_pair_votes(a, b, origins0, origins1, (100, 75))
         assert len(mm) > 0 and np.array_equal(votes, ref)
+    finally:
+        tm.PRESELECTION_SP_CONF.clear(); tm.PRESELECTION_SP_CONF.update(old_sp)
+        tm.PRESELECTION_LG_CONF.clear(); tm.PRESELECTION_LG_CONF.update(old_lg)
+
+
+def _resize_linear(lib, img, h, w):
+    src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))
+    dst = torch.empty(h, w, dtype=torch.float32)
+    rc = lib.dim_op_resize_linear_f32(ctypes.c_void_p(src.data_ptr()), img.shape[0], img.shape[1], ctypes.c_void_p(dst.data_ptr()), h, w, 0, None)
+    assert rc == 0, lib.dim_last_error()
+    return dst.numpy()
+
+
+@pytest.mark.parametrize("shape,out", [((48, 64), (96, 128)), ((37, 53), (74, 106)), ((30, 41), (97, 71)), ((20, 20), (20, 20)), ((40, 30), (17, 90))])
+def test_resize_linear_matches_oracle_bit_exact(emu_lib, shape, out):
+    """quality HIGHEST: resize_image switches to cv2 INTER_LINEAR when an axis is enlarged (utils/image.py:52-57)."""
+    img = (np.random.default_rng(9).random(shape) * 255).astype(np.float32)
+    ref = tile_ref.resize_linear(img, (out[1], out[0]))
+    got = _resize_linear(emu_lib, img, out[0], out[1])
+    assert got.shape == ref.shape == (out[0], out[1]) and np.array_equal(got, ref)
+    assert got.min() >= img.min() - 1e-3 and got.max() <= img.max() + 1e-3
+    if shape == out:
+        assert np.array_equal(got, img)                                    # identity size: pixel centres coincide
+    if out == (2 * shape[0], 2 * shape[1]):                               # exact 2x: interior weights are 0.25 / 0.75
+        assert abs(got[1, 1] - (0.75 * (0.75 * img[0, 0] + 0.25 * img[0, 1]) + 0.25 * (0.75 * img[1, 0] + 0.25 * img[1, 1]))) < 1e-3
+
+
+def test_affine_selection_equals_the_reference_code(emu_lib):
+    """tests/golden/tile_affine.npz holds the tile pairs the REFERENCE's own PRESELECTION_AFFINE_TRANSFORM statements
+    (matcher_base.py:1244-1333, executed from source by oracle/make_golden.py) select; product and oracle must agree."""
+    z = np.load(GOLD / "tile_affine.npz")
+    o0 = {i: tuple(int(x) for x in v) for i, v in enumerate(z["origins0"])}
+    o1 = {i: tuple(int(x) for x in v) for i, v in enumerate(z["origins1"])}
+    ts, ov, size1 = tuple(int(x) for x in z["tile_size"]), int(z["overlap"]), tuple(int(x) for x in z["size1"])
+    n_nonempty = 0
+    for name in z["names"]:
+        M = z[f"{name}/M"]
+        M = None if M.shape[0] == 0 else M
+        ref = [tuple(map(int, p)) for p in z[f"{name}/pairs"]]
+        got = tm.select_tile_pairs_affine(z[f"{name}/kp0"], z[f"{name}/kp1"], o0, o1, ts, ov, size1, int(z[f"{name}/mm"]), M=M)
+        assert got == ref, name
+        assert tile_ref.affine_tile_pairs(z[f"{name}/kp0"], z[f"{name}/kp1"], M, o0, o1, ts, ov, size1, int(z[f"{name}/mm"])) == ref, name
+        n_nonempty += len(ref) > 0
+    assert n_nonempty >= 10
+    # the estimator stand-ins recover a known similarity from contaminated matches (cv2 absent: own RANSAC, then TLS)
+    rng = np.random.default_rng(0)
+    a = (rng.random((400, 2)) * 1000).astype(np.float32)
+    th = 0.3
+    Mt = np.array([[0.9 * np.cos(th), -0.9 * np.sin(th), 50], [0.9 * np.sin(th), 0.9 * np.cos(th), -20]])
+    b = (np.c_[a, np.ones(400)] @ Mt.T + rng.normal(0, 0.7, (400, 2))).astype(np.float32)
+    b[:120] = rng.random((120, 2)) * 1000
+    M = tm.estimate_affine_from_matches(a, b)
+    assert M.dtype == np.float32 and M.shape == (2, 3) and np.abs(M - Mt).max() < 0.5 and np.abs(M[:, :2] - Mt[:, :2]).max() < 2e-3
+    assert np.abs(tm._affine_total_least_squares(a[120:], b[120:]) - Mt).max() < 0.5
+    same = np.tile(np.array([[5.0, 5.0]], np.float32), (10, 1))
+    assert np.array_equal(tm.estimate_affine_from_matches(same, same), np.array([[1, 0, 0], [0, 1, 0]], np.float32))   # failure -> identity
+    for q, size in (("HIGHEST", (4001, 5999)), ("MEDIUM", (777, 1023)), ("LOWEST", (15, 9)), ("HIGH", (3, 4))):
+        assert tm.get_size_by_quality(q, size) == tile_ref.get_size_by_quality(q, size)
+    with pytest.raises(ValueError, match="Invalid tile selection method"):
+        tm.select_tile_pairs("NOPE", [0], [0])
+
+
+@pytest.mark.parametrize("quality", ["MEDIUM", "HIGHEST"])
+def test_preselection_at_other_qualities_and_affine_match_the_oracle_chain(emu_lib, quality):
+    """tile_selection with quality != HIGH (MB:1026-1034: resize_image before tiling and before the preselection down-sampling)
+    and the PRESELECTION_AFFINE_TRANSFORM hook: quality resize -> down-sample -> SuperPoint -> LightGlue on the library, votes /
+    matched points / selected tile pairs vs the same chain on the oracle."""
+    rng = np.random.default_rng(21)
+    shapes = [(150, 201), (161, 190)] if quality == "MEDIUM" else [(40, 52), (44, 48)]
+    imgs = [(rng.random(sh) * 255).astype(np.float32) for sh in shapes]
+    sp_sd = weights.synthetic_superpoint_state_dict(0)
+    lg_sd = weights.synthetic_lightglue_state_dict(0, 256)
+    old_sp, old_lg = dict(tm.PRESELECTION_SP_CONF), dict(tm.PRESELECTION_LG_CONF)
+    tm.PRESELECTION_SP_CONF.update(max_keypoints=60, nms_radius=2)
+    tm.PRESELECTION_LG_CONF.update(n_layers=2, filter_threshold=0.0)
+    try:
+        cfg = {"general": {"tile_size": (40, 30), "tile_overlap": 4, "quality": quality, "tile_preselection_size": 64, "min_matches_per_tile": 1,
+                           "allow_synthetic_weights": True},
+               "matcher": {"name": "lightglue", "n_layers": 2, "allow_synthetic_weights": True}}
+
+        class Host(tm.BatchedTileMatchingMixin):
+            config, _device, _lib, min_matches_per_tile = cfg, "cpu", emu_lib, 1
+
+        host = Host()
+        host._tile_preselector = tm.TilePreselector(sp_sd, lg_sd, tile_preselection_size=64, device="cpu", lib=emu_lib)
+        feats, scales, resized = [], [], []
+        for im in imgs:
+            big = tile_ref.resize_image(im, tile_ref.get_size_by_quality(quality, im.shape)[::-1])
+            assert big.shape == tile_ref.get_size_by_quality(quality, im.shape)
+            size, scale, new = tile_ref.preselection_sizes(big.shape, 64)
+            small = tile_ref.resize_area(big, new)
+            assert np.array_equal(host._tile_preselector.downsample(im, quality)[0].numpy(), small / np.float32(255.0))
+            feats.append(superpoint_ref.superpoint_forward(torch.from_numpy(small / np.float32(255.0))[None, None], sp_sd, dict(tm.PRESELECTION_SP_CONF)))
+            scales.append(scale); resized.append(big)
+        k0, k1 = feats[0]["keypoints"].float(), feats[1]["keypoints"].float()
+        s0, s1 = 1 + k0.max(0).values - k0.min(0).values, 1 + k1.max(0).values - k1.min(0).values
+        r = lightglue_ref.lightglue_forward(k0, feats[0]["descriptors"].t().contiguous(), s0, k1, feats[1]["descriptors"].t().contiguous(), s1,
+                                            lg_sd, dict(tm.PRESELECTION_LG_CONF))
+        mm = r["matches"].numpy()
+        a, b = k0.numpy()[mm[:, 0]] / np.float32(scales[0]), k1.numpy()[mm[:, 1]] / np.float32(scales[1])
+        assert len(mm) >= 3
+        o0, o1 = tm.tile_grid(resized[0].shape, (40, 30), 4), tm.tile_grid(resized[1].shape, (40, 30), 4)
+        ref_pre = tile_ref.select_tile_pairs("PRESELECTION", list(o0), list(o1), tile_ref.tile_pair_votes(a, b, o0, o1, (40, 30)), 1)
+        assert host.tile_selection("i0", "i1", "PRESELECTION", image0=imgs[0], image1=imgs[1]) == ref_pre
+        ga, gb = host._tile_preselector.matched_points("i0", imgs[0], "i1", imgs[1], quality)
+        assert np.array_equal(ga, a) and np.array_equal(gb, b)
+        M = tm.estimate_affine_from_matches(a, b)
+        ref_aff = tile_ref.affine_tile_pairs(a, b, M, o0, o1, (40, 30), 4, resized[1].shape, 1)
+        assert host.tile_selection("i0", "i1", "PRESELECTION_AFFINE_TRANSFORM", image0=imgs[0], image1=imgs[1]) == ref_aff
+        assert len(ref_pre) > 0 or len(ref_aff) > 0
     finally:
         tm.PRESELECTION_SP_CONF.clear(); tm.PRESELECTION_SP_CONF.update(old_sp)
         tm.PRESELECTION_LG_CONF.clear(); tm.PRESELECTION_LG_CONF.update(old_lg)
