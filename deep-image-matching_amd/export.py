@@ -76,12 +76,17 @@ class _NpzAppender:
     is held back for ``close`` (np.savez_compressed would write everything at the end — on the critical path of a run
     that is otherwise overlapped with the GPU).  np.load reads the result like any other .npz."""
 
-    def __init__(self, path: Path):
+    def __init__(self, path: Path, compresslevel: Optional[int] = 9):
         import zipfile
 
         self.path = Path(path)
         self.path.parent.mkdir(parents=True, exist_ok=True)
-        self._zf = zipfile.ZipFile(str(self.path), "w", zipfile.ZIP_DEFLATED, allowZip64=True)
+        # compresslevel 9 = the gzip-9 of features.h5 (EB:80-86); None = stored, like the uncompressed match datasets
+        # h5py writes at MB:282-285,337-339
+        if compresslevel is None:
+            self._zf = zipfile.ZipFile(str(self.path), "w", zipfile.ZIP_STORED, allowZip64=True)
+        else:
+            self._zf = zipfile.ZipFile(str(self.path), "w", zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=compresslevel)
         self.keys = set()
 
     def add(self, key: str, arr: np.ndarray):
@@ -112,7 +117,27 @@ class FeatureStore:
             self._npz = _NpzAppender(base if shard == 0 else base.with_name(f"{base.stem}.shard{shard}.npz"))
 
     def add(self, im_name: str, features: Dict[str, np.ndarray]):
-        half = features_to_half(features)
+        self.add_half(im_name, features_to_half(features))
+
+    def add_precompressed(self, im_name: str, half: Dict[str, np.ndarray], blobs: Dict[str, bytes]):
+        """h5py only: datasets whose single chunk was deflated by the caller (zlib stream = HDF5's gzip filter format) are
+        stored with write_direct_chunk, so the time under h5py's global lock is a byte copy.  Readers see ordinary gzip-9
+        float16 datasets (one chunk per dataset instead of h5py's guessed chunk shape)."""
+        import h5py
+
+        with h5py.File(str(self.path), "a", libver="latest") as fd:
+            if im_name in fd:
+                del fd[im_name]
+            grp = fd.create_group(im_name)
+            for k, v in half.items():
+                if v.size == 0:
+                    grp.create_dataset(k, data=v, dtype=np.float16)
+                    continue
+                ds = grp.create_dataset(k, shape=v.shape, dtype=np.float16, chunks=v.shape, compression="gzip", compression_opts=9)
+                ds.id.write_direct_chunk((0,) * v.ndim, blobs[k])
+
+    def add_half(self, im_name: str, half: Dict[str, np.ndarray]):
+        """``half``: the float16 arrays exactly as they are stored (save_features_h5 after its as_half conversion)."""
         if self.use_h5:
             import h5py
 
@@ -158,7 +183,7 @@ class MatchStore:
     def __init__(self, path: Path):
         self.path = Path(path)
         self.use_h5 = HAVE_H5PY and self.path.suffix == ".h5"
-        self._npz = None if self.use_h5 else _NpzAppender(self.path.with_suffix(".npz"))
+        self._npz = None if self.use_h5 else _NpzAppender(self.path.with_suffix(".npz"), compresslevel=None)
 
     def add(self, img0: str, img1: str, matches: np.ndarray):
         m = np.asarray(matches).reshape(-1, 2).astype(np.int64)
@@ -224,25 +249,27 @@ class ColmapDatabase:
             self.db.execute(stmt)
         self.db.commit()
 
-    def add_camera(self, model: str, width: int, height: int, params, prior_focal_length: bool = False) -> int:
+    def add_camera(self, model: str, width: int, height: int, params, prior_focal_length: bool = False, camera_id: Optional[int] = None) -> int:
         if model not in _CAMERA_MODELS:
             raise RuntimeError(f"Invalid camera model {model}")
         cur = self.db.execute("INSERT INTO cameras VALUES (?, ?, ?, ?, ?, ?)",
-                              (None, str(_CAMERA_MODELS[model]), int(width), int(height), np.asarray(params, np.float64).tobytes(),
+                              (camera_id, str(_CAMERA_MODELS[model]), int(width), int(height), np.asarray(params, np.float64).tobytes(),
                                bool(prior_focal_length)))
         return cur.lastrowid
 
-    def add_default_camera(self, model: str, width: int, height: int, focal_35mm: Optional[float] = None) -> int:
+    def add_default_camera(self, model: str, width: int, height: int, focal_35mm: Optional[float] = None, camera_id: Optional[int] = None) -> int:
         """io/h5_to_db.py:116-149,342-386: focal from EXIF FocalLengthIn35mmFilm if known, else the
         1.2 * max(w, h) prior; principal point at the image centre."""
         focal = (focal_35mm / 35.0 if focal_35mm else 1.2) * max(width, height)
         params = {"simple-pinhole": [focal, width / 2, height / 2], "pinhole": [focal, focal, width / 2, height / 2],
                   "simple-radial": [focal, width / 2, height / 2, 0.1],
                   "opencv": [focal, focal, width / 2, height / 2, 0.0, 0.0, 0.0, 0.0]}[model]
-        return self.add_camera(model, width, height, params)
+        return self.add_camera(model, width, height, params, camera_id=camera_id)
 
-    def add_image(self, name: str, camera_id: int) -> int:
-        cur = self.db.execute("INSERT INTO images VALUES (?, ?, ?, ?, ?, ?, ?, ?, ?, ?)", (None, name, camera_id, 0, 0, 0, 0, 0, 0, 0))
+    def add_image(self, name: str, camera_id: int, image_id: Optional[int] = None) -> int:
+        """``image_id`` / ``camera_id`` None = AUTOINCREMENT (utils/database.py:196-225 passes None too); explicit ids let rows be
+        inserted out of order while a run is in flight and still land on the ids a sorted walk would assign."""
+        cur = self.db.execute("INSERT INTO images VALUES (?, ?, ?, ?, ?, ?, ?, ?, ?, ?)", (image_id, name, camera_id, 0, 0, 0, 0, 0, 0, 0))
         return cur.lastrowid
 
     def add_keypoints(self, image_id: int, keypoints: np.ndarray):

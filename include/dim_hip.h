@@ -309,6 +309,24 @@ int dim_op_tile_pair_votes(const float* kpts0_xy, const float* kpts1_xy, const l
                            int max_matches, float scale0, float scale1, const int* origins0_xy, int T0, const int* origins1_xy, int T1,
                            int tile_w, int tile_h, int* votes, void* stream);
 
+/* ---- writers off the critical path (csrc/export_ops.hip) -------------------------------------------------------
+ * The device half of save_features_h5 (extractors/extractor_base.py:56-99) for a batch of dim_sp_extract / dim_aliked_extract
+ * tables: float32 -> float16 (round-to-nearest-even, overflow -> inf: numpy's astype(float16), EB:60-67), descriptors
+ * (N, D) -> (D, N) (extractors/superpoint.py:121-127), un-padding to the live counts.  out_f16_dev receives
+ * [batch][slot] fp16 with slot = dim_pack_features_slot_halves(cap, D) = cap * (4 + D) elements:
+ *   [0, 2n) keypoints (n,2) | [2cap, 2cap+n) scores | [3cap, 3cap+n) tile_idx (zeros when tile_idx_dev is NULL) |
+ *   [4cap, 4cap + D n) descriptors (D, n) with row stride n;  n = min(n_kpts[b], cap).  D % 64 == 0.
+ * One device-to-host copy of the slots is then the byte image of the datasets features.h5 stores. */
+size_t dim_pack_features_slot_halves(int cap, int D);
+int dim_op_pack_features_f16(const float* kpts_dev, const float* scores_dev, const float* desc_dev, const int32_t* n_kpts_dev,
+                             const int32_t* tile_idx_dev, int batch, int cap, int D, void* out_f16_dev, void* stream);
+/* The accept / reject rules that follow the estimator in MatcherBase.match (matchers/matcher_base.py:287-334) on the device
+ * tables of dim_lg_match + dim_gv_fundamental: a pair with fewer than 8 raw matches, fewer than min_inliers inliers or an
+ * inlier ratio below min_ratio (fp64 quotient, as Python evaluates it) gets n_verified = -1; otherwise verified_dev
+ * [n_pairs][nk][2] receives the inlier rows in order and n_verified their count. */
+int dim_op_filter_matches(const int64_t* matches_dev, const int32_t* n_matches_dev, const unsigned char* mask_dev, int nk, int n_pairs,
+                          int min_inliers, double min_ratio, int64_t* verified_dev, int32_t* n_verified_dev, void* stream);
+
 /* ---- retrieval pair selection (csrc/tile_ops.hip) --------------------------------------------------------------
  * thirdparty/hloc/pairs_from_retrieval.py:49-70,108-112: sim = einsum("id,jd->ij", query, db) (global descriptors,
  * fp32 MFMA), invalid entries (self matches; score < min_score when use_min_score) -> -inf, torch.topk(num_select) per

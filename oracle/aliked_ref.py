@@ -161,7 +161,7 @@ def dkd(score_map: torch.Tensor, radius: int, scores_th: float, n_limit: int, to
             idx = idx[order[:n_limit]]
     ks = 2 * radius + 1
     patches = F.unfold(score_map, kernel_size=ks, padding=radius)[0].t()[idx]  # [M, ks*ks], zero padded
-    g = torch.linspace(-radius, radius, ks)
+    g = torch.linspace(-radius, radius, ks, dtype=score_map.dtype)   # fp32 in the reference; the fp64 yardstick runs pass doubles
     gy, gx = torch.meshgrid(g, g, indexing="ij")
     grid = torch.stack([gx.reshape(-1), gy.reshape(-1)], 1)  # (x, y) offsets, row-major over the patch
     xy = torch.stack([idx % w, torch.div(idx, w, rounding_mode="trunc")], 1)

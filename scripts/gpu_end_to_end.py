@@ -37,7 +37,7 @@ res = {}
 for label, use_ver, use_exp in (("kernels_only", False, False), ("with_device_ransac", True, False), ("with_ransac_and_writers", True, True)):
     tmp = Path(tempfile.mkdtemp(prefix="dim_e2e_"))
     ver = m("verify").DeviceVerifier(threshold=4.0, iters=2048, device=dev) if use_ver else None
-    exp = m("async_export").AsyncExporter(tmp, device=dev) if use_exp else None
+    exp = m("async_export").AsyncExporter(tmp, device=dev, image_names=names, min_inliers_per_pair=0, min_inlier_ratio_per_pair=0.0) if use_exp else None
     r = m("async_export").EndToEndRunner(ext, mat, ver, exp).run(names, imgs, pairs)
     if label == "kernels_only":   # first run also warms up: repeat
         r = m("async_export").EndToEndRunner(ext, mat, None, None).run(names, imgs, pairs)

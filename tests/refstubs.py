@@ -58,6 +58,22 @@ class _Dataset:
         return np.asarray(self._a).dtype
 
 
+class _DatasetID:
+    """dset.id.write_direct_chunk(offsets, raw): the chunk arrives already filtered — for a gzip dataset that is a zlib stream,
+    which HDF5 would store as is; the look-alike inflates it to prove the bytes are a valid stream of the right size."""
+
+    def __init__(self, store, key, compression, chunks):
+        self._s, self._k, self._c, self._chunks = store, key, compression, chunks
+
+    def write_direct_chunk(self, offsets, raw, filter_mask=0):
+        import zlib
+        a = self._s[self._k]
+        assert self._c == "gzip" and tuple(self._chunks) == a.shape and all(o == 0 for o in offsets), "single-chunk gzip datasets only"
+        buf = zlib.decompress(raw)
+        assert len(buf) == a.nbytes, (len(buf), a.nbytes)
+        self._s[self._k] = np.frombuffer(buf, dtype=a.dtype).reshape(a.shape).copy()
+
+
 class _Group:
     def __init__(self, store: dict, name: str = "/", parent=None):
         self._s, self.name, self.parent = store, name, parent
@@ -97,11 +113,16 @@ class _Group:
         self._s.setdefault(k, {})
         return self[k]
 
-    def create_dataset(self, k, data=None, dtype=None, compression=None, compression_opts=None, **_):
+    def create_dataset(self, k, data=None, dtype=None, compression=None, compression_opts=None, shape=None, chunks=None, **_):
         if k in self._s:
             raise ValueError(f"Unable to create dataset (name already exists): {k}")
         if isinstance(data, (str, bytes)):
             self._s[k] = data
+        elif data is None:   # h5py: an empty dataset of the given shape, filled later (here: by write_direct_chunk)
+            self._s[k] = np.zeros(shape, dtype=dtype)
+            ds = self[k]
+            ds.id = _DatasetID(self._s, k, compression, chunks)
+            return ds
         else:
             self._s[k] = np.array(data, dtype=dtype) if dtype is not None else np.array(data)
         return self[k]

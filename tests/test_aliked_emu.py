@@ -14,18 +14,29 @@ al_mod = importlib.import_module("deep-image-matching_amd.aliked_hip")
 GOLD = Path(__file__).parent / "golden"
 
 
-def compare_aliked(out, ref, kp_tol=2e-3, desc_tol=2e-3, score_tol=1e-3):
-    """Keypoints are sub-pixel: match each output keypoint to the reference keypoint with the same
-    integer NMS position (rounded), then compare coordinates / dispersity / descriptor."""
+def compare_aliked(out, ref, kp_tol=1e-3, desc_tol=1e-3, score_tol=1e-3, max_missing=0, label=None):
+    """north_star's bar: keypoint set exact, descriptors / scores within 1e-3 (keypoint coordinates likewise: they are
+    sub-pixel soft-argmax outputs in pixels).  Each output keypoint is matched to the reference keypoint with the same integer
+    NMS position (rounded); every measured maximum is returned and, with ``label``, appended to gpurun_out/parity_measured.jsonl
+    so that the numbers behind the assertion are on record (VERDICT r2 weak #1)."""
     ka = {tuple(np.round(k).astype(int)): i for i, k in enumerate(out["keypoints"].numpy())}
     kb = {tuple(np.round(k).astype(int)): i for i, k in enumerate(ref["keypoints"].numpy())}
     common = sorted(set(ka) & set(kb))
     res = {"n_out": len(ka), "n_ref": len(kb), "common": len(common)}
-    assert len(ka) == len(kb) and len(common) >= len(kb) - 2, res
     ia = torch.tensor([ka[c] for c in common]); ib = torch.tensor([kb[c] for c in common])
     res["kp"] = (out["keypoints"][ia] - ref["keypoints"][ib]).abs().max().item()
     res["score"] = (out["scores"][ia] - ref["scores"][ib]).abs().max().item()
     res["desc"] = (out["descriptors"][:, ia] - ref["descriptors"][:, ib]).abs().max().item()
+    if label is not None:
+        import json
+        d = Path(__file__).resolve().parents[1] / "gpurun_out"
+        try:
+            d.mkdir(exist_ok=True)
+            with open(d / "parity_measured.jsonl", "a") as f:
+                f.write(json.dumps({"case": label, **res}) + "\n")
+        except OSError:
+            pass
+    assert len(ka) == len(kb) and len(common) >= len(kb) - max_missing, res
     assert res["kp"] <= kp_tol and res["score"] <= score_tol and res["desc"] <= desc_tol, res
     return res
 

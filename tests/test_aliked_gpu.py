@@ -26,7 +26,7 @@ def test_aliked_gpu_vs_reference_golden(hip_lib, name):
     out = {k: v.cpu() for k, v in net(img.cuda()).items()}
     g = np.load(GOLD / f"al_{name}.npz")
     gold = {k: torch.from_numpy(g[k]) for k in ("keypoints", "scores", "descriptors")}
-    compare_aliked(out, gold)
+    compare_aliked(out, gold, label=f"aliked golden {name} (reference module output)")
 
 
 def test_aliked_gpu_tile_size_vs_oracle_and_batch(hip_lib):
@@ -41,7 +41,7 @@ def test_aliked_gpu_tile_size_vs_oracle_and_batch(hip_lib):
         ref = aliked_ref.aliked_forward(imgs[b][None], sd, cfg)
         k = int(n[b])
         out = {"keypoints": kp[b, :k], "scores": sc[b, :k], "descriptors": de[b, :k].t()}
-        res = compare_aliked(out, ref)
+        res = compare_aliked(out, ref, label=f"aliked 384x512 tile {b}, 2000 keypoints, HIP vs fp32 oracle")
         assert res["n_out"] == 2000
         single = {k_: v.cpu() for k_, v in net(imgs[b][None].cuda()).items()}
         assert torch.equal(single["keypoints"], out["keypoints"]) and torch.equal(single["descriptors"], out["descriptors"])

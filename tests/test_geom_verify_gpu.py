@@ -91,3 +91,39 @@ def test_retrieval_topk_gpu_vs_torch(hip_lib):
         ref = {names[int(j)] for j, v in zip(tk.indices[i], tk.values[i]) if torch.isfinite(v)}
         bad += len(ref ^ set(by_q.get(names[i], [])))
     assert len(got) == N * K and bad <= 4
+
+
+def test_device_ransac_vs_the_reference_estimator_iou(hip_lib):
+    """VERDICT r2 next #1d: agreement of dim_gv_fundamental with the estimator the reference actually calls
+    (cv2.findFundamentalMat(..., USAC_MAGSAC, gv_threshold, 0.9999, 10000), utils/geometric_verification.py:140-152) on synthetic
+    two-view cases, as inlier-set IoU, driven through verify.HostVerifierPool (the reference's estimator on a thread pool).
+    cv2 is not part of this image; the test runs wherever OpenCV is importable and is skipped (recorded) otherwise —
+    the parity of f3 against cv2 therefore stays UNPINNED here."""
+    import json
+    from pathlib import Path
+    verify = importlib.import_module("deep-image-matching_amd.verify")
+    out_dir = Path(__file__).resolve().parents[1] / "gpurun_out"
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        try:
+            out_dir.mkdir(exist_ok=True)
+            with open(out_dir / "parity_measured.jsonl", "a") as f:
+                f.write(json.dumps({"case": "device RANSAC vs cv2 USAC_MAGSAC", "status": "cv2 not importable on this box: unpinned"}) + "\n")
+        except OSError:
+            pass
+        pytest.skip("cv2 is not importable on this box")
+    cases = [geom_ref.synthetic_two_view(ni, no, seed=s, noise_px=0.4) for s, (ni, no) in enumerate([(1500, 500), (1000, 1000), (300, 100), (1800, 200)])]
+    pool = verify.HostVerifierPool(method="MAGSAC", threshold=2.0, confidence=0.9999, max_iters=10000, workers=4)
+    dv = verify.DeviceVerifier(threshold=2.0, iters=4096, seed=1)
+    ious = []
+    for x0, x1, is_in, _ in cases:
+        m = np.stack([np.arange(len(x0)), np.arange(len(x0))], 1)
+        _, ref_mask = pool.submit(x0, x1, m).result()
+        _, got = dv.verify_pair(x0, x1, m)
+        iou = (ref_mask & got).sum() / max(1, (ref_mask | got).sum())
+        ious.append(float(iou))
+    pool.shutdown()
+    with open(out_dir / "parity_measured.jsonl", "a") as f:
+        f.write(json.dumps({"case": "device RANSAC vs cv2 USAC_MAGSAC inlier IoU", "iou": ious}) + "\n")
+    assert min(ious) >= 0.9, ious
