@@ -110,9 +110,9 @@ def test_config5_aliked_full_tile_vs_oracle(hip_lib):
     img = torch.rand(1, 3, 1000, 1500, generator=torch.Generator().manual_seed(12))
     net = _m("aliked_hip").AlikedHIP(sd, cfg, max_batch=1, max_hw=(1000, 1500), capacity=4000)
     out = {k: v.cpu() for k, v in net(img.cuda()).items()}
-    ref = aliked_ref.aliked_forward(img, sd, cfg)
-    res = compare_aliked(out, ref, label="aliked 1500x1000 tile, 4000 keypoints, HIP vs fp32 oracle")
-    assert res["n_out"] == 4000
+    ref = aliked_ref.aliked_forward(img, sd, cfg, taps=True)
+    res = compare_aliked(out, ref, label="aliked 1500x1000 tile, 4000 keypoints, HIP vs fp32 oracle", ref_score_map=ref["score_map"])
+    assert res["n_out"] == 4000 and res.get("near_tie_keypoints", 0) <= 2
 
 
 def test_config5_batched_tile_matching_vs_the_sequential_loop_with_the_oracle_matcher(hip_lib):
