@@ -65,8 +65,13 @@ X6_PASSES = 3                     # fp16 MFMA terms per fp32-accurate product st
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (configs2: 20 x 50 pairs) / 1 (config4: one pass over the 10 000-pair job)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (configs2) / 1 (config4: one reduced pass)")
+    ap.add_argument("--workload", choices=("configs2", "config4"), default="configs2", help="configs2 (default, the headline line): BASELINE configs[2]; "
+                    "config4: BASELINE configs[3], 150 images -> first 10 000 exhaustive pairs through PairMatchingPipeline "
+                    "(phases 1-4 of SURVEY 8(e), STRONG scaling: the job is fixed, ranks share it)")
+    ap.add_argument("--images", type=int, default=150, help="config4 only")
+    ap.add_argument("--job-pairs", type=int, default=10000, help="config4 only")
     ap.add_argument("--pairs", type=int, default=50, help="pairs per step per GPU (50 x 20 steps = the 1000 pairs of configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lib", default=None, help="developer knob: path of an alternative libdim_hip build to load")
@@ -77,7 +82,12 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="(default since round 1) kept for compatibility")
     ap.add_argument("--main-region-only", action="store_true", help="skip the second (other-schedule) region: used for the rocprofv3 passes")
     ap.add_argument("--cpu-sample-pairs", type=int, default=4)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 20 if a.workload == "configs2" else 1
+    if a.warmup is None:
+        a.warmup = 3 if a.workload == "configs2" else 1
+    return a
 
 
 def respawn_under_torchrun(a):
@@ -169,6 +179,84 @@ def cpu_baseline(n_pairs: int):
                       f"9-layer forwards) after 1 warm-up pair, {what} on torch CPU, {cores} threads"}
 
 
+def run_config4(a, rank, world, dev, dist, lib):
+    """BASELINE configs[3] (SURVEY 8(d) "config 4"): `--images` synthetic 1024^2 images -> the first `--job-pairs` exhaustive
+    pairs (pairs_generator.py:37-38 order) through pipeline.PairMatchingPipeline: images sharded i mod world, ONE all-gather of
+    the feature tables, pairs sharded round-robin, ONE all-gather of the match tables.  STRONG scaling: the job is fixed.  A
+    "step" is one pass over the whole job; per-phase wall times are the max over ranks."""
+    sp = importlib.import_module(PKG + ".superpoint_hip")
+    lg = importlib.import_module(PKG + ".lightglue_hip")
+    pl = importlib.import_module(PKG + ".pipeline")
+    weights = importlib.import_module(PKG + ".weights")
+    capi = importlib.import_module(PKG + ".capi")
+    B, K, W = a.pairs, a.steps, a.warmup
+    cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
+    conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
+    ext = sp.SuperPointHIP(weights.synthetic_superpoint_state_dict(1234), cfg, max_batch=B, max_hw=(1024, 1024), capacity=2048, device=dev)
+    mat = lg.LightGlueHIP(weights.synthetic_lightglue_state_dict(0, 256), conf, max_pairs=B, max_kpts=2048, device=dev)
+    pipe = pl.PairMatchingPipeline(ext, mat, rank, world)
+    imgs = torch.stack([torch.rand(1024, 1024, generator=torch.Generator().manual_seed(s)) for s in range(a.images)]).to(dev)
+    pairs = pl.exhaustive_pairs(a.images, a.job_pairs)
+    P = int(pairs.shape[0])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(W):   # reduced pass: both networks, both collectives, every buffer size class touched once
+        nw = min(a.images, 2 * B * world)
+        pipe.match_all(pipe.extract_all(imgs[:nw]), pl.exhaustive_pairs(nw, B * world))
+    barrier()
+    capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong(1 << 13)))   # DIM_PROF_LG_SELF_ATTN: the self-attention launches
+    phases = {"extract_s": 0.0, "feature_gather_s": 0.0, "match_s": 0.0, "match_gather_s": 0.0}
+    t0 = time.perf_counter()
+    total_matches = 0
+    for _ in range(K):
+        table = pipe.extract_all(imgs)
+        cnt, mt, ms = pipe.match_all(table, pairs)
+        for k in phases:
+            phases[k] += pipe.timings[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_ms, launches = ctypes.c_double(), ctypes.c_int()
+    capi.check(lib, lib.dim_profile_stop(ctypes.byref(tot_ms), ctypes.byref(launches)))
+    total_matches = int(cnt.sum().item())
+    tt = torch.tensor([dt] + [phases[k] for k in phases], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt[0].item())
+    sat_total, sat_sites = capi.saturation(lib, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), reset=True)
+    if rank == 0:
+        per_rank_pairs = (P + world - 1) // world
+        attn_ms = tot_ms.value / max(1, launches.value)
+        # one self-attention launch = 2B items x 4 heads: QK^T + AV = 77.3 GFLOP per pair over 9 layers (SURVEY 8(d)); the last
+        # batch of a shard may be smaller, so the algorithmic work per launch is averaged over the launches actually made
+        gflop_per_launch = 77.3 * per_rank_pairs * K / max(1, launches.value)
+        line = {
+            "metric": "image-pairs/s (SuperPoint+LightGlue, 1024^2, 2048 kpts)", "value": K * P / dt, "unit": "image-pairs/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[3] (config 4): {a.images} synthetic 1024x1024 images -> first {P} exhaustive pairs, extraction amortised over "
+                                   "the images + 1 LightGlue match per pair (fixed-work, 9 layers), through PairMatchingPipeline phases 1-4",
+                       "images": a.images, "job_pairs": P, "pair_batch": B, "gflop_per_pair": LG_GFLOP_PER_PAIR + SP_GFLOP_PER_IMAGE * a.images / P,
+                       "sharding": f"images i mod {world}, ONE all-gather of feature tables ({pipe.timings['feature_gather_bytes'] / 1e6:.0f} MB), pairs "
+                                   f"round-robin, ONE all-gather of match tables ({pipe.timings['match_gather_bytes'] / 1e6:.0f} MB)"},
+            "phases_s_max_over_ranks": {k: float(v) / K for k, v in zip(phases, tt[1:].tolist())},
+            "matches_total": total_matches, "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
+            "roofline": {"kernel": "attn_x6_kernel<2> self-attention launches (flash attention, fp16x3 on the fp16 MFMA)", "bound": "mfma",
+                         "achieved": gflop_per_launch / attn_ms, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gflop_per_launch / attn_ms / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": attn_ms,
+                         "launches": launches.value, "algorithmic_gflop_per_launch": gflop_per_launch},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -198,6 +286,8 @@ def main():
         k, v = kv.split("=")
         lib.dim_tune_set(int(k), int(v))
 
+    if a.workload == "config4":
+        return run_config4(a, rank, world, dev, dist, lib)
     P, K, W = a.pairs, a.steps, a.warmup
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
     conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
@@ -211,17 +301,21 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     pool = [torch.rand(2 * P, 1024, 1024, generator=g).to(dev) for _ in range(n_pool)]
     size_tab = torch.full((2 * P, 2), 1024.0, device=dev)
-    # per-rank match tables of the whole job (filled step by step, exchanged once at the end)
+    # per-rank match table of the whole job in exchange format (SURVEY 8(e) phase 4): ONE flat int32 buffer
+    # [counts: T*P | rows: T*P*NK x (idx0, idx1, score bits)], filled step by step (dim_op_pack_match_rows: 12-byte rows, zero
+    # beyond a pair's count), exchanged with ONE all-gather at the end.  dim_lg_match's own outputs are double-buffered.
     T = K
-    tab = {
-        "matches": torch.zeros(T, P, NK, 2, dtype=torch.int64, device=dev),
-        "scores": torch.zeros(T, P, NK, dtype=torch.float32, device=dev),
-        "n_matches": torch.zeros(T, P, dtype=torch.int32, device=dev),
-        "matches01": torch.zeros(T, P, 2, NK, dtype=torch.int32, device=dev),
-        "mscores01": torch.zeros(T, P, 2, NK, dtype=torch.float32, device=dev),
-        "stop": torch.zeros(T, P, dtype=torch.int32, device=dev),
-        "prune01": torch.zeros(T, P, 2, NK, dtype=torch.int32, device=dev),
-    }
+    flat = torch.zeros(T * P + T * P * NK * 3, dtype=torch.int32, device=dev)
+    cnt_tab, row_tab = flat[: T * P].view(T, P), flat[T * P:].view(T, P, NK, 3)
+    outs = [{
+        "matches": torch.zeros(P, NK, 2, dtype=torch.int64, device=dev),
+        "scores": torch.zeros(P, NK, dtype=torch.float32, device=dev),
+        "n_matches": torch.zeros(P, dtype=torch.int32, device=dev),
+        "matches01": torch.zeros(P, 2, NK, dtype=torch.int32, device=dev),
+        "mscores01": torch.zeros(P, 2, NK, dtype=torch.float32, device=dev),
+        "stop": torch.zeros(P, dtype=torch.int32, device=dev),
+        "prune01": torch.zeros(P, 2, NK, dtype=torch.int32, device=dev),
+    } for _ in range(2)]
 
     # Main timed region: extraction and matching back-to-back on one stream, so that a kernel's HIP-event
     # duration is its own (the roofline figure) and agrees with the rocprofv3 trace.  The two-stream schedule —
@@ -254,7 +348,10 @@ def main():
             with torch.cuda.stream(sB):
                 sB.wait_event(ev[cur])
                 kp, sc, de, n = feats[cur]
-                mat.match_batch(kp, de, n, size_tab, n_pairs=P, out={k: v[i % T] for k, v in tab.items()})
+                o = mat.match_batch(kp, de, n, size_tab, n_pairs=P, out=outs[cur])
+                capi.check(lib, lib.dim_op_pack_match_rows(capi.ptr(o["matches"]), capi.ptr(o["scores"]), capi.ptr(o["n_matches"]), NK, P,
+                                                            capi.ptr(row_tab[i % T]), ctypes.c_void_p(sB.cuda_stream)))
+                cnt_tab[i % T].copy_(o["n_matches"])
                 done_lg[cur].record(sB)
         torch.cuda.current_stream(dev).wait_stream(sA)
         torch.cuda.current_stream(dev).wait_stream(sB)
@@ -277,13 +374,9 @@ def main():
     t0 = time.perf_counter()
     n_last = run(K, W, overlap)
     capi.check(lib, lib.dim_op_read_clocks(ctypes.c_void_p(clk.data_ptr() + 16), stream_ptr))
-    if dist is not None:  # one collective for the whole job: per-rank match tables -> every rank
-        cnt_all = torch.empty(world * T * P, dtype=torch.int32, device=dev)
-        m_all = torch.empty(world * T * P * NK * 2, dtype=torch.int64, device=dev)
-        s_all = torch.empty(world * T * P * NK, dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(cnt_all, tab["n_matches"].reshape(-1))
-        dist.all_gather_into_tensor(m_all, tab["matches"].reshape(-1))
-        dist.all_gather_into_tensor(s_all, tab["scores"].reshape(-1))
+    if dist is not None:  # ONE collective for the whole job: per-rank match tables (counts + 12-byte rows) -> every rank
+        flat_all = torch.empty(world * flat.numel(), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(flat_all, flat)
     barrier()
     dt = time.perf_counter() - t0
     tot_ms, launches = ctypes.c_double(), ctypes.c_int()
@@ -339,7 +432,8 @@ def main():
                                    "2 extractions + 1 match per pair, LightGlue fixed-work (9 layers, no early stop/pruning), "
                                    "seeded synthetic weights", "pairs_per_step_per_gpu": P, "image": "1024x1024",
                        "keypoints": 2048, "all_2048_kpts": n_kpts_ok, "gflop_per_pair": 2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR,
-                       "sharding": f"pairs sharded over {world} rank(s), one RCCL all-gather of match tables at the end",
+                       "sharding": f"pairs sharded over {world} rank(s); ONE RCCL all-gather of the match tables at the end "
+                                   f"(flat int32: counts + (idx0, idx1, score) rows, {flat.numel() * 4 / 1e6:.1f} MB per rank)",
                        "streams": "extraction of batch i+1 overlaps matching of batch i (2 HIP streams)" if overlap else "single stream"},
             ("single_stream" if overlap else "two_stream_overlap"): None if a.main_region_only else {
                 "value": pairs_total / dt2, "unit": "image-pairs/s", "ms_per_step": dt2 / K * 1e3,
@@ -356,8 +450,8 @@ def main():
                                       "split-precision passes are not credited, so frac <= 1/3); mfma_pipe_util = x 3 passes = what the "
                                       "MFMA-busy counter shows (profiles/r02_pmc_mfma_summary.txt)",
                          "frac_of_fp32_mfma_peak": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "isolated": {"note": "same kernel, same launches, timed right after the timed region with no LightGlue work "
-                                              "sharing the GPU (in the timed region the two streams overlap, so a launch is stretched)",
+                         "isolated": {"note": "same kernel, same launches, timed again right after the timed region in two extraction-only batches "
+                                              "(the main region is single-stream, so the two agree unless --overlap is given)",
                                       "avg_launch_ms": iso_ms.value / max(1, iso_n.value),
                                       "achieved": gflop_per_launch / (iso_ms.value / max(1, iso_n.value)),
                                       "frac": gflop_per_launch / (iso_ms.value / max(1, iso_n.value)) / PEAK_BF16_MFMA_TFLOPS},

@@ -98,6 +98,29 @@ __global__ __launch_bounds__(256) void filter_matches_kernel(const long long* __
     if (mk[i]) { o[2 * (size_t)w] = m[2 * (size_t)i]; o[2 * (size_t)w + 1] = m[2 * (size_t)i + 1]; ++w; }
 }
 
+// Match tables for the end-of-job exchange (SURVEY §8(e) phase 4): dim_lg_match's (idx0, idx1) int64 rows + fp32 scores ->
+// 12-byte (idx0:int32, idx1:int32, score bits) rows, zero beyond the pair's live count, so that ONE all-gather of a flat
+// int32 buffer carries counts and rows; and the inverse with the round-robin shard order undone (pair p of the job was
+// matched by rank p % world as its (p / world)-th pair; src_of_pair maps p -> row of the gathered buffer).
+__global__ __launch_bounds__(256) void pack_match_rows_kernel(const long long* __restrict__ matches, const float* __restrict__ scores,
+                                                              const int* __restrict__ n_matches, int nk, int* __restrict__ rows) {
+  const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nk) return;
+  const bool live = i < n_matches[p];
+  const size_t r = (size_t)p * nk + i;
+  rows[3 * r] = live ? (int)matches[2 * r] : 0;
+  rows[3 * r + 1] = live ? (int)matches[2 * r + 1] : 0;
+  rows[3 * r + 2] = live ? __float_as_int(scores[r]) : 0;
+}
+__global__ __launch_bounds__(256) void unpack_match_rows_kernel(const int* __restrict__ rows, const int* __restrict__ src_of_pair, int nk,
+                                                                long long* __restrict__ matches, float* __restrict__ scores) {
+  const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nk) return;
+  const size_t s = ((size_t)(src_of_pair ? src_of_pair[p] : p) * nk + i) * 3, d = (size_t)p * nk + i;
+  matches[2 * d] = rows[s]; matches[2 * d + 1] = rows[s + 1];
+  scores[d] = __int_as_float(rows[s + 2]);
+}
+
 }  // namespace
 
 size_t dim_pack_features_slot_halves(int cap, int D) { return (size_t)cap * (size_t)(4 + D); }
@@ -118,6 +141,24 @@ int dim_op_filter_matches(const int64_t* matches_dev, const int32_t* n_matches_d
   DIM_REQUIRE(nk > 0 && n_pairs > 0, "dim_op_filter_matches: bad sizes");
   hipLaunchKernelGGL(filter_matches_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, (const long long*)matches_dev, n_matches_dev,
                      mask_dev, nk, min_inliers, min_ratio, (long long*)verified_dev, n_verified_dev);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+int dim_op_pack_match_rows(const int64_t* matches_dev, const float* scores_dev, const int32_t* n_matches_dev, int nk, int n_pairs,
+                           int32_t* rows_dev, void* stream) {
+  DIM_REQUIRE(matches_dev && scores_dev && n_matches_dev && rows_dev && nk > 0 && n_pairs > 0, "dim_op_pack_match_rows: bad arguments");
+  hipLaunchKernelGGL(pack_match_rows_kernel, dim3(cdiv(nk, 256), n_pairs), dim3(256), 0, (hipStream_t)stream, (const long long*)matches_dev,
+                     scores_dev, n_matches_dev, nk, rows_dev);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+int dim_op_unpack_match_rows(const int32_t* rows_dev, const int32_t* src_of_pair_dev, int nk, int n_pairs, int64_t* matches_dev,
+                             float* scores_dev, void* stream) {
+  DIM_REQUIRE(rows_dev && matches_dev && scores_dev && nk > 0 && n_pairs > 0, "dim_op_unpack_match_rows: bad arguments");
+  hipLaunchKernelGGL(unpack_match_rows_kernel, dim3(cdiv(nk, 256), n_pairs), dim3(256), 0, (hipStream_t)stream, rows_dev, src_of_pair_dev, nk,
+                     (long long*)matches_dev, scores_dev);
   DIM_LAUNCH_CHECK();
   return 0;
 }

@@ -4,13 +4,16 @@ The reference is single-process / single-device (image_matching.py:413-494: one
 ``extract`` per image, one ``match`` per pair).  Here one process drives one GPU and
 
   phase 1  images  i ≡ rank (mod world) are extracted locally (batched dim_sp_extract),
-  phase 2  ONE all-gather of the fixed-slot feature tables makes every rank hold all
-           features (n_img x cap x (2 + 1 + D) floats + n_img counts),
+  phase 2  ONE all-gather makes every rank hold all features: the extractor writes its outputs straight into the
+           sections [kpts | scores | descriptors | counts] of one flat fp32 buffer per rank (fixed slots,
+           n_img/world x cap x (2 + 1 + D) floats + the counts' bit patterns), which is exchanged as it is,
   phase 3  the pair list (``itertools.combinations`` order for bruteforce,
            pairs_generator.py:37-38) is sharded round-robin, each rank matches its shard
            in batches (dim_lg_match with a pair-index table: no feature copies),
-  phase 4  ONE all-gather of the per-rank match tables (counts + padded (idx0, idx1)
-           rows + scores) gives every rank the complete result.
+  phase 4  ONE all-gather of the per-rank match tables gives every rank the complete result: a flat int32
+           buffer [counts | stop | (idx0, idx1, score bits) rows] (12-byte rows, zero beyond a
+           pair's count; packed and un-packed by dim_op_pack_match_rows / dim_op_unpack_match_rows, the latter
+           also undoing the round-robin shard order).
 
 No collective sits on the per-pair data path.  ``torch.distributed`` backend "nccl" is
 RCCL over xGMI on the GPU box; the same code runs under "gloo" on CPU tensors in the
@@ -68,6 +71,7 @@ class PairMatchingPipeline:
 
     def __init__(self, extractor, matcher, rank: int = 0, world: int = 1):
         self.ext, self.mat, self.rank, self.world = extractor, matcher, rank, world
+        self.timings: dict = {}     # per-phase wall times of the last extract_all / match_all on this rank (seconds) + gathered bytes
 
     # ---- phases 1+2 ------------------------------------------------------------------------
     @torch.no_grad()
@@ -75,30 +79,43 @@ class PairMatchingPipeline:
         """images [n_img, H, W] float32 in [0,1], identical on every rank (or at least the
         rank's own shard valid).  Returns the GLOBAL feature table (kpts [n_img,cap,2],
         scores [n_img,cap], desc [n_img,cap,D], n [n_img], size [n_img,2]) on every rank."""
+        import time
         n_img, H, W = images.shape
         mine = shard_indices(n_img, self.rank, self.world)
         per = (n_img + self.world - 1) // self.world
-        cap, dev = self.ext.capacity, images.device
-        kp = torch.zeros(per, cap, 2, dtype=torch.float32, device=dev)
-        sc = torch.zeros(per, cap, dtype=torch.float32, device=dev)
-        de = torch.zeros(per, cap, 256, dtype=torch.float32, device=dev)
-        n = torch.zeros(per, dtype=torch.int32, device=dev)
+        cap, dev, D = self.ext.capacity, images.device, 256
+        # one flat buffer per rank, sections [kp | sc | de | n]: the extractor writes into views of it, the collective ships it whole
+        sizes = (per * cap * 2, per * cap, per * cap * D, per)
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        o = [0]
+        for z in sizes:
+            o.append(o[-1] + z)
+        kp, sc, de = flat[o[0]:o[1]].view(per, cap, 2), flat[o[1]:o[2]].view(per, cap), flat[o[2]:o[3]].view(per, cap, D)
+        n = flat[o[3]:o[4]].view(torch.int32)
         B = self.ext.max_batch
+        t0 = time.perf_counter()
 
         def run():  # every batch of the shard is enqueued back to back; the fp16x3 range guard is read once per phase
             for s in range(0, len(mine), B):
                 idx = mine[s:s + B]
-                k_, s_, d_, n_ = self.ext.extract_batch(images[idx.to(dev)].contiguous())
-                kp[s:s + len(idx)], sc[s:s + len(idx)], de[s:s + len(idx)], n[s:s + len(idx)] = k_, s_, d_, n_
+                b = len(idx)
+                self.ext.extract_batch(images[idx.to(dev)].contiguous(), out=(kp[s:s + b], sc[s:s + b], de[s:s + b], n[s:s + b]))
 
-        _guarded(self.ext, run, "pipeline extraction")
-        # phase 2: one all-gather per table; slot (r, j) holds image j*world + r
-        kp_g, sc_g, de_g, n_g = (_all_gather_cat(t, self.world) for t in (kp, sc, de, n))
+        _guarded(self.ext, run, "pipeline extraction")     # synchronises (guard read-back)
+        t1 = time.perf_counter()
+        g = _all_gather_cat(flat[None], self.world)         # phase 2: ONE collective, [world, flat]
         if self.world > 1:
+            # slot (r, j) holds image j*world + r: gather the sections into image order
             order = torch.arange(self.world * per, device=dev).reshape(self.world, per).t().reshape(-1)[:n_img]
-            kp_g, sc_g, de_g, n_g = kp_g[order], sc_g[order], de_g[order], n_g[order]
+            kp_g = g[:, o[0]:o[1]].reshape(self.world * per, cap, 2)[order]
+            sc_g = g[:, o[1]:o[2]].reshape(self.world * per, cap)[order]
+            de_g = g[:, o[2]:o[3]].reshape(self.world * per, cap, D)[order]
+            n_g = g[:, o[3]:o[4]].reshape(self.world * per).view(torch.int32)[order]
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
         else:
-            kp_g, sc_g, de_g, n_g = kp_g[:n_img], sc_g[:n_img], de_g[:n_img], n_g[:n_img]
+            kp_g, sc_g, de_g, n_g = kp[:n_img], sc[:n_img], de[:n_img], n[:n_img]
+        self.timings.update(extract_s=t1 - t0, feature_gather_s=time.perf_counter() - t1, feature_gather_bytes=int(flat.numel() * 4 * self.world))
         if image_sizes is None:  # DIM stores image.shape[:2] = (H, W) (extractor_base.py:227, Q4)
             image_sizes = torch.tensor([[float(H), float(W)]] * n_img)
         return kp_g.contiguous(), sc_g.contiguous(), de_g.contiguous(), n_g.contiguous(), image_sizes.to(dev, torch.float32).contiguous()
@@ -110,44 +127,62 @@ class PairMatchingPipeline:
         Returns, on every rank, (n_matches [P], matches [P,NK,2] int64, scores [P,NK]) in the
         order of ``pairs``; with ``aux`` additionally (stop [P] int32, prune01 [P,2,NK] int32) — the reference's
         "stop" / "prune0" / "prune1" outputs (LGN:570-577), gathered the same way (parity tests)."""
+        import ctypes
+        import time
+        from . import capi
         kp, sc, de, n, size = table
         dev = kp.device
+        lib = self.mat.lib
         P = pairs.shape[0]
         mine = shard_indices(P, self.rank, self.world)
         per = (P + self.world - 1) // self.world
         NK, B = self.mat.nk, self.mat.max_pairs
-        cnt = torch.zeros(per, dtype=torch.int32, device=dev)
-        mt = torch.zeros(per, NK, 2, dtype=torch.int64, device=dev)
-        ms = torch.zeros(per, NK, dtype=torch.float32, device=dev)
-        stp = torch.zeros(per, dtype=torch.int32, device=dev)
-        prn = torch.zeros(per, 2, NK, dtype=torch.int32, device=dev) if aux else None
+        # flat int32 buffer per rank: [cnt: per | stop: per | rows: per*NK*3 | (aux) prune: per*2*NK]
+        sizes = (per, per, per * NK * 3, per * 2 * NK if aux else 0)
+        flat = torch.zeros(sum(sizes), dtype=torch.int32, device=dev)
+        o = [0]
+        for z in sizes:
+            o.append(o[-1] + z)
+        cnt, stp, rows = flat[o[0]:o[1]], flat[o[1]:o[2]], flat[o[2]:o[3]].view(per, NK, 3)
+        prn = flat[o[3]:o[4]].view(per, 2, NK) if aux else None
         my_pairs = pairs[mine].to(dev, torch.int32).contiguous()
+        stream = (lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) if dev.type == "cuda" else (lambda: None)
+        t0 = time.perf_counter()
 
         def run():
+            out = None
             for s in range(0, len(mine), B):
                 pp = my_pairs[s:s + B].contiguous()
-                o = self.mat.match_batch(kp, de, n, size, pair_idx=pp)
                 b = pp.shape[0]
-                live = torch.arange(NK, device=dev)[None, :] < o["n_matches"][:, None]  # rows beyond n_matches are unspecified
-                cnt[s:s + b] = o["n_matches"]
-                mt[s:s + b] = torch.where(live[..., None], o["matches"], torch.zeros_like(o["matches"]))
-                ms[s:s + b] = torch.where(live, o["scores"], torch.zeros_like(o["scores"]))
-                stp[s:s + b] = o["stop"]
+                out = self.mat.match_batch(kp, de, n, size, pair_idx=pp, n_pairs=b, out=out)   # the first chunk is the largest: buffers are reused
+                with self.mat._ctx():
+                    capi.check(lib, lib.dim_op_pack_match_rows(capi.ptr(out["matches"]), capi.ptr(out["scores"]), capi.ptr(out["n_matches"]), NK, b,
+                                                                capi.ptr(rows[s:s + b]), stream()))
+                cnt[s:s + b] = out["n_matches"][:b]
+                stp[s:s + b] = out["stop"][:b]
                 if aux:
-                    prn[s:s + b] = o["prune01"]
+                    prn[s:s + b] = out["prune01"][:b]
 
-        _guarded(self.mat, run, "pipeline matching")
-        cnt_g, mt_g, ms_g = (_all_gather_cat(t, self.world) for t in (cnt, mt, ms))
-        if self.world > 1:
-            order = torch.arange(self.world * per, device=dev).reshape(self.world, per).t().reshape(-1)[:P]
-            cnt_g, mt_g, ms_g = cnt_g[order], mt_g[order], ms_g[order]
-        else:
-            cnt_g, mt_g, ms_g = cnt_g[:P], mt_g[:P], ms_g[:P]
+        _guarded(self.mat, run, "pipeline matching")       # synchronises
+        t1 = time.perf_counter()
+        g = _all_gather_cat(flat[None], self.world)         # phase 4: ONE collective, [world, flat]
+        # pair p was matched by rank p % world as its (p // world)-th pair
+        src = (torch.arange(P, device=dev) % self.world) * per + torch.arange(P, device=dev) // self.world
+        cnt_g = g[:, o[0]:o[1]].reshape(-1)[src].contiguous()
+        stp_g = g[:, o[1]:o[2]].reshape(-1)[src].contiguous()
+        rows_g = g[:, o[2]:o[3]].reshape(self.world * per, NK, 3) if self.world > 1 else rows
+        mt_g = torch.empty(P, NK, 2, dtype=torch.int64, device=dev)
+        ms_g = torch.empty(P, NK, dtype=torch.float32, device=dev)
+        rows_c = rows_g.contiguous()
+        src32 = src.to(torch.int32).contiguous()
+        with self.mat._ctx():
+            capi.check(lib, lib.dim_op_unpack_match_rows(capi.ptr(rows_c), capi.ptr(src32), NK, P, capi.ptr(mt_g), capi.ptr(ms_g), stream()))
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        self.timings.update(match_s=t1 - t0, match_gather_s=time.perf_counter() - t1, match_gather_bytes=int(flat.numel() * 4 * self.world))
         if aux:
-            stp_g, prn_g = _all_gather_cat(stp, self.world), _all_gather_cat(prn, self.world)
-            if self.world > 1:
-                stp_g, prn_g = stp_g[order], prn_g[order]
-            return cnt_g, mt_g, ms_g, stp_g[:P], prn_g[:P]
+            prn_g = g[:, o[3]:o[4]].reshape(self.world * per, 2, NK)[src].contiguous()
+            return cnt_g, mt_g, ms_g, stp_g, prn_g
         return cnt_g, mt_g, ms_g
 
     @staticmethod

@@ -327,6 +327,15 @@ int dim_op_pack_features_f16(const float* kpts_dev, const float* scores_dev, con
 int dim_op_filter_matches(const int64_t* matches_dev, const int32_t* n_matches_dev, const unsigned char* mask_dev, int nk, int n_pairs,
                           int min_inliers, double min_ratio, int64_t* verified_dev, int32_t* n_verified_dev, void* stream);
 
+/* End-of-job exchange of the per-rank match tables (SURVEY §8(e) phase 4; no reference counterpart — the reference is single
+ * process): dim_lg_match's (S,2) int64 lists + scores -> [n_pairs][nk][3] int32 rows (idx0, idx1, score bits), zero beyond
+ * n_matches, ready for ONE all-gather of a flat int32 buffer; and back to int64 / fp32 tables, reading row src_of_pair[p]
+ * of the gathered buffer for output pair p (NULL = identity), which undoes the round-robin shard order. */
+int dim_op_pack_match_rows(const int64_t* matches_dev, const float* scores_dev, const int32_t* n_matches_dev, int nk, int n_pairs,
+                           int32_t* rows_dev, void* stream);
+int dim_op_unpack_match_rows(const int32_t* rows_dev, const int32_t* src_of_pair_dev, int nk, int n_pairs, int64_t* matches_dev,
+                             float* scores_dev, void* stream);
+
 /* ---- retrieval pair selection (csrc/tile_ops.hip) --------------------------------------------------------------
  * thirdparty/hloc/pairs_from_retrieval.py:49-70,108-112: sim = einsum("id,jd->ij", query, db) (global descriptors,
  * fp32 MFMA), invalid entries (self matches; score < min_score when use_min_score) -> -inf, torch.topk(num_select) per

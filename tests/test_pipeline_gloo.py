@@ -46,8 +46,17 @@ def _worker(rank, world, port, lib_path, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
+    calls = []
+    orig = dist.all_gather_into_tensor
+
+    def counting(out, inp, *a, **k):     # ONE collective per exchange phase, counts + rows in one flat buffer
+        calls.append((inp.dtype, inp.numel()))
+        return orig(out, inp, *a, **k)
+
+    dist.all_gather_into_tensor = counting
     table, res = _run(lib_path, rank, world)
-    torch.save({"table": [t.clone() for t in table], "res": [t.clone() for t in res]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.all_gather_into_tensor = orig
+    torch.save({"table": [t.clone() for t in table], "res": [t.clone() for t in res], "collectives": calls}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,6 +76,10 @@ def test_two_rank_pipeline_equals_single_process(tmp_path):
             assert torch.equal(a, b)
         for a, b in zip(got["res"], res1):
             assert torch.equal(a, b)
+        # phase 2: one fp32 buffer [kp | sc | de | n] of 3 image slots x 12 keypoints; phase 4: one int32 buffer
+        # [cnt | stop | (idx0, idx1, score) rows] of 4 pair slots (7 pairs over 2 ranks) x NK rows
+        nk = res1[1].shape[1]
+        assert got["collectives"] == [(torch.float32, 3 * 12 * (2 + 1 + 256) + 3), (torch.int32, 4 + 4 + 4 * nk * 3)], got["collectives"]
     pl = importlib.import_module("deep-image-matching_amd.pipeline")
     lists = pl.PairMatchingPipeline.to_match_lists(*res1)
     assert len(lists) == 7 and all(m.shape[1] == 2 for m, _ in lists)
