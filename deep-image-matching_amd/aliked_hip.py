@@ -52,6 +52,7 @@ class AlikedHIP:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[dict] = None, max_batch: int = 1, max_hw=(1024, 1024),
                  capacity: Optional[int] = None, device="cuda", lib=None):
         self.cfg = {**self.default_config, **(cfg or {})}
+        self.on_saturation = self.cfg.pop("on_saturation", "fallback")
         self.lib = lib if lib is not None else capi.load()
         self.device = torch.device(device)
         if lib is None and self.device.type != "cuda":
@@ -112,12 +113,19 @@ class AlikedHIP:
                                                              capi.ptr(n), self._stream()))
         return kp, sc, de, n
 
+    def extract_batch_guarded(self, images: torch.Tensor, logger=None):
+        """extract_batch under the fp16x3 range guard (capi.run_guarded): the full- and half-resolution convolutions and the GEMMs
+        run as fp16 splits on the matrix cores (aliked_x3.hip, gemm_x6.hip), exact for |activation| <= 4094; a call that
+        leaves that range is repeated on the fp32 paths.  Synchronises."""
+        with self._ctx():
+            return capi.run_guarded(self.lib, self._stream(), lambda: self.extract_batch(images), "ALIKED", self.on_saturation, logger)
+
     @torch.no_grad()
     def __call__(self, image: torch.Tensor) -> dict:
         """image [1,C,H,W] (the reference's input).  Returns DIM's feature dict for one image (device
         tensors): keypoints (N,2), descriptors (128,N), scores (N,) (= dispersities, Q8)."""
         img = image[0].permute(1, 2, 0).contiguous().to(self.device, torch.float32)[None]
-        kp, sc, de, n = self.extract_batch(img)
+        kp, sc, de, n = self.extract_batch_guarded(img)
         k = int(n[0].item())
         return {"keypoints": kp[0, :k], "scores": sc[0, :k], "descriptors": de[0, :k].t()}
 

@@ -62,7 +62,7 @@ def ptr(t):
 # ---- arithmetic selection and the fp16x3 range guard ------------------------------------------------------
 ARITHMETIC = {"fp16x3": 2, "bf16x6": 1, "fp32": 0}
 SAT_SITES = 16  # DIM_SAT_SITES
-SAT_NAMES = ["sp_image", "sp_encoder", "sp_heads", "lg_input", "lg_qkv", "lg_ffn", "lg_desc", "op"]
+SAT_NAMES = ["sp_image", "sp_encoder", "sp_heads", "lg_input", "lg_qkv", "lg_ffn", "lg_desc", "op", "aliked"]
 _arith = {}  # id(lib) -> current mode (the library default is fp16x3)
 
 

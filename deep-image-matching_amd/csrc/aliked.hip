@@ -340,6 +340,72 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restric
   }
 }
 
+// The product path of the same stage.  score_head.0 (1x1, 128 -> 8) and the bilinear up-sampling are both linear, so the
+// projection of the three up-sampled groups commutes with the interpolation:
+//   W0[32g .. 32g+31] . up(f_g)(y, x) = up(W0[32g ..] . f_g)(y, x)
+// q_g = f_g x W0[32g:32g+32] is evaluated ONCE at the map's own resolution (1/4, 1/64, 1/1024 of the pixels; al_conv1x1<32, 8>)
+// and the full-resolution pass interpolates 8 instead of 32 channels per map: 12 corner reads of 32 B and 96 FMAs per pixel
+// where the unfactored form needs 12 x 128 B and 384 + 768.  Thread = pixel: the 16 -> 32 conv of x1, SELU, its share of the
+// projection, the three 8-channel interpolations, SELU.  Rounding differs from the unfactored order by fp32 reassociation only.
+__global__ __launch_bounds__(256) void al_assemble_proj_kernel(const float* __restrict__ x1, const float* __restrict__ q2,
+                                                               const float* __restrict__ q3, const float* __restrict__ q4,
+                                                               const float* __restrict__ w1, const float* __restrict__ ws0,
+                                                               float* __restrict__ s8, int Hp, int Wp) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= Hp * Wp) return;
+  const int y = i / Wp, x = i - y * Wp;
+  float sacc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sacc[k] = 0.f;
+  {
+    const float* src = x1 + ((size_t)b * Hp * Wp + i) * 16;
+    float a[16];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) { const float4 v = *(const float4*)(src + c4 * 4); a[c4 * 4] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w; }
+#pragma unroll
+    for (int co = 0; co < 32; co += 4) {
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(a[ci], w1[ci * 32 + co + j], o[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = selu_(o[j]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc[k] = fmaf(o[j], ws0[(co + j) * 8 + k], sacc[k]);
+      }
+    }
+  }
+  float up[3][8];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int fac = g == 0 ? 2 : (g == 1 ? 8 : 32);
+    const float* map = g == 0 ? q2 : (g == 1 ? q3 : q4);
+    const int h = Hp / fac, w = Wp / fac;
+    const UpIdx uy = up_index(y, h, Hp), ux = up_index(x, w, Wp);
+    const float* base = map + (size_t)b * h * w * 8;
+    const float* p00 = base + ((size_t)uy.i0 * w + ux.i0) * 8;
+    const float* p01 = base + ((size_t)uy.i0 * w + ux.i1) * 8;
+    const float* p10 = base + ((size_t)uy.i1 * w + ux.i0) * 8;
+    const float* p11 = base + ((size_t)uy.i1 * w + ux.i1) * 8;
+#pragma unroll
+    for (int c = 0; c < 8; c += 4) {
+      const float4 a = *(const float4*)(p00 + c), bq = *(const float4*)(p01 + c), cq = *(const float4*)(p10 + c), d = *(const float4*)(p11 + c);
+      up[g][c + 0] = uy.l0 * (ux.l0 * a.x + ux.l1 * bq.x) + uy.l1 * (ux.l0 * cq.x + ux.l1 * d.x);
+      up[g][c + 1] = uy.l0 * (ux.l0 * a.y + ux.l1 * bq.y) + uy.l1 * (ux.l0 * cq.y + ux.l1 * d.y);
+      up[g][c + 2] = uy.l0 * (ux.l0 * a.z + ux.l1 * bq.z) + uy.l1 * (ux.l0 * cq.z + ux.l1 * d.z);
+      up[g][c + 3] = uy.l0 * (ux.l0 * a.w + ux.l1 * bq.w) + uy.l1 * (ux.l0 * cq.w + ux.l1 * d.w);
+    }
+  }
+  float o8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o8[k] = selu_((sacc[k] + up[0][k]) + (up[1][k] + up[2][k]));
+  float* sd = s8 + ((size_t)b * Hp * Wp + i) * 8;
+  *(float4*)sd = make_float4(o8[0], o8[1], o8[2], o8[3]);
+  *(float4*)(sd + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+}
+
 // ---------------------------------------------------------------------------
 // DKD soft-argmax refinement (ALN:176-216): one thread per keypoint.
 __global__ __launch_bounds__(256) void al_dkd_refine_kernel(const float* __restrict__ score, const float* __restrict__ kpts_px,
@@ -559,6 +625,7 @@ int launch_al_conv1x1(const float* in, int cin, const float* w, const float* bia
   else if (cin == 64 && cout == 32) AL_C1(64, 32);
   else if (cin == 64 && cout == 128) AL_C1(64, 128);
   else if (cin == 128 && cout == 32) AL_C1(128, 32);
+  else if (cin == 32 && cout == 8) AL_C1(32, 8);
   else { dim_set_error("aliked conv1x1: unsupported channels %d -> %d", cin, cout); return -2; }
 #undef AL_C1
   DIM_LAUNCH_CHECK();
@@ -589,8 +656,8 @@ int launch_al_bn_apply(const float* x, const float* alpha, const float* beta, co
   DIM_LAUNCH_CHECK();
   return 0;
 }
-int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, float* cols, float* out, int cout,
-                          int batch, int H, int W, hipStream_t s) {
+int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, const SplitWeights* wx, unsigned* sat,
+                          float* cols, float* out, int cout, int batch, int H, int W, hipStream_t s) {
   DIM_REQUIRE(cout % 32 == 0 && (cin == 32 || cin == 64 || cin == 128), "deform conv: cin %d cout %d", cin, cout);
   const int rows = batch * H * W;
   const dim3 grid((unsigned)(((size_t)rows * 9 * (cin / 4) + 255) / 256));
@@ -600,6 +667,7 @@ int launch_al_deform_conv(const float* in, int cin, const float* offsets, int of
   DIM_LAUNCH_CHECK();
   GemmArgs g;
   g.A0 = cols; g.lda0 = 9 * cin; g.B = w; g.ldb = cout; g.C = out; g.ldc = cout; g.M = rows; g.N = cout; g.K = 9 * cin;
+  if (wx != nullptr) { g.set_split(*wx); g.sat = sat; return launch_gemm_x6(g, 1, s); }   // fp16x3 on the matrix cores
   return launch_gemm(g, 1, s);
 }
 int launch_al_clamp(float* x, size_t n, float lim, hipStream_t s) {
@@ -611,6 +679,12 @@ int launch_al_assemble(const float* x1, const float* f2, const float* f3, const 
                        float* x1234, float* s8, int batch, int Hp, int Wp, hipStream_t s) {
   if (x1234) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_assemble_kernel<true>), dim3(cdiv(Hp * Wp, 64), batch), dim3(256), 0, s, x1, f2, f3, f4, w1, ws0, x1234, s8, Hp, Wp);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(al_assemble_kernel<false>), dim3(cdiv(Hp * Wp, 64), batch), dim3(256), 0, s, x1, f2, f3, f4, w1, ws0, x1234, s8, Hp, Wp);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_al_assemble_proj(const float* x1, const float* q2, const float* q3, const float* q4, const float* w1, const float* ws0, float* s8,
+                            int batch, int Hp, int Wp, hipStream_t s) {
+  hipLaunchKernelGGL(al_assemble_proj_kernel, dim3(cdiv(Hp * Wp, 256), batch), dim3(256), 0, s, x1, q2, q3, q4, w1, ws0, s8, Hp, Wp);
   DIM_LAUNCH_CHECK();
   return 0;
 }

@@ -22,6 +22,10 @@ struct dim_aliked {
   float *dh_o0_w, *dh_o0_b, *dh_o2_w, *dh_o2_b, *dh_sf, *dh_agg;
   // activations
   float *P, *raw, *act, *x1, *p2, *idn, *x2, *p3, *off, *x3, *p4, *x4, *f2, *f3, *f4, *x1234, *s8, *s4a, *s4b, *score, *nms;
+  SplitWeights x_b1c1, x_b1c2, x_b2c1, x_b2c2, x_b2ds;   // fp16x3 fragments of the full- / half-resolution convolutions (aliked_x3.hip)
+  double* tile_partial;
+  SplitWeights g_b3r1, g_b3r2, g_b3ds, g_b4r1, g_b4r2, g_b4ds, g_hc2, g_hc3, g_hc4, g_o0, g_sf, g_agg;   // fp16x3 GEMM operands (gemm_x6.hip)
+  float *q2, *q3, *q4;   // score_head.0 projections of f2 / f3 / f4 at their own resolutions (8 channels)
   float *cand_score, *kpts_px, *sc_tmp, *kpts_norm, *kscore, *patches, *hidden, *feats, *feats2, *bn_alpha, *bn_beta, *mean, *thr_eff, *cols;
   double* partial;
   int *cand_idx, *rowcount, *rowoff, *ncand;
@@ -59,6 +63,28 @@ std::vector<float> relayout(const float* w, int co, int ci, int k, int ci_pad, i
     for (int b = 0; b < ci; ++b)
       for (int t = 0; t < k * k; ++t) o[((size_t)t * ci_pad + b) * co_pad + a] = w[((size_t)a * ci + b) * k * k + t];
   return o;
+}
+// [K][N] fp32 conv operand (K = tap * cin_pad + ci) -> fp16x3 MFMA fragments + per-channel inverse scales (n_pad = 32)
+int upload_x3(dim_aliked* h, SplitWeights* dst, const std::vector<float>& w_kn, int K, int N) {
+  if (!dim_all_finite(w_kn.data(), w_kn.size())) { dim_set_error("non-finite value in the weights"); return -1; }
+  std::vector<unsigned short> host(gemm_split_weight_elems(K, 32, 2));
+  split_weights(w_kn.data(), K, N, 32, 2, host.data(), dst);
+  unsigned short* d = nullptr;
+  if (dev_alloc(h, &d, host.size()) != 0) return -1;
+  if (hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); return -1; }
+  dst->dev = d; dst->mode = 2; dst->n_pad = 32;
+  return 0;
+}
+// [K][N] fp32 GEMM operand -> fp16x3 planes in gemm_x6's fragment order (n_pad = multiple of 128)
+int upload_x3g(dim_aliked* h, SplitWeights* dst, const float* w_kn, int K, int N) {
+  const int n_pad = (N + 127) / 128 * 128;
+  std::vector<unsigned short> host(gemm_split_weight_elems(K, n_pad, 2));
+  split_weights(w_kn, K, N, n_pad, 2, host.data(), dst);
+  unsigned short* d = nullptr;
+  if (dev_alloc(h, &d, host.size()) != 0) return -1;
+  if (hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); return -1; }
+  dst->dev = d; dst->mode = 2; dst->n_pad = n_pad;
+  return 0;
 }
 std::vector<float> padvec(const float* b, int n, int n_pad) {
   std::vector<float> v(n_pad, 0.0f);
@@ -104,6 +130,26 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
   AL_TRY(upload(h, &h->b4o2_w, relayout(w->block4_off2_w, 18, 128, 3, 128, 20))); AL_TRY(upload(h, &h->b4o2_b, padvec(w->block4_off2_b, 18, 20)));
   AL_TRY(upload(h, &h->b4r2, relayout(w->block4_reg2, 128, 128, 3, 128, 128)));
   AL_TRY(upload(h, &h->b4ds_w, relayout(w->block4_ds_w, 128, 64, 1, 64, 128))); AL_TRY(upload(h, &h->b4ds_b, padvec(w->block4_ds_b, 128, 128)));
+  AL_TRY(upload_x3(h, &h->x_b1c1, relayout(w->block1_conv1, 16, 3, 3, 16, 16), 9 * 16, 16));
+  AL_TRY(upload_x3(h, &h->x_b1c2, relayout(w->block1_conv2, 16, 16, 3, 16, 16), 9 * 16, 16));
+  AL_TRY(upload_x3(h, &h->x_b2c1, relayout(w->block2_conv1, 32, 16, 3, 16, 32), 9 * 16, 32));
+  AL_TRY(upload_x3(h, &h->x_b2c2, relayout(w->block2_conv2, 32, 32, 3, 32, 32), 9 * 32, 32));
+  AL_TRY(upload_x3(h, &h->x_b2ds, relayout(w->block2_ds_w, 32, 16, 1, 16, 32), 16, 32));
+  {  // the same operands the fp32 GEMMs use ([K][N] row-major), split for the matrix cores
+    auto kn = [&](const float* w_, int co, int ci, int k) { return relayout(w_, co, ci, k, ci, co); };
+    AL_TRY(upload_x3g(h, &h->g_b3r1, kn(w->block3_reg1, 64, 32, 3).data(), 288, 64)); AL_TRY(upload_x3g(h, &h->g_b3r2, kn(w->block3_reg2, 64, 64, 3).data(), 576, 64));
+    AL_TRY(upload_x3g(h, &h->g_b3ds, kn(w->block3_ds_w, 64, 32, 1).data(), 32, 64));
+    AL_TRY(upload_x3g(h, &h->g_b4r1, kn(w->block4_reg1, 128, 64, 3).data(), 576, 128)); AL_TRY(upload_x3g(h, &h->g_b4r2, kn(w->block4_reg2, 128, 128, 3).data(), 1152, 128));
+    AL_TRY(upload_x3g(h, &h->g_b4ds, kn(w->block4_ds_w, 128, 64, 1).data(), 64, 128));
+    AL_TRY(upload_x3g(h, &h->g_hc2, kn(w->conv2, 32, 32, 1).data(), 32, 32)); AL_TRY(upload_x3g(h, &h->g_hc3, kn(w->conv3, 32, 64, 1).data(), 64, 32));
+    AL_TRY(upload_x3g(h, &h->g_hc4, kn(w->conv4, 32, 128, 1).data(), 128, 32));
+    AL_TRY(upload_x3g(h, &h->g_sf, kn(w->desc_sf, 128, 128, 1).data(), 128, 128));
+    AL_TRY(upload_x3g(h, &h->g_agg, w->desc_agg, 2048, 128));
+    std::vector<float> o0((size_t)1152 * 32);
+    for (int co = 0; co < 32; ++co)
+      for (int k = 0; k < 1152; ++k) o0[(size_t)k * 32 + co] = w->desc_off0_w[(size_t)co * 1152 + k];
+    AL_TRY(upload_x3g(h, &h->g_o0, o0.data(), 1152, 32));
+  }
   const int bnc[8] = {16, 16, 32, 32, 64, 64, 128, 128};
   for (int i = 0; i < 8; ++i) {
     AL_TRY(upload(h, &h->bn_g[i], padvec(w->bn_weight[i], bnc[i], bnc[i])));
@@ -130,14 +176,16 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
   AL_TRY(dev_alloc(h, &h->x2, B * NP / 4 * 32)); AL_TRY(dev_alloc(h, &h->p3, B * NP / 64 * 32)); AL_TRY(dev_alloc(h, &h->off, B * NP / 64 * 20));
   AL_TRY(dev_alloc(h, &h->x3, B * NP / 64 * 64)); AL_TRY(dev_alloc(h, &h->p4, B * NP / 1024 * 64)); AL_TRY(dev_alloc(h, &h->x4, B * NP / 1024 * 128));
   AL_TRY(dev_alloc(h, &h->f2, B * NP / 4 * 32)); AL_TRY(dev_alloc(h, &h->f3, B * NP / 64 * 32)); AL_TRY(dev_alloc(h, &h->f4, B * NP / 1024 * 32));
+  AL_TRY(dev_alloc(h, &h->q2, B * NP / 4 * 8)); AL_TRY(dev_alloc(h, &h->q3, B * NP / 64 * 8)); AL_TRY(dev_alloc(h, &h->q4, B * NP / 1024 * 8));
   AL_TRY(dev_alloc(h, &h->s8, B * NP * 8)); AL_TRY(dev_alloc(h, &h->s4a, B * NP * 4));
   AL_TRY(dev_alloc(h, &h->s4b, B * NP * 4)); AL_TRY(dev_alloc(h, &h->score, B * NP)); AL_TRY(dev_alloc(h, &h->nms, B * NP));
   AL_TRY(dev_alloc(h, &h->cand_score, B * NP)); AL_TRY(dev_alloc(h, &h->cand_idx, B * NP)); AL_TRY(dev_alloc(h, &h->rowcount, B * Hp));
   AL_TRY(dev_alloc(h, &h->rowoff, B * Hp)); AL_TRY(dev_alloc(h, &h->ncand, B)); AL_TRY(dev_alloc(h, &h->kpts_px, B * cap * 2));
   AL_TRY(dev_alloc(h, &h->sc_tmp, B * cap)); AL_TRY(dev_alloc(h, &h->kpts_norm, B * cap * 2)); AL_TRY(dev_alloc(h, &h->kscore, B * cap));
   AL_TRY(dev_alloc(h, &h->patches, B * cap * 1152)); AL_TRY(dev_alloc(h, &h->hidden, B * cap * 32)); AL_TRY(dev_alloc(h, &h->feats, B * cap * 2048));
-  AL_TRY(dev_alloc(h, &h->feats2, B * cap * 2048)); AL_TRY(dev_alloc(h, &h->bn_alpha, B * 128)); AL_TRY(dev_alloc(h, &h->bn_beta, B * 128));
+  AL_TRY(dev_alloc(h, &h->feats2, B * cap * 2048)); AL_TRY(dev_alloc(h, &h->bn_alpha, 2 * B * 128)); AL_TRY(dev_alloc(h, &h->bn_beta, 2 * B * 128));   // two slots: a conv's input and output BatchNorm
   AL_TRY(dev_alloc(h, &h->mean, B)); AL_TRY(dev_alloc(h, &h->thr_eff, B)); AL_TRY(dev_alloc(h, &h->partial, B * 256 * 128 * 2));
+  AL_TRY(dev_alloc(h, &h->tile_partial, al_convx3_partial_doubles((int)B, (int)Hp, (int)Wp)));
 #undef AL_TRY
   *out = h;
   return 0;
@@ -157,11 +205,18 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   const int NP = Hp * Wp, r = h->cfg.nms_radius, cap = h->capacity;
 #define AL_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
   // 1x1 convolutions on NHWC maps are plain GEMMs over pixels (weights already [cin][cout])
-  auto conv1x1 = [&](const float* in, int ci, const float* w1, const float* bias, float* out, int co, int npx, int act) -> int {
+  // GEMMs: fp16x3 on the matrix cores (gemm_x6.hip) under the default arithmetic, plain fp32 MFMA otherwise
+  const bool x3 = dim_precision_mode() == 2;
+  unsigned* const sat_al = dim_sat_counter(DIM_SAT_ALIKED);
+  auto gemm = [&](GemmArgs& g, const SplitWeights& wx, int nb) -> int {
+    if (x3 && g.K % 32 == 0) { g.set_split(wx); g.sat = sat_al; return launch_gemm_x6(g, nb, s); }
+    return launch_gemm(g, nb, s);
+  };
+  auto conv1x1 = [&](const float* in, int ci, const float* w1, const SplitWeights& wx, const float* bias, float* out, int co, int npx, int act) -> int {
     GemmArgs g;
     g.A0 = in; g.lda0 = ci; g.B = w1; g.ldb = co; g.bias = bias; g.C = out; g.ldc = co; g.M = npx; g.N = co; g.K = ci;
     g.relu = act == AL_ACT_SELU ? 2 : 0;
-    return launch_gemm(g, 1, s);
+    return gemm(g, wx, 1);
   };
   auto bn = [&](const float* x, int npx, int C, int i, const float* res, float* dst) -> int {
     int rc = launch_al_bn_stats(x, batch, npx, C, h->bn_g[i], h->bn_b[i], h->partial, h->bn_alpha, h->bn_beta, s);
@@ -169,42 +224,84 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     return launch_al_bn_apply(x, h->bn_alpha, h->bn_beta, res, dst, batch, npx, C, s);
   };
   AL_RUN(launch_al_pad_replicate(images_dev, h->P, batch, H, W, Hp, Wp, pad_t, pad_l, in_channels, s));
+  // Full- and half-resolution convolutions: fp16x3 on the matrix cores with the BatchNorm statistics reduced in the conv
+  // epilogue (aliked_x3.hip) under the default arithmetic; the fp32 VALU kernels + a separate statistics pass otherwise
+  // (dim_tune_set(1, 0 | 1): A/B checks and the range-guard fallback).
+  // conv -> train-mode BN statistics -> (alpha, beta) of BatchNorm layer i in slot `slot` of bn_alpha / bn_beta.  in_bn >= 0: the
+  // input is the previous convolution's RAW output and its BatchNorm + SELU (slot in_bn) is applied while the tile is staged.
+  const bool fuse_bn = x3 && dim_aliked_fuse_bn();
+  auto ab = [&](int slot, float** a, float** bta) { *a = h->bn_alpha + (size_t)slot * batch * 128; *bta = h->bn_beta + (size_t)slot * batch * 128; };
+  auto conv_bn = [&](const float* in, int in_c, int cin_pad, int taps, const SplitWeights& wx, const float* wv, float* out, int co,
+                     int Hh, int Ww, int i, int slot, int in_bn) -> int {
+    float *a, *bt, *ia = nullptr, *ib = nullptr;
+    ab(slot, &a, &bt);
+    if (in_bn >= 0) ab(in_bn, &ia, &ib);
+    if (x3) {
+      int n_wg = 0, rc;
+      if ((rc = launch_al_convx3(in, in_c, cin_pad, taps, wx, nullptr, out, co, batch, Hh, Ww, h->tile_partial, &n_wg, ia, ib, s))) return rc;
+      return launch_al_bn_final_tiles(h->tile_partial, n_wg, batch, Hh * Ww, co, h->bn_g[i], h->bn_b[i], a, bt, s);
+    }
+    int rc = launch_al_conv3x3(in, in_c, wv, nullptr, out, co, batch, Hh, Ww, AL_ACT_NONE, 0, 0, Hh, Ww, s);
+    if (rc) return rc;
+    return launch_al_bn_stats(out, batch, Hh * Ww, co, h->bn_g[i], h->bn_b[i], h->partial, a, bt, s);
+  };
+  auto apply = [&](const float* x, int slot, const float* res, float* dst, int npx, int C) -> int {
+    float *a, *bt;
+    ab(slot, &a, &bt);
+    return launch_al_bn_apply(x, a, bt, res, dst, batch, npx, C, s);
+  };
   // block1 (ConvBlock, ALN:367-393)
-  AL_RUN(launch_al_conv3x3(h->P, 3, h->b1c1, nullptr, h->raw, 16, batch, Hp, Wp, AL_ACT_NONE, 0, 0, Hp, Wp, s));
-  AL_RUN(bn(h->raw, NP, 16, 0, nullptr, h->act));
-  AL_RUN(launch_al_conv3x3(h->act, 16, h->b1c2, nullptr, h->raw, 16, batch, Hp, Wp, AL_ACT_NONE, 0, 0, Hp, Wp, s));
-  AL_RUN(bn(h->raw, NP, 16, 1, nullptr, h->x1));
+  AL_RUN(conv_bn(h->P, 3, 16, 9, h->x_b1c1, h->b1c1, h->raw, 16, Hp, Wp, 0, 0, -1));
+  if (fuse_bn) {
+    AL_RUN(conv_bn(h->raw, 16, 16, 9, h->x_b1c2, h->b1c2, h->act, 16, Hp, Wp, 1, 1, 0));   // bn1 + SELU of conv1 in the staging; raw output -> act
+    AL_RUN(apply(h->act, 1, nullptr, h->x1, NP, 16));
+  } else {
+    AL_RUN(apply(h->raw, 0, nullptr, h->act, NP, 16));
+    AL_RUN(conv_bn(h->act, 16, 16, 9, h->x_b1c2, h->b1c2, h->raw, 16, Hp, Wp, 1, 1, -1));
+    AL_RUN(apply(h->raw, 1, nullptr, h->x1, NP, 16));
+  }
   // block2 (ResBlock, plain convs)
   AL_RUN(launch_al_avgpool(h->x1, h->p2, batch, Hp, Wp, 16, 2, s));
-  AL_RUN(launch_al_conv3x3(h->p2, 16, h->b2c1, nullptr, h->raw, 32, batch, H2, W2, AL_ACT_NONE, 0, 0, H2, W2, s));
-  AL_RUN(bn(h->raw, H2 * W2, 32, 2, nullptr, h->act));
-  AL_RUN(launch_al_conv3x3(h->act, 32, h->b2c2, nullptr, h->raw, 32, batch, H2, W2, AL_ACT_NONE, 0, 0, H2, W2, s));
-  AL_RUN(launch_al_conv1x1(h->p2, 16, h->b2ds_w, h->b2ds_b, h->idn, 32, batch * H2 * W2, AL_ACT_NONE, s));  // K = 16: below the GEMM's K granule
-  AL_RUN(bn(h->raw, H2 * W2, 32, 3, h->idn, h->x2));
+  AL_RUN(conv_bn(h->p2, 16, 16, 9, h->x_b2c1, h->b2c1, h->raw, 32, H2, W2, 2, 0, -1));
+  if (x3) AL_RUN(launch_al_convx3(h->p2, 16, 16, 1, h->x_b2ds, h->b2ds_b, h->idn, 32, batch, H2, W2, nullptr, nullptr, nullptr, nullptr, s));
+  else AL_RUN(launch_al_conv1x1(h->p2, 16, h->b2ds_w, h->b2ds_b, h->idn, 32, batch * H2 * W2, AL_ACT_NONE, s));  // K = 16: below the GEMM's K granule
+  if (fuse_bn) {
+    AL_RUN(conv_bn(h->raw, 32, 32, 9, h->x_b2c2, h->b2c2, h->act, 32, H2, W2, 3, 1, 0));
+    AL_RUN(apply(h->act, 1, h->idn, h->x2, H2 * W2, 32));
+  } else {
+    AL_RUN(apply(h->raw, 0, nullptr, h->act, H2 * W2, 32));
+    AL_RUN(conv_bn(h->act, 32, 32, 9, h->x_b2c2, h->b2c2, h->raw, 32, H2, W2, 3, 1, -1));
+    AL_RUN(apply(h->raw, 1, h->idn, h->x2, H2 * W2, 32));
+  }
   // block3 / block4 (ResBlock with DeformableConv2d, ALN:274-330)
   auto dcn_block = [&](const float* x, int Hh, int Ww, int ci, int co, const float* o1w, const float* o1b, const float* r1,
-                       const float* o2w, const float* o2b, const float* r2, const float* dsw, const float* dsb, int bni, float* dst) -> int {
+                       const float* o2w, const float* o2b, const float* r2, const float* dsw, const float* dsb, int bni, float* dst,
+                       const SplitWeights& xr1, const SplitWeights& xr2, const SplitWeights& xds) -> int {
     const float lim = (float)(Hh > Ww ? Hh : Ww) / 4.0f;
     int rc;
     if ((rc = launch_al_conv3x3(x, ci, o1w, o1b, h->off, 18, batch, Hh, Ww, AL_ACT_NONE, 0, 0, Hh, Ww, s))) return rc;
     if ((rc = launch_al_clamp(h->off, (size_t)batch * Hh * Ww * 18, lim, s))) return rc;
-    if ((rc = launch_al_deform_conv(x, ci, h->off, 18, r1, h->cols, h->raw, co, batch, Hh, Ww, s))) return rc;
+    if ((rc = launch_al_deform_conv(x, ci, h->off, 18, r1, x3 ? &xr1 : nullptr, sat_al, h->cols, h->raw, co, batch, Hh, Ww, s))) return rc;
     if ((rc = bn(h->raw, Hh * Ww, co, bni, nullptr, h->act))) return rc;
     if ((rc = launch_al_conv3x3(h->act, co, o2w, o2b, h->off, 18, batch, Hh, Ww, AL_ACT_NONE, 0, 0, Hh, Ww, s))) return rc;
     if ((rc = launch_al_clamp(h->off, (size_t)batch * Hh * Ww * 18, lim, s))) return rc;
-    if ((rc = launch_al_deform_conv(h->act, co, h->off, 18, r2, h->cols, h->raw, co, batch, Hh, Ww, s))) return rc;
-    if ((rc = conv1x1(x, ci, dsw, dsb, h->idn, co, batch * Hh * Ww, AL_ACT_NONE))) return rc;
+    if ((rc = launch_al_deform_conv(h->act, co, h->off, 18, r2, x3 ? &xr2 : nullptr, sat_al, h->cols, h->raw, co, batch, Hh, Ww, s))) return rc;
+    if ((rc = conv1x1(x, ci, dsw, xds, dsb, h->idn, co, batch * Hh * Ww, AL_ACT_NONE))) return rc;
     return bn(h->raw, Hh * Ww, co, bni + 1, h->idn, dst);
   };
   AL_RUN(launch_al_avgpool(h->x2, h->p3, batch, H2, W2, 32, 4, s));
-  AL_RUN(dcn_block(h->p3, H8, W8, 32, 64, h->b3o1_w, h->b3o1_b, h->b3r1, h->b3o2_w, h->b3o2_b, h->b3r2, h->b3ds_w, h->b3ds_b, 4, h->x3));
+  AL_RUN(dcn_block(h->p3, H8, W8, 32, 64, h->b3o1_w, h->b3o1_b, h->b3r1, h->b3o2_w, h->b3o2_b, h->b3r2, h->b3ds_w, h->b3ds_b, 4, h->x3, h->g_b3r1, h->g_b3r2, h->g_b3ds));
   AL_RUN(launch_al_avgpool(h->x3, h->p4, batch, H8, W8, 64, 4, s));
-  AL_RUN(dcn_block(h->p4, H32, W32, 64, 128, h->b4o1_w, h->b4o1_b, h->b4r1, h->b4o2_w, h->b4o2_b, h->b4r2, h->b4ds_w, h->b4ds_b, 6, h->x4));
+  AL_RUN(dcn_block(h->p4, H32, W32, 64, 128, h->b4o1_w, h->b4o1_b, h->b4r1, h->b4o2_w, h->b4o2_b, h->b4r2, h->b4ds_w, h->b4ds_b, 6, h->x4, h->g_b4r1, h->g_b4r2, h->g_b4ds));
   // feature aggregation + score head (ALN:656-669)
-  AL_RUN(conv1x1(h->x2, 32, h->hc2, nullptr, h->f2, 32, batch * H2 * W2, AL_ACT_SELU));
-  AL_RUN(conv1x1(h->x3, 64, h->hc3, nullptr, h->f3, 32, batch * H8 * W8, AL_ACT_SELU));
-  AL_RUN(conv1x1(h->x4, 128, h->hc4, nullptr, h->f4, 32, batch * H32 * W32, AL_ACT_SELU));
-  AL_RUN(launch_al_assemble(h->x1, h->f2, h->f3, h->f4, h->hc1, h->sh0, nullptr, h->s8, batch, Hp, Wp, s));  // s8 only; x1234 stays virtual
+  AL_RUN(conv1x1(h->x2, 32, h->hc2, h->g_hc2, nullptr, h->f2, 32, batch * H2 * W2, AL_ACT_SELU));
+  AL_RUN(conv1x1(h->x3, 64, h->hc3, h->g_hc3, nullptr, h->f3, 32, batch * H8 * W8, AL_ACT_SELU));
+  AL_RUN(conv1x1(h->x4, 128, h->hc4, h->g_hc4, nullptr, h->f4, 32, batch * H32 * W32, AL_ACT_SELU));
+  // s8 only; x1234 stays virtual.  The 32 -> 8 projections of the three up-sampled groups run at the maps' own resolutions
+  AL_RUN(launch_al_conv1x1(h->f2, 32, h->sh0 + 32 * 8, nullptr, h->q2, 8, batch * H2 * W2, AL_ACT_NONE, s));
+  AL_RUN(launch_al_conv1x1(h->f3, 32, h->sh0 + 64 * 8, nullptr, h->q3, 8, batch * H8 * W8, AL_ACT_NONE, s));
+  AL_RUN(launch_al_conv1x1(h->f4, 32, h->sh0 + 96 * 8, nullptr, h->q4, 8, batch * H32 * W32, AL_ACT_NONE, s));
+  AL_RUN(launch_al_assemble_proj(h->x1, h->q2, h->q3, h->q4, h->hc1, h->sh0, h->s8, batch, Hp, Wp, s));
   const AlFeat F{h->x1, h->f2, h->f3, h->f4, h->hc1, Hp, Wp};
   AL_RUN(launch_al_conv3x3(h->s8, 8, h->sh2, nullptr, h->s4a, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));
   AL_RUN(launch_al_conv3x3(h->s4a, 4, h->sh4, nullptr, h->s4b, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));
@@ -225,7 +322,7 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     GemmArgs g;
     g.A0 = h->patches; g.lda0 = 1152; g.strideA0 = (long long)cap * 1152; g.B = h->dh_o0_w; g.ldb = 32; g.bias = h->dh_o0_b;
     g.C = h->hidden; g.ldc = 32; g.strideC = (long long)cap * 32; g.M = cap; g.N = 32; g.K = 1152; g.rows = n_kpts_dev;
-    AL_RUN(launch_gemm(g, batch, s));
+    AL_RUN(gemm(g, h->g_o0, batch));
   }
   AL_RUN(launch_al_sddh_sample(F, h->kpts_norm, n_kpts_dev, h->hidden, h->dh_o2_w, h->dh_o2_b, h->feats, batch, H, W, pad_t, pad_l, cap, s));
   {
@@ -233,13 +330,13 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     g.A0 = h->feats; g.lda0 = 128; g.strideA0 = (long long)cap * 2048; g.B = h->dh_sf; g.ldb = 128;
     g.C = h->feats2; g.ldc = 128; g.strideC = (long long)cap * 2048; g.M = cap * 16; g.N = 128; g.K = 128;
     g.rows = n_kpts_dev; g.rows_scale = 16; g.relu = 2;
-    AL_RUN(launch_gemm(g, batch, s));
+    AL_RUN(gemm(g, h->g_sf, batch));
   }
   {
     GemmArgs g;  // einsum("ncp,pcd->nd") with agg_weights [p][c][d] == [n][p*128+c] x [p*128+c][d]
     g.A0 = h->feats2; g.lda0 = 2048; g.strideA0 = (long long)cap * 2048; g.B = h->dh_agg; g.ldb = 128;
     g.C = desc_dev; g.ldc = 128; g.strideC = (long long)cap * 128; g.M = cap; g.N = 128; g.K = 2048; g.rows = n_kpts_dev;
-    AL_RUN(launch_gemm(g, batch, s));
+    AL_RUN(gemm(g, h->g_agg, batch));
   }
   AL_RUN(launch_al_normalize_rows(desc_dev, n_kpts_dev, batch, cap, 128, s));
 #undef AL_RUN

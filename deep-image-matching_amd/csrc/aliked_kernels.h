@@ -19,12 +19,16 @@ int launch_al_bn_stats(const float* x, int batch, int n_pixels, int C, const flo
 int launch_al_bn_apply(const float* x, const float* alpha, const float* beta, const float* residual, float* out, int batch,
                        int n_pixels, int C, hipStream_t s);
 // deformable 3x3 conv (ALN:274-330): offsets [b][H][W][off_c>=18] (dy,dx per tap, already clamped), no bias
-int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, float* cols, float* out, int cout,
-                          int batch, int H, int W, hipStream_t s);
+// wx != nullptr: the [9 cin][cout] product runs as fp16x3 on gemm_x6 (range guard counter `sat`), else as fp32 MFMA
+int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, const SplitWeights* wx, unsigned* sat,
+                          float* cols, float* out, int cout, int batch, int H, int W, hipStream_t s);
 int launch_al_clamp(float* x, size_t n, float lim, hipStream_t s);
 // feature aggregation + first score-head layer (ALN:657-668)
 int launch_al_assemble(const float* x1, const float* f2, const float* f3, const float* f4, const float* w1, const float* ws0,
                        float* x1234, float* s8, int batch, int Hp, int Wp, hipStream_t s);
+// the product form of the same stage: q_g = f_g x score_head.0[32g:32g+32] at the maps' own resolutions (8 channels), interpolated
+int launch_al_assemble_proj(const float* x1, const float* q2, const float* q3, const float* q4, const float* w1, const float* ws0, float* s8,
+                            int batch, int Hp, int Wp, hipStream_t s);
 // DKD sub-pixel refinement (ALN:176-216) and SDDH pieces (ALN:503-558)
 int launch_al_dkd_refine(const float* score, const float* kpts_px, const int* n_kpts, float* kpts_norm, float* disp,
                          float* kscore, float* kpts_out, int batch, int H, int W, int capacity, int radius, hipStream_t s);
@@ -37,3 +41,14 @@ int launch_al_sddh_sample(const AlFeat& F, const float* kpts_norm, const int* n_
 int launch_al_normalize_rows(float* x, const int* n_rows, int batch, int capacity, int C, hipStream_t s);
 int launch_al_mean(const float* x, int batch, int n, double* partial, float* mean, hipStream_t s);
 int launch_al_pick_threshold(const int* ncand, const float* mean, float thr, float* thr_out, int batch, hipStream_t s);
+
+// ---- fp16x3 matrix-core path of the small-channel convolutions (aliked_x3.hip) ----
+// weights: split_weights(K = taps * cin_pad, N = cout, n_pad = 32, mode 2).  partial (optional): fp64 (sum, sum of squares) per
+// (image, workgroup, output channel) for the train-mode BatchNorm that follows; *n_wg_out = workgroups per image.
+size_t al_convx3_partial_doubles(int batch, int H, int W);
+// in_alpha / in_beta (optional, [batch][in_c]): the input is the RAW output of the previous convolution and selu(x * alpha + beta) —
+// its BatchNorm + activation — is applied while the tile is staged (no separate bn_apply pass over the map).
+int launch_al_convx3(const float* in, int in_c, int cin_pad, int taps, const SplitWeights& w, const float* bias, float* out, int cout,
+                     int batch, int H, int W, double* partial, int* n_wg_out, const float* in_alpha, const float* in_beta, hipStream_t s);
+int launch_al_bn_final_tiles(const double* partial, int n_wg, int batch, int n_pixels, int C, const float* gamma, const float* beta_w,
+                             float* alpha, float* beta, hipStream_t s);

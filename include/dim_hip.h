@@ -77,6 +77,7 @@ enum {
   DIM_SAT_LG_FFN,         /* ffn.0 output after LayerNorm+GELU */
   DIM_SAT_LG_DESC,        /* residual stream after ffn.3 */
   DIM_SAT_OP,             /* operator-level entry points (dim_op_*_x6) */
+  DIM_SAT_ALIKED,         /* ALIKED: inputs of the split-precision convolutions / GEMMs (image, BatchNorm+SELU outputs, SDDH samples) */
   DIM_SAT_SITES = 16
 };
 int dim_saturation_read(unsigned* counts_host, unsigned long long* total, int reset, void* stream);

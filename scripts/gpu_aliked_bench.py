@@ -1,6 +1,8 @@
 import importlib, sys, os, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-al=importlib.import_module('deep-image-matching_amd.aliked_hip'); weights=importlib.import_module('deep-image-matching_amd.weights')
+al=importlib.import_module('deep-image-matching_amd.aliked_hip'); weights=importlib.import_module('deep-image-matching_amd.weights'); capi=importlib.import_module('deep-image-matching_amd.capi')
+for a in sys.argv[1:]:   # KEY=VALUE -> dim_tune_set (e.g. 9=0: no BatchNorm folding; 1=0: the fp32 paths)
+    if '=' in a and a.split('=')[0].isdigit(): capi.load().dim_tune_set(int(a.split('=')[0]), int(a.split('=')[1]))
 cfg={"model_name":"aliked-n16rot","max_num_keypoints":4000,"detection_threshold":0.2,"nms_radius":2}
 res={}
 for (B,H,W) in ((1,1024,1024),(8,1024,1024),(4,1000,1500)):

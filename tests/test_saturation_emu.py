@@ -89,3 +89,41 @@ def test_weight_scales_are_per_output_channel(emu_lib):
     scale = (A.double().abs() @ Wt.double().abs())
     rel = ((C.double() - ref).abs() / scale).max().item()
     assert rel < 4e-7, rel
+
+
+def test_aliked_range_guard_and_the_three_arithmetics(emu_lib):
+    """ALIKED's full- / half-resolution convolutions and GEMMs run as fp16x3 on the matrix cores (aliked_x3.hip, gemm_x6.hip) under
+    the default arithmetic: (a) a benign image leaves the guard silent and equals the oracle; (b) the SAME network through the
+    fp32 VALU / fp32-MFMA paths (dim_tune_set(1, 0)) gives the same keypoints — the two implementations check each other;
+    (c) an image 5000x out of range trips DIM_SAT_ALIKED and the guarded call comes back correct through the fp32 paths."""
+    from oracle import aliked_ref
+    from tests import golden_cases as gc
+    from tests.test_aliked_emu import compare_aliked
+    al_mod = importlib.import_module("deep-image-matching_amd.aliked_hip")
+    case = gc.AL_CASES["rgb_pad"]
+    sd, img = gc.al_weights(case), gc.al_image(case)
+    net = al_mod.AlikedHIP(sd, case["cfg"], max_batch=1, max_hw=(case["H"], case["W"]), capacity=4096, device="cpu", lib=emu_lib)
+    hwc = img[0].permute(1, 2, 0).contiguous()[None]
+    capi.saturation(emu_lib, None, reset=True)
+    kp, sc, de, n = net.extract_batch(hwc)
+    total, sites = capi.saturation(emu_lib, None, reset=True)
+    assert total == 0, sites
+    ref = aliked_ref.aliked_forward(img, sd, case["cfg"])
+    k = int(n[0])
+    compare_aliked({"keypoints": kp[0, :k], "scores": sc[0, :k], "descriptors": de[0, :k].t()}, ref)
+    prev = capi.set_arithmetic(emu_lib, 0)
+    try:
+        kp0, sc0, de0, n0 = net.extract_batch(hwc)
+    finally:
+        capi.set_arithmetic(emu_lib, prev)
+    k0 = int(n0[0])
+    compare_aliked({"keypoints": kp0[0, :k0], "scores": sc0[0, :k0], "descriptors": de0[0, :k0].t()}, ref)
+    assert k0 == k and (de0[0, :k] - de[0, :k]).abs().max().item() < 1e-4 and not torch.equal(de0[0, :k], de[0, :k])   # two different code paths
+    big = img * 5000.0                                  # |image| > 4094: outside the exact range of the fp16 split
+    net.extract_batch(big[0].permute(1, 2, 0).contiguous()[None])
+    total, sites = capi.saturation(emu_lib, None, reset=True)
+    assert total > 0 and "aliked" in sites
+    out = {k_: v.cpu() for k_, v in net(big).items()}   # guarded: repeated on the fp32 paths
+    assert capi.get_arithmetic(emu_lib) == 2
+    # train-mode BatchNorm makes the network (nearly) invariant to the input scale: same oracle call on the scaled image
+    compare_aliked(out, aliked_ref.aliked_forward(big, sd, case["cfg"]))
