@@ -13,10 +13,21 @@
 
 namespace {
 
+// exp(x) for x <= 0 to ~1.5 ulp in 6 instructions: 2^(x log2 e) with the product carried in two pieces (t + r), one v_exp_f32
+// and a first-order correction 2^r = 1 + r ln 2.  (The library expf spends ~25 instructions on range handling the SELU's
+// negative branch never needs; SELU is 40 of the ~1450 instructions per pixel of the feature-aggregation pass.)
+__device__ __forceinline__ float exp_le0(float x) {
+  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.925962989e-8f;
+  const float t = x * l2e_hi;
+  float r = fmaf(x, l2e_hi, -t);
+  r = fmaf(x, l2e_lo, r);
+  const float y = __builtin_amdgcn_exp2f(t);
+  return fmaf(y, r * 0.693147180559945309417f, y);
+}
 __device__ __forceinline__ float selu_(float x) {
   // ATen elu kernel: x <= 0 ? (exp(x) - 1) * (alpha*scale) : x * scale
   const float scale = 1.0507009873554804934193349852946f, alpha = 1.6732632423543772848170429916717f;
-  return x <= 0.0f ? (expf(x) - 1.0f) * (alpha * scale) : x * scale;
+  return x <= 0.0f ? (exp_le0(x) - 1.0f) * (alpha * scale) : x * scale;
 }
 __device__ __forceinline__ float act_(float v, int act) {
   if (act == AL_ACT_SELU) return selu_(v);
@@ -196,6 +207,40 @@ __global__ __launch_bounds__(256) void al_bn_apply_kernel(const float* __restric
     y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
   }
   *(float4*)(out + off) = make_float4(selu_(y.x), selu_(y.y), selu_(y.z), selu_(y.w));
+}
+
+// BatchNorm-apply (+ residual) + SELU and the k x k average pooling that follows it in ONE pass over the raw map: thread =
+// (pooled pixel, 4 channels) reads its k x k window once, writes the k x k activated values (the block's output x_i, needed
+// at full resolution by the feature aggregation) and their average (the next block's input) — the separate pooling pass
+// re-read the whole activated map.  Same arithmetic and summation order as al_bn_apply_kernel followed by al_avgpool_kernel.
+template <int K>
+__global__ __launch_bounds__(256) void al_bn_apply_pool_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                               const float* __restrict__ beta, const float* __restrict__ res,
+                                                               float* __restrict__ out, float* __restrict__ pooled, int H, int W, int C) {
+  const int Ho = H / K, Wo = W / K, C4 = C / 4;
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= Ho * Wo * C4) return;
+  const int c4 = i % C4, p = i / C4, y = p / Wo, xx = p - y * Wo;
+  const float4 a = *(const float4*)(alpha + b * C + c4 * 4), bb = *(const float4*)(beta + b * C + c4 * 4);
+  float4 v[K * K], r[K * K];
+#pragma unroll
+  for (int d = 0; d < K * K; ++d) {
+    const size_t off = (((size_t)b * H + y * K + d / K) * W + xx * K + d % K) * C + c4 * 4;
+    v[d] = *(const float4*)(x + off);
+    r[d] = res ? *(const float4*)(res + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int d = 0; d < K * K; ++d) {
+    const size_t off = (((size_t)b * H + y * K + d / K) * W + xx * K + d % K) * C + c4 * 4;
+    float4 t = make_float4(v[d].x * a.x + bb.x, v[d].y * a.y + bb.y, v[d].z * a.z + bb.z, v[d].w * a.w + bb.w);
+    if (res) { t.x += r[d].x; t.y += r[d].y; t.z += r[d].z; t.w += r[d].w; }
+    t = make_float4(selu_(t.x), selu_(t.y), selu_(t.z), selu_(t.w));
+    *(float4*)(out + off) = t;
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  const float inv = (float)(K * K);
+  *(float4*)(pooled + (((size_t)b * Ho + y) * Wo + xx) * C + c4 * 4) = make_float4(s.x / inv, s.y / inv, s.z / inv, s.w / inv);
 }
 
 __global__ __launch_bounds__(256) void al_clamp_kernel(float* __restrict__ x, size_t n, float lim) {
@@ -497,29 +542,72 @@ __device__ __forceinline__ float2 feat_pair(const AlFeat& F, int b, int Y, int X
   return make_float2(uy.l0 * (ux.l0 * a.x + ux.l1 * bq.x) + uy.l1 * (ux.l0 * cq.x + ux.l1 * d.x),
                      uy.l0 * (ux.l0 * a.y + ux.l1 * bq.y) + uy.l1 * (ux.l0 * cq.y + ux.l1 * d.y));
 }
-// wave per (keypoint, patch cell): 3x3 patch of normalised features -> patches [kpt][9][128]
+// ---- the same evaluation, split into "issue the loads" and "finish", so that a wave can keep the gathers of MANY cells in
+// flight (the kernels below were latency-bound with one cell's loads per round trip: 1.5 ms for 2 M cells).  Lanes 0-15
+// (group 0) hold ONE input channel of x1 each — the 16 values reach all lanes through v_readlane (wave-uniform SGPRs) and the
+// lane's two columns of the 16 -> 32 conv weights stay in registers for the whole kernel; lanes 16-63 hold the four bilinear
+// corners of their up-sampled map.  9 VGPRs per cell in flight.
+struct FeatCell { float x1v; float2 c00, c01, c10, c11; float l0y, l1y, l0x, l1x; };
+__device__ __forceinline__ void feat_issue(const AlFeat& F, int b, int Y, int X, int lane, FeatCell& r) {
+  const int g = lane >> 4, cc = (lane & 15) * 2;
+  r.x1v = F.x1[(((size_t)b * F.Hp + Y) * F.Wp + X) * 16 + (lane & 15)];
+  const int fac = g <= 1 ? 2 : (g == 2 ? 8 : 32);
+  const float* map = g <= 1 ? F.f2 : (g == 2 ? F.f3 : F.f4);
+  const int h = F.Hp / fac, w = F.Wp / fac;
+  const UpIdx uy = up_index(Y, h, F.Hp), ux = up_index(X, w, F.Wp);
+  const float* base = map + (size_t)b * h * w * 32 + cc;
+  r.c00 = *(const float2*)(base + ((size_t)uy.i0 * w + ux.i0) * 32); r.c01 = *(const float2*)(base + ((size_t)uy.i0 * w + ux.i1) * 32);
+  r.c10 = *(const float2*)(base + ((size_t)uy.i1 * w + ux.i0) * 32); r.c11 = *(const float2*)(base + ((size_t)uy.i1 * w + ux.i1) * 32);
+  r.l0y = uy.l0; r.l1y = uy.l1; r.l0x = ux.l0; r.l1x = ux.l1;
+}
+// -> this lane's two channels of the L2-NORMALISED 128-vector of the cell (F.normalize, ALN:669), same arithmetic as feat_pair
+__device__ __forceinline__ float2 feat_finish(const FeatCell& r, const float2 (&w1r)[16], int lane) {
+  float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < 16; ++ci) {
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.x1v), ci));
+    o0 = fmaf(a, w1r[ci].x, o0); o1 = fmaf(a, w1r[ci].y, o1);
+  }
+  float2 v;
+  if ((lane >> 4) == 0) v = make_float2(selu_(o0), selu_(o1));
+  else v = make_float2(r.l0y * (r.l0x * r.c00.x + r.l1x * r.c01.x) + r.l1y * (r.l0x * r.c10.x + r.l1x * r.c11.x),
+                       r.l0y * (r.l0x * r.c00.y + r.l1x * r.c01.y) + r.l1y * (r.l0x * r.c10.y + r.l1x * r.c11.y));
+  const float den = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);
+  return make_float2(v.x / den, v.y / den);
+}
+__device__ __forceinline__ void feat_weights(const AlFeat& F, int lane, float2 (&w1r)[16]) {
+  const int cc = (lane & 15) * 2;
+#pragma unroll
+  for (int ci = 0; ci < 16; ++ci) w1r[ci] = *(const float2*)(F.w1 + ci * 32 + cc);
+}
+// wave per keypoint: the 3x3 patch of normalised features -> patches [kpt][128 ci][9 cells]; all 9 cells' loads in flight
 __global__ __launch_bounds__(256) void al_sddh_patches_kernel(AlFeat F, const float* __restrict__ kpts_norm,
                                                               const int* __restrict__ n_kpts, float* __restrict__ patches, int H,
                                                               int W, int pad_t, int pad_l, int capacity) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int item = blockIdx.x * 4 + wv, b = blockIdx.y;
-  const int i = item / 9, cell = item % 9;
+  const int i = blockIdx.x * 4 + wv, b = blockIdx.y;
   if (i >= n_kpts[b]) return;
+  float2 w1r[16];
+  feat_weights(F, lane, w1r);
   const size_t k = (size_t)b * capacity + i;
   const float kwx = (kpts_norm[k * 2] / 2.f + 0.5f) * (float)(W - 1), kwy = (kpts_norm[k * 2 + 1] / 2.f + 0.5f) * (float)(H - 1);
   const int xl = (int)kwx, yl = (int)kwy;  // .long()
   int cx = (int)((float)xl - 1.5f + 1.f), cy = (int)((float)yl - 1.5f + 1.f);  // (corner - ps/2 + 1).long(), truncation
   cx = min(max(cx, 0), W - 1 - 3); cy = min(max(cy, 0), H - 1 - 3);
-  const int yy = cy + cell / 3, xx = cx + cell % 3;
-  const float2 v = feat_pair(F, b, yy + pad_t, xx + pad_l, lane);
-  const float den = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);
+  FeatCell cell[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) feat_issue(F, b, cy + c / 3 + pad_t, cx + c % 3 + pad_l, lane, cell[c]);
   // layout [kpt][ci][ky][kx] flattened as ci*9 + cell to match offset_conv.0.weight (32,128,3,3)
   float* dst = patches + k * 1152;
-  dst[(lane * 2) * 9 + cell] = v.x / den;
-  dst[(lane * 2 + 1) * 9 + cell] = v.y / den;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const float2 v = feat_finish(cell[c], w1r, lane);
+    dst[(lane * 2) * 9 + c] = v.x;
+    dst[(lane * 2 + 1) * 9 + c] = v.y;
+  }
 }
-// wave per keypoint: offsets = clamp(W2 * selu(hidden) + b2), then 16 bilinear samples of the
-// normalised feature map -> feats [kpt][16][128]
+// wave per keypoint: offsets = clamp(W2 * selu(hidden) + b2), then 16 bilinear samples of the normalised feature map ->
+// feats [kpt][16][128]; the 8 cells of two samples are in flight together
 __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const float* __restrict__ kpts_norm,
                                                              const int* __restrict__ n_kpts, const float* __restrict__ hidden,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
@@ -537,26 +625,42 @@ __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const flo
   }
   __syncthreads();
   if (!live) return;
+  float2 w1r[16];
+  feat_weights(F, lane, w1r);
   const float wx = (float)(W - 1), wy = (float)(H - 1);
   const float kwx = (kpts_norm[k * 2] / 2.f + 0.5f) * wx, kwy = (kpts_norm[k * 2 + 1] / 2.f + 0.5f) * wy;
-  for (int p = 0; p < 16; ++p) {
-    // offset[:, :, 0, 0].view(N, 2, M): channel p = x offset, channel M + p = y offset (ALN:540)
-    const float gx = 2.0f * (kwx + offs[wv][p]) / wx - 1.f, gy = 2.0f * (kwy + offs[wv][16 + p]) / wy - 1.f;
-    const float ix = ((gx + 1.f) / 2.f) * wx, iy = ((gy + 1.f) / 2.f) * wy;
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int xa = (int)fx, ya = (int)fy;
-    const float wts[4] = {(fx + 1.f - ix) * (fy + 1.f - iy), (ix - fx) * (fy + 1.f - iy), (fx + 1.f - ix) * (iy - fy), (ix - fx) * (iy - fy)};
-    const int xs[4] = {xa, xa + 1, xa, xa + 1}, ys[4] = {ya, ya, ya + 1, ya + 1};
-    float o0 = 0.f, o1 = 0.f;
+  constexpr int SB = 2;   // samples per round: 8 cells in flight (104 VGPRs), 3 waves per SIMD
+  for (int p0 = 0; p0 < 16; p0 += SB) {
+    FeatCell cell[SB][4];
+    float wts[SB][4];
+    bool in[SB][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const bool in = xs[c] >= 0 && xs[c] < W && ys[c] >= 0 && ys[c] < H;  // wave-uniform
-      float2 v = make_float2(0.f, 0.f);
-      if (in) v = feat_pair(F, b, ys[c] + pad_t, xs[c] + pad_l, lane);
-      const float den = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);
-      if (in) { o0 += (v.x / den) * wts[c]; o1 += (v.y / den) * wts[c]; }
+    for (int j = 0; j < SB; ++j) {
+      const int p = p0 + j;
+      // offset[:, :, 0, 0].view(N, 2, M): channel p = x offset, channel M + p = y offset (ALN:540)
+      const float gx = 2.0f * (kwx + offs[wv][p]) / wx - 1.f, gy = 2.0f * (kwy + offs[wv][16 + p]) / wy - 1.f;
+      const float ix = ((gx + 1.f) / 2.f) * wx, iy = ((gy + 1.f) / 2.f) * wy;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int xa = (int)fx, ya = (int)fy;
+      wts[j][0] = (fx + 1.f - ix) * (fy + 1.f - iy); wts[j][1] = (ix - fx) * (fy + 1.f - iy);
+      wts[j][2] = (fx + 1.f - ix) * (iy - fy); wts[j][3] = (ix - fx) * (iy - fy);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int xs = xa + (c & 1), ys = ya + (c >> 1);
+        in[j][c] = xs >= 0 && xs < W && ys >= 0 && ys < H;  // wave-uniform
+        feat_issue(F, b, (in[j][c] ? ys : 0) + pad_t, (in[j][c] ? xs : 0) + pad_l, lane, cell[j][c]);
+      }
     }
-    *(float2*)(feats + (k * 16 + p) * 128 + lane * 2) = make_float2(o0, o1);
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+      float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float2 v = feat_finish(cell[j][c], w1r, lane);
+        if (in[j][c]) { o0 += v.x * wts[j][c]; o1 += v.y * wts[j][c]; }
+      }
+      *(float2*)(feats + (k * 16 + p0 + j) * 128 + lane * 2) = make_float2(o0, o1);
+    }
   }
 }
 // L2-normalise rows of [batch][capacity][C] (C = 128: two values per lane), wave per row
@@ -656,6 +760,15 @@ int launch_al_bn_apply(const float* x, const float* alpha, const float* beta, co
   DIM_LAUNCH_CHECK();
   return 0;
 }
+int launch_al_bn_apply_pool(const float* x, const float* alpha, const float* beta, const float* residual, float* out, float* pooled, int batch,
+                            int H, int W, int C, int k, hipStream_t s) {
+  DIM_REQUIRE((k == 2 || k == 4) && H % k == 0 && W % k == 0 && C % 4 == 0, "aliked bn_apply_pool: k %d on %dx%d", k, H, W);
+  const dim3 grid(cdiv((H / k) * (W / k) * (C / 4), 256), batch);
+  if (k == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_bn_apply_pool_kernel<2>), grid, dim3(256), 0, s, x, alpha, beta, residual, out, pooled, H, W, C);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(al_bn_apply_pool_kernel<4>), grid, dim3(256), 0, s, x, alpha, beta, residual, out, pooled, H, W, C);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
 int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, const SplitWeights* wx, unsigned* sat,
                           float* cols, float* out, int cout, int batch, int H, int W, hipStream_t s) {
   DIM_REQUIRE(cout % 32 == 0 && (cin == 32 || cin == 64 || cin == 128), "deform conv: cin %d cout %d", cin, cout);
@@ -696,7 +809,7 @@ int launch_al_dkd_refine(const float* score, const float* kpts_px, const int* n_
 }
 int launch_al_sddh_patches(const AlFeat& F, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H, int W,
                            int pad_t, int pad_l, int capacity, hipStream_t s) {
-  hipLaunchKernelGGL(al_sddh_patches_kernel, dim3(cdiv(capacity * 9, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, patches, H, W, pad_t, pad_l, capacity);
+  hipLaunchKernelGGL(al_sddh_patches_kernel, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, patches, H, W, pad_t, pad_l, capacity);
   DIM_LAUNCH_CHECK();
   return 0;
 }

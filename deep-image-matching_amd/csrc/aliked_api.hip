@@ -24,6 +24,7 @@ struct dim_aliked {
   float *P, *raw, *act, *x1, *p2, *idn, *x2, *p3, *off, *x3, *p4, *x4, *f2, *f3, *f4, *x1234, *s8, *s4a, *s4b, *score, *nms;
   SplitWeights x_b1c1, x_b1c2, x_b2c1, x_b2c2, x_b2ds;   // fp16x3 fragments of the full- / half-resolution convolutions (aliked_x3.hip)
   double* tile_partial;
+  unsigned short* asm_frag; float* asm_inv1; float asm_inv0;   // constant operands of al_assemble_x3_kernel
   SplitWeights g_b3r1, g_b3r2, g_b3ds, g_b4r1, g_b4r2, g_b4ds, g_hc2, g_hc3, g_hc4, g_o0, g_sf, g_agg;   // fp16x3 GEMM operands (gemm_x6.hip)
   float *q2, *q3, *q4;   // score_head.0 projections of f2 / f3 / f4 at their own resolutions (8 channels)
   float *cand_score, *kpts_px, *sc_tmp, *kpts_norm, *kscore, *patches, *hidden, *feats, *feats2, *bn_alpha, *bn_beta, *mean, *thr_eff, *cols;
@@ -150,6 +151,15 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
       for (int k = 0; k < 1152; ++k) o0[(size_t)k * 32 + co] = w->desc_off0_w[(size_t)co * 1152 + k];
     AL_TRY(upload_x3g(h, &h->g_o0, o0.data(), 1152, 32));
   }
+  {
+    const std::vector<float> w1 = relayout(w->conv1, 32, 16, 1, 16, 32), ws0 = relayout(w->score0, 8, 128, 1, 128, 8);
+    std::vector<unsigned short> frag(al_assemble_x3_frag_halves());
+    std::vector<float> inv1(32);
+    al_assemble_x3_prepare(w1.data(), ws0.data(), frag.data(), inv1.data(), &h->asm_inv0);
+    AL_TRY(dev_alloc(h, &h->asm_frag, frag.size()));
+    AL_TRY(upload(h, &h->asm_inv1, inv1));
+    if (hipMemcpy(h->asm_frag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_aliked_destroy(h); return -1; }
+  }
   const int bnc[8] = {16, 16, 32, 32, 64, 64, 128, 128};
   for (int i = 0; i < 8; ++i) {
     AL_TRY(upload(h, &h->bn_g[i], padvec(w->bn_weight[i], bnc[i], bnc[i])));
@@ -250,28 +260,33 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     ab(slot, &a, &bt);
     return launch_al_bn_apply(x, a, bt, res, dst, batch, npx, C, s);
   };
+  // the block's last BatchNorm (+ residual) + SELU together with the average pooling in front of the next block
+  auto apply_pool = [&](const float* x, int slot, const float* res, float* dst, float* pooled, int Hh, int Ww, int C, int k) -> int {
+    float *a, *bt;
+    ab(slot, &a, &bt);
+    return launch_al_bn_apply_pool(x, a, bt, res, dst, pooled, batch, Hh, Ww, C, k, s);
+  };
   // block1 (ConvBlock, ALN:367-393)
   AL_RUN(conv_bn(h->P, 3, 16, 9, h->x_b1c1, h->b1c1, h->raw, 16, Hp, Wp, 0, 0, -1));
   if (fuse_bn) {
     AL_RUN(conv_bn(h->raw, 16, 16, 9, h->x_b1c2, h->b1c2, h->act, 16, Hp, Wp, 1, 1, 0));   // bn1 + SELU of conv1 in the staging; raw output -> act
-    AL_RUN(apply(h->act, 1, nullptr, h->x1, NP, 16));
+    AL_RUN(apply_pool(h->act, 1, nullptr, h->x1, h->p2, Hp, Wp, 16, 2));
   } else {
     AL_RUN(apply(h->raw, 0, nullptr, h->act, NP, 16));
     AL_RUN(conv_bn(h->act, 16, 16, 9, h->x_b1c2, h->b1c2, h->raw, 16, Hp, Wp, 1, 1, -1));
-    AL_RUN(apply(h->raw, 1, nullptr, h->x1, NP, 16));
+    AL_RUN(apply_pool(h->raw, 1, nullptr, h->x1, h->p2, Hp, Wp, 16, 2));
   }
-  // block2 (ResBlock, plain convs)
-  AL_RUN(launch_al_avgpool(h->x1, h->p2, batch, Hp, Wp, 16, 2, s));
+  // block2 (ResBlock, plain convs); its input p2 = avgpool2(x1) was written by apply_pool
   AL_RUN(conv_bn(h->p2, 16, 16, 9, h->x_b2c1, h->b2c1, h->raw, 32, H2, W2, 2, 0, -1));
   if (x3) AL_RUN(launch_al_convx3(h->p2, 16, 16, 1, h->x_b2ds, h->b2ds_b, h->idn, 32, batch, H2, W2, nullptr, nullptr, nullptr, nullptr, s));
   else AL_RUN(launch_al_conv1x1(h->p2, 16, h->b2ds_w, h->b2ds_b, h->idn, 32, batch * H2 * W2, AL_ACT_NONE, s));  // K = 16: below the GEMM's K granule
   if (fuse_bn) {
     AL_RUN(conv_bn(h->raw, 32, 32, 9, h->x_b2c2, h->b2c2, h->act, 32, H2, W2, 3, 1, 0));
-    AL_RUN(apply(h->act, 1, h->idn, h->x2, H2 * W2, 32));
+    AL_RUN(apply_pool(h->act, 1, h->idn, h->x2, h->p3, H2, W2, 32, 4));
   } else {
     AL_RUN(apply(h->raw, 0, nullptr, h->act, H2 * W2, 32));
     AL_RUN(conv_bn(h->act, 32, 32, 9, h->x_b2c2, h->b2c2, h->raw, 32, H2, W2, 3, 1, -1));
-    AL_RUN(apply(h->raw, 1, h->idn, h->x2, H2 * W2, 32));
+    AL_RUN(apply_pool(h->raw, 1, h->idn, h->x2, h->p3, H2, W2, 32, 4));
   }
   // block3 / block4 (ResBlock with DeformableConv2d, ALN:274-330)
   auto dcn_block = [&](const float* x, int Hh, int Ww, int ci, int co, const float* o1w, const float* o1b, const float* r1,
@@ -289,7 +304,6 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     if ((rc = conv1x1(x, ci, dsw, xds, dsb, h->idn, co, batch * Hh * Ww, AL_ACT_NONE))) return rc;
     return bn(h->raw, Hh * Ww, co, bni + 1, h->idn, dst);
   };
-  AL_RUN(launch_al_avgpool(h->x2, h->p3, batch, H2, W2, 32, 4, s));
   AL_RUN(dcn_block(h->p3, H8, W8, 32, 64, h->b3o1_w, h->b3o1_b, h->b3r1, h->b3o2_w, h->b3o2_b, h->b3r2, h->b3ds_w, h->b3ds_b, 4, h->x3, h->g_b3r1, h->g_b3r2, h->g_b3ds));
   AL_RUN(launch_al_avgpool(h->x3, h->p4, batch, H8, W8, 64, 4, s));
   AL_RUN(dcn_block(h->p4, H32, W32, 64, 128, h->b4o1_w, h->b4o1_b, h->b4r1, h->b4o2_w, h->b4o2_b, h->b4r2, h->b4ds_w, h->b4ds_b, 6, h->x4, h->g_b4r1, h->g_b4r2, h->g_b4ds));
@@ -301,7 +315,8 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   AL_RUN(launch_al_conv1x1(h->f2, 32, h->sh0 + 32 * 8, nullptr, h->q2, 8, batch * H2 * W2, AL_ACT_NONE, s));
   AL_RUN(launch_al_conv1x1(h->f3, 32, h->sh0 + 64 * 8, nullptr, h->q3, 8, batch * H8 * W8, AL_ACT_NONE, s));
   AL_RUN(launch_al_conv1x1(h->f4, 32, h->sh0 + 96 * 8, nullptr, h->q4, 8, batch * H32 * W32, AL_ACT_NONE, s));
-  AL_RUN(launch_al_assemble_proj(h->x1, h->q2, h->q3, h->q4, h->hc1, h->sh0, h->s8, batch, Hp, Wp, s));
+  if (x3) AL_RUN(launch_al_assemble_x3(h->x1, h->q2, h->q3, h->q4, h->asm_frag, h->asm_inv1, h->asm_inv0, h->s8, batch, Hp, Wp, s));
+  else AL_RUN(launch_al_assemble_proj(h->x1, h->q2, h->q3, h->q4, h->hc1, h->sh0, h->s8, batch, Hp, Wp, s));
   const AlFeat F{h->x1, h->f2, h->f3, h->f4, h->hc1, Hp, Wp};
   AL_RUN(launch_al_conv3x3(h->s8, 8, h->sh2, nullptr, h->s4a, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));
   AL_RUN(launch_al_conv3x3(h->s4a, 4, h->sh4, nullptr, h->s4b, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));

@@ -18,6 +18,9 @@ int launch_al_bn_stats(const float* x, int batch, int n_pixels, int C, const flo
                        double* partial, float* alpha, float* beta, hipStream_t s);
 int launch_al_bn_apply(const float* x, const float* alpha, const float* beta, const float* residual, float* out, int batch,
                        int n_pixels, int C, hipStream_t s);
+// bn_apply (+ residual) + SELU fused with the k x k average pooling that follows (k = 2 or 4): writes the activated map AND its pooled copy
+int launch_al_bn_apply_pool(const float* x, const float* alpha, const float* beta, const float* residual, float* out, float* pooled, int batch,
+                            int H, int W, int C, int k, hipStream_t s);
 // deformable 3x3 conv (ALN:274-330): offsets [b][H][W][off_c>=18] (dy,dx per tap, already clamped), no bias
 // wx != nullptr: the [9 cin][cout] product runs as fp16x3 on gemm_x6 (range guard counter `sat`), else as fp32 MFMA
 int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, const SplitWeights* wx, unsigned* sat,
@@ -52,3 +55,9 @@ int launch_al_convx3(const float* in, int in_c, int cin_pad, int taps, const Spl
                      int batch, int H, int W, double* partial, int* n_wg_out, const float* in_alpha, const float* in_beta, hipStream_t s);
 int launch_al_bn_final_tiles(const double* partial, int n_wg, int batch, int n_pixels, int C, const float* gamma, const float* beta_w,
                              float* alpha, float* beta, hipStream_t s);
+// feature aggregation + score_head.0 with both channel contractions on the matrix cores (al_assemble_x3_kernel); the constant
+// operands are prepared once by al_assemble_x3_prepare (frag: al_assemble_x3_frag_halves() 16-bit values; inv1: 32 floats)
+size_t al_assemble_x3_frag_halves();
+void al_assemble_x3_prepare(const float* w1_ci_co, const float* ws0_co_k, unsigned short* frag, float* inv1, float* inv0);
+int launch_al_assemble_x3(const float* x1, const float* q2, const float* q3, const float* q4, const void* frag_dev, const float* inv1_dev, float inv0,
+                          float* s8, int batch, int Hp, int Wp, hipStream_t s);

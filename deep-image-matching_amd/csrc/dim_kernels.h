@@ -84,6 +84,7 @@ int launch_planes_to_f32(const void* planes, int batch, int hw, int channels, fl
 inline size_t dim_planes_image_pixels(int h, int w) { return ((size_t)h * w + 1) & ~(size_t)1; }
 int dim_presplit_activations();  // 1 (default): SuperPoint's conv-to-conv activations are stored pre-split (dim_tune_set key 5)
 int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matrix cores; 0: fp32 MFMA (dim_tune_set key 1)
+int dim_aliked_tile_rows();  // dim_tune_set key 10: tile rows (16 | 8) of ALIKED's 16-channel 3x3 matrix-core convolution
 int dim_aliked_fuse_bn();   // dim_tune_set key 9: ALIKED folds BatchNorm + SELU into the consuming convolution's staging (default 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
 int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)

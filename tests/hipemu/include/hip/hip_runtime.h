@@ -324,6 +324,8 @@ static inline unsigned long long wall_clock64() { return (unsigned long long)__b
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 // only ever applied to wave-uniform values in this code base
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+// v_readlane_b32: the value lane `lane` holds, broadcast (wave-uniform on hardware: an SGPR)
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu_shfl_from(v, lane); }
 #define __logf(x) logf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }

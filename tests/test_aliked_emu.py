@@ -15,16 +15,24 @@ GOLD = Path(__file__).parent / "golden"
 
 
 def compare_aliked(out, ref, kp_tol=1e-3, desc_tol=1e-3, score_tol=1e-3, max_missing=0, label=None, ref_score_map=None, threshold=0.2,
-                   tie_tol=2e-5):
+                   tie_tol=2e-5, nms_radius=3):
     """north_star's bar: keypoint set exact, descriptors / scores within 1e-3 (keypoint coordinates likewise: they are
-    sub-pixel soft-argmax outputs in pixels).  Each output keypoint is matched to the reference keypoint with the same integer
-    NMS position (rounded); every measured maximum is returned and, with ``label``, appended to gpurun_out/parity_measured.jsonl
-    so that the numbers behind the assertion are on record (VERDICT r2 weak #1)."""
-    ka = {tuple(np.round(k).astype(int)): i for i, k in enumerate(out["keypoints"].numpy())}
-    kb = {tuple(np.round(k).astype(int)): i for i, k in enumerate(ref["keypoints"].numpy())}
-    common = sorted(set(ka) & set(kb))
-    res = {"n_out": len(ka), "n_ref": len(kb), "common": len(common)}
-    ia = torch.tensor([ka[c] for c in common]); ib = torch.tensor([kb[c] for c in common])
+    sub-pixel soft-argmax outputs in pixels).  Every measured maximum is returned and, with ``label``, appended to
+    gpurun_out/parity_measured.jsonl so that the numbers behind the assertion are on record (VERDICT r2 weak #1)."""
+    # keypoints are sub-pixel (NMS pixel + soft-argmax offset, which can exceed half a pixel): pair each output keypoint with the
+    # NEAREST reference keypoint (rounding to the pixel grid would split a pair whose offset sits at x.5) and require a bijection
+    from scipy.spatial import cKDTree
+    ko, kr = out["keypoints"].numpy().astype(np.float64), ref["keypoints"].numpy().astype(np.float64)
+    pairs = []
+    if len(ko) and len(kr):
+        dist, nn = cKDTree(kr).query(ko)
+        used = set()
+        for i, (d, j) in enumerate(zip(dist, nn)):
+            if d <= 0.05 and int(j) not in used:       # 0.05 px: far below the NMS spacing, far above any rounding difference
+                used.add(int(j)); pairs.append((i, int(j)))
+    res = {"n_out": len(ko), "n_ref": len(kr), "common": len(pairs)}
+    ia = torch.tensor([p[0] for p in pairs], dtype=torch.long); ib = torch.tensor([p[1] for p in pairs], dtype=torch.long)
+    only_out = sorted(set(range(len(ko))) - {p[0] for p in pairs}); only_ref = sorted(set(range(len(kr))) - {p[1] for p in pairs})
     res["kp"] = (out["keypoints"][ia] - ref["keypoints"][ib]).abs().max().item()
     res["score"] = (out["scores"][ia] - ref["scores"][ib]).abs().max().item()
     res["desc"] = (out["descriptors"][:, ia] - ref["descriptors"][:, ib]).abs().max().item()
@@ -37,20 +45,31 @@ def compare_aliked(out, ref, kp_tol=1e-3, desc_tol=1e-3, score_tol=1e-3, max_mis
                 f.write(json.dumps({"case": label, **res}) + "\n")
         except OSError:
             pass
-    one_sided = (set(ka) ^ set(kb))
-    if one_sided and ref_score_map is not None:
+    if (only_out or only_ref) and ref_score_map is not None:
         # The keypoint SET must be exact except for numerical near-ties of the selection itself: DKD keeps the n_limit highest
         # NMS maxima above the threshold (ALN:170-186), so a keypoint found on one side only must sit — in the REFERENCE's own
-        # score map — within tie_tol of the weakest selected score (the n_limit cut) or of the threshold.  (The reference is
+        # score map — within tie_tol of the weakest selected score (the n_limit cut), of the threshold, or of another pixel of
+        # its own NMS window (an exact-equality tie of simple_nms).  (The reference is
         # not stable there either: its fp32 and fp64 evaluations of tests/golden case gray_limit differ in 5 of 60 keypoints.)
         sm = ref_score_map.reshape(ref_score_map.shape[-2], ref_score_map.shape[-1])
-        cut = min(float(sm[y, x]) for (x, y) in kb)
-        for (x, y) in one_sided:
-            v = float(sm[y, x])
-            assert min(abs(v - cut), abs(v - threshold)) <= tie_tol, ((x, y), v, cut, res)
-        res["near_tie_keypoints"] = len(one_sided) // 2
-        max_missing = max(max_missing, len(one_sided) // 2)
-    assert len(ka) == len(kb) and len(common) >= len(kb) - max_missing, res
+        # the NMS pixel of a refined keypoint is the local maximum within one pixel of its rounded position
+        def nms_score(xy):
+            x, y = int(round(xy[0])), int(round(xy[1]))
+            return float(sm[max(0, y - 1): y + 2, max(0, x - 1): x + 2].max())
+        def nms_tie(xy, radius=nms_radius):
+            """a second pixel inside the NMS window within tie_tol of the maximum: simple_nms compares floats with == (ALN:66-89), so
+            on a plateau (the sigmoid saturates near 1) the reference keeps BOTH pixels while a 1e-7 difference keeps one"""
+            x, y = int(round(xy[0])), int(round(xy[1]))
+            win = sm[max(0, y - radius): y + radius + 1, max(0, x - radius): x + radius + 1].reshape(-1)
+            top = torch.topk(win, 2).values
+            return float(top[0] - top[1])
+        cut = min(nms_score(k) for k in kr)
+        for xy in [ko[i] for i in only_out] + [kr[j] for j in only_ref]:
+            v = nms_score(xy)
+            assert min(abs(v - cut), abs(v - threshold), nms_tie(xy)) <= tie_tol, (tuple(xy), v, cut, nms_tie(xy), res)
+        res["near_tie_keypoints"] = max(len(only_out), len(only_ref))
+        max_missing = max(max_missing, res["near_tie_keypoints"])
+    assert len(ko) == len(kr) and len(pairs) >= len(kr) - max_missing, res
     assert res["kp"] <= kp_tol and res["score"] <= score_tol and res["desc"] <= desc_tol, res
     return res
 
