@@ -13,17 +13,6 @@
 
 namespace {
 
-// exp(x) for x <= 0 to ~1.5 ulp in 6 instructions: 2^(x log2 e) with the product carried in two pieces (t + r), one v_exp_f32
-// and a first-order correction 2^r = 1 + r ln 2.  (The library expf spends ~25 instructions on range handling the SELU's
-// negative branch never needs; SELU is 40 of the ~1450 instructions per pixel of the feature-aggregation pass.)
-__device__ __forceinline__ float exp_le0(float x) {
-  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.925962989e-8f;
-  const float t = x * l2e_hi;
-  float r = fmaf(x, l2e_hi, -t);
-  r = fmaf(x, l2e_lo, r);
-  const float y = __builtin_amdgcn_exp2f(t);
-  return fmaf(y, r * 0.693147180559945309417f, y);
-}
 __device__ __forceinline__ float selu_(float x) {
   // ATen elu kernel: x <= 0 ? (exp(x) - 1) * (alpha*scale) : x * scale
   const float scale = 1.0507009873554804934193349852946f, alpha = 1.6732632423543772848170429916717f;
@@ -572,7 +561,7 @@ __device__ __forceinline__ float2 feat_finish(const FeatCell& r, const float2 (&
   if ((lane >> 4) == 0) v = make_float2(selu_(o0), selu_(o1));
   else v = make_float2(r.l0y * (r.l0x * r.c00.x + r.l1x * r.c01.x) + r.l1y * (r.l0x * r.c10.x + r.l1x * r.c11.x),
                        r.l0y * (r.l0x * r.c00.y + r.l1x * r.c01.y) + r.l1y * (r.l0x * r.c10.y + r.l1x * r.c11.y));
-  const float den = fmaxf(sqrtf(wave_sum(v.x * v.x + v.y * v.y)), 1e-12f);
+  const float den = fmaxf(sqrtf(wave_sum_dpp(v.x * v.x + v.y * v.y)), 1e-12f);   // DPP reduction: no LDS round trips in the gather loop
   return make_float2(v.x / den, v.y / den);
 }
 __device__ __forceinline__ void feat_weights(const AlFeat& F, int lane, float2 (&w1r)[16]) {

@@ -59,6 +59,8 @@ static int g_fold_out_proj = 1;
 int dim_fold_out_proj() { return g_fold_out_proj; }
 static int g_fuse_kv = 1;
 int dim_fuse_kv() { return g_fuse_kv; }
+static int g_fuse_ffn_ln = 1;
+int dim_fuse_ffn_ln() { return g_fuse_ffn_ln; }
 static int g_al_tile_rows = 16;
 int dim_aliked_tile_rows() { return g_al_tile_rows; }
 static int g_al_fuse_bn = 1;
@@ -226,6 +228,7 @@ int dim_tune_set(int key, int value) {
   if (key == 8) g_fuse_kv = value;
   if (key == 9) g_al_fuse_bn = value;
   if (key == 10) g_al_tile_rows = value;
+  if (key == 11) g_fuse_ffn_ln = value;
   return 0;
 }
 

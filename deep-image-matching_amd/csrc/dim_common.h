@@ -99,6 +99,39 @@ template <> struct SplitMma<2> {
   __device__ static __forceinline__ int tb(int t) { const int v[3] = {0, 1, 0}; return v[t]; }
 };
 
+// exp(x) for x <= 0 to ~1.5 ulp in 6 instructions: 2^(x log2 e) with the product carried in two pieces (t + r), one v_exp_f32
+// and a first-order correction 2^r = 1 + r ln 2.  (The library expf spends ~25 instructions on range handling the SELU's
+// negative branch never needs; SELU is 40 of the ~1450 instructions per pixel of the feature-aggregation pass.)
+__device__ __forceinline__ float exp_le0(float x) {
+  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.925962989e-8f;
+  const float t = x * l2e_hi;
+  float r = fmaf(x, l2e_hi, -t);
+  r = fmaf(x, l2e_lo, r);
+  const float y = __builtin_amdgcn_exp2f(t);
+  return fmaf(y, r * 0.693147180559945309417f, y);
+}
+// erf to < 1 ulp without branches (both ranges evaluated, one select): minimax polynomials for |x| <= 0.927734375
+// (x + x p(x^2)) and beyond (1 - exp(q(|x|))), 13 fma + one v_exp_f32.  The library erff costs ~45 instructions per value
+// in divergent branches, which made the LayerNorm + GELU pass instruction-bound (3.3 TB/s) instead of HBM-bound.
+__device__ __forceinline__ float erf_1ulp(float a) {
+  const float t = fabsf(a), s = a * a;
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f), a);
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  return t > 0.927734375f ? big : fmaf(q, a, a);
+}
+
 // row index inside a 32x32 MFMA tile held by (lane-half h, register r)
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -106,6 +139,27 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
+}
+// The same total without the LDS crossbar: __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipe round trip per step, six dependent
+// ones per reduction), DPP moves run at VALU rate.  quad_perm (lane ^ 1, lane ^ 2), row_half_mirror and row_mirror give every
+// lane the sum of its row of 16; the four row totals are wave-uniform values read with v_readlane.  (Different association
+// than wave_sum: use one of the two consistently per quantity.)
+__device__ __forceinline__ float dpp_f(float v, const int ctrl) {
+  switch (ctrl) {
+    case 0xB1: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    case 0x4E: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    case 0x141: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+    default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+  }
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_f(v, 0xB1);
+  v += dpp_f(v, 0x4E);
+  v += dpp_f(v, 0x141);
+  v += dpp_f(v, 0x140);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -49,6 +49,10 @@ struct GemmArgs {
   // (kv_img: [item][4 heads][kv_tiles][KV_TILE_STRIDE x 16 B]), K with the rotary embedding applied when kv_enc != nullptr
   // ([item][kv_nmax][64] cos | sin) — what kv_prep_kernel did in a separate pass over the fp32 projections.
   void* kv_img = nullptr; int kv_tiles = 0, kv_kblock = -1, kv_vblock = -1, kv_nmax = 0; const float* kv_enc = nullptr;
+  // LightGlue ffn.0 (N = 512, fp16x3): when ln_gamma != nullptr the block spans ALL 512 columns of 64 rows and the epilogue applies
+  // LayerNorm(512, eps 1e-5, affine) + erf-GELU (LGN:141-142) before the store — the separate lg_ln_gelu pass (a read and a write
+  // of the 512-wide hidden tensor) disappears.  Needs N == n_pad == 512, no residual, no activation.
+  const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
 };
 constexpr int KV_TILE_STRIDE = 3 * 8 * 32 + 3 * 2 * 2 * 64;  // 16-byte slots reserved per (item, head, 32-key tile) image (bf16x6 fills all 1536)
 bool gemm_x6_fuses_kv(int M, int n_pad, int batch, int split_mode);  // true when launch_gemm_x6 will honour kv_img for this shape
@@ -88,6 +92,7 @@ int dim_aliked_tile_rows();  // dim_tune_set key 10: tile rows (16 | 8) of ALIKE
 int dim_aliked_fuse_bn();   // dim_tune_set key 9: ALIKED folds BatchNorm + SELU into the consuming convolution's staging (default 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
 int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)
+int dim_fuse_ffn_ln();       // 1 (default): LightGlue's LayerNorm + GELU run in the epilogue of ffn.0 (64 x 512 blocks; dim_tune_set key 11)
 int dim_fuse_kv();           // 1 (default): LightGlue's K | V tile images written by the projection GEMM's epilogue (dim_tune_set key 8)
 int dim_nms_big_tiles();     // 1 (default): 64 x 64 NMS tiles on large score maps (dim_tune_set key 7; 2 = forced)
 void dim_nms_set_big_tiles(int v);

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 4) void gemm_mfma_kernel(GemmArgs a) {
         float v = acc[m][n][r] + bv;
         if (R) v += R[(size_t)row * a.ldr + col];
         if (a.relu == 1) v = fmaxf(v, 0.0f);
-        else if (a.relu == 2) v = v <= 0.0f ? (expf(v) - 1.0f) * 1.7580993408473768599402175208123f : v * 1.0507009873554804934193349852946f;
+        else if (a.relu == 2) v = v <= 0.0f ? (exp_le0(v) - 1.0f) * 1.7580993408473768599402175208123f : v * 1.0507009873554804934193349852946f;
         C[(size_t)row * a.ldc + col] = v;
         if (a.sat) vmax = fmaxf(vmax, fabsf(v));
       }

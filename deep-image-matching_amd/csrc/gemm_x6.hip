@@ -45,13 +45,14 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
   constexpr int NPL = S::NPL, NLD = BM / 32;        // float4 loads per thread and chunk
   constexpr int BN = 32 * NT * WN;
-  static_assert(KV == 0 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
+  static_assert(KV == 0 || KV == 3 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
+  static_assert(KV != 3 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4), "the LayerNorm + GELU epilogue exists for the fp16x3 64 x 512 block");
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
   const int m0 = blockIdx.x * BM, n0 = by * BN;
   if (m0 >= rows || n0 >= a.N) return;
-  constexpr bool kblk = KV == 1, vblk = KV == 2;
+  constexpr bool kblk = KV == 1, vblk = KV == 2, lng = KV == 3;
 
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN, lx = lane & 31, half = lane >> 5;
@@ -214,6 +215,90 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     return;
   }
 
+  if (lng) {
+    // ---- LayerNorm(512) + GELU over the block's full rows (LGN:141-142), then the store.  v = acc * inv + bias is
+    // re-evaluated from the accumulators in each of the three passes (one fma) instead of being kept in 128 more registers.
+    // Row statistics: in-lane over the wave's 4 column tiles, DPP over the 16-lane rows, then through LDS (the activation
+    // staging buffer is free after the K loop) over the 4 x 4 sixteen-lane groups that share a block row; mean first, then
+    // the centred sum of squares — the two-pass form lg_ln_gelu_kernel (and ATen) use. ----
+    float* const red = (float*)Ap;                 // [wave 4][lane group 4][32 (m, r)] partials, then [64] row results at +512
+    float bv[NT], iv[NT], gm[NT], bt[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = n0 + wn * (32 * NT) + n * 32 + lx;
+      bv[n] = a.bias[col]; iv[n] = a.inv_ch[col]; gm[n] = a.ln_gamma[col]; bt[n] = a.ln_beta[col];
+    }
+    const int q = lane >> 4;
+    float rowv[MT * 16];
+    auto block_rows = [&](float (&part)[MT * 16], float scale_) {   // part[(m, r)] per lane -> total over the block row, x scale_
+#pragma unroll
+      for (int j = 0; j < MT * 16; ++j) {
+        float v = part[j];
+        v += dpp_f(v, 0xB1); v += dpp_f(v, 0x4E); v += dpp_f(v, 0x141); v += dpp_f(v, 0x140);
+        if ((lane & 15) == 0) red[(wv * 4 + q) * 32 + j] = v;
+      }
+      __syncthreads();
+      if (t < 64) {   // block row t: (m, r, half) with t = 32 m + (r & 3) + 8 (r >> 2) + 4 half
+        const int m = t >> 5, w_ = t & 31, hf = (w_ >> 2) & 1, r = (w_ & 3) + 4 * (w_ >> 3), j = m * 16 + r;
+        float tot = 0.0f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) tot += red[(w4 * 4 + 2 * hf) * 32 + j] + red[(w4 * 4 + 2 * hf + 1) * 32 + j];
+        red[512 + t] = tot * scale_;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[m * 16 + r] = red[512 + m * 32 + mfma_row(r, half)];
+      __syncthreads();
+    };
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sm_ = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) sm_ += acc[m][n][r] * iv[n] + bv[n];
+        rowv[m * 16 + r] = sm_;
+      }
+    block_rows(rowv, 1.0f / 512.0f);               // rowv = mean of the row
+    float sq[MT * 16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s2 = 0.0f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { const float d = (acc[m][n][r] * iv[n] + bv[n]) - rowv[m * 16 + r]; s2 += d * d; }
+        sq[m * 16 + r] = s2;
+      }
+    block_rows(sq, 1.0f / 512.0f);                 // sq = biased variance of the row
+    const dim_rsrc Cr = buf_rsrc(a.C + (size_t)z * a.strideC, ((size_t)(rows - 1) * a.ldc + a.N) * sizeof(float));
+    const unsigned ldc4 = (unsigned)a.ldc * 4u;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const unsigned row0 = (unsigned)(m0 + m * 32 + 4 * half);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float mean = rowv[m * 16 + r], rstd = 1.0f / sqrtf(sq[m * 16 + r] + 1e-5f);
+        const unsigned rb = (row0 + (unsigned)((r & 3) + 8 * (r >> 2))) * ldc4;
+#pragma unroll
+        for (int n = 0; n < NT; n += 2) {
+          float y0 = ((acc[m][n][r] * iv[n] + bv[n]) - mean) * rstd * gm[n] + bt[n];
+          float y1 = ((acc[m][n + 1][r] * iv[n + 1] + bv[n + 1]) - mean) * rstd * gm[n + 1] + bt[n + 1];
+          y0 = 0.5f * y0 * (1.0f + erf_1ulp(y0 * 0.70710678118654752440f));
+          y1 = 0.5f * y1 * (1.0f + erf_1ulp(y1 * 0.70710678118654752440f));
+          vmax = sat_track(vmax, y0, y1);
+          buf_store_f32(Cr, rb + (unsigned)(n0 + wn * (32 * NT) + n * 32 + lx) * 4u, y0);
+          buf_store_f32(Cr, rb + (unsigned)(n0 + wn * (32 * NT) + (n + 1) * 32 + lx) * 4u, y1);
+        }
+      }
+    }
+    sat_report(a.sat, vmax);
+    return;
+  }
+
   // Epilogue through buffer descriptors (dim_common.h): 32-bit offsets, no per-element branches.  The descriptor of C / R
   // ends after the item's last valid row, so rows past the ragged end are dropped (stores) / read as zero (loads) by the
   // hardware; a column past N selects the out-of-range offset.  Per (m, n) tile all 16 residual values are requested
@@ -250,7 +335,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
       } else if (a.relu == 2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = v[r] <= 0.0f ? (expf(v[r]) - 1.0f) * 1.7580993408473768599402175208123f : v[r] * 1.0507009873554804934193349852946f;
+        for (int r = 0; r < 16; ++r) v[r] = v[r] <= 0.0f ? (exp_le0(v[r]) - 1.0f) * 1.7580993408473768599402175208123f : v[r] * 1.0507009873554804934193349852946f;
       }
       // range guard over all 16 values, unconditionally: rows past the ragged end are duplicates of the last valid row
       // (load_chunk clamps) plus a zero residual, padded columns hold the bias of the last valid column
@@ -272,6 +357,11 @@ __global__ __launch_bounds__(256, ((BM / (32 * (4 / WN))) * NT >= 8 ? 2 : 3)) vo
 // transposed K image / V image — three inlined bodies, one register allocation each), so that the 2 or 3 column blocks of
 // a row block run next to each other on the same XCD and the activation rows come from HBM once (as separate launches
 // the three blocks each re-read them: 116 + 162 + 121 us where the traffic of one pass allows ~ 170).
+// LightGlue's ffn.0 with LayerNorm + GELU in the epilogue: one workgroup owns 64 rows x all 512 columns
+__global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 64 * RS];
+  gemm_x6_body<2, 64, 4, 3, 4>(a, Ap, 0);
+}
 __global__ __launch_bounds__(256, 2) void gemm_x6_qkv_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 128 * RS];
   const int by = (int)blockIdx.y;
@@ -302,6 +392,13 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
   DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
   if (batch <= 0 || a.M <= 0 || a.N <= 0) return 0;
+  if (a.ln_gamma != nullptr) {
+    DIM_REQUIRE(a.split_mode == 2 && a.N == 512 && a.n_pad == 512 && a.ln_beta && a.bias && a.R == nullptr && a.relu == 0 && a.kv_img == nullptr,
+                "gemm_x6: the LayerNorm + GELU epilogue needs the fp16x3 512-column ffn.0 shape");
+    hipLaunchKernelGGL(gemm_x6_ffn_ln_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    DIM_LAUNCH_CHECK();
+    return 0;
+  }
   const bool small = small_problem(a.M, a.N, batch);
   DIM_REQUIRE(a.kv_img == nullptr || (!small && wide_block(a.M, a.n_pad, batch, a.split_mode)), "gemm_x6: K|V images need the 128 x 256 block (gemm_x6_fuses_kv)");
   if (small) {

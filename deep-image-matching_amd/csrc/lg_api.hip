@@ -220,10 +220,14 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
   LG_RUN(launch_lg_init(st, kpts_tab_dev, desc_tab_dev, n_tab_dev, size_tab_dev, pair_idx_dev, cap, h->input_dim, h->Wr,
                         h->input_dim == 256 ? 1 : 0, sat(DIM_SAT_LG_INPUT), s));
   const bool fold = x6 && dim_fold_out_proj();  // split modes: out_proj folded into ffn.0 (one GEMM less per block)
+  // fp16x3 at batch sizes that fill the GPU with 64-row blocks: LayerNorm + GELU run in ffn.0's epilogue (dim_tune_set key 11)
+  const bool fuse_ln = pmode == 2 && dim_fuse_ffn_ln() && (dim_fuse_ffn_ln() == 2 || (long)((N + 63) / 64) * I >= 512);   // 2 = forced (tests)
   auto gemm_items = [&](const float* A, int lda, long long sA, const float* A1, int lda1, long long sA1, int ksplit,
                         const float* B, const SplitWeights* Bx, int ldb, const float* bias, const float* R, float* C, int ldc,
-                        long long sC, int Nn, int K, int flag_eq, unsigned* sat_ctr = nullptr) -> int {
+                        long long sC, int Nn, int K, int flag_eq, unsigned* sat_ctr = nullptr, const float* ln_g = nullptr,
+                        const float* ln_b = nullptr) -> int {
     GemmArgs g;
+    g.ln_gamma = ln_g; g.ln_beta = ln_b;
     g.A0 = A; g.lda0 = lda; g.strideA0 = sA; g.A1 = A1; g.lda1 = lda1; g.strideA1 = sA1; g.ksplit = ksplit;
     g.B = B; g.ldb = ldb; g.bias = bias; g.R = R; g.ldr = ldc; g.strideR = sC; g.C = C; g.ldc = ldc; g.strideC = sC;
     g.M = N; g.N = Nn; g.K = K; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = flag_eq;
@@ -262,12 +266,13 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     LG_RUN(launch_lg_attention(st, 0, s, fuse_kv ? 1 : 0));
     dim_prof_end(DIM_PROF_LG_SELF_ATTN, s);
     if (fold) {  // out_proj folded into ffn.0: A = [desc | ctx]
-      LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.sffn0f_x, 512, w.sffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+      LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.sffn0f_x, 512, w.sffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0,
+                        fuse_ln ? st.sat_ffn : nullptr, fuse_ln ? w.sln_w : nullptr, fuse_ln ? w.sln_b : nullptr));
     } else {
       LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.out_w, w.out_x, 256, w.out_b, nullptr, st.msg, 256, s256, 256, 256, 0));
       LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.sffn0_w, w.sffn0_x, 512, w.sffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
     }
-    LG_RUN(launch_lg_ln_gelu(st, w.sln_w, w.sln_b, s));
+    if (!(fold && fuse_ln)) LG_RUN(launch_lg_ln_gelu(st, w.sln_w, w.sln_b, s));
     LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.sffn3_w, w.sffn3_x, 256, w.sffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0, sat(DIM_SAT_LG_DESC)));
     // ---- cross block (LGN:186-211) ----
     if (fuse_kv) LG_RUN(gemm_qkv(w.cqkv_x, w.cqkv_b, 512, 0, false));
@@ -276,12 +281,13 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     LG_RUN(launch_lg_attention(st, 1, s, fuse_kv ? 1 : 0));
     dim_prof_end(DIM_PROF_LG_CROSS_ATTN, s);
     if (fold) {
-      LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.cffn0f_x, 512, w.cffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0));
+      LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.cffn0f_x, 512, w.cffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0,
+                        fuse_ln ? st.sat_ffn : nullptr, fuse_ln ? w.cln_w : nullptr, fuse_ln ? w.cln_b : nullptr));
     } else {
       LG_RUN(gemm_items(st.ctx, 256, s256, nullptr, 0, 0, 0, w.cout_w, w.cout_x, 256, w.cout_b, nullptr, st.msg, 256, s256, 256, 256, 0));
       LG_RUN(gemm_items(st.desc, 256, s256, st.msg, 256, s256, 256, w.cffn0_w, w.cffn0_x, 512, w.cffn0_b, nullptr, st.hid, 512, s512, 512, 512, 0));
     }
-    LG_RUN(launch_lg_ln_gelu(st, w.cln_w, w.cln_b, s));
+    if (!(fold && fuse_ln)) LG_RUN(launch_lg_ln_gelu(st, w.cln_w, w.cln_b, s));
     LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.cffn3_w, w.cffn3_x, 256, w.cffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0, sat(DIM_SAT_LG_DESC)));
     // ---- adaptive depth / width (LGN:494-516) ----
     const bool last = (i == Lr - 1);

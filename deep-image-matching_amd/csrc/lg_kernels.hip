@@ -74,28 +74,6 @@ __global__ __launch_bounds__(256) void lg_rotary_kernel(LgState st) {
 }
 
 // ---------------------------------------------------------------------------
-// erf to < 1 ulp without branches (both ranges evaluated, one select): minimax polynomials for |x| <= 0.927734375
-// (x + x p(x^2)) and beyond (1 - exp(q(|x|))), 13 fma + one v_exp_f32.  The library erff costs ~45 instructions per value
-// in divergent branches, which made the LayerNorm + GELU pass instruction-bound (3.3 TB/s) instead of HBM-bound.
-__device__ __forceinline__ float erf_1ulp(float a) {
-  const float t = fabsf(a), s = a * a;
-  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-  r = fmaf(r, s, u);
-  r = fmaf(r, t, -1.06777877e-1f);
-  r = fmaf(r, t, -6.34846687e-1f);
-  r = fmaf(r, t, -1.28717512e-1f);
-  r = fmaf(r, t, -t);
-  const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f), a);
-  float q = -5.96761703e-4f;
-  q = fmaf(q, s, 4.99119423e-3f);
-  q = fmaf(q, s, -2.67681349e-2f);
-  q = fmaf(q, s, 1.12819925e-1f);
-  q = fmaf(q, s, -3.76125336e-1f);
-  q = fmaf(q, s, 1.28379166e-1f);
-  return t > 0.927734375f ? big : fmaf(q, a, a);
-}
-
 // LayerNorm(512, eps 1e-5, affine) + exact-erf GELU in place on hid (LGN:141-142).
 // one wave per row, 8 values per lane.
 __global__ __launch_bounds__(256) void lg_ln_gelu_kernel(LgState st, const float* __restrict__ gamma,

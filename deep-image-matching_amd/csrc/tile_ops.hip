@@ -132,6 +132,24 @@ __global__ __launch_bounds__(256) void resize_linear_kernel(const float* __restr
   dst[i] = div255 ? out / 255.0f : out;
 }
 
+// Tile slicing for _extract_by_tile (extractors/extractor_base.py:279-328: the image is zero padded by Tiler.compute_tiles_by_size,
+// unfolded into windows, and every window goes through _frame2tensor's / 255): one pass from the image as it arrived on the
+// device ([H][W][C] fp32, 0..255) straight into the extractor's batch [n][th][tw][C]; pixels outside the image are the zero
+// padding.  No padded copy of the image, no stack, no separate division pass.
+__global__ __launch_bounds__(256) void gather_tiles_kernel(const float* __restrict__ img, int H, int W, int C, const int* __restrict__ origins_xy,
+                                                           int th, int tw, float* __restrict__ out, int div255) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int tile = blockIdx.y;
+  if (i >= (size_t)th * tw * C) return;
+  const int c = (int)(i % C);
+  const size_t p = i / C;
+  const int y = (int)(p / tw), x = (int)(p - (size_t)y * tw);
+  const int gy = origins_xy[2 * tile + 1] + y, gx = origins_xy[2 * tile] + x;
+  float v = 0.0f;
+  if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img[((size_t)gy * W + gx) * C + c];
+  out[(size_t)tile * th * tw * C + i] = div255 ? v / 255.0f : v;
+}
+
 // thread = match.  Both keypoints are scaled back to full resolution (kp / scale, fp32 like numpy) and
 // tested against every tile rectangle with the strict inequalities of points_in_rect (MB:1410-1412).
 __global__ __launch_bounds__(256) void tile_votes_kernel(const float* __restrict__ k0, const float* __restrict__ k1,
@@ -221,6 +239,16 @@ int dim_op_resize_area_f32(const float* src, int H, int W, float* dst, int h, in
 int dim_op_resize_linear_f32(const float* src, int H, int W, float* dst, int h, int w, int div255, void* stream) {
   DIM_REQUIRE(src && dst && H > 0 && W > 0 && h > 0 && w > 0, "dim_op_resize_linear_f32: bad arguments");
   hipLaunchKernelGGL(resize_linear_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, (hipStream_t)stream, src, H, W, dst, h, w, div255);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+int dim_op_gather_tiles_f32(const float* image_dev, int H, int W, int C, const int32_t* origins_xy_dev, int n_tiles, int tile_h, int tile_w,
+                            float* out_dev, int div255, void* stream) {
+  DIM_REQUIRE(image_dev && origins_xy_dev && out_dev && H > 0 && W > 0 && C > 0 && n_tiles > 0 && tile_h > 0 && tile_w > 0, "dim_op_gather_tiles_f32: bad arguments");
+  const size_t per = (size_t)tile_h * tile_w * C;
+  hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)((per + 255) / 256), n_tiles), dim3(256), 0, (hipStream_t)stream, image_dev, H, W, C,
+                     origins_xy_dev, tile_h, tile_w, out_dev, div255);
   DIM_LAUNCH_CHECK();
   return 0;
 }

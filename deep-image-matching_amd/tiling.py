@@ -14,6 +14,8 @@ from __future__ import annotations
 import math
 from typing import Dict, Tuple, Union
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -116,17 +118,22 @@ class BatchedTilingMixin:
         net = self._ensure_batch(th, tw, self.tile_batch)
         dev = net.device
         src = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).to(dev)
-        if src.dim() == 2:
-            src = src[..., None]
-        padded = torch.zeros(H + pad[0] + pad[1], W + pad[2] + pad[3], src.shape[2], dtype=torch.float32, device=dev)
-        padded[pad[0]:pad[0] + H, pad[2]:pad[2] + W] = src
+        C = 1 if src.dim() == 2 else int(src.shape[2])
         idxs = sorted(origins)
         per_tile = {}
+        from . import capi
+        import ctypes
+        lib = net.lib
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
         for s in range(0, len(idxs), self.tile_batch):
             chunk = idxs[s:s + self.tile_batch]
-            stack = torch.stack([padded[(i // n_cols) * stride[0]:(i // n_cols) * stride[0] + th,
-                                        (i % n_cols) * stride[1]:(i % n_cols) * stride[1] + tw] for i in chunk]) / 255.0
-            t = stack[..., 0].contiguous() if self.grayscale else stack.contiguous()  # [B,H,W] or [B,H,W,C]
+            # dim_op_gather_tiles_f32: zero padding, tile slicing and _frame2tensor's / 255 in one pass from the image as it arrived
+            og = torch.tensor([origins[i] for i in chunk], dtype=torch.int32, device=dev).contiguous()
+            t = torch.empty((len(chunk), th, tw) if self.grayscale and C == 1 else (len(chunk), th, tw, C), dtype=torch.float32, device=dev)
+            with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
+                capi.check(lib, lib.dim_op_gather_tiles_f32(capi.ptr(src), H, W, C, capi.ptr(og), len(chunk), th, tw, capi.ptr(t), 1, stream))
+            if self.grayscale and C != 1:
+                t = t[..., 0].contiguous()   # a colour array handed to a grey extractor: channel 0, as stack[..., 0] did
             # under the fp16x3 range guard; SuperPoint in keep-all mode also repeats a batch that overflowed its slots
             run = getattr(net, "extract_batch_guarded", net.extract_batch)
             kp, sc, de, n = run(t)

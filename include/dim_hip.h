@@ -302,6 +302,11 @@ int dim_op_conv1a_f32(const float* in, const float* w_tap_cout, const float* bia
  * images' (x,y) and are divided by scale0/scale1 in fp32 as numpy does; origins are (x,y) int32 pairs;
  * votes[T0*T1] is zeroed by the call. */
 int dim_op_resize_area_f32(const float* src, int H, int W, float* dst, int h, int w, int div255, void* stream);
+/* Tile slicing of _extract_by_tile (extractors/extractor_base.py:279-328) on the device: image_dev [H][W][C] fp32 as the numpy array
+ * arrived (0..255), origins (x, y) int32 per tile (negative / overhanging = the Tiler's zero padding) ->
+ * out_dev [n_tiles][tile_h][tile_w][C], optionally / 255 (_frame2tensor). */
+int dim_op_gather_tiles_f32(const float* image_dev, int H, int W, int C, const int32_t* origins_xy_dev, int n_tiles, int tile_h, int tile_w,
+                            float* out_dev, int div255, void* stream);
 /* cv2.resize(img, size, interpolation=cv2.INTER_LINEAR) (pixel-centre bilinear, OpenCV 4.11 restated): what
  * utils/image.py:52-57 resize_image uses when the target size enlarges the image — quality HIGHEST in
  * extractor_base.py:392-412 and tile_selection (matcher_base.py:1026-1034). */

@@ -296,9 +296,12 @@ static inline void __builtin_amdgcn_s_waitcnt(int imm) {
 // DPP quad permutes used by the kernels: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2)
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
   (void)old;
+  const int me = (int)hipemu::cur->lane;
+  if (ctrl == 0x141) return hipemu_shfl_from(src, (me & ~7) | (7 - (me & 7)));      // row_half_mirror: reverse within 8 lanes
+  if (ctrl == 0x140) return hipemu_shfl_from(src, (me & ~15) | (15 - (me & 15)));   // row_mirror: reverse within a row of 16
   const int x = ctrl == 0xB1 ? 1 : (ctrl == 0x4E ? 2 : -1);
   if (x < 0) { fprintf(stderr, "hipemu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
-  return hipemu_shfl_from(src, (int)hipemu::cur->lane ^ x);
+  return hipemu_shfl_from(src, me ^ x);
 }
 static inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel) {
   const unsigned long long both = ((unsigned long long)hi << 32) | lo;

@@ -64,6 +64,8 @@ def compare_aliked(out, ref, kp_tol=1e-3, desc_tol=1e-3, score_tol=1e-3, max_mis
             top = torch.topk(win, 2).values
             return float(top[0] - top[1])
         cut = min(nms_score(k) for k in kr)
+        res["one_sided"] = {"out": [(ko[i].tolist(), nms_score(ko[i]), nms_tie(ko[i])) for i in only_out],
+                            "ref": [(kr[j].tolist(), nms_score(kr[j]), nms_tie(kr[j])) for j in only_ref], "cut": cut}
         for xy in [ko[i] for i in only_out] + [kr[j] for j in only_ref]:
             v = nms_score(xy)
             assert min(abs(v - cut), abs(v - threshold), nms_tie(xy)) <= tie_tol, (tuple(xy), v, cut, nms_tie(xy), res)

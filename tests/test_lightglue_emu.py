@@ -125,3 +125,27 @@ def test_batch_with_ragged_and_empty_images_on_the_projection_written_images(emu
                 assert S == 0 and r["stop"] == 1
     finally:
         emu_lib.dim_tune_set(6, 1)
+
+
+def test_ffn_layernorm_gelu_epilogue_equals_the_separate_pass(emu_lib):
+    """dim_tune_set(11, 2) forces the 64 x 512 ffn.0 block whose epilogue applies LayerNorm(512) + erf-GELU (the production
+    path at large batches) at the golden sizes; (11, 0) keeps ffn.0 -> lg_ln_gelu_kernel.  Same statistics (two-pass mean /
+    centred variance), different reduction tree: the scores agree to fp32 rounding, every integer output is identical, and
+    both equal the oracle and the reference goldens (ragged counts, adaptive depth and width, 128-d inputs)."""
+    n_diff = 0
+    for name, case in gc.LG_CASES.items():
+        outs = {}
+        try:
+            for mode in (0, 2):
+                emu_lib.dim_tune_set(11, mode)
+                out, ref = run_case(emu_lib, case)
+                compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+                outs[mode] = out
+        finally:
+            emu_lib.dim_tune_set(11, 1)
+        a, b = outs[0], outs[2]
+        assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches"][0], b["matches"][0]) and int(a["stop"]) == int(b["stop"]), name
+        if a["matching_scores0"].numel():
+            assert (a["matching_scores0"] - b["matching_scores0"]).abs().max().item() < 2e-5, name
+            n_diff += int(not torch.equal(a["dense"], b["dense"]))
+    assert n_diff > 0        # two different code paths really ran
