@@ -43,8 +43,8 @@ __device__ __forceinline__ float selu_x3(float x) {   // ATen's elu kernel, as a
 }
 
 // TAPS: 9 (3x3, zero padding 1) or 1 (1x1).  CIN: padded input channels (16 or 32).  TH: tile rows (multiple of 4).
-template <int CIN, int TAPS, int TH>
-__global__ __launch_bounds__(256) void al_convx3_kernel(const float* __restrict__ in, int in_c, const u32x4* __restrict__ wfrag,
+template <int CIN, int TAPS, int TH, bool WREG = true>
+__global__ __launch_bounds__(256, (WREG ? 2 : 3)) void al_convx3_kernel(const float* __restrict__ in, int in_c, const u32x4* __restrict__ wfrag,
                                                         const float* __restrict__ inv_ch, const float* __restrict__ bias,
                                                         float* __restrict__ out, int out_c, int H, int W, int tiles_x,
                                                         double* __restrict__ partial, int n_wg, unsigned* __restrict__ sat,
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void al_convx3_kernel(const float* __restrict_
   // ---- stage the halo tile: fp32 -> two fp16 planes.  ALL global loads of the tile are issued before the first value is
   // used (one exposed HBM round trip per workgroup instead of one per loop iteration: with a load inside every iteration the
   // first version of this kernel spent 25 us per workgroup waiting), and — for CIN = 16 — so are the 18 weight fragments. ----
-  constexpr bool WPRE = (TAPS * KS <= 9);   // all weight fragments fit in registers (72 VGPRs)
+  constexpr bool WPRE = WREG && (TAPS * KS <= 9);   // all weight fragments held in registers (72 VGPRs) — or streamed one tap ahead through L1
   u32x4 wreg[WPRE ? TAPS * KS : 1][2];
   if (WPRE) {
 #pragma unroll
@@ -406,14 +406,16 @@ int launch_al_convx3(const float* in, int in_c, int cin_pad, int taps, const Spl
                      int batch, int H, int W, double* partial, int* n_wg_out, const float* in_alpha, const float* in_beta, hipStream_t s) {
   DIM_REQUIRE((cin_pad == 16 || cin_pad == 32) && (taps == 1 || taps == 9) && cout <= 32 && w.n_pad == 32 && w.mode == 2,
               "aliked convx3: unsupported shape cin_pad %d taps %d cout %d", cin_pad, taps, cout);
-  const int th = (cin_pad == 16 && taps == 9 && dim_aliked_tile_rows() == 16) ? 16 : 8;
+  // dim_tune_set key 10: 16 (default) = 16-row tiles, weights in registers; 17 = 16-row tiles, weights streamed (3 workgroups per CU); 8 = 8-row tiles
+  const int th = (cin_pad == 16 && taps == 9 && dim_aliked_tile_rows() >= 16) ? 16 : 8;
   const int tx = cdiv(W, 32), ty = cdiv(H, th);
   const dim3 grid(tx * ty, 1, batch);
   if (n_wg_out) *n_wg_out = tx * ty;
   unsigned* sat = dim_sat_counter(DIM_SAT_ALIKED);
   const u32x4* wf = (const u32x4*)w.dev;
-#define AL_X3(CI, TP, TH_) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_convx3_kernel<CI, TP, TH_>), grid, dim3(256), 0, s, in, in_c, wf, w.inv_ch(), bias, out, cout, H, W, tx, partial, tx * ty, sat, in_alpha, in_beta)
-  if (cin_pad == 16 && taps == 9 && th == 16) AL_X3(16, 9, 16);
+#define AL_X3(CI, TP, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_convx3_kernel<CI, TP, __VA_ARGS__>), grid, dim3(256), 0, s, in, in_c, wf, w.inv_ch(), bias, out, cout, H, W, tx, partial, tx * ty, sat, in_alpha, in_beta)
+  if (cin_pad == 16 && taps == 9 && th == 16 && dim_aliked_tile_rows() == 16) AL_X3(16, 9, 16);
+  else if (cin_pad == 16 && taps == 9 && th == 16) AL_X3(16, 9, 16, false);
   else if (cin_pad == 16 && taps == 9) AL_X3(16, 9, 8);
   else if (cin_pad == 32 && taps == 9) AL_X3(32, 9, 8);
   else if (cin_pad == 16 && taps == 1) AL_X3(16, 1, 8);

@@ -13,11 +13,12 @@ def sync_time(fn, reps=1):
     for _ in range(reps): out = fn()
     torch.cuda.synchronize(); return out, (time.perf_counter() - t0) / reps
 
-general = {"tile_size": (1500, 1000), "tile_overlap": 0, "tile_preselection_size": 1024, "min_matches_per_tile": 5, "quality": "HIGH"}
+general = {"tile_size": (1500, 1000), "tile_overlap": 0, "tile_preselection_size": 1024, "min_matches_per_tile": 5, "quality": "HIGH",
+           "allow_synthetic_weights": True}
 ex = plugins.AlikedExtractor({"general": general, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 4000,
-                                                                 "detection_threshold": 0.2, "nms_radius": 3}})
+                                                                 "detection_threshold": 0.2, "nms_radius": 3, "allow_synthetic_weights": True}})
 mt = plugins.LightGlueMatcher({"general": general, "matcher": {"name": "lightglue", "depth_confidence": 0.95, "width_confidence": 0.99,
-                                                               "filter_threshold": 0.1}}, local_features="aliked")
+                                                               "filter_threshold": 0.1, "allow_synthetic_weights": True}}, local_features="aliked")
 rng = np.random.default_rng(0)
 base = rng.integers(0, 256, (4000, 6000, 3), dtype=np.uint8).astype(np.float32)
 img0, img1 = base, np.roll(base, (300, 500), axis=(0, 1)).copy()

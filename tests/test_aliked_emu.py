@@ -15,7 +15,7 @@ GOLD = Path(__file__).parent / "golden"
 
 
 def compare_aliked(out, ref, kp_tol=1e-3, desc_tol=1e-3, score_tol=1e-3, max_missing=0, label=None, ref_score_map=None, threshold=0.2,
-                   tie_tol=2e-5, nms_radius=3):
+                   tie_tol=2e-5, nms_radius=3, n_limit=None):
     """north_star's bar: keypoint set exact, descriptors / scores within 1e-3 (keypoint coordinates likewise: they are
     sub-pixel soft-argmax outputs in pixels).  Every measured maximum is returned and, with ``label``, appended to
     gpurun_out/parity_measured.jsonl so that the numbers behind the assertion are on record (VERDICT r2 weak #1)."""
@@ -63,7 +63,11 @@ def compare_aliked(out, ref, kp_tol=1e-3, desc_tol=1e-3, score_tol=1e-3, max_mis
             win = sm[max(0, y - radius): y + radius + 1, max(0, x - radius): x + radius + 1].reshape(-1)
             top = torch.topk(win, 2).values
             return float(top[0] - top[1])
-        cut = min(nms_score(k) for k in kr)
+        # the n_limit cut of the REFERENCE: the n_limit-th largest NMS maximum above the threshold (DKD, ALN:150-186)
+        nms = aliked_ref._simple_nms(ref_score_map.reshape(1, 1, *sm.shape), nms_radius)[0, 0].clone()
+        nms[:nms_radius] = 0; nms[-nms_radius:] = 0; nms[:, :nms_radius] = 0; nms[:, -nms_radius:] = 0
+        cand = torch.sort(sm[nms > threshold], descending=True).values
+        cut = float(cand[n_limit - 1]) if n_limit is not None and len(cand) > n_limit else threshold
         res["one_sided"] = {"out": [(ko[i].tolist(), nms_score(ko[i]), nms_tie(ko[i])) for i in only_out],
                             "ref": [(kr[j].tolist(), nms_score(kr[j]), nms_tie(kr[j])) for j in only_ref], "cut": cut}
         for xy in [ko[i] for i in only_out] + [kr[j] for j in only_ref]:

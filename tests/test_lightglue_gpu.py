@@ -76,6 +76,7 @@ def test_lightglue_gpu_full_size_kv_images_from_the_projection_gemm(hip_lib, mod
     lg = _lg()
     try:
         hip_lib.dim_tune_set(6, 2)
+        hip_lib.dim_tune_set(11, 2)      # ... and ffn.0 with LayerNorm + GELU in its epilogue (the other large-batch-only kernel)
         net = lg.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=2048)
         out = _cpu(net(_data(f0, f1), dense=True))
         ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, conf, taps=True)
@@ -94,6 +95,7 @@ def test_lightglue_gpu_full_size_kv_images_from_the_projection_gemm(hip_lib, mod
                     "image1": {"keypoints": kt[b, :counts[b]][None], "descriptors": dt[b, :counts[b]][None], "image_size": st[b][None]}}
             singles.append(_cpu(net(data)))
         hip_lib.dim_tune_set(6, 1)
+        hip_lib.dim_tune_set(11, 1)
         big = lg.LightGlueHIP(sd, conf, max_pairs=8, max_kpts=2048)
         o = {k: v.cpu() for k, v in big.match_batch(kt.cuda(), dt.cuda(), nt.cuda(), st.cuda(), pair_idx=pairs.cuda()).items()}
         for p, r in enumerate(singles):
@@ -105,6 +107,7 @@ def test_lightglue_gpu_full_size_kv_images_from_the_projection_gemm(hip_lib, mod
             torch.testing.assert_close(o["scores"][p, :S], r["scores"][0], rtol=1e-3, atol=1e-9)
     finally:
         hip_lib.dim_tune_set(6, 1)
+        hip_lib.dim_tune_set(11, 1)
 
 
 def test_lightglue_gpu_batch_equals_single_and_pair_index(hip_lib):
