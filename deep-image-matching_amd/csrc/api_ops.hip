@@ -194,6 +194,17 @@ int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3, int n_pad, con
   return launch_gemm_x6(g, 1, (hipStream_t)stream);
 }
 
+int dim_op_gemm_x6_ln_gelu_f32(const float* A, int lda, const void* w_x3, const float* bias, const float* ln_gamma, const float* ln_beta,
+                               float* C, int ldc, int M, int K, void* stream) {
+  DIM_REQUIRE(w_x3 && ((const SplitWeights*)w_x3)->n_pad == 512 && ((const SplitWeights*)w_x3)->mode == 2, "dim_op_gemm_x6_ln_gelu_f32: needs an fp16x3 512-column weight handle");
+  DIM_REQUIRE(A && bias && ln_gamma && ln_beta && C, "dim_op_gemm_x6_ln_gelu_f32: null argument");
+  GemmArgs g;
+  g.A0 = A; g.lda0 = lda; g.set_split(*(const SplitWeights*)w_x3); g.bias = bias; g.ln_gamma = ln_gamma; g.ln_beta = ln_beta;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = 512; g.K = K;
+  g.sat = dim_sat_counter(DIM_SAT_OP);
+  return launch_gemm_x6(g, 1, (hipStream_t)stream);
+}
+
 int dim_convx6_create(const float* w_oihw_host, int cin, int cout, void** out_dev) {
   DIM_REQUIRE(w_oihw_host && out_dev && (cin == 64 || cin == 128) && cout % 64 == 0, "dim_convx6_create: bad argument");
   const int mode = g_precision_mode == 1 ? 1 : 2;

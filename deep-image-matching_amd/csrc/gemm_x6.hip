@@ -105,9 +105,12 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     // Issue order matters: vector-memory loads retire in order, so the weight fragments this chunk's MFMAs
     // need are requested BEFORE the next chunk's activation prefetch — the wait in front of the first MFMA
     // then covers the (L2-resident) fragments only and the HBM latency of the prefetch hides behind the MFMAs.
-    u32x4 fb[2][NT][NPL];
+    // (the 64 x 512 LayerNorm block holds 8 accumulators AND 4 column tiles of fragments per step: it requests one k-step's
+    // fragments at a time — 32 instead of 64 registers — so that the accumulators can live in the AGPR half of the file)
+    constexpr int FKS = lng ? 1 : 2;
+    u32x4 fb[FKS][NT][NPL];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < FKS; ++ks)
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
 #pragma unroll
@@ -119,6 +122,12 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (lng && ks == 1) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) fb[0][n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + (k0 >> 4) + 1) * 2 + half) * 32 + lx];
+      }
       u32x4 fa[MT][NPL];
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
@@ -131,14 +140,14 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fb[ks][n][S::tb(tm)], fa[m][S::ta(tm)], acc[m][n]);
+            for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fb[lng ? 0 : ks][n][S::tb(tm)], fa[m][S::ta(tm)], acc[m][n]);
       } else {
 #pragma unroll
         for (int tm = 0; tm < S::NT; ++tm)
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[ks][n][S::tb(tm)], acc[m][n]);
+            for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[lng ? 0 : ks][n][S::tb(tm)], acc[m][n]);
       }
     }
     __syncthreads();
@@ -221,7 +230,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     // Row statistics: in-lane over the wave's 4 column tiles, DPP over the 16-lane rows, then through LDS (the activation
     // staging buffer is free after the K loop) over the 4 x 4 sixteen-lane groups that share a block row; mean first, then
     // the centred sum of squares — the two-pass form lg_ln_gelu_kernel (and ATen) use. ----
-    float* const red = (float*)Ap;                 // [wave 4][lane group 4][32 (m, r)] partials, then [64] row results at +512
+    float* const red = (float*)Ap;                 // [wave 4][lane group 4][32 (m, r)] partial sums
     float bv[NT], iv[NT], gm[NT], bt[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -238,18 +247,22 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
         if ((lane & 15) == 0) red[(wv * 4 + q) * 32 + j] = v;
       }
       __syncthreads();
-      if (t < 64) {   // block row t: (m, r, half) with t = 32 m + (r & 3) + 8 (r >> 2) + 4 half
-        const int m = t >> 5, w_ = t & 31, hf = (w_ >> 2) & 1, r = (w_ & 3) + 4 * (w_ >> 3), j = m * 16 + r;
-        float tot = 0.0f;
+      // every lane sums the 8 partials (4 waves x the 2 sixteen-lane groups of its lane half) of each of its 32 rows itself, with
+      // 16-byte reads, in a fixed order.  (A first version let wave 0 alone form the 64 row totals and publish them through LDS
+      // for a second barrier-separated read: correct on the emulator and at one workgroup per CU, but on hardware with two
+      // co-resident workgroups ~1 row in 1000 came back with stale statistics — found by the fp64 op test at 204 800 rows,
+      // scripts/gpu_ffn_ln_check.py; this single-stage form is deterministic there.)
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) tot += red[(w4 * 4 + 2 * hf) * 32 + j] + red[(w4 * 4 + 2 * hf + 1) * 32 + j];
-        red[512 + t] = tot * scale_;
+      for (int j4 = 0; j4 < MT * 16; j4 += 4) {
+        f32x4 tot = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          const f32x4 p0 = *(const f32x4*)&red[(w4 * 4 + 2 * half) * 32 + j4], p1 = *(const f32x4*)&red[(w4 * 4 + 2 * half + 1) * 32 + j4];
+          tot += p0 + p1;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[j4 + e] = tot[e] * scale_;
       }
-      __syncthreads();
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[m * 16 + r] = red[512 + m * 32 + mfma_row(r, half)];
       __syncthreads();
     };
 #pragma unroll
@@ -353,15 +366,15 @@ __global__ __launch_bounds__(256, ((BM / (32 * (4 / WN))) * NT >= 8 ? 2 : 3)) vo
   __shared__ unsigned Ap[SplitMma<MODE>::NPL * BM * RS];
   gemm_x6_body<MODE, BM, NT, 0, WN>(a, Ap, (int)blockIdx.y);
 }
-// LightGlue's q|k|v projection in ONE launch: blockIdx.y selects the column block and with it the code path (plain fp32 /
-// transposed K image / V image — three inlined bodies, one register allocation each), so that the 2 or 3 column blocks of
-// a row block run next to each other on the same XCD and the activation rows come from HBM once (as separate launches
-// the three blocks each re-read them: 116 + 162 + 121 us where the traffic of one pass allows ~ 170).
 // LightGlue's ffn.0 with LayerNorm + GELU in the epilogue: one workgroup owns 64 rows x all 512 columns
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 64 * RS];
   gemm_x6_body<2, 64, 4, 3, 4>(a, Ap, 0);
 }
+// LightGlue's q|k|v projection in ONE launch: blockIdx.y selects the column block and with it the code path (plain fp32 /
+// transposed K image / V image — three inlined bodies, one register allocation each), so that the 2 or 3 column blocks of
+// a row block run next to each other on the same XCD and the activation rows come from HBM once (as separate launches
+// the three blocks each re-read them: 116 + 162 + 121 us where the traffic of one pass allows ~ 170).
 __global__ __launch_bounds__(256, 2) void gemm_x6_qkv_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 128 * RS];
   const int by = (int)blockIdx.y;

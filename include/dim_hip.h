@@ -272,6 +272,11 @@ void dim_x3_destroy(void* handle);
 int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3_handle, int n_pad, const float* bias, const float* residual, int ldr,
                        float* C, int ldc, int M, int N, int K, int act, void* stream);
 
+/* LightGlue's ffn.0 -> LayerNorm(512, eps 1e-5) -> erf-GELU (LGN:141-142,157-158) as ONE kernel: C[M][512] =
+ * gelu(layer_norm(A[M][K] * W + bias)); w_x3_handle from dim_x3_create(K, 512) under the default arithmetic. */
+int dim_op_gemm_x6_ln_gelu_f32(const float* A, int lda, const void* w_x3_handle, const float* bias, const float* ln_gamma, const float* ln_beta,
+                               float* C, int ldc, int M, int K, void* stream);
+
 /* 3x3/s1/p1 conv, NHWC fp32, weights [9][cin][cout], bias+ReLU and optional
  * 2x2 max-pool fused (SPN:161-171).  cin in {64,128}, cout % 64 == 0. */
 int dim_op_conv3x3_nhwc_f32(const float* in, const float* w_tap_cin_cout, const float* bias, float* out, int batch,

@@ -139,3 +139,17 @@ def test_lightglue_gpu_batch_equals_single_and_pair_index(hip_lib):
         assert torch.equal(o["matches01"][p, 0, :counts[a]].long(), r["matches0"][0])
         if counts[a] == 0 or counts[b] == 0:
             assert S == 0 and r["stop"] == 1
+
+
+def test_ffn_layernorm_gelu_fused_op_at_production_rows(hip_lib):
+    """ffn.0 -> LayerNorm -> GELU as one kernel (gemm_x6.hip, 64 x 512 blocks) vs an fp64 evaluation at a row count that puts
+    TWO workgroups on every CU (65 536 rows = 1024 workgroups), twice.  The first version of its row reduction was correct on
+    the emulator and at one workgroup per CU and returned ~1 row in 1000 with stale statistics here (and different ones on
+    every run) — only this test, at this size, showed it."""
+    from tests.test_ops_emu import _ffn_ln_gelu_case
+    for M in (2048 + 37, 65536):
+        C1, ref = _ffn_ln_gelu_case(hip_lib, M, 512, seed=M, device="cuda")
+        C2, _ = _ffn_ln_gelu_case(hip_lib, M, 512, seed=M, device="cuda")
+        err = (C1.double() - ref).abs().max(1).values
+        assert int((err > 1e-5).sum()) == 0 and float(err.max()) < 1e-5, (M, float(err.max()), (err > 1e-5).nonzero().reshape(-1)[:8].tolist())
+        assert torch.equal(C1, C2), M

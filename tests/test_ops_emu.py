@@ -158,3 +158,32 @@ def test_fp16x3_range_behaviour(emu_lib, regime):
     if regime != "overflow":
         ref, mag = A.double() @ W.double(), A.abs().double() @ W.abs().double()
         assert ((C.double() - ref).abs() / mag).max().item() < (2e-6 if regime == "tiny" else 4e-7)
+
+
+def _ffn_ln_gelu_case(lib, M, K, seed, device="cpu"):
+    """gelu(layer_norm(A W + b)) through dim_op_gemm_x6_ln_gelu_f32 -> (device result, fp64 reference)."""
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g) * 1.5
+    W = (torch.randn(K, 512, generator=g) / K ** 0.5).contiguous()
+    bias, gamma, beta = torch.randn(512, generator=g) * 0.1, 1.0 + 0.2 * torch.randn(512, generator=g), 0.1 * torch.randn(512, generator=g)
+    dev, npad = ctypes.c_void_p(), ctypes.c_int()
+    assert lib.dim_x3_create(p(W), K, 512, ctypes.byref(dev), ctypes.byref(npad)) == 0 and npad.value == 512
+    Ad, bd, gd, btd = (t.to(device).contiguous() for t in (A, bias, gamma, beta))
+    C = torch.full((M, 512), -7.0, device=device)
+    try:
+        rc = lib.dim_op_gemm_x6_ln_gelu_f32(p(Ad), K, dev, p(bd), p(gd), p(btd), p(C), 512, M, K, None)
+        assert rc == 0, lib.dim_last_error()
+        if device != "cpu":
+            torch.cuda.synchronize()
+    finally:
+        lib.dim_x3_destroy(dev)
+    h = A.double() @ W.double() + bias.double()
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(h, (512,), gamma.double(), beta.double(), 1e-5))
+    return C.cpu(), ref
+
+
+@pytest.mark.parametrize("M,K", [(64, 512), (150, 512), (67, 256)])
+def test_ffn_layernorm_gelu_fused_op_vs_fp64(emu_lib, M, K):
+    """LightGlue's ffn.0 -> LayerNorm -> GELU as one kernel (64 x 512 blocks; ragged last block) against an fp64 evaluation."""
+    C, ref = _ffn_ln_gelu_case(emu_lib, M, K, seed=M + K)
+    assert (C.double() - ref).abs().max().item() < 5e-6
