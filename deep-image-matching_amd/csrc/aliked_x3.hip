@@ -176,6 +176,8 @@ __global__ __launch_bounds__(256, (WREG ? 2 : 3)) void al_convx3_kernel(const fl
   float s1 = 0.0f, s2 = 0.0f;
   const bool interior = ty0 + TH <= H && tx0 + 32 <= W;
   float* const dtile = out + (((size_t)b * H + ty0) * W + tx0) * out_c + lx;
+  // (staging the outputs through LDS for 16-byte stores was measured: 411 -> 467 us per full-resolution layer — the two extra
+  // barriers and the LDS round trip cost more than the 64-byte store pieces; the direct stores stay)
   if (interior) {
     if (cok) {
 #pragma unroll
@@ -272,7 +274,7 @@ __device__ __forceinline__ AsmIdx asm_up_index(int dst, int in_size, int out_siz
   u.l0 = 1.f - u.l1;
   return u;
 }
-__global__ __launch_bounds__(256) void al_assemble_x3_kernel(const float* __restrict__ x1, const float* __restrict__ q2,
+__global__ __launch_bounds__(256, 4) void al_assemble_x3_kernel(const float* __restrict__ x1, const float* __restrict__ q2,
                                                              const float* __restrict__ q3, const float* __restrict__ q4,
                                                              const u32x4* __restrict__ w1f, const float* __restrict__ w1inv,
                                                              const u32x4* __restrict__ w0f, float w0inv, float* __restrict__ s8, int Hp,
@@ -292,9 +294,8 @@ __global__ __launch_bounds__(256) void al_assemble_x3_kernel(const float* __rest
 #pragma unroll
   for (int r = 0; r < 16; ++r) inv1[r] = w1inv[mfma_row(r, half)];
   float vmax = 0.0f;
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int i = blockIdx.x * 256 + wv * 64 + m * 32 + lx;
+  {   // one 32-pixel M-tile per wave (two per wave cost 174 registers and half the resident waves: the kernel waits on loads)
+    const int i = blockIdx.x * 128 + wv * 32 + lx;
     const bool ok = i < npx;
     const int ic = ok ? i : npx - 1;
     const float* src = x1 + ((size_t)b * npx + ic) * 16 + half * 8;
@@ -393,7 +394,7 @@ int launch_al_assemble_x3(const float* x1, const float* q2, const float* q3, con
                           float* s8, int batch, int Hp, int Wp, hipStream_t s) {
   const u32x4* w1f = (const u32x4*)frag_dev;
   const u32x4* w0f = w1f + 2 * 2 * 32;
-  hipLaunchKernelGGL(al_assemble_x3_kernel, dim3(cdiv(Hp * Wp, 256), batch), dim3(256), 0, s, x1, q2, q3, q4, w1f, inv1_dev, w0f, inv0, s8, Hp, Wp,
+  hipLaunchKernelGGL(al_assemble_x3_kernel, dim3(cdiv(Hp * Wp, 128), batch), dim3(256), 0, s, x1, q2, q3, q4, w1f, inv1_dev, w0f, inv0, s8, Hp, Wp,
                      dim_sat_counter(DIM_SAT_ALIKED));
   DIM_LAUNCH_CHECK();
   return 0;

@@ -247,21 +247,21 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
         if ((lane & 15) == 0) red[(wv * 4 + q) * 32 + j] = v;
       }
       __syncthreads();
-      // every lane sums the 8 partials (4 waves x the 2 sixteen-lane groups of its lane half) of each of its 32 rows itself, with
-      // 16-byte reads, in a fixed order.  (A first version let wave 0 alone form the 64 row totals and publish them through LDS
-      // for a second barrier-separated read: correct on the emulator and at one workgroup per CU, but on hardware with two
-      // co-resident workgroups ~1 row in 1000 came back with stale statistics — found by the fp64 op test at 204 800 rows,
-      // scripts/gpu_ffn_ln_check.py; this single-stage form is deterministic there.)
+      // One row total per lane: lane (lx, half) sums the 8 partials (4 waves x the 2 sixteen-lane groups of its lane half) of row
+      // slot j = lx in a fixed order; the 32 totals of a half then reach all of its lanes through v_readlane (wave-uniform values,
+      // no second trip through LDS).  (A first version let wave 0 alone form the 64 row totals and publish them through LDS for a
+      // second barrier-separated read: correct on the emulator and at one workgroup per CU, but on hardware with two co-resident
+      // workgroups ~1 row in 1000 came back with stale statistics — found by the fp64 op test at 204 800 rows,
+      // scripts/gpu_ffn_ln_check.py.  Letting every lane read all 256 partials itself was correct but cost 30 % of the kernel.)
+      float tot = 0.0f;
 #pragma unroll
-      for (int j4 = 0; j4 < MT * 16; j4 += 4) {
-        f32x4 tot = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int w4 = 0; w4 < 4; ++w4) tot += red[(w4 * 4 + 2 * half) * 32 + lx] + red[(w4 * 4 + 2 * half + 1) * 32 + lx];
+      tot *= scale_;
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) {
-          const f32x4 p0 = *(const f32x4*)&red[(w4 * 4 + 2 * half) * 32 + j4], p1 = *(const f32x4*)&red[(w4 * 4 + 2 * half + 1) * 32 + j4];
-          tot += p0 + p1;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part[j4 + e] = tot[e] * scale_;
+      for (int j = 0; j < MT * 16; ++j) {
+        const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), j));
+        const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 32 + j));
+        part[j] = half ? a1 : a0;
       }
       __syncthreads();
     };

@@ -57,7 +57,7 @@ def test_lowres_chain_vs_the_oracle_at_the_reference_sizes(hip_lib):
         ref = superpoint_ref.superpoint_forward(torch.from_numpy(small)[None, None], sp_sd, dict(pairs_mod.LOWRES_SP_CONF))
         k = int(nt[i])
         kp, sc, de, n = sel._sp.extract_batch_guarded(sel.downsample(im)[None].contiguous())     # the same call extract() made, with the scores
-        assert int(n[0]) == k and torch.equal(kp[0], kt[i]) and torch.equal(de[0], dt[i])
+        assert int(n[0]) == k and torch.equal(kp[0, :k], kt[i, :k]) and torch.equal(de[0, :k], dt[i, :k])
         out = {"keypoints": kt[i, :k].cpu(), "scores": sc[0, :k].cpu(), "descriptors": dt[i, :k].t().cpu()}
         res = compare_superpoint(out, ref)
         order_is_reference_like(out, k_limited=True)
