@@ -61,6 +61,8 @@ static int g_fuse_kv = 1;
 int dim_fuse_kv() { return g_fuse_kv; }
 static int g_fuse_ffn_ln = 1;
 int dim_fuse_ffn_ln() { return g_fuse_ffn_ln; }
+static int g_attn_probe = 0;
+int dim_attn_probe() { return g_attn_probe; }
 static int g_al_tile_rows = 16;
 int dim_aliked_tile_rows() { return g_al_tile_rows; }
 static int g_al_fuse_bn = 1;
@@ -240,6 +242,7 @@ int dim_tune_set(int key, int value) {
   if (key == 9) g_al_fuse_bn = value;
   if (key == 10) g_al_tile_rows = value;
   if (key == 11) g_fuse_ffn_ln = value;
+  if (key == 12) g_attn_probe = value;
   return 0;
 }
 

@@ -190,7 +190,8 @@ int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pai
   LG_TRY(dev_alloc(h, &st.prune, I * N)); LG_TRY(dev_alloc(h, &st.done, P)); LG_TRY(dev_alloc(h, &st.cnt_lt, P));
   { unsigned char* kvp = nullptr; LG_TRY(dev_alloc(h, &kvp, I * 4 * ((N + 31) / 32) * 1536 * 16)); st.kv_img = kvp; }
   st.attn_part_items = (int)(I < 8 ? I : 8);  // key-split attention only pays for <= 4 pairs
-  LG_TRY(dev_alloc(h, &st.attn_part, (size_t)st.attn_part_items * 4 * N * 4 * 68));
+  if (dim_attn_probe()) st.attn_part_items = (int)I;   // timing probes (dim_tune_set key 12): 16 partial records per row for every item
+  LG_TRY(dev_alloc(h, &st.attn_part, (size_t)st.attn_part_items * 4 * N * (dim_attn_probe() ? 16 : 4) * 68));
   LG_TRY(dev_alloc(h, &st.tdesc, I * N * 256)); LG_TRY(dev_alloc(h, &st.tenc, I * N * 64)); LG_TRY(dev_alloc(h, &st.tind, I * N));
 #undef LG_TRY
   *out = h;

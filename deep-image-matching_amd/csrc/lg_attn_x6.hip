@@ -36,6 +36,7 @@ struct AttnArgs6 {
   int splits;            // key range cut into `splits` parts per (query block, head, item): small batches only
   int qblocks, groups;   // workgroups per (item, head) group = qblocks (incl. splits); groups = 4 * items (XCD-aware 1-D grid)
   float* part;           // [items][4][nmax][splits][PART] partial (unnormalised O, running max, running sum)
+  int probe;             // timing probes of the shared-score-tile question (dim_tune_set key 12); 0 in the product
   unsigned* sat;         // fp16x3 range guard on the rotated K (the rotation can grow |k| by sqrt 2) and on V
   int q_img;             // cross attention with images written by the projection GEMM (gemm_x6.hip KV): there is no fp32 qk —
                          // the Q operand is this item's own K image, and the softmax scale is applied to the scores instead
@@ -198,13 +199,18 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+    // (probe 1 — timing only, results wrong: every second key tile of a cross launch runs WITHOUT its score MFMAs = the 25 % of the
+    // launch's MFMAs a score tile shared by the two directions would not execute.  Every second TILE rather than every second
+    // item: the XCD-aware mapping above sends the odd items to XCDs 4..7, which would idle while 0..3 set the launch time.)
+    if (!(a.probe == 1 && (kt & 32))) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      u32x4 kf[NPL];
+      for (int s = 0; s < 4; ++s) {
+        u32x4 kf[NPL];
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) kf[p] = Kp[(p * 8 + 2 * s + half) * 32 + lx];
+        for (int p = 0; p < NPL; ++p) kf[p] = Kp[(p * 8 + 2 * s + half) * 32 + lx];
 #pragma unroll
-      for (int tm = 0; tm < S::NT; ++tm) sacc = S::mma(kf[S::ta(tm)], qf[s][S::tb(tm)], sacc);
+        for (int tm = 0; tm < S::NT; ++tm) sacc = S::mma(kf[S::ta(tm)], qf[s][S::tb(tm)], sacc);
+      }
     }
     // fp16x3: sacc holds scale^2 x the scores; the exact power-of-two factor is applied inside the fused
     // multiply-add of the exponent below (and once to the tile maximum) instead of to all 16 values
@@ -267,6 +273,14 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
         oacc[0] = S::mma(vf[0][S::ta(tm)], pf[S::tb(tm)], oacc[0]);
         oacc[1] = S::mma(vf[1][S::ta(tm)], pf[S::tb(tm)], oacc[1]);
       }
+    }
+    // (probe 3 — timing only: the second direction of a shared score tile cannot keep its output across query blocks; per
+    // 32-key tile the workgroup would write a 32 x (64 + m + l) partial record.  Every second tile writes a record of that size
+    // here: the volume of one direction, spread over all XCDs.)
+    if (a.probe == 3 && (kt & 32)) {
+      float* pp = a.part + (((((size_t)item * 4 + head) * ((a.tiles + 1) >> 1) + (kt >> 6)) * (a.qblocks / a.splits) + qb) * 256 + t) * 8;
+      *(float4*)pp = make_float4(oacc[0][0], oacc[0][1], oacc[0][2], oacc[0][3]);
+      *(float4*)(pp + 4) = make_float4(oacc[1][0], oacc[1][1], oacc[1][2], oacc[1][3]);
     }
   }
 
@@ -331,6 +345,8 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
   const int wgs = cdiv(st.nmax, 128) * 4 * st.n_items;
   a.part = st.attn_part;
   a.splits = (st.attn_part && st.n_items <= st.attn_part_items) ? (wgs <= 128 ? 4 : (wgs <= 256 ? 2 : 1)) : 1;
+  a.probe = cross ? dim_attn_probe() : 0;
+  if (a.probe == 2) a.splits = 16;  // probe 2: every query block's key range in 16 parts -> the partial-record volume of a shared score tile, written AND merged
   a.qblocks = cdiv(st.nmax, 128) * a.splits;
   a.groups = 4 * st.n_items;
   dim3 grid((unsigned)(cdiv(a.groups, 8) * 8 * a.qblocks));  // whole rounds of 8 groups, one per XCD (surplus workgroups exit)
