@@ -90,6 +90,47 @@ def merge_tile_features(per_tile: Dict[int, dict], origins: Dict[int, Tuple[int,
     return {"keypoints": kpts, "descriptors": desc, "scores": scores, "tile_idx": tidx}
 
 
+def merge_tile_features_device(lib, dev, stream, tables, origins_xy, tile_ids, image_shape, select_unique: bool = True) -> dict:
+    """merge_tile_features on the device (csrc/tile_merge.hip: shift, border filter, np.unique's lexicographic order and
+    first-occurrence rule, descriptor transpose) from the extractor's per-chunk device tables (kp [T,cap,2], scores [T,cap],
+    desc [T,cap,D], n [T]); ONE device-to-host copy of the final arrays.  EB:330-390."""
+    import contextlib
+    import ctypes
+    from . import capi
+    if len(tables) == 1:
+        kp, sc, de, n = tables[0]
+    else:  # more tiles than one extractor batch: one table (capacities can differ after a keep-all regrow)
+        cap = max(int(t[0].shape[1]) for t in tables)
+        def pad(x):
+            if x.shape[1] == cap:
+                return x
+            y = x.new_zeros((x.shape[0], cap) + tuple(x.shape[2:]))
+            y[:, :x.shape[1]] = x
+            return y
+        kp, sc, de = (torch.cat([pad(t[k]) for t in tables]) for k in range(3))
+        n = torch.cat([t[3] for t in tables])
+    kp, sc, de, n = kp.contiguous(), sc.contiguous(), de.contiguous(), n.to(torch.int32).contiguous()
+    T, cap, D = int(de.shape[0]), int(de.shape[1]), int(de.shape[2])
+    assert T == len(tile_ids) == len(origins_xy)
+    og = torch.tensor(origins_xy, dtype=torch.int32, device=dev).reshape(T, 2).contiguous()
+    ids = torch.tensor([float(i) for i in tile_ids], dtype=torch.float32, device=dev)
+    lib.dim_op_merge_tiles_workspace_bytes.restype = ctypes.c_size_t
+    ws = torch.empty(int(lib.dim_op_merge_tiles_workspace_bytes(T, cap)), dtype=torch.uint8, device=dev)
+    rows = T * cap
+    o_kp = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+    o_sc = torch.empty(rows, dtype=torch.float32, device=dev)
+    o_ti = torch.empty(rows, dtype=torch.float32, device=dev)
+    o_de = torch.empty(rows * D, dtype=torch.float32, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
+        capi.check(lib, lib.dim_op_merge_tiles(capi.ptr(kp), capi.ptr(sc), capi.ptr(de), capi.ptr(n), capi.ptr(og), capi.ptr(ids), T, cap, D,
+                                               int(image_shape[0]), int(image_shape[1]), int(bool(select_unique)), capi.ptr(ws),
+                                               capi.ptr(o_kp), capi.ptr(o_sc), capi.ptr(o_ti), capi.ptr(o_de), capi.ptr(n_out), stream))
+    N = int(n_out.item())
+    return {"keypoints": o_kp[:N].cpu().numpy(), "descriptors": o_de[:D * N].reshape(D, N).cpu().numpy(),
+            "scores": o_sc[:N].cpu().numpy(), "tile_idx": o_ti[:N].cpu().numpy()}
+
+
 class BatchedTilingMixin:
     """Overrides ExtractorBase._extract_by_tile with the batched version.  Needs ``self._net``
     (SuperPointHIP / AlikedHIP built by ``self._ensure_batch``), ``self.grayscale`` and
@@ -120,7 +161,7 @@ class BatchedTilingMixin:
         src = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).to(dev)
         C = 1 if src.dim() == 2 else int(src.shape[2])
         idxs = sorted(origins)
-        per_tile = {}
+        tables = []
         from . import capi
         import ctypes
         lib = net.lib
@@ -140,8 +181,5 @@ class BatchedTilingMixin:
             if hasattr(self, "_regrow") and self._regrow(net, len(chunk)):
                 net = self._ensure_batch(th, tw, self.tile_batch)
                 kp, sc, de, n = getattr(net, "extract_batch_guarded", net.extract_batch)(t)
-            kp, sc, de, n = kp.cpu().numpy(), sc.cpu().numpy(), de.cpu().numpy(), n.cpu().numpy()
-            for j, i in enumerate(chunk):
-                k = int(n[j])
-                per_tile[i] = {"keypoints": kp[j, :k].copy(), "scores": sc[j, :k].copy(), "descriptors": de[j, :k].T.copy()}
-        return merge_tile_features(per_tile, origins, image.shape, self.descriptor_size, select_unique)
+            tables.append((kp, sc, de, n))
+        return merge_tile_features_device(lib, dev, stream, tables, [origins[i] for i in idxs], idxs, image.shape, select_unique)

@@ -46,7 +46,11 @@ int dim_device_synchronize(void);
  * key 5 = 1 (default) SuperPoint conv-to-conv activations stored pre-split (fp16x3), 0 = fp32;
  * key 6 = split-precision GEMM block: 1 (default) 128 x 256 when the launch fills the GPU, 0 = always 128 x 128,
  * 2 = always 128 x 256 (tests); key 7 = simple_nms tiles: 1 (default) 64 x 64 on large maps, 0 = 32 x 32, 2 = always 64 x 64;
- * key 8 = 1 (default) LightGlue's K | V attention tile images written by the projection GEMM, 0 = separate pre-split pass. */
+ * key 8 = 1 (default) LightGlue's K | V attention tile images written by the projection GEMM, 0 = separate pre-split pass;
+ * key 9 = 1 (default) ALIKED BatchNorm + SELU applied while the consumer stages its input, 0 = separate pass; key 10 = ALIKED fp16x3
+ * convolution tile rows (16 default, 8, 17 = 16 with streamed weights); key 11 = 1 (default) LightGlue's LayerNorm + GELU in the
+ * epilogue of ffn.0 when the launch fills the GPU, 2 = always (tests), 0 = separate kernel; key 12 = cross-attention timing probes
+ * (scripts/gpu_attn_probe.py; 0 in the product — 1 and 3 give wrong results by design). */
 int dim_tune_set(int key, int value);
 
 /* Per-launch-site timing with HIP events recorded on the launch stream (bench.py's
@@ -307,6 +311,17 @@ int dim_op_conv1a_f32(const float* in, const float* w_tap_cout, const float* bia
  * images' (x,y) and are divided by scale0/scale1 in fp32 as numpy does; origins are (x,y) int32 pairs;
  * votes[T0*T1] is zeroed by the call. */
 int dim_op_resize_area_f32(const float* src, int H, int W, float* dst, int h, int w, int div255, void* stream);
+/* The tail of _extract_by_tile (extractors/extractor_base.py:330-390) on the device: per-tile tables kpts [n_tiles][cap][2], scores
+ * [n_tiles][cap], desc [n_tiles][cap][D], live counts n_tab [n_tiles] (device), tile origins (x, y) int32 and the tile numbers as
+ * floats (tile_ids, the values of "tile_idx") -> keypoints shifted to image coordinates, those within 2 px of the (image_h,
+ * image_w) border dropped, concatenated in tile order and, with select_unique, sorted + de-duplicated exactly like
+ * np.unique(kpts, axis=0, return_index=True) (lexicographic by (x, y), first occurrence kept).  Outputs (device, sized for
+ * n_tiles * cap rows): out_kpts [N][2], out_scores [N], out_tile_idx [N], out_desc = the contiguous (D, N) array in the first
+ * D * N floats, *n_out = N.  workspace: dim_op_merge_tiles_workspace_bytes(n_tiles, cap) bytes of device memory. */
+size_t dim_op_merge_tiles_workspace_bytes(int n_tiles, int cap);
+int dim_op_merge_tiles(const float* kpts_tab, const float* scores_tab, const float* desc_tab, const int32_t* n_tab, const int32_t* origins_xy,
+                       const float* tile_ids, int n_tiles, int cap, int D, int image_h, int image_w, int select_unique, void* workspace,
+                       float* out_kpts, float* out_scores, float* out_tile_idx, float* out_desc, int32_t* n_out, void* stream);
 /* Tile slicing of _extract_by_tile (extractors/extractor_base.py:279-328) on the device: image_dev [H][W][C] fp32 as the numpy array
  * arrived (0..255), origins (x, y) int32 per tile (negative / overhanging = the Tiler's zero padding) ->
  * out_dev [n_tiles][tile_h][tile_w][C], optionally / 255 (_frame2tensor). */

@@ -139,6 +139,19 @@ def test_tiling_path_and_oom_fallback_through_the_reference_flow(dim):
     h5 = importlib.import_module("deep_image_matching.io.h5")
     f0, f1 = h5.get_features(fp, imgs[0].name), h5.get_features(fp, imgs[1].name)
     assert set(np.unique(f0["tile_idx"]).astype(int)) == {0, 1, 2, 3} and f0["keypoints"].shape[0] > 400
+    # the REAL ExtractorBase._extract_by_tile (EB:279-390: Tiler, one _extract per tile, the numpy shift / border filter / np.unique
+    # merge) on the same array == the batched override with its on-device merge (csrc/tile_merge.hip), bit for bit
+    base = importlib.import_module("deep_image_matching.extractors.extractor_base").ExtractorBase
+    rng = np.random.default_rng(5)
+    for shape, ov in (((120, 160), 0), ((130, 150), 16)):            # the second: padded tiles + overlapping tiles (duplicates)
+        img = rng.integers(0, 256, shape).astype(np.float32)
+        ex.config["general"]["tile_overlap"] = ov
+        want = base._extract_by_tile(ex, img.copy(), select_unique=True)
+        got = ex._extract_by_tile(img.copy(), select_unique=True)
+        assert want["keypoints"].shape[0] > 100
+        for k in ("keypoints", "descriptors", "scores", "tile_idx"):
+            assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), (k, shape, ov)
+    ex.config["general"]["tile_overlap"] = cfg.general["tile_overlap"]
     m = plugins.LightGlueMatcher(cfg, local_features="superpoint")
     matches_path = cfg.general["output_dir"] / "matches.h5"
     by_tile = m.match(fp, matches_path, imgs[0], imgs[1])            # -> BatchedTileMatchingMixin._match_by_tile (GRID)
