@@ -132,6 +132,31 @@ __device__ __forceinline__ float erf_1ulp(float a) {
   return t > 0.927734375f ? big : fmaf(q, a, a);
 }
 
+// The same function on a pair of values with the polynomial chains as packed fp32 FMAs (v_pk_fma_f32: two lanes' worth of work per
+// issue slot); bit-identical to erf_1ulp per element.  The fused ffn.0 + LayerNorm + GELU epilogue is VALU-bound without it.
+__device__ __forceinline__ f32x2 erf2_1ulp(f32x2 a) {
+  const f32x2 t = __builtin_elementwise_abs(a), s = a * a;
+  auto k = [](float c) { return f32x2{c, c}; };
+  f32x2 r = __builtin_elementwise_fma(k(-1.72853470e-5f), t, k(3.83197126e-4f));
+  const f32x2 u = __builtin_elementwise_fma(k(-3.88396438e-3f), t, k(2.42546219e-2f));
+  r = __builtin_elementwise_fma(r, s, u);
+  r = __builtin_elementwise_fma(r, t, k(-1.06777877e-1f));
+  r = __builtin_elementwise_fma(r, t, k(-6.34846687e-1f));
+  r = __builtin_elementwise_fma(r, t, k(-1.28717512e-1f));
+  r = __builtin_elementwise_fma(r, t, -t);
+  r = r * k(1.44269504088896340736f);
+  f32x2 q = __builtin_elementwise_fma(k(-5.96761703e-4f), s, k(4.99119423e-3f));
+  q = __builtin_elementwise_fma(q, s, k(-2.67681349e-2f));
+  q = __builtin_elementwise_fma(q, s, k(1.12819925e-1f));
+  q = __builtin_elementwise_fma(q, s, k(-3.76125336e-1f));
+  q = __builtin_elementwise_fma(q, s, k(1.28379166e-1f));
+  const f32x2 small = __builtin_elementwise_fma(q, a, a);
+  f32x2 o;
+  o[0] = t[0] > 0.927734375f ? copysignf(1.0f - __builtin_amdgcn_exp2f(r[0]), a[0]) : small[0];
+  o[1] = t[1] > 0.927734375f ? copysignf(1.0f - __builtin_amdgcn_exp2f(r[1]), a[1]) : small[1];
+  return o;
+}
+
 // row index inside a 32x32 MFMA tile held by (lane-half h, register r)
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 

@@ -39,7 +39,10 @@ constexpr int KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
 //     waves of 64 x 128 every fragment was fetched twice per workgroup and the per-CU vector-memory path (64 B / clk), not
 //     the matrix pipe or HBM latency, was what the kernel ran at (an experiment that made every activation prefetch an L2
 //     hit changed nothing).  The activation fragments come from LDS, which has the bandwidth to feed 4 waves.
-template <int MODE, int BM, int NT, int KV, int WN>
+// PROBE (timing experiments only, scripts/gpu_gemm_probe.py; 0 in every product instantiation): bit 0 = the activation rows of all
+// workgroups come from the first 2048 rows (cache-resident), bit 1 = every chunk re-reads the weight fragments of chunk 0 (L1 hits),
+// bit 2 = no MFMAs, bit 3 = the weight fragments are loaded once, before the K loop.  Results are wrong by design.
+template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false>
 __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, int by) {
   using S = SplitMma<MODE>;
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
@@ -82,7 +85,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       // rows past the ragged end re-read the last valid row (always mapped): GEMM rows are independent and the
       // epilogue never stores them, so they need no zeroing — no branch, and no VALU touching the prefetch
       // registers before the split (anything earlier would drag the wait for them into the MFMA phase)
-      ra[i] = *(const float4*)(src + (size_t)min(m0 + row, rows - 1) * ld + kk0 + q * 4);
+      ra[i] = *(const float4*)(src + (size_t)((PROBE & 1) ? ((m0 + row) & 2047) : min(m0 + row, rows - 1)) * ld + kk0 + q * 4);
     }
   };
   auto store_chunk = [&]() {
@@ -98,8 +101,69 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     }
   };
 
+  // one 16-wide k-step of the chunk staged in LDS against the weight fragments fbk[n][plane]
+  auto mma_step = [&](int ks, const u32x4 (&fbk)[NT][NPL]) {
+    u32x4 fa[MT][NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * (32 * MT) + m * 32 + lx) * RS + ks * 8 + half * 4];
+    // cross terms smallest first; the accumulators interleave so no MFMA waits on its predecessor
+    if (PROBE & 4) {  // no MFMAs: keep the operands alive
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n][0] += __uint_as_float(fa[m][0][0] ^ fbk[n][1][0]);
+    } else if (kblk) {  // transposed tiles: the weights are the A operand
+#pragma unroll
+      for (int tm = 0; tm < S::NT; ++tm)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fbk[n][S::tb(tm)], fa[m][S::ta(tm)], acc[m][n]);
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < S::NT; ++tm)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fbk[n][S::tb(tm)], acc[m][n]);
+    }
+  };
+  auto load_b = [&](int kstep, u32x4 (&fbk)[NT][NPL]) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) fbk[n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + kstep) * 2 + half) * 32 + lx];
+  };
+
   load_chunk(0);
-  for (int k0 = 0; k0 < a.K; k0 += KC) {
+  const int k_end = (PROBE & 32) ? KC : a.K;   // probe bit 5: one K chunk only
+  if (PIPE) {
+    // Weight fragments double-buffered per k-STEP: the fragments of step s + 1 are requested before the MFMAs of step s, so the
+    // (L2) latency of every request hides behind 3 * MT * NT MFMAs instead of standing in front of them twice per chunk, in the
+    // registers the one-chunk-at-a-time form already used (2 steps x NT x NPL).  Vector-memory loads retire in order: the next
+    // chunk's activation prefetch is issued AFTER the fragments of this chunk's second step and BEFORE those of the next chunk's
+    // first step, which are not waited for until after the next barrier — by then the prefetch is needed anyway.
+    u32x4 fb0[NT][NPL], fb1[NT][NPL];
+    load_b(0, fb0);
+    for (int k0 = 0; k0 < k_end; k0 += KC) {
+      store_chunk();
+      __syncthreads();
+      const int kst = (PROBE & 2) ? 0 : (k0 >> 4);
+      if (!(PROBE & 8)) load_b(kst + 1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_chunk(min(k0 + KC, a.K - KC));   // unconditional: see below
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(PROBE & 8)) load_b(min(kst + 2, KS - 2), fb0);   // the last chunk harmlessly re-reads its own first step
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(1, (PROBE & 8) ? fb0 : fb1);
+      __syncthreads();
+    }
+  } else
+  for (int k0 = 0; k0 < k_end; k0 += KC) {
     store_chunk();
     __syncthreads();
     // Issue order matters: vector-memory loads retire in order, so the weight fragments this chunk's MFMAs
@@ -109,12 +173,11 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     // fragments at a time — 32 instead of 64 registers — so that the accumulators can live in the AGPR half of the file)
     constexpr int FKS = lng ? 1 : 2;
     u32x4 fb[FKS][NT][NPL];
+    const int kf0 = (PROBE & 2) ? 0 : (k0 >> 4);
+    if (!(PROBE & 8) || k0 == 0) {
 #pragma unroll
-    for (int ks = 0; ks < FKS; ++ks)
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) fb[ks][n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + (k0 >> 4) + ks) * 2 + half) * 32 + lx];
+      for (int ks = 0; ks < FKS; ++ks) load_b(kf0 + ks, fb[ks]);
+    }
     // unconditional (the last iteration harmlessly re-reads its own chunk): a branch here would make the compiler
     // size every wait in the MFMA phase for the path WITHOUT the prefetch, i.e. wait for the prefetch on the other
     __builtin_amdgcn_sched_barrier(0);
@@ -122,33 +185,8 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (lng && ks == 1) {
-#pragma unroll
-        for (int p = 0; p < NPL; ++p)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) fb[0][n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + (k0 >> 4) + 1) * 2 + half) * 32 + lx];
-      }
-      u32x4 fa[MT][NPL];
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * (32 * MT) + m * 32 + lx) * RS + ks * 8 + half * 4];
-      // cross terms smallest first; the four accumulators interleave so no MFMA waits on its predecessor
-      if (kblk) {  // transposed tiles: the weights are the A operand
-#pragma unroll
-        for (int tm = 0; tm < S::NT; ++tm)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fb[lng ? 0 : ks][n][S::tb(tm)], fa[m][S::ta(tm)], acc[m][n]);
-      } else {
-#pragma unroll
-        for (int tm = 0; tm < S::NT; ++tm)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], fb[lng ? 0 : ks][n][S::tb(tm)], acc[m][n]);
-      }
+      if (lng && ks == 1 && !(PROBE & 8)) load_b(kf0 + 1, fb[0]);
+      mma_step(ks, fb[lng ? 0 : ks]);
     }
     __syncthreads();
   }
@@ -225,8 +263,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   }
 
   if (lng) {
-    // ---- LayerNorm(512) + GELU over the block's full rows (LGN:141-142), then the store.  v = acc * inv + bias is
-    // re-evaluated from the accumulators in each of the three passes (one fma) instead of being kept in 128 more registers.
+    // ---- LayerNorm(512) + GELU over the block's full rows (LGN:141-142), then the store.
     // Row statistics: in-lane over the wave's 4 column tiles, DPP over the 16-lane rows, then through LDS (the activation
     // staging buffer is free after the K loop) over the 4 x 4 sixteen-lane groups that share a block row; mean first, then
     // the centred sum of squares — the two-pass form lg_ln_gelu_kernel (and ATen) use. ----
@@ -265,14 +302,27 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       }
       __syncthreads();
     };
+    // v = acc * inv + bias once, in place (inv is a power of two: the fused multiply-add rounds like the separate product and
+    // sum); from here on the arithmetic runs on column pairs (n, n + 1) as packed fp32 operations — the epilogue is ~ 5000 VALU
+    // instructions per thread against 768 MFMAs, and is what the kernel ran at before the polynomial chains were packed
+    static_assert(NT % 2 == 0, "column pairs");
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; n += 2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const f32x2 v = __builtin_elementwise_fma(f32x2{acc[m][n][r], acc[m][n + 1][r]}, f32x2{iv[n], iv[n + 1]}, f32x2{bv[n], bv[n + 1]});
+          acc[m][n][r] = v[0]; acc[m][n + 1][r] = v[1];
+        }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float sm_ = 0.0f;
+        f32x2 sm_ = {0.0f, 0.0f};
 #pragma unroll
-        for (int n = 0; n < NT; ++n) sm_ += acc[m][n][r] * iv[n] + bv[n];
-        rowv[m * 16 + r] = sm_;
+        for (int n = 0; n < NT; n += 2) sm_ += f32x2{acc[m][n][r], acc[m][n + 1][r]};
+        rowv[m * 16 + r] = sm_[0] + sm_[1];
       }
     block_rows(rowv, 1.0f / 512.0f);               // rowv = mean of the row
     float sq[MT * 16];
@@ -280,10 +330,11 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float s2 = 0.0f;
+        const f32x2 mean2 = {rowv[m * 16 + r], rowv[m * 16 + r]};
+        f32x2 s2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int n = 0; n < NT; ++n) { const float d = (acc[m][n][r] * iv[n] + bv[n]) - rowv[m * 16 + r]; s2 += d * d; }
-        sq[m * 16 + r] = s2;
+        for (int n = 0; n < NT; n += 2) { const f32x2 d = f32x2{acc[m][n][r], acc[m][n + 1][r]} - mean2; s2 = __builtin_elementwise_fma(d, d, s2); }
+        sq[m * 16 + r] = s2[0] + s2[1];
       }
     block_rows(sq, 1.0f / 512.0f);                 // sq = biased variance of the row
     const dim_rsrc Cr = buf_rsrc(a.C + (size_t)z * a.strideC, ((size_t)(rows - 1) * a.ldc + a.N) * sizeof(float));
@@ -295,16 +346,18 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float mean = rowv[m * 16 + r], rstd = 1.0f / sqrtf(sq[m * 16 + r] + 1e-5f);
+        const f32x2 mean2 = {mean, mean}, rstd2 = {rstd, rstd};
         const unsigned rb = (row0 + (unsigned)((r & 3) + 8 * (r >> 2))) * ldc4;
 #pragma unroll
         for (int n = 0; n < NT; n += 2) {
-          float y0 = ((acc[m][n][r] * iv[n] + bv[n]) - mean) * rstd * gm[n] + bt[n];
-          float y1 = ((acc[m][n + 1][r] * iv[n + 1] + bv[n + 1]) - mean) * rstd * gm[n + 1] + bt[n + 1];
-          y0 = 0.5f * y0 * (1.0f + erf_1ulp(y0 * 0.70710678118654752440f));
-          y1 = 0.5f * y1 * (1.0f + erf_1ulp(y1 * 0.70710678118654752440f));
-          vmax = sat_track(vmax, y0, y1);
-          buf_store_f32(Cr, rb + (unsigned)(n0 + wn * (32 * NT) + n * 32 + lx) * 4u, y0);
-          buf_store_f32(Cr, rb + (unsigned)(n0 + wn * (32 * NT) + (n + 1) * 32 + lx) * 4u, y1);
+          const f32x2 d = (f32x2{acc[m][n][r], acc[m][n + 1][r]} - mean2) * rstd2;
+          const f32x2 y = __builtin_elementwise_fma(d, f32x2{gm[n], gm[n + 1]}, f32x2{bt[n], bt[n + 1]});
+          const f32x2 e = erf2_1ulp(y * f32x2{0.70710678118654752440f, 0.70710678118654752440f});
+          const f32x2 hy = y * f32x2{0.5f, 0.5f};
+          const f32x2 g = __builtin_elementwise_fma(hy, e, hy);     // 0.5 y (1 + erf(y / sqrt 2))
+          vmax = sat_track(vmax, g[0], g[1]);
+          buf_store_f32(Cr, rb + (unsigned)(n0 + wn * (32 * NT) + n * 32 + lx) * 4u, g[0]);
+          buf_store_f32(Cr, rb + (unsigned)(n0 + wn * (32 * NT) + (n + 1) * 32 + lx) * 4u, g[1]);
         }
       }
     }
@@ -318,7 +371,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   // before any is used; the uniform decisions (residual? activation?) are hoisted.
   const dim_rsrc Cr = buf_rsrc(a.C + (size_t)z * a.strideC, ((size_t)(rows - 1) * a.ldc + a.N) * sizeof(float));
   const dim_rsrc Rr = buf_rsrc(a.R ? a.R + (size_t)z * a.strideR : a.C, a.R ? ((size_t)(rows - 1) * a.ldr + a.N) * sizeof(float) : 0);
-  const bool has_r = a.R != nullptr;
+  const bool has_r = a.R != nullptr && !(PROBE & 16);   // probe bit 4: no residual loads, one store per thread
   const unsigned ldc4 = (unsigned)a.ldc * 4u, ldr4 = (unsigned)a.ldr * 4u;
   float vmax = 0.0f;  // fp16x3 range guard on what this thread stores (dim_common.h)
 #pragma unroll
@@ -354,6 +407,13 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       // (load_chunk clamps) plus a zero residual, padded columns hold the bias of the last valid column
 #pragma unroll
       for (int r = 0; r < 16; r += 2) vmax = sat_track(vmax, v[r], v[r + 1]);
+      if (PROBE & 16) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += v[r];
+        if (m == 0 && n == 0) buf_store_f32(Cr, cbase, sum); else vmax = fmaxf(vmax, sum);
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) buf_store_f32(Cr, cbase + (unsigned)((r & 3) + 8 * (r >> 2)) * ldc4, v[r]);
     }
@@ -364,12 +424,22 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 template <int MODE, int BM, int NT = 2, int WN = 2>
 __global__ __launch_bounds__(256, ((BM / (32 * (4 / WN))) * NT >= 8 ? 2 : 3)) void gemm_x6_kernel(GemmArgs a) {
   __shared__ unsigned Ap[SplitMma<MODE>::NPL * BM * RS];
-  gemm_x6_body<MODE, BM, NT, 0, WN>(a, Ap, (int)blockIdx.y);
+  gemm_x6_body<MODE, BM, NT, 0, WN, 0, (WN == 4)>(a, Ap, (int)blockIdx.y);   // the wide block runs the pipelined K loop
 }
 // LightGlue's ffn.0 with LayerNorm + GELU in the epilogue: one workgroup owns 64 rows x all 512 columns
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 64 * RS];
-  gemm_x6_body<2, 64, 4, 3, 4>(a, Ap, 0);
+  gemm_x6_body<2, 64, 4, 3, 4, 0, true>(a, Ap, 0);
+}
+template <int PROBE, bool PIPE = false>
+__global__ __launch_bounds__(256, 2) void gemm_x6_probe_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 128 * RS];
+  gemm_x6_body<2, 128, 2, 0, 4, PROBE, PIPE>(a, Ap, (int)blockIdx.y);
+}
+template <int PROBE, bool PIPE = false>
+__global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_probe_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 64 * RS];
+  gemm_x6_body<2, 64, 4, 3, 4, PROBE, PIPE>(a, Ap, 0);
 }
 // LightGlue's q|k|v projection in ONE launch: blockIdx.y selects the column block and with it the code path (plain fp32 /
 // transposed K image / V image — three inlined bodies, one register allocation each), so that the 2 or 3 column blocks of
@@ -378,9 +448,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_kernel(GemmArgs a) {
 __global__ __launch_bounds__(256, 2) void gemm_x6_qkv_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 128 * RS];
   const int by = (int)blockIdx.y;
-  if (by == a.kv_kblock) gemm_x6_body<2, 128, 2, 1, 4>(a, Ap, by);
-  else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4>(a, Ap, by);
-  else gemm_x6_body<2, 128, 2, 0, 4>(a, Ap, by);
+  if (by == a.kv_kblock) gemm_x6_body<2, 128, 2, 1, 4, 0, true>(a, Ap, by);
+  else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4, 0, true>(a, Ap, by);
+  else gemm_x6_body<2, 128, 2, 0, 4, 0, true>(a, Ap, by);
 }
 }  // namespace
 
@@ -408,7 +478,18 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   if (a.ln_gamma != nullptr) {
     DIM_REQUIRE(a.split_mode == 2 && a.N == 512 && a.n_pad == 512 && a.ln_beta && a.bias && a.R == nullptr && a.relu == 0 && a.kv_img == nullptr,
                 "gemm_x6: the LayerNorm + GELU epilogue needs the fp16x3 512-column ffn.0 shape");
-    hipLaunchKernelGGL(gemm_x6_ffn_ln_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    const dim3 lg(cdiv(a.M, 64), 1, batch);
+    switch (dim_gemm_probe()) {
+      case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<1>), lg, dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<2>), lg, dim3(256), 0, s, a); break;
+      case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<4>), lg, dim3(256), 0, s, a); break;
+      case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<8>), lg, dim3(256), 0, s, a); break;
+      case 9: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<9>), lg, dim3(256), 0, s, a); break;
+      case 100: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<0, true>), lg, dim3(256), 0, s, a); break;
+      case 104: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<4, true>), lg, dim3(256), 0, s, a); break;
+      case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<32>), lg, dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(gemm_x6_ffn_ln_kernel, lg, dim3(256), 0, s, a);
+    }
     DIM_LAUNCH_CHECK();
     return 0;
   }
@@ -424,7 +505,20 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
       DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
       DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == (int)grid.y - 1, "gemm_x6: the K and V blocks must be the last two");
       hipLaunchKernelGGL(gemm_x6_qkv_kernel, grid, dim3(256), 0, s, a);
-    } else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);
+    } else switch (dim_gemm_probe()) {
+      case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<1>), grid, dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<2>), grid, dim3(256), 0, s, a); break;
+      case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<4>), grid, dim3(256), 0, s, a); break;
+      case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<8>), grid, dim3(256), 0, s, a); break;
+      case 9: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<9>), grid, dim3(256), 0, s, a); break;
+      case 100: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<0, true>), grid, dim3(256), 0, s, a); break;
+      case 104: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<4, true>), grid, dim3(256), 0, s, a); break;
+      case 116: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<16, true>), grid, dim3(256), 0, s, a); break;
+      case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<48>), grid, dim3(256), 0, s, a); break;
+      case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<32>), grid, dim3(256), 0, s, a); break;
+      case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<16>), grid, dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);
+    }
   } else {
     dim3 grid(cdiv(a.M, 128), cdiv(a.N, BN), batch);
     if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128>), grid, dim3(256), 0, s, a);
