@@ -59,7 +59,7 @@ static int g_fold_out_proj = 1;
 int dim_fold_out_proj() { return g_fold_out_proj; }
 static int g_fuse_kv = 1;
 int dim_fuse_kv() { return g_fuse_kv; }
-static int g_fuse_ffn_ln = 1;
+static int g_fuse_ffn_ln = 3;
 int dim_fuse_ffn_ln() { return g_fuse_ffn_ln; }
 static int g_gemm_probe = 0;
 int dim_gemm_probe() { return g_gemm_probe; }
@@ -165,13 +165,16 @@ int dim_op_simple_nms_f32(const float* score_map, float* out, int batch, int H, 
 
 // Op-level handles: a host struct holding the pre-split device operand for the precision mode that was active
 // at creation (dim_tune_set key 1: 2 = fp16x3, 1 = bf16x6).
-int dim_x3_create(const float* w_kn_host, int K, int N, void** out_dev, int* n_pad_out) {
+static int x3_create(const float* w_kn_host, int K, int N, void** out_dev, int* n_pad_out, int kperm);
+int dim_x3_create(const float* w_kn_host, int K, int N, void** out_dev, int* n_pad_out) { return x3_create(w_kn_host, K, N, out_dev, n_pad_out, 0); }
+int dim_x3_create_kperm(const float* w_kn_host, int K, int N, void** out_dev, int* n_pad_out) { return x3_create(w_kn_host, K, N, out_dev, n_pad_out, 1); }
+static int x3_create(const float* w_kn_host, int K, int N, void** out_dev, int* n_pad_out, int kperm) {
   DIM_REQUIRE(w_kn_host && out_dev && n_pad_out && K > 0 && N > 0, "dim_x3_create: bad argument");
   const int mode = g_precision_mode == 1 ? 1 : 2;
   const int n_pad = (N + 127) / 128 * 128;
   std::vector<unsigned short> host(gemm_split_weight_elems(K, n_pad, mode));
   SplitWeights* w = new SplitWeights();
-  split_weights(w_kn_host, K, N, n_pad, mode, host.data(), w);
+  split_weights(w_kn_host, K, N, n_pad, mode, host.data(), w, kperm);
   void* d = nullptr;
   if (hipMalloc(&d, host.size() * 2) != hipSuccess || hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
     delete w;
@@ -206,6 +209,19 @@ int dim_op_gemm_x6_ln_gelu_f32(const float* A, int lda, const void* w_x3, const 
   g.A0 = A; g.lda0 = lda; g.set_split(*(const SplitWeights*)w_x3); g.bias = bias; g.ln_gamma = ln_gamma; g.ln_beta = ln_beta;
   g.C = C; g.ldc = ldc; g.M = M; g.N = 512; g.K = K;
   g.sat = dim_sat_counter(DIM_SAT_OP);
+  return launch_gemm_x6(g, 1, (hipStream_t)stream);
+}
+
+int dim_op_ffn_fused_f32(const float* A, int lda, const void* w0_x3, const float* bias0, const float* ln_gamma, const float* ln_beta,
+                         const void* w3_x3_kperm, const float* bias3, const float* residual, int ldr, float* C, int ldc, int M, int K, void* stream) {
+  DIM_REQUIRE(w0_x3 && ((const SplitWeights*)w0_x3)->n_pad == 512 && ((const SplitWeights*)w0_x3)->mode == 2, "dim_op_ffn_fused_f32: needs an fp16x3 512-column ffn.0 handle");
+  DIM_REQUIRE(w3_x3_kperm && ((const SplitWeights*)w3_x3_kperm)->n_pad == 256 && ((const SplitWeights*)w3_x3_kperm)->mode == 2, "dim_op_ffn_fused_f32: needs an fp16x3 256-column ffn.3 handle (dim_x3_create_kperm)");
+  DIM_REQUIRE(A && bias0 && ln_gamma && ln_beta && bias3 && residual && C, "dim_op_ffn_fused_f32: null argument");
+  GemmArgs g;
+  g.A0 = A; g.lda0 = lda; g.set_split(*(const SplitWeights*)w0_x3); g.bias = bias0; g.ln_gamma = ln_gamma; g.ln_beta = ln_beta;
+  g.set_split2(*(const SplitWeights*)w3_x3_kperm); g.bias2 = bias3; g.R = residual; g.ldr = ldr;
+  g.C = C; g.ldc = ldc; g.M = M; g.N = 512; g.K = K;
+  g.sat = dim_sat_counter(DIM_SAT_OP); g.sat2 = dim_sat_counter(DIM_SAT_OP);
   return launch_gemm_x6(g, 1, (hipStream_t)stream);
 }
 

@@ -221,6 +221,10 @@ __device__ __forceinline__ void buf_store_u16(dim_rsrc r, unsigned byte_off, uns
 __device__ __forceinline__ unsigned lane_swap1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
 // byte select from {hi, lo} (v_perm_b32): selector byte k in 0..3 picks lo byte k, 4..7 picks hi byte k - 4
 __device__ __forceinline__ unsigned byte_perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// ... with a wave-uniform byte offset in an SGPR on top of the per-lane one.  The hardware range check covers the per-lane offset
+// only: keep everything that can run past the end (the row) in byte_off.
+__device__ __forceinline__ float buf_load_f32_s(dim_rsrc r, unsigned byte_off, unsigned uniform_off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)uniform_off, 0)); }
+__device__ __forceinline__ void buf_store_f32_s(dim_rsrc r, unsigned byte_off, unsigned uniform_off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, (int)uniform_off, 0); }
 __device__ __forceinline__ float buf_load_f32(dim_rsrc r, unsigned byte_off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0)); }
 
 // LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane straight from global memory into LDS at the WAVE-UNIFORM base + lane * 16

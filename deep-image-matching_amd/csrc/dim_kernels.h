@@ -53,6 +53,11 @@ struct GemmArgs {
   // LayerNorm(512, eps 1e-5, affine) + erf-GELU (LGN:141-142) before the store — the separate lg_ln_gelu pass (a read and a write
   // of the 512-wide hidden tensor) disappears.  Needs N == n_pad == 512, no residual, no activation.
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
+  // ... and when B2x3 != nullptr the same workgroup goes on to ffn.3 (512 -> 256; weights split with the k permutation of
+  // split_weights(kperm = 1)) + bias2 + residual R: C [M][256] = R + gelu(layer_norm(A W + bias)) W2 + bias2, the hidden tensor
+  // never stored (gemm_x6_ffn_fused_kernel).  sat guards the hidden values, sat2 the outputs.
+  const unsigned short* B2x3 = nullptr; const float* inv_ch2 = nullptr; const float* bias2 = nullptr; unsigned* sat2 = nullptr;
+  void set_split2(const SplitWeights& w) { B2x3 = w.dev; inv_ch2 = w.inv_ch(); }
 };
 constexpr int KV_TILE_STRIDE = 3 * 8 * 32 + 3 * 2 * 2 * 64;  // 16-byte slots reserved per (item, head, 32-key tile) image (bf16x6 fills all 1536)
 bool gemm_x6_fuses_kv(int M, int n_pad, int batch, int split_mode);  // true when launch_gemm_x6 will honour kv_img for this shape
@@ -62,7 +67,9 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s);
 // host: [K][N] fp32 -> the pre-split device layout; elems = planes * n_pad * K 16-bit values + 2 * n_pad for the fp32
 // per-column inverse scales in the tail (sw->scale_off); fills sw->mode / n_pad / scale_off (not sw->dev)
 size_t gemm_split_weight_elems(int K, int n_pad, int mode);
-void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, SplitWeights* sw);
+void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, SplitWeights* sw, int kperm = 0);
+// kperm = 1: inside every 16-wide k-step, k value 8 (e >> 2) + 4 hf + (e & 3) is stored at (k-half hf, element e) — the order in which
+// a transposed MFMA result tile presents its rows when it is reused as an operand (gemm_x6_ffn_fused_kernel)
 
 // ---------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution over NHWC fp32 images as an implicit GEMM
@@ -94,7 +101,8 @@ int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside 
 int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)
 int dim_gemm_probe();        // 0 (product); timing probes of the wide fp16x3 GEMM blocks (dim_tune_set key 13; gemm_x6.hip PROBE)
 int dim_attn_probe();        // 0 (product); 1 / 2 / 3: timing probes of cross attention (dim_tune_set key 12; lg_attn_x6.hip)
-int dim_fuse_ffn_ln();       // 1 (default): LightGlue's LayerNorm + GELU run in the epilogue of ffn.0 (64 x 512 blocks; dim_tune_set key 11)
+int dim_fuse_ffn_ln();       // dim_tune_set key 11.  3 (default): LightGlue's whole feed-forward (ffn.0, LayerNorm, GELU, ffn.3, residual) is one kernel when the
+                             // launch fills the GPU with 64-row blocks, 4 = always (tests); 1 / 2: only LayerNorm + GELU in ffn.0's epilogue; 0: separate kernels
 int dim_fuse_kv();           // 1 (default): LightGlue's K | V tile images written by the projection GEMM's epilogue (dim_tune_set key 8)
 int dim_nms_big_tiles();     // 1 (default): 64 x 64 NMS tiles on large score maps (dim_tune_set key 7; 2 = forced)
 void dim_nms_set_big_tiles(int v);

@@ -48,14 +48,15 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
   constexpr int NPL = S::NPL, NLD = BM / 32;        // float4 loads per thread and chunk
   constexpr int BN = 32 * NT * WN;
-  static_assert(KV == 0 || KV == 3 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
+  static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
+  static_assert(KV != 4 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4 && NT == 4), "the fused ffn exists for the fp16x3 64 x 512 block");
   static_assert(KV != 3 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4), "the LayerNorm + GELU epilogue exists for the fp16x3 64 x 512 block");
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
   const int m0 = blockIdx.x * BM, n0 = by * BN;
   if (m0 >= rows || n0 >= a.N) return;
-  constexpr bool kblk = KV == 1, vblk = KV == 2, lng = KV == 3;
+  constexpr bool ffn = KV == 4, kblk = KV == 1 || ffn, vblk = KV == 2, lng = KV == 3;   // (ffn computes its hidden tile transposed, like the K image)
 
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN, lx = lane & 31, half = lane >> 5;
@@ -171,7 +172,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     // then covers the (L2-resident) fragments only and the HBM latency of the prefetch hides behind the MFMAs.
     // (the 64 x 512 LayerNorm block holds 8 accumulators AND 4 column tiles of fragments per step: it requests one k-step's
     // fragments at a time — 32 instead of 64 registers — so that the accumulators can live in the AGPR half of the file)
-    constexpr int FKS = lng ? 1 : 2;
+    constexpr int FKS = (lng || ffn) ? 1 : 2;
     u32x4 fb[FKS][NT][NPL];
     const int kf0 = (PROBE & 2) ? 0 : (k0 >> 4);
     if (!(PROBE & 8) || k0 == 0) {
@@ -185,10 +186,191 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (lng && ks == 1 && !(PROBE & 8)) load_b(kf0 + 1, fb[0]);
-      mma_step(ks, fb[lng ? 0 : ks]);
+      if ((lng || ffn) && ks == 1 && !(PROBE & 8)) load_b(kf0 + 1, fb[0]);
+      mma_step(ks, fb[(lng || ffn) ? 0 : ks]);
     }
     __syncthreads();
+  }
+
+  if constexpr (ffn) {
+    // ================= LightGlue's whole feed-forward in one workgroup (LGN:141-142,159,209): the 64 x 512 hidden tile never
+    // leaves the CU.  The K loop above produced it TRANSPOSED (weights as the A operand): lane = token lx (+ 32 m), register r of
+    // tile n = hidden unit 128 wn + 32 n + (r & 3) + 8 (r >> 2) + 4 half — exactly the operand layout of the next product
+    // (lane = row, 8 consecutive registers = the k values of one lane half), so after LayerNorm + GELU the tile is split in
+    // place into fp16 pieces and fed to ffn.3 as the A operand straight from registers.  The k ORDER inside a 16-step differs
+    // from the natural one (register j of half h is unit 8 (j >> 2) + 4 h + (j & 3) of the step); ffn.3's weight fragments are
+    // packed with the same permutation on the host (split_weights, kperm).  Every wave holds 128 of the 512 hidden units, i.e. a
+    // K-slice of ffn.3: the four partial 64 x 256 outputs are reduced through LDS, 64 columns at a time, each wave ending up
+    // with one 32 x 32 tile that it finishes (scale, bias, residual, range guard) and stores. =================
+    float* const prm = (float*)(Ap + NPL * BM * RS);   // [inv0 | bias0 | gamma | beta] x 512 — filled before the K loop
+    float* const red = prm + 2048;                     // [2 passes][4 waves][64 tokens]
+    float* const xbuf = red + 512;                     // [4 owner tiles][3 sources][4 register quads][64 lanes][4]
+    // ---- v = acc * inv + bias in place; LayerNorm statistics per token: registers + lane halves + the four waves ----
+    float part[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) part[m] = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int ub = wn * 128 + n * 32 + 8 * rq + 4 * half;
+        const float4 iv = *(const float4*)(prm + ub), bv = *(const float4*)(prm + 512 + ub);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc[m][n][4 * rq + 0] = fmaf(acc[m][n][4 * rq + 0], iv.x, bv.x);
+          acc[m][n][4 * rq + 1] = fmaf(acc[m][n][4 * rq + 1], iv.y, bv.y);
+          acc[m][n][4 * rq + 2] = fmaf(acc[m][n][4 * rq + 2], iv.z, bv.z);
+          acc[m][n][4 * rq + 3] = fmaf(acc[m][n][4 * rq + 3], iv.w, bv.w);
+          part[m] += (acc[m][n][4 * rq + 0] + acc[m][n][4 * rq + 1]) + (acc[m][n][4 * rq + 2] + acc[m][n][4 * rq + 3]);
+        }
+      }
+    float mean[MT], rstd[MT];
+    auto token_total = [&](float (&p)[MT], float* region, float (&out)[MT]) {   // sum over the 512 units of the lane's tokens
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float v = p[m] + __shfl_xor(p[m], 32);
+        if (half == 0) region[wn * 64 + m * 32 + lx] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < MT; ++m) out[m] = (region[m * 32 + lx] + region[64 + m * 32 + lx]) + (region[128 + m * 32 + lx] + region[192 + m * 32 + lx]);
+    };
+    token_total(part, red, mean);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { mean[m] *= 1.0f / 512.0f; part[m] = 0.0f; }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc[m][n][r] - mean[m]; part[m] = fmaf(d, d, part[m]); }
+    token_total(part, red + 256, rstd);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) rstd[m] = 1.0f / sqrtf(rstd[m] * (1.0f / 512.0f) + 1e-5f);
+    // ---- normalise, GELU, range guard, split: tile (m, n) -> hq[m][n][plane][q] (q = which 8 registers = which k-step) ----
+    u32x4 hq[MT][NT][NPL][2];
+    float vmax = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int ub = wn * 128 + n * 32 + 8 * rq + 4 * half;
+        const float4 gm = *(const float4*)(prm + 1024 + ub), bt = *(const float4*)(prm + 1536 + ub);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const f32x2 mean2 = {mean[m], mean[m]}, rstd2 = {rstd[m], rstd[m]};
+          const f32x2 half2 = {0.5f, 0.5f}, rt2 = {0.70710678118654752440f, 0.70710678118654752440f};
+          f32x2 y0 = (f32x2{acc[m][n][4 * rq], acc[m][n][4 * rq + 1]} - mean2) * rstd2;
+          f32x2 y1 = (f32x2{acc[m][n][4 * rq + 2], acc[m][n][4 * rq + 3]} - mean2) * rstd2;
+          y0 = __builtin_elementwise_fma(y0, f32x2{gm.x, gm.y}, f32x2{bt.x, bt.y});
+          y1 = __builtin_elementwise_fma(y1, f32x2{gm.z, gm.w}, f32x2{bt.z, bt.w});
+          const f32x2 e0 = erf2_1ulp(y0 * rt2), e1 = erf2_1ulp(y1 * rt2);
+          const f32x2 h0 = y0 * half2, h1 = y1 * half2;
+          const f32x2 g0 = __builtin_elementwise_fma(h0, e0, h0), g1 = __builtin_elementwise_fma(h1, e1, h1);
+          vmax = sat_track(sat_track(vmax, g0[0], g0[1]), g1[0], g1[1]);
+          unsigned p0[NPL], p1[NPL];
+          S::split(g0[0], g0[1], S::act_scale(), p0);
+          S::split(g1[0], g1[1], S::act_scale(), p1);
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) { hq[m][n][pl][rq >> 1][2 * (rq & 1)] = p0[pl]; hq[m][n][pl][rq >> 1][2 * (rq & 1) + 1] = p1[pl]; }
+        }
+      }
+    sat_report(a.sat, vmax);
+    // ---- ffn.3 over this wave's 128 hidden units (8 k-steps: step ks = tile n = ks / 2, registers 8 (ks & 1) ..), 64 output
+    // columns per round; weight fragments one k-step ahead ----
+    const u32x4* const Bf2 = (const u32x4*)a.B2x3;
+    constexpr int NB2 = 8, KS2 = 32;   // 256 columns, 512 hidden units
+    const dim_rsrc Cr = buf_rsrc(a.C + (size_t)z * a.strideC, ((size_t)(rows - 1) * a.ldc + 256) * sizeof(float));
+    const dim_rsrc Rr = buf_rsrc(a.R + (size_t)z * a.strideR, ((size_t)(rows - 1) * a.ldr + 256) * sizeof(float));
+    float vmax2 = 0.0f;
+    // output tile of this wave in every round: rows 32 (wn >> 1) .., columns 64 grp + 32 (wn & 1) ..  One per-lane byte offset (first
+    // row of the lane half, lane column); the register's row step and the round's column step are wave-uniform and ride in the
+    // scalar offset — which the hardware range check ignores, so rows past the ragged end are predicated off explicitly
+    const int orow = m0 + 32 * (wn >> 1) + 4 * half;
+    const unsigned obase = (unsigned)orow * (unsigned)a.ldc * 4u + (unsigned)(32 * (wn & 1) + lx) * 4u;
+    for (int grp = 0; grp < 4; ++grp) {
+      f32x16 acc2[MT][2];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[m][ct][r] = 0.0f;
+      auto load_w3 = [&](int ks, u32x4 (&f)[2][NPL]) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) f[ct][p] = Bf2[((((size_t)p * NB2 + 2 * grp + ct) * KS2 + wn * 8 + ks) * 2 + half) * 32 + lx];
+      };
+      auto step2 = [&](const u32x4 (&hm0)[NPL], const u32x4 (&hm1)[NPL], const u32x4 (&f)[2][NPL]) {
+#pragma unroll
+        for (int tm = 0; tm < S::NT; ++tm)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            acc2[0][ct] = S::mma(hm0[S::ta(tm)], f[ct][S::tb(tm)], acc2[0][ct]);
+            acc2[1][ct] = S::mma(hm1[S::ta(tm)], f[ct][S::tb(tm)], acc2[1][ct]);
+          }
+      };
+      u32x4 fa2[2][NPL], fb2[2][NPL];
+      load_w3(0, fa2);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        load_w3(2 * n + 1, fb2);
+        __builtin_amdgcn_sched_barrier(0);
+        { const u32x4 h0[NPL] = {hq[0][n][0][0], hq[0][n][1][0]}, h1[NPL] = {hq[1][n][0][0], hq[1][n][1][0]}; step2(h0, h1, fa2); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (n + 1 < NT) load_w3(2 * n + 2, fa2);
+        __builtin_amdgcn_sched_barrier(0);
+        { const u32x4 h0[NPL] = {hq[0][n][0][1], hq[0][n][1][1]}, h1[NPL] = {hq[1][n][0][1], hq[1][n][1][1]}; step2(h0, h1, fb2); }
+      }
+      // the residual of the tile this wave will own (tile wn: rows 32 (wn >> 1) .., columns 64 grp + 32 (wn & 1) ..), requested
+      // before the exchange so that its latency hides behind it
+      const int ocol = 64 * grp + 32 * (wn & 1) + lx;
+      const unsigned goff = (unsigned)__builtin_amdgcn_readfirstlane(grp * 256);
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2);
+        rv[r] = orow + k < rows ? buf_load_f32_s(Rr, obase, goff + (unsigned)k * (unsigned)a.ldc * 4u) : 0.0f;
+      }
+      // ---- exchange: tile t = (m = t >> 1, ct = t & 1) belongs to wave t; the other three waves hand over their partial sums ----
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4)
+        if (t4 != wn) {
+          const int src = wn < t4 ? wn : wn - 1;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+            *(float4*)(xbuf + ((((t4 * 3 + src) * 4 + rq) * 64 + lane) << 2)) =
+                make_float4(acc2[t4 >> 1][t4 & 1][4 * rq], acc2[t4 >> 1][t4 & 1][4 * rq + 1], acc2[t4 >> 1][t4 & 1][4 * rq + 2], acc2[t4 >> 1][t4 & 1][4 * rq + 3]);
+        }
+      __syncthreads();
+      float own[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a0 = (wn & 1) ? acc2[0][1][r] : acc2[0][0][r], a1 = (wn & 1) ? acc2[1][1][r] : acc2[1][0][r];
+        own[r] = (wn >> 1) ? a1 : a0;
+      }
+#pragma unroll
+      for (int src = 0; src < 3; ++src) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const float4 o = *(const float4*)(xbuf + ((((wn * 3 + src) * 4 + rq) * 64 + lane) << 2));
+          own[4 * rq] += o.x; own[4 * rq + 1] += o.y; own[4 * rq + 2] += o.z; own[4 * rq + 3] += o.w;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one source (16 registers) in flight at a time: the hidden tile occupies half the file
+      }
+      const float iv3 = a.inv_ch2[ocol], bv3 = a.bias2[ocol];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = (own[r] * iv3 + bv3) + rv[r];
+        vmax2 = fmaxf(vmax2, fabsf(v));
+        const int k = (r & 3) + 8 * (r >> 2);
+        if (orow + k < rows) buf_store_f32_s(Cr, obase, goff + (unsigned)k * (unsigned)a.ldc * 4u, v);
+      }
+      __syncthreads();   // the exchange buffer is rewritten by the next round
+    }
+    sat_report(a.sat2, vmax2);
+    return;
   }
 
   if (kblk || vblk) {
@@ -441,6 +623,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_probe_kernel(GemmArgs a
   __shared__ unsigned Ap[2 * 64 * RS];
   gemm_x6_body<2, 64, 4, 3, 4, PROBE, PIPE>(a, Ap, 0);
 }
+// LightGlue's ffn.0 -> LayerNorm -> GELU -> ffn.3 (+ residual) in one kernel: 64 rows per workgroup, the hidden tensor stays on the CU
+constexpr int FFN_LDS_DWORDS = 2 * 64 * RS + 2048 + 512 + 4 * 3 * 4 * 64 * 4;
+__global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[FFN_LDS_DWORDS];
+  float* const prm = (float*)(Ap + 2 * 64 * RS);
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    prm[i] = a.inv_ch[i]; prm[512 + i] = a.bias[i]; prm[1024 + i] = a.ln_gamma[i]; prm[1536 + i] = a.ln_beta[i];
+  }   // (visible to every wave after the K loop's barriers)
+  gemm_x6_body<2, 64, 4, 4, 4, 0, false>(a, Ap, 0);   // (the k-step-pipelined loop needs 32 more registers here: measured slower, 613 vs 592 us)
+}
 // LightGlue's q|k|v projection in ONE launch: blockIdx.y selects the column block and with it the code path (plain fp32 /
 // transposed K image / V image — three inlined bodies, one register allocation each), so that the 2 or 3 column blocks of
 // a row block run next to each other on the same XCD and the activation rows come from HBM once (as separate launches
@@ -475,6 +667,14 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
   DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
   if (batch <= 0 || a.M <= 0 || a.N <= 0) return 0;
+  if (a.ln_gamma != nullptr && a.B2x3 != nullptr) {
+    DIM_REQUIRE(a.split_mode == 2 && a.N == 512 && a.n_pad == 512 && a.K % KC == 0 && a.ln_beta && a.bias && a.bias2 && a.inv_ch2 && a.R && a.C && a.relu == 0 &&
+                a.kv_img == nullptr && a.ldr == a.ldc && a.strideR == a.strideC,
+                "gemm_x6: the fused feed-forward needs the fp16x3 512 -> 256 shapes, a residual laid out like the output and both bias vectors");
+    hipLaunchKernelGGL(gemm_x6_ffn_fused_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    DIM_LAUNCH_CHECK();
+    return 0;
+  }
   if (a.ln_gamma != nullptr) {
     DIM_REQUIRE(a.split_mode == 2 && a.N == 512 && a.n_pad == 512 && a.ln_beta && a.bias && a.R == nullptr && a.relu == 0 && a.kv_img == nullptr,
                 "gemm_x6: the LayerNorm + GELU epilogue needs the fp16x3 512-column ffn.0 shape");
@@ -540,7 +740,7 @@ static unsigned short host_bf16_rne(float x) {
 }
 static size_t gemm_split_piece_elems(int K, int n_pad, int mode) { return (size_t)(mode == 2 ? 2 : 3) * n_pad * K; }
 size_t gemm_split_weight_elems(int K, int n_pad, int mode) { return gemm_split_piece_elems(K, n_pad, mode) + 2 * (size_t)n_pad; }
-void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, SplitWeights* sw) {
+void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigned short* out, SplitWeights* sw, int kperm) {
   const int NB = n_pad / 32, KS = K / 16, npl = mode == 2 ? 2 : 3;
   sw->mode = mode; sw->n_pad = n_pad; sw->scale_off = gemm_split_piece_elems(K, n_pad, mode);
   for (size_t i = 0; i < gemm_split_weight_elems(K, n_pad, mode); ++i) out[i] = 0;
@@ -562,7 +762,8 @@ void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigne
   for (int k = 0; k < K; ++k)
     for (int n = 0; n < N; ++n) {
       float x = w_kn[(size_t)k * N + n] * wsc[n];
-      const int nb = n / 32, j = n % 32, ks = k / 16, hf = (k % 16) / 8, e = k % 8;
+      const int nb = n / 32, j = n % 32, ks = k / 16, pos = k % 16;
+      const int hf = kperm ? (pos >> 2) & 1 : pos / 8, e = kperm ? ((pos >> 3) << 2) | (pos & 3) : pos % 8;
       for (int p = 0; p < npl; ++p) {
         unsigned short bits;
         float piece;

@@ -19,6 +19,7 @@ struct LayerW {
   SplitWeights qkv_x[3], out_x[3], sffn0_x[3], sffn3_x[3], cqkv_x[3], cout_x[3], cffn0_x[3], cffn3_x[3], proj_x[3];
   // out_proj folded into ffn.0 (split modes): [desc | ctx] * [W1a ; Wout*W1b] + (b1 + bout*W1b)
   SplitWeights sffn0f_x[3], cffn0f_x[3];
+  SplitWeights sffn3p_x[3], cffn3p_x[3];   // ffn.3 with the k permutation of the fused feed-forward kernel (gemm_x6.hip, KV == 4)
   float *sffn0f_b, *cffn0f_b;
 };
 }  // namespace
@@ -56,11 +57,11 @@ int upload(dim_lg* h, float** dst, const std::vector<float>& v) {
   return 0;
 }
 // [K][N] fp32 GEMM operand -> device split planes for both split modes
-int upload_x3(dim_lg* h, SplitWeights* dst, const std::vector<float>& w_kn, int K, int N) {
+int upload_x3(dim_lg* h, SplitWeights* dst, const std::vector<float>& w_kn, int K, int N, int kperm = 0) {
   const int n_pad = (N + 127) / 128 * 128;
   for (int mode = 1; mode <= 2; ++mode) {
     std::vector<unsigned short> host(gemm_split_weight_elems(K, n_pad, mode));
-    split_weights(w_kn.data(), K, N, n_pad, mode, host.data(), &dst[mode]);
+    split_weights(w_kn.data(), K, N, n_pad, mode, host.data(), &dst[mode], kperm);
     unsigned short* d = nullptr;
     if (dev_alloc(h, &d, host.size()) != 0) return -1;
     if (hipMemcpy(d, host.data(), host.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
@@ -168,6 +169,8 @@ int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pai
       LG_TRY(upload_x3(h, d.sffn0f_x, wf, 512, 512)); LG_TRY(upload(h, &d.sffn0f_b, bf));
       fold_out_proj(transpose(s.cross_out_w, 256, 256), vec(s.cross_out_b, 256), transpose(s.cross_ffn0_w, 512, 512), vec(s.cross_ffn0_b, 512), wf, bf);
       LG_TRY(upload_x3(h, d.cffn0f_x, wf, 512, 512)); LG_TRY(upload(h, &d.cffn0f_b, bf));
+      LG_TRY(upload_x3(h, d.sffn3p_x, transpose(s.self_ffn3_w, 256, 512), 512, 256, 1));
+      LG_TRY(upload_x3(h, d.cffn3p_x, transpose(s.cross_ffn3_w, 256, 512), 512, 256, 1));
     }
     LG_TRY(upload(h, &d.match_w, vec(s.assign_match_w, 256))); LG_TRY(upload(h, &d.match_b, vec(s.assign_match_b, 1)));
     // final_proj / d^0.25 (LGN:268-270): 256^0.25 = 4, a power of two -> folding the scale is exact
@@ -236,6 +239,17 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     if (x6) { g.set_split(Bx[pmode]); return launch_gemm_x6(g, I, s); }
     return launch_gemm(g, I, s);
   };
+  // ... and ffn.3 + the residual in the same kernel (dim_tune_set key 11 = 3 / 4 = forced): the hidden tensor is never stored
+  const bool fuse_ffn = fold && pmode == 2 && (dim_fuse_ffn_ln() == 4 || (dim_fuse_ffn_ln() == 3 && (long)((N + 63) / 64) * I >= 512));
+  auto ffn_fused = [&](const SplitWeights* w0, const float* b0, const float* lg, const float* lb, const SplitWeights* w3, const float* b3) -> int {
+    GemmArgs g;
+    g.A0 = st.desc; g.lda0 = 256; g.strideA0 = s256; g.A1 = st.ctx; g.lda1 = 256; g.strideA1 = s256; g.ksplit = 256;
+    g.bias = b0; g.ln_gamma = lg; g.ln_beta = lb; g.set_split(w0[2]); g.set_split2(w3[2]); g.bias2 = b3;
+    g.R = st.desc; g.ldr = 256; g.strideR = s256; g.C = st.desc; g.ldc = 256; g.strideC = s256;
+    g.M = N; g.N = 512; g.K = 512; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = 0;
+    g.sat = st.sat_ffn; g.sat2 = sat(DIM_SAT_LG_DESC);
+    return launch_gemm_x6(g, I, s);
+  };
   // fp16x3 at batch sizes that run the 128 x 256 GEMM block: the q|k|v projections write the attention kernel's K | V tile
   // images themselves (rotary + pre-split in the epilogue; dim_tune_set key 8 = 0 keeps the separate kv_prep pass)
   const bool fuse_kv = pmode == 2 && dim_fuse_kv() && gemm_x6_fuses_kv(N, 512, I, 2);
@@ -266,6 +280,8 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     dim_prof_begin(DIM_PROF_LG_SELF_ATTN, s);
     LG_RUN(launch_lg_attention(st, 0, s, fuse_kv ? 1 : 0));
     dim_prof_end(DIM_PROF_LG_SELF_ATTN, s);
+    if (fuse_ffn) LG_RUN(ffn_fused(w.sffn0f_x, w.sffn0f_b, w.sln_w, w.sln_b, w.sffn3p_x, w.sffn3_b));
+    else {
     if (fold) {  // out_proj folded into ffn.0: A = [desc | ctx]
       LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.sffn0f_x, 512, w.sffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0,
                         fuse_ln ? st.sat_ffn : nullptr, fuse_ln ? w.sln_w : nullptr, fuse_ln ? w.sln_b : nullptr));
@@ -275,12 +291,15 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     }
     if (!(fold && fuse_ln)) LG_RUN(launch_lg_ln_gelu(st, w.sln_w, w.sln_b, s));
     LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.sffn3_w, w.sffn3_x, 256, w.sffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0, sat(DIM_SAT_LG_DESC)));
+    }
     // ---- cross block (LGN:186-211) ----
     if (fuse_kv) LG_RUN(gemm_qkv(w.cqkv_x, w.cqkv_b, 512, 0, false));
     else LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.cqkv_w, w.cqkv_x, 512, w.cqkv_b, nullptr, st.qkv, 768, s768, 512, 256, 0, st.sat_qkv));
     dim_prof_begin(DIM_PROF_LG_CROSS_ATTN, s);
     LG_RUN(launch_lg_attention(st, 1, s, fuse_kv ? 1 : 0));
     dim_prof_end(DIM_PROF_LG_CROSS_ATTN, s);
+    if (fuse_ffn) LG_RUN(ffn_fused(w.cffn0f_x, w.cffn0f_b, w.cln_w, w.cln_b, w.cffn3p_x, w.cffn3_b));
+    else {
     if (fold) {
       LG_RUN(gemm_items(st.desc, 256, s256, st.ctx, 256, s256, 256, nullptr, w.cffn0f_x, 512, w.cffn0f_b, nullptr, st.hid, 512, s512, 512, 512, 0,
                         fuse_ln ? st.sat_ffn : nullptr, fuse_ln ? w.cln_w : nullptr, fuse_ln ? w.cln_b : nullptr));
@@ -290,6 +309,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     }
     if (!(fold && fuse_ln)) LG_RUN(launch_lg_ln_gelu(st, w.cln_w, w.cln_b, s));
     LG_RUN(gemm_items(st.hid, 512, s512, nullptr, 0, 0, 0, w.cffn3_w, w.cffn3_x, 256, w.cffn3_b, st.desc, st.desc, 256, s256, 256, 512, 0, sat(DIM_SAT_LG_DESC)));
+    }
     // ---- adaptive depth / width (LGN:494-516) ----
     const bool last = (i == Lr - 1);
     if (!last && (early || prune))

@@ -48,8 +48,9 @@ int dim_device_synchronize(void);
  * 2 = always 128 x 256 (tests); key 7 = simple_nms tiles: 1 (default) 64 x 64 on large maps, 0 = 32 x 32, 2 = always 64 x 64;
  * key 8 = 1 (default) LightGlue's K | V attention tile images written by the projection GEMM, 0 = separate pre-split pass;
  * key 9 = 1 (default) ALIKED BatchNorm + SELU applied while the consumer stages its input, 0 = separate pass; key 10 = ALIKED fp16x3
- * convolution tile rows (16 default, 8, 17 = 16 with streamed weights); key 11 = 1 (default) LightGlue's LayerNorm + GELU in the
- * epilogue of ffn.0 when the launch fills the GPU, 2 = always (tests), 0 = separate kernel; key 12 = cross-attention timing probes
+ * convolution tile rows (16 default, 8, 17 = 16 with streamed weights); key 11 = LightGlue's feed-forward: 3 (default) ffn.0 +
+ * LayerNorm + GELU + ffn.3 + residual as one kernel when the launch fills the GPU, 4 = always (tests), 1 / 2 = LayerNorm + GELU in
+ * ffn.0's epilogue only (when large / always), 0 = separate kernels; key 12 = cross-attention timing probes
  * (scripts/gpu_attn_probe.py; 0 in the product — 1 and 3 give wrong results by design). */
 int dim_tune_set(int key, int value);
 
@@ -280,6 +281,14 @@ int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3_handle, int n_p
  * gelu(layer_norm(A[M][K] * W + bias)); w_x3_handle from dim_x3_create(K, 512) under the default arithmetic. */
 int dim_op_gemm_x6_ln_gelu_f32(const float* A, int lda, const void* w_x3_handle, const float* bias, const float* ln_gamma, const float* ln_beta,
                                float* C, int ldc, int M, int K, void* stream);
+
+/* LightGlue's whole feed-forward (LGN:141-142,159,209) as ONE kernel: C[M][256] = residual + gelu(layer_norm(A[M][K] * W0 + bias0)) *
+ * W3 + bias3, the 512-wide hidden tensor kept on the compute unit.  w0 from dim_x3_create(K, 512); w3 from dim_x3_create_kperm(512,
+ * 256) (the same split, rows of every 16-step stored in the order the kernel's register-resident operand presents them). */
+int dim_x3_create_kperm(const float* w_kn_host, int K, int N, void** out_handle, int* n_pad_out);
+int dim_op_ffn_fused_f32(const float* A, int lda, const void* w0_x3_handle, const float* bias0, const float* ln_gamma, const float* ln_beta,
+                         const void* w3_x3_kperm_handle, const float* bias3, const float* residual, int ldr, float* C, int ldc, int M, int K,
+                         void* stream);
 
 /* 3x3/s1/p1 conv, NHWC fp32, weights [9][cin][cout], bias+ReLU and optional
  * 2x2 max-pool fused (SPN:161-171).  cin in {64,128}, cout % 64 == 0. */

@@ -35,5 +35,5 @@ for mode in ("fixed", "default"):
             if eq and S:
                 worst = max(worst, float((o["scores"][p, :S].log() - s.log()).abs().max()))
         res[f"{mode}_ln{ln}"] = {"pairs_with_equal_matches": same, "max_abs_log_score_diff": worst, "batch_rerun_bit_equal": rerun}
-lib.dim_tune_set(11, 1)
+lib.dim_tune_set(11, 3)
 print(json.dumps(res, indent=1))

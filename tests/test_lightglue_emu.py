@@ -136,16 +136,17 @@ def test_ffn_layernorm_gelu_epilogue_equals_the_separate_pass(emu_lib):
     for name, case in list(gc.LG_CASES.items())[:3]:     # ragged counts, adaptive depth / width; the 128-d cases add nothing to this kernel
         outs = {}
         try:
-            for mode in (0, 2):
+            for mode in (0, 2, 4):
                 emu_lib.dim_tune_set(11, mode)
                 out, ref = run_case(emu_lib, case)
                 compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
                 outs[mode] = out
         finally:
-            emu_lib.dim_tune_set(11, 1)
-        a, b = outs[0], outs[2]
-        assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches"][0], b["matches"][0]) and int(a["stop"]) == int(b["stop"]), name
-        if a["matching_scores0"].numel():
-            assert (a["matching_scores0"] - b["matching_scores0"]).abs().max().item() < 2e-5, name
-            n_diff += int(not torch.equal(a["dense"], b["dense"]))
+            emu_lib.dim_tune_set(11, 3)
+        for other in (2, 4):      # 4 = the whole feed-forward in one kernel (hidden tile register-resident, ffn.3's K split over the waves)
+            a, b = outs[0], outs[other]
+            assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches"][0], b["matches"][0]) and int(a["stop"]) == int(b["stop"]), (name, other)
+            if a["matching_scores0"].numel():
+                assert (a["matching_scores0"] - b["matching_scores0"]).abs().max().item() < 2e-5, (name, other)
+                n_diff += int(not torch.equal(a["dense"], b["dense"]))
     assert n_diff > 0        # two different code paths really ran

@@ -76,7 +76,7 @@ def test_lightglue_gpu_full_size_kv_images_from_the_projection_gemm(hip_lib, mod
     lg = _lg()
     try:
         hip_lib.dim_tune_set(6, 2)
-        hip_lib.dim_tune_set(11, 2)      # ... and ffn.0 with LayerNorm + GELU in its epilogue (the other large-batch-only kernel)
+        hip_lib.dim_tune_set(11, 4)      # ... and the one-kernel feed-forward (the other large-batch-only kernel)
         net = lg.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=2048)
         out = _cpu(net(_data(f0, f1), dense=True))
         ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, conf, taps=True)
@@ -95,7 +95,7 @@ def test_lightglue_gpu_full_size_kv_images_from_the_projection_gemm(hip_lib, mod
                     "image1": {"keypoints": kt[b, :counts[b]][None], "descriptors": dt[b, :counts[b]][None], "image_size": st[b][None]}}
             singles.append(_cpu(net(data)))
         hip_lib.dim_tune_set(6, 1)
-        hip_lib.dim_tune_set(11, 1)
+        hip_lib.dim_tune_set(11, 3)
         big = lg.LightGlueHIP(sd, conf, max_pairs=8, max_kpts=2048)
         o = {k: v.cpu() for k, v in big.match_batch(kt.cuda(), dt.cuda(), nt.cuda(), st.cuda(), pair_idx=pairs.cuda()).items()}
         for p, r in enumerate(singles):
@@ -107,7 +107,7 @@ def test_lightglue_gpu_full_size_kv_images_from_the_projection_gemm(hip_lib, mod
             torch.testing.assert_close(o["scores"][p, :S], r["scores"][0], rtol=1e-3, atol=1e-9)
     finally:
         hip_lib.dim_tune_set(6, 1)
-        hip_lib.dim_tune_set(11, 1)
+        hip_lib.dim_tune_set(11, 3)
 
 
 def test_lightglue_gpu_batch_equals_single_and_pair_index(hip_lib):
@@ -152,4 +152,16 @@ def test_ffn_layernorm_gelu_fused_op_at_production_rows(hip_lib):
         C2, _ = _ffn_ln_gelu_case(hip_lib, M, 512, seed=M, device="cuda")
         err = (C1.double() - ref).abs().max(1).values
         assert int((err > 1e-5).sum()) == 0 and float(err.max()) < 1e-5, (M, float(err.max()), (err > 1e-5).nonzero().reshape(-1)[:8].tolist())
+        assert torch.equal(C1, C2), M
+
+
+def test_ffn_fused_op_at_production_rows(hip_lib):
+    """The whole feed-forward as one kernel (gemm_x6_ffn_fused_kernel: hidden tile register-resident, ffn.3's K split over the four
+    waves, partial sums exchanged through LDS) vs fp64 at row counts that put two workgroups on every CU, twice."""
+    from tests.test_ops_emu import _ffn_fused_case
+    for M in (2048 + 37, 65536):
+        C1, ref = _ffn_fused_case(hip_lib, M, 512, seed=M, device="cuda")
+        C2, _ = _ffn_fused_case(hip_lib, M, 512, seed=M, device="cuda")
+        err = (C1.double() - ref).abs().max(1).values
+        assert int((err > 2e-5).sum()) == 0, (M, float(err.max()), (err > 2e-5).nonzero().reshape(-1)[:8].tolist())
         assert torch.equal(C1, C2), M

@@ -187,3 +187,34 @@ def test_ffn_layernorm_gelu_fused_op_vs_fp64(emu_lib, M, K):
     """LightGlue's ffn.0 -> LayerNorm -> GELU as one kernel (64 x 512 blocks; ragged last block) against an fp64 evaluation."""
     C, ref = _ffn_ln_gelu_case(emu_lib, M, K, seed=M + K)
     assert (C.double() - ref).abs().max().item() < 5e-6
+
+
+def _ffn_fused_case(lib, M, K, seed, device="cpu"):
+    """residual + gelu(layer_norm(A W0 + b0)) W3 + b3 through dim_op_ffn_fused_f32 -> (device result, fp64 reference)."""
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g) * 1.5
+    W0 = (torch.randn(K, 512, generator=g) / K ** 0.5).contiguous()
+    W3 = (torch.randn(512, 256, generator=g) / 512 ** 0.5).contiguous()
+    b0, gamma, beta = torch.randn(512, generator=g) * 0.1, 1.0 + 0.2 * torch.randn(512, generator=g), 0.1 * torch.randn(512, generator=g)
+    b3, R = torch.randn(256, generator=g) * 0.1, torch.randn(M, 256, generator=g)
+    h0, h3, npad = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int()
+    assert lib.dim_x3_create(p(W0), K, 512, ctypes.byref(h0), ctypes.byref(npad)) == 0 and npad.value == 512
+    assert lib.dim_x3_create_kperm(p(W3), 512, 256, ctypes.byref(h3), ctypes.byref(npad)) == 0 and npad.value == 256
+    Ad, b0d, gd, btd, b3d, Rd = (t.to(device).contiguous() for t in (A, b0, gamma, beta, b3, R))
+    C = torch.full((M, 256), -7.0, device=device)
+    try:
+        rc = lib.dim_op_ffn_fused_f32(p(Ad), K, h0, p(b0d), p(gd), p(btd), h3, p(b3d), p(Rd), 256, p(C), 256, M, K, None)
+        assert rc == 0, lib.dim_last_error()
+        if device != "cpu":
+            torch.cuda.synchronize()
+    finally:
+        lib.dim_x3_destroy(h0); lib.dim_x3_destroy(h3)
+    h = torch.nn.functional.gelu(torch.nn.functional.layer_norm(A.double() @ W0.double() + b0.double(), (512,), gamma.double(), beta.double(), 1e-5))
+    return C.cpu(), R.double() + h @ W3.double() + b3.double()
+
+
+@pytest.mark.parametrize("M,K", [(64, 512), (150, 512), (67, 256)])
+def test_ffn_fused_op_vs_fp64(emu_lib, M, K):
+    """ffn.0 -> LayerNorm -> GELU -> ffn.3 + residual as one kernel (hidden tile register-resident; ragged last block) vs fp64."""
+    C, ref = _ffn_fused_case(emu_lib, M, K, seed=M + K)
+    assert (C.double() - ref).abs().max().item() < 1e-5
