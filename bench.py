@@ -448,7 +448,7 @@ def main():
                          "mfma_pipe_util": conv_tflops * X6_PASSES / PEAK_BF16_MFMA_TFLOPS,
                          "peak_note": "frac = ALGORITHMIC fp32 FLOP/s / dense fp16 MFMA peak (2500 TFLOP/s, the precision issued; the 3 "
                                       "split-precision passes are not credited, so frac <= 1/3); mfma_pipe_util = x 3 passes = what the "
-                                      "MFMA-busy counter shows (profiles/r02_pmc_mfma_summary.txt)",
+                                      "MFMA-busy counter shows (profiles/r03_pmc_mfma_summary.txt)",
                          "frac_of_fp32_mfma_peak": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "isolated": {"note": "same kernel, same launches, timed again right after the timed region in two extraction-only batches "
                                               "(the main region is single-stream, so the two agree unless --overlap is given)",
