@@ -79,6 +79,14 @@ def lg_case(name: str, m: int = 96, n: int = 80, seed: int = 5, n_layers: int = 
             sd[f"transformers.{i}.self_attn.Wqkv.bias"][rows] *= 4096.0
             sd[f"transformers.{i}.self_attn.out_proj.weight"] /= 4096.0
         guard = True
+    elif name == "hidden_x8192":  # LayerNorm's affine x 8192 and ffn.3 / 8192: GELU is not homogeneous, so the function changes, but the point is
+        # the RANGE: the hidden tensor (what ffn.3's split consumes) leaves +-4094 and the guard of whichever kernel produces it must fire
+        for i in range(n_layers):
+            for blk in ("self_attn", "cross_attn"):
+                sd[f"transformers.{i}.{blk}.ffn.1.weight"] *= 8192.0
+                sd[f"transformers.{i}.{blk}.ffn.1.bias"] *= 8192.0
+                sd[f"transformers.{i}.{blk}.ffn.3.weight"] /= 8192.0
+        guard = True
     elif name == "outlier":
         sd["transformers.0.self_attn.ffn.3.weight"][3, 11] *= 100.0
     elif name == "tiny_desc":
@@ -88,4 +96,4 @@ def lg_case(name: str, m: int = 96, n: int = 80, seed: int = 5, n_layers: int = 
     return sd, f0, f1, conf, guard
 
 
-LG_CASES = ["desc_1e5", "ffn_x512", "v_x4096", "outlier", "tiny_desc"]
+LG_CASES = ["desc_1e5", "ffn_x512", "v_x4096", "hidden_x8192", "outlier", "tiny_desc"]

@@ -40,9 +40,23 @@ def test_superpoint_adversarial_ranges(emu_lib, name):
         strict(img)
 
 
+@pytest.mark.parametrize("big", [False, True], ids=["small-batch-kernels", "large-batch-kernels"])
 @pytest.mark.parametrize("name", adv.LG_CASES)
-def test_lightglue_adversarial_ranges(emu_lib, name):
+def test_lightglue_adversarial_ranges(emu_lib, name, big):
+    """big: the kernels that only large batches select — 128 x 256 GEMM blocks writing the K | V tile images (dim_tune_set 6 = 2) and
+    the one-kernel feed-forward (11 = 4), whose range guards sit in different code — forced at this size."""
+    if big and name in ("desc_1e5", "tiny_desc"):
+        pytest.skip("input-side cases: the same init kernel on both paths")
     sd, f0, f1, conf, expect_guard = adv.lg_case(name, m=40, n=36, n_layers=2)
+    if big:
+        emu_lib.dim_tune_set(6, 2); emu_lib.dim_tune_set(11, 4)
+    try:
+        _lightglue_adversarial(emu_lib, name, sd, f0, f1, conf, expect_guard)
+    finally:
+        emu_lib.dim_tune_set(6, 1); emu_lib.dim_tune_set(11, 3)
+
+
+def _lightglue_adversarial(emu_lib, name, sd, f0, f1, conf, expect_guard):
     net = lg_mod.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=64, device="cpu", lib=emu_lib)
     data = {"image0": {"keypoints": f0["kpts"][None], "descriptors": f0["desc"][None], "image_size": f0["size"][None]},
             "image1": {"keypoints": f1["kpts"][None], "descriptors": f1["desc"][None], "image_size": f1["size"][None]}}

@@ -39,8 +39,22 @@ def test_superpoint_gpu_adversarial_ranges(hip_lib, name):
     compare_superpoint(out, ref)
 
 
+@pytest.mark.parametrize("big", [False, True], ids=["small-batch-kernels", "large-batch-kernels"])
 @pytest.mark.parametrize("name", adv.LG_CASES)
-def test_lightglue_gpu_adversarial_ranges(hip_lib, name):
+def test_lightglue_gpu_adversarial_ranges(hip_lib, name, big):
+    """big: the large-batch-only kernels (K | V images from the 128 x 256 projection blocks, dim_tune_set 6 = 2; the one-kernel
+    feed-forward, 11 = 4) forced at this size: their range guards are different code."""
+    if big and name in ("desc_1e5", "tiny_desc"):
+        pytest.skip("input-side cases: the same init kernel on both paths")
+    if big:
+        hip_lib.dim_tune_set(6, 2); hip_lib.dim_tune_set(11, 4)
+    try:
+        _lightglue_gpu_adversarial(hip_lib, name)
+    finally:
+        hip_lib.dim_tune_set(6, 1); hip_lib.dim_tune_set(11, 3)
+
+
+def _lightglue_gpu_adversarial(hip_lib, name):
     capi, _, lg_mod = _mods()
     sd, f0, f1, conf, expect_guard = adv.lg_case(name, m=500, n=430, n_layers=3)
     net = lg_mod.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=512)
