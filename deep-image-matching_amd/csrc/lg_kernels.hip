@@ -471,13 +471,195 @@ int launch_lg_prune(const LgState& st, int layer, double width_conf, float thr, 
   DIM_LAUNCH_CHECK();
   return 0;
 }
+// ---- the same four passes for the common shape (row stride a multiple of 4, at most 2048 keypoints): every element of the
+// similarity is read ONCE per pass as part of a 16-byte load with all of a thread's loads in flight together (the generic kernels
+// above walk a row twice in 4-byte steps, one dependent load per iteration: 0.38 ms per pass and 50 pairs, 2.2 TB/s).  A row lives in
+// 8 float4 registers per lane; a column group of 4 columns per thread keeps online (max, sum) pairs.  exp(x) for x <= 0 is the
+// 6-instruction exp_le0 (dim_common.h, ~1.5 ulp). ----
+constexpr int ROW_CH = 8;   // float4 chunks per lane: 64 lanes x 4 x 8 = 2048 columns
+__device__ __forceinline__ float exp_le0_z(float d) { return d > -INFINITY ? exp_le0(d) : 0.0f; }   // exp(d), d <= 0, with exp(-inf) = 0 (exp_le0 itself returns NaN there)
+__global__ __launch_bounds__(256) void lg_row_stats4_kernel(LgState st, int tag, const float* __restrict__ w_match,
+                                                            const float* __restrict__ b_match) {
+  const int item = blockIdx.y, p = item >> 1, side = item & 1;
+  if (st.done[p] != tag) return;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n = st.n_cur[item];
+  if (row >= n) return;
+  const size_t r = (size_t)item * st.nmax + row;
+  const float4 d = *(const float4*)(st.desc + r * 256 + lane * 4);
+  const float4 wm = *(const float4*)(w_match + lane * 4);
+  const float z = wave_sum(d.x * wm.x + d.y * wm.y + d.z * wm.z + d.w * wm.w) + b_match[0];
+  if (lane == 0) st.zls[r] = logsigmoidf_(z);
+  if (side != 0) return;
+  const int ncol = st.n_cur[item + 1];
+  const float4* srow = (const float4*)(st.sim + ((size_t)p * st.nmax + row) * st.nmax);
+  float4 x[ROW_CH];
+#pragma unroll
+  for (int c = 0; c < ROW_CH; ++c) {
+    const int j = (c * 64 + lane) * 4;
+    x[c] = j < ncol ? srow[c * 64 + lane] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);   // (the row's padding is readable)
+    if (j + 1 >= ncol) x[c].y = -INFINITY;
+    if (j + 2 >= ncol) x[c].z = -INFINITY;
+    if (j + 3 >= ncol) x[c].w = -INFINITY;
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < ROW_CH; ++c) m = fmaxf(m, fmaxf(fmaxf(x[c].x, x[c].y), fmaxf(x[c].z, x[c].w)));
+  m = wave_max(m);
+  float s = 0.f;
+  if (m > -INFINITY) {
+#pragma unroll
+    for (int c = 0; c < ROW_CH; ++c) s += (exp_le0_z(x[c].x - m) + exp_le0_z(x[c].y - m)) + (exp_le0_z(x[c].z - m) + exp_le0_z(x[c].w - m));
+  }
+  s = wave_sum(s);
+  if (lane == 0) { st.rmax[r] = m; st.rlse[r] = logf(s); }
+}
+// thread = 4 adjacent columns x every 16th row; workgroup = 256 columns
+__global__ __launch_bounds__(1024) void lg_col_stats4_kernel(LgState st, int tag) {
+  __shared__ float4 redm[16][64], reds[16][64];
+  const int p = blockIdx.y;
+  if (st.done[p] != tag) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 256 + tx * 4;
+  const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
+  if (blockIdx.x * 256 >= ncol) return;
+  const bool ok = col < ncol;
+  const float* sp = st.sim + (size_t)p * st.nmax * st.nmax + col;
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+#pragma unroll 4
+    for (int i = ty; i < nrow; i += 16) {
+      const float4 v = *(const float4*)(sp + (size_t)i * st.nmax);
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // online: rescale the running sum when the maximum moves
+        const float mn = fmaxf(m[e], xv[e]);
+        sm[e] = sm[e] * exp_le0_z(m[e] - mn) + exp_le0(xv[e] - mn);   // first element: 0 * exp(-inf) = 0
+        m[e] = mn;
+      }
+    }
+  }
+  redm[ty][tx] = make_float4(m[0], m[1], m[2], m[3]); reds[ty][tx] = make_float4(sm[0], sm[1], sm[2], sm[3]);
+  __syncthreads();
+  if (ty < 4 && ok) {   // thread (tx, e = ty): merges the 16 row groups of column col + e
+    const int e = ty;
+    if (col + e < ncol) {
+      float M = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) M = fmaxf(M, ((const float*)&redm[g][tx])[e]);
+      float S = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float mg = ((const float*)&redm[g][tx])[e];
+        if (mg > -INFINITY) S += ((const float*)&reds[g][tx])[e] * exp_le0(mg - M);
+      }
+      const size_t r = (size_t)(2 * p + 1) * st.nmax + col + e;
+      st.rmax[r] = M; st.rlse[r] = logf(S);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void lg_row_argmax4_kernel(LgState st, int tag, float* __restrict__ dense) {
+  const int p = blockIdx.y;
+  if (st.done[p] != tag) return;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
+  if (row >= nrow) return;
+  const size_t r0 = (size_t)(2 * p) * st.nmax + row, c0 = (size_t)(2 * p + 1) * st.nmax;
+  const float rm = st.rmax[r0], rl = st.rlse[r0], z0 = st.zls[r0];
+  const float4* srow = (const float4*)(st.sim + ((size_t)p * st.nmax + row) * st.nmax);
+  const float4 *cm4 = (const float4*)(st.rmax + c0), *cl4 = (const float4*)(st.rlse + c0), *cz4 = (const float4*)(st.zls + c0);
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int c = 0; c < ROW_CH; ++c) {
+    const int j = (c * 64 + lane) * 4;
+    if (j < ncol) {
+      const float4 x = srow[c * 64 + lane], cm = cm4[c * 64 + lane], cl = cl4[c * 64 + lane], cz = cz4[c * 64 + lane];
+      const float xv[4] = {x.x, x.y, x.z, x.w}, cmv[4] = {cm.x, cm.y, cm.z, cm.w}, clv[4] = {cl.x, cl.y, cl.z, cl.w}, czv[4] = {cz.x, cz.y, cz.z, cz.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (j + e < ncol) {
+          const float v = lg_score(xv[e], rm, rl, cmv[e], clv[e], z0, czv[e]);
+          if (dense) dense[((size_t)p * (st.nmax + 1) + row) * (st.nmax + 1) + j + e] = v;
+          if (v > best) { best = v; bi = j + e; }   // a lane walks its columns in ascending order: the first maximum stays
+        }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) { st.best[r0] = best; st.arg[r0] = bi; }
+}
+__global__ __launch_bounds__(1024) void lg_col_argmax4_kernel(LgState st, int tag) {
+  __shared__ float4 redv[16][64];
+  __shared__ int redi[16][64][4];
+  const int p = blockIdx.y;
+  if (st.done[p] != tag) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 256 + tx * 4;
+  const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
+  if (blockIdx.x * 256 >= ncol) return;
+  const bool ok = col < ncol;
+  const size_t r0 = (size_t)(2 * p) * st.nmax, c = (size_t)(2 * p + 1) * st.nmax + (ok ? col : 0);
+  const float4 cm = *(const float4*)(st.rmax + c), cl = *(const float4*)(st.rlse + c), z1 = *(const float4*)(st.zls + c);
+  const float cmv[4] = {cm.x, cm.y, cm.z, cm.w}, clv[4] = {cl.x, cl.y, cl.z, cl.w}, z1v[4] = {z1.x, z1.y, z1.z, z1.w};
+  const float* sp = st.sim + (size_t)p * st.nmax * st.nmax + col;
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  if (ok) {
+#pragma unroll 4
+    for (int i = ty; i < nrow; i += 16) {
+      const float4 x = *(const float4*)(sp + (size_t)i * st.nmax);
+      const float rm = st.rmax[r0 + i], rl = st.rlse[r0 + i], z0 = st.zls[r0 + i];
+      const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = lg_score(xv[e], rm, rl, cmv[e], clv[e], z0, z1v[e]);
+        if (v > best[e]) { best[e] = v; bi[e] = i; }
+      }
+    }
+  }
+  redv[ty][tx] = make_float4(best[0], best[1], best[2], best[3]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) redi[ty][tx][e] = bi[e];
+  __syncthreads();
+  if (ty < 4 && ok && col + ty < ncol) {
+    const int e = ty;
+    float b = -INFINITY;
+    int ix = 0x7fffffff;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {  // first maximal row index wins ties (Tensor.max on CPU)
+      const float ov = ((const float*)&redv[g][tx])[e];
+      const int oi = redi[g][tx][e];
+      if (ov > b || (ov == b && oi < ix)) { b = ov; ix = oi; }
+    }
+    st.best[c + e] = b; st.arg[c + e] = ix;
+  }
+}
+static bool assign_fast_shape(const LgState& st) { return (st.nmax & 3) == 0 && st.nmax <= 256 * ROW_CH; }
+
 int launch_lg_assign_stats(const LgState& st, int tag, const float* w_match, const float* b_match, hipStream_t s) {
+  if (assign_fast_shape(st)) {
+    hipLaunchKernelGGL(lg_row_stats4_kernel, dim3(cdiv(st.nmax, 4), st.n_items), dim3(256), 0, s, st, tag, w_match, b_match);
+    hipLaunchKernelGGL(lg_col_stats4_kernel, dim3(cdiv(st.nmax, 256), st.n_pairs), dim3(1024), 0, s, st, tag);
+    DIM_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(lg_row_stats_kernel, dim3(cdiv(st.nmax, 4), st.n_items), dim3(256), 0, s, st, tag, w_match, b_match);
   hipLaunchKernelGGL(lg_col_stats_kernel, dim3(cdiv(st.nmax, 64), st.n_pairs), dim3(1024), 0, s, st, tag);
   DIM_LAUNCH_CHECK();
   return 0;
 }
 int launch_lg_assign_argmax(const LgState& st, int tag, float* dense_scores, hipStream_t s) {
+  if (assign_fast_shape(st)) {
+    hipLaunchKernelGGL(lg_row_argmax4_kernel, dim3(cdiv(st.nmax, 4), st.n_pairs), dim3(256), 0, s, st, tag, dense_scores);
+    hipLaunchKernelGGL(lg_col_argmax4_kernel, dim3(cdiv(st.nmax, 256), st.n_pairs), dim3(1024), 0, s, st, tag);
+    DIM_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(lg_row_argmax_kernel, dim3(cdiv(st.nmax, 4), st.n_pairs), dim3(256), 0, s, st, tag, dense_scores);
   hipLaunchKernelGGL(lg_col_argmax_kernel, dim3(cdiv(st.nmax, 64), st.n_pairs), dim3(1024), 0, s, st, tag);
   DIM_LAUNCH_CHECK();
