@@ -64,6 +64,9 @@ bool gemm_x6_fuses_kv(int M, int n_pad, int batch, int split_mode);  // true whe
 int launch_gemm(const GemmArgs& a, int batch, hipStream_t s);
 // fp32-accurate GEMM on the 16-bit matrix cores (gemm_x6.hip); needs a.set_split(...).
 int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s);
+// C = A * B^T, both operands fp32 activations split on the fly (bt layout of launch_gemm: B [n][k], ragged rows AND cols); the
+// producers of A and B must be range-guarded in split_mode 2
+int launch_gemm_x6_nt(const GemmArgs& a, int batch, int split_mode, hipStream_t s);
 // host: [K][N] fp32 -> the pre-split device layout; elems = planes * n_pad * K 16-bit values + 2 * n_pad for the fp32
 // per-column inverse scales in the tail (sw->scale_off); fills sw->mode / n_pad / scale_off (not sw->dev)
 size_t gemm_split_weight_elems(int K, int n_pad, int mode);

@@ -318,13 +318,14 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     if (last || early) {
       // ---- assignment for the pairs that stopped at this layer (LGN:540-542) ----
       const int tag = i + 1;
-      LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.proj_w, w.proj_x, 256, w.proj_b, nullptr, st.md, 256, s256, 256, 256, tag));
+      LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.proj_w, w.proj_x, 256, w.proj_b, nullptr, st.md, 256, s256, 256, 256, tag, sat(DIM_SAT_LG_DESC)));   // guarded: the similarity splits it
       GemmArgs g;
       g.A0 = st.md; g.lda0 = 256; g.strideA0 = 2 * s256; g.B = st.md + s256; g.ldb = 256; g.strideB = 2 * s256; g.bt = 1;
       g.C = st.sim; g.ldc = N; g.strideC = (long long)N * N; g.M = N; g.N = N; g.K = 256;
       g.rows = st.n_cur; g.rows_mul = 2; g.rows_off = 0; g.cols = st.n_cur; g.cols_mul = 2; g.cols_off = 1;
       g.flag = st.done; g.flag_shift = 0; g.flag_eq = tag;
-      LG_RUN(launch_gemm(g, n_pairs, s));
+      if (x6) LG_RUN(launch_gemm_x6_nt(g, n_pairs, pmode, s));   // split-precision on the 16-bit matrix cores like every other product
+      else LG_RUN(launch_gemm(g, n_pairs, s));
       LG_RUN(launch_lg_assign_stats(st, tag, w.match_w, w.match_b, s));
       LG_RUN(launch_lg_assign_argmax(st, tag, dense_scores_dev, s));
     }
