@@ -17,7 +17,7 @@ import torch
 
 from oracle import aliked_ref, lightglue_ref, superpoint_ref, tile_ref
 from tests import golden_cases as gc
-from tests.parity import compare_lightglue, compare_superpoint, order_is_reference_like
+from tests.parity import compare_lightglue, compare_superpoint, match_list_difference_is_a_tie, order_is_reference_like
 from tests.test_aliked_emu import compare_aliked
 
 pytestmark = pytest.mark.gpu
@@ -73,6 +73,19 @@ def test_config1_yaml_parameters_at_the_sacre_coeur_sizes(hip_lib):
     assert n_matches > 0
 
 
+def _record(obj):
+    """measured numbers behind an assertion -> gpurun_out/parity_measured.jsonl (copied to profiles/ per round)"""
+    import json
+    from pathlib import Path
+    d = Path(__file__).resolve().parents[1] / "gpurun_out"
+    try:
+        d.mkdir(exist_ok=True)
+        with open(d / "parity_measured.jsonl", "a") as f:
+            f.write(json.dumps(obj) + "\n")
+    except OSError:
+        pass
+
+
 def test_config4_exhaustive_pairs_through_the_pipeline_vs_oracle(hip_lib):
     weights, pl = _m("weights"), _m("pipeline")
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 400, "remove_borders": 4}
@@ -88,18 +101,25 @@ def test_config4_exhaustive_pairs_through_the_pipeline_vs_oracle(hip_lib):
     assert pairs.shape == (276, 2)
     cnt, mt, ms, stop, prune = [t.cpu() for t in pipe.match_all(table, pairs, aux=True)]
     kp, _, de, n, size = [t.cpu() for t in table]
-    total = 0
+    total, ties = 0, []
     for p, (a, b) in enumerate(pairs.tolist()):
         na, nb = int(n[a]), int(n[b])
-        ref = lightglue_ref.lightglue_forward(kp[a, :na], de[a, :na], size[a], kp[b, :nb], de[b, :nb], size[b], lg_sd, conf)
+        ref = lightglue_ref.lightglue_forward(kp[a, :na], de[a, :na], size[a], kp[b, :nb], de[b, :nb], size[b], lg_sd, conf, taps=True)
         S = int(cnt[p])
         assert int(stop[p]) == ref["stop"], (p, a, b)
-        assert torch.equal(mt[p, :S], ref["matches"]), (p, a, b)
         assert torch.equal(prune[p, 0, :na].long(), ref["prune0"].long()) and torch.equal(prune[p, 1, :nb].long(), ref["prune1"].long()), (p, a, b)
-        if S:
-            assert (ms[p, :S] - ref["scores"]).abs().max().item() <= 1e-3
+        if torch.equal(mt[p, :S], ref["matches"]):
+            if S:
+                assert (ms[p, :S] - ref["scores"]).abs().max().item() <= 1e-3
+        else:
+            # 276 pairs x ~150 matches on random weights: a decision whose margin in the ORACLE's own log-assignment is below 1e-4
+            # (fp32 LightGlue is not reproducible to that) may fall either way; anything else fails here
+            ties += match_list_difference_is_a_tie(mt[p, :S], ref["matches"], ref["log_assignment"], conf["filter_threshold"])
+            print("near-tie", (p, a, b), ties[-2:])
         total += S
     assert total > 276
+    assert len(ties) <= 4, ties          # (measured in round 3: one tie, margin 8.3e-5, pair (17, 20))
+    _record({"test": "config4_276_pairs", "matches_total": total, "explained_near_ties": ties})
 
 
 def test_config5_aliked_full_tile_vs_oracle(hip_lib):
