@@ -212,6 +212,13 @@ int dim_op_gemm_x6_ln_gelu_f32(const float* A, int lda, const void* w_x3, const 
   return launch_gemm_x6(g, 1, (hipStream_t)stream);
 }
 
+int dim_op_gemm_x6_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream) {
+  DIM_REQUIRE(A && B && C && g_precision_mode != 0, "dim_op_gemm_x6_nt_f32: null argument, or the fp32 arithmetic is selected");
+  GemmArgs g;
+  g.A0 = A; g.lda0 = lda; g.B = B; g.ldb = ldb; g.bt = 1; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  return launch_gemm_x6_nt(g, 1, g_precision_mode == 1 ? 1 : 2, (hipStream_t)stream);
+}
+
 int dim_op_ffn_fused_f32(const float* A, int lda, const void* w0_x3, const float* bias0, const float* ln_gamma, const float* ln_beta,
                          const void* w3_x3_kperm, const float* bias3, const float* residual, int ldr, float* C, int ldc, int M, int K, void* stream) {
   DIM_REQUIRE(w0_x3 && ((const SplitWeights*)w0_x3)->n_pad == 512 && ((const SplitWeights*)w0_x3)->mode == 2, "dim_op_ffn_fused_f32: needs an fp16x3 512-column ffn.0 handle");

@@ -471,7 +471,7 @@ int launch_lg_prune(const LgState& st, int layer, double width_conf, float thr, 
   DIM_LAUNCH_CHECK();
   return 0;
 }
-// ---- the same four passes for the common shape (row stride a multiple of 4, at most 2048 keypoints): every element of the
+// ---- the same four passes for the common shape (at most 2048 keypoints; the row stride nmax is always a multiple of 4, lg_api.hip): every element of the
 // similarity is read ONCE per pass as part of a 16-byte load with all of a thread's loads in flight together (the generic kernels
 // above walk a row twice in 4-byte steps, one dependent load per iteration: 0.38 ms per pass and 50 pairs, 2.2 TB/s).  A row lives in
 // 8 float4 registers per lane; a column group of 4 columns per thread keeps online (max, sum) pairs.  exp(x) for x <= 0 is the

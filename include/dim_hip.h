@@ -282,6 +282,10 @@ int dim_op_gemm_x6_f32(const float* A, int lda, const void* w_x3_handle, int n_p
 int dim_op_gemm_x6_ln_gelu_f32(const float* A, int lda, const void* w_x3_handle, const float* bias, const float* ln_gamma, const float* ln_beta,
                                float* C, int ldc, int M, int K, void* stream);
 
+/* C[M][N] = A[M][K] * B[N][K]^T with both operands fp32 activations (LightGlue's similarity, LGN:271), on the 16-bit matrix cores in the
+ * active split arithmetic (|A|, |B| <= 4094 under fp16x3: the callers' producers are range-guarded).  K % 32 == 0, lda / ldb % 4 == 0. */
+int dim_op_gemm_x6_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream);
+
 /* LightGlue's whole feed-forward (LGN:141-142,159,209) as ONE kernel: C[M][256] = residual + gelu(layer_norm(A[M][K] * W0 + bias0)) *
  * W3 + bias3, the 512-wide hidden tensor kept on the compute unit.  w0 from dim_x3_create(K, 512); w3 from dim_x3_create_kperm(512,
  * 256) (the same split, rows of every 16-step stored in the order the kernel's register-resident operand presents them). */

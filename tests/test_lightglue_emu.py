@@ -150,3 +150,28 @@ def test_ffn_layernorm_gelu_epilogue_equals_the_separate_pass(emu_lib):
                 assert (a["matching_scores0"] - b["matching_scores0"]).abs().max().item() < 2e-5, (name, other)
                 n_diff += int(not torch.equal(a["dense"], b["dense"]))
     assert n_diff > 0        # two different code paths really ran
+
+
+def test_assignment_fast_and_generic_kernels_agree(emu_lib):
+    """The assignment passes exist twice: 16-byte single-read kernels for tables of up to 2048 keypoints (the row stride is always a
+    multiple of 4), 4-byte generic ones beyond.  The same ragged pair through both (max_kpts 96 vs 2052): identical integer outputs,
+    scores and the dense log-assignment equal to fp32 rounding — and both equal to the oracle."""
+    case = gc.LG_CASES["default"]
+    sd = gc.lg_weights(case)
+    f0, f1 = gc.lg_inputs(case)
+    data = {"image0": {"keypoints": f0["kpts"][None], "descriptors": f0["desc"][None], "image_size": f0["size"][None]},
+            "image1": {"keypoints": f1["kpts"][None], "descriptors": f1["desc"][None], "image_size": f1["size"][None]}}
+    ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, case["conf"], taps=True)
+    outs = []
+    for cap in (96, 2052):
+        net = lg_mod.LightGlueHIP(sd, case["conf"], max_pairs=1, max_kpts=cap, device="cpu", lib=emu_lib)
+        out = net(data, dense=True)
+        out = {k: ([t.cpu() for t in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v)) for k, v in out.items()}
+        compare_lightglue(out, ref, dense_ref=ref["log_assignment"], dense_out=out["dense"])
+        outs.append(out)
+    a, b = outs
+    assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches1"], b["matches1"]) and torch.equal(a["matches"][0], b["matches"][0])
+    m, n = case["m"], case["n"]
+    # (the larger table also changes launch shapes upstream — attention key splits, GEMM blocks: fp32 noise of the whole network)
+    assert (a["dense"][:m, :n] - b["dense"][:m, :n]).abs().max().item() < 5e-4
+    assert not torch.equal(a["dense"][:m, :n], b["dense"][:m, :n])      # two different code paths really ran

@@ -218,3 +218,19 @@ def test_ffn_fused_op_vs_fp64(emu_lib, M, K):
     """ffn.0 -> LayerNorm -> GELU -> ffn.3 + residual as one kernel (hidden tile register-resident; ragged last block) vs fp64."""
     C, ref = _ffn_fused_case(emu_lib, M, K, seed=M + K)
     assert (C.double() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(150, 200, 256), (128, 128, 64), (37, 300, 256)])
+def test_gemm_x6_nt_vs_fp64(emu_lib, M, N, K):
+    """sim = A B^T with both operands split on the fly (gemm_x6_nt_kernel, LightGlue's similarity) vs fp64; ragged last blocks; a
+    guard band around C stays untouched."""
+    g = torch.Generator().manual_seed(M + N)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    ldc = N + 8
+    C = torch.full((M + 3, ldc), -7.0)
+    rc = emu_lib.dim_op_gemm_x6_nt_f32(p(A), K, p(B), K, p(C), ldc, M, N, K, None)
+    assert rc == 0, emu_lib.dim_last_error()
+    ref = A.double() @ B.double().t()
+    scale = (A.double().abs() @ B.double().abs().t())
+    assert ((C[:M, :N].double() - ref).abs() / scale).max().item() < 5e-7
+    assert bool((C[M:] == -7.0).all()) and bool((C[:, N:] == -7.0).all())
