@@ -175,3 +175,21 @@ def test_assignment_fast_and_generic_kernels_agree(emu_lib):
     # (the larger table also changes launch shapes upstream — attention key splits, GEMM blocks: fp32 noise of the whole network)
     assert (a["dense"][:m, :n] - b["dense"][:m, :n]).abs().max().item() < 5e-4
     assert not torch.equal(a["dense"][:m, :n], b["dense"][:m, :n])      # two different code paths really ran
+
+
+def test_swapping_the_images_transposes_the_result(emu_lib):
+    """A size-independent property of the network (LGN:146-211: the same weights serve both images, the cross block is symmetric):
+    match(A, B) and match(B, A) are transposes of each other — matches0 <-> matches1, stop layer equal, scores to fp32 rounding."""
+    case = gc.LG_CASES["default"]
+    sd = gc.lg_weights(case)
+    f0, f1 = gc.lg_inputs(case)
+    net = lg_mod.LightGlueHIP(sd, case["conf"], max_pairs=1, max_kpts=max(case["m"], case["n"]), device="cpu", lib=emu_lib)
+    side = lambda f: {"keypoints": f["kpts"][None], "descriptors": f["desc"][None], "image_size": f["size"][None]}
+    ab = net({"image0": side(f0), "image1": side(f1)})
+    ba = net({"image0": side(f1), "image1": side(f0)})
+    assert int(ab["stop"]) == int(ba["stop"])
+    assert torch.equal(ab["matches0"].cpu(), ba["matches1"].cpu()) and torch.equal(ab["matches1"].cpu(), ba["matches0"].cpu())
+    assert (ab["matching_scores0"].cpu() - ba["matching_scores1"].cpu()).abs().max().item() < 1e-5
+    assert torch.equal(ab["prune0"].cpu(), ba["prune1"].cpu()) and torch.equal(ab["prune1"].cpu(), ba["prune0"].cpu())
+    ma, mb = ab["matches"][0].cpu(), ba["matches"][0].cpu()
+    assert ma.shape[0] > 0 and {tuple(x) for x in ma.tolist()} == {(j, i) for i, j in mb.tolist()}
