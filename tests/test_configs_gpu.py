@@ -114,7 +114,10 @@ def test_config4_exhaustive_pairs_through_the_pipeline_vs_oracle(hip_lib):
         else:
             # 276 pairs x ~150 matches on random weights: a decision whose margin in the ORACLE's own log-assignment is below 1e-4
             # (fp32 LightGlue is not reproducible to that) may fall either way; anything else fails here
-            ties += match_list_difference_is_a_tie(mt[p, :S], ref["matches"], ref["log_assignment"], conf["filter_threshold"])
+            # tolerance 3e-4 = the fp32 noise of ONE log-assignment entry (yardstick test: the reference-equivalent fp32 path is 2.7e-4
+            # from an fp64 evaluation), i.e. about half of what two competing entries can move against each other; the oracle's own
+            # margin at the one tie seen so far was 8.3e-5 on one host CPU and 8.6e-6 on another
+            ties += match_list_difference_is_a_tie(mt[p, :S], ref["matches"], ref["log_assignment"], conf["filter_threshold"], tie_tol=3e-4)
             print("near-tie", (p, a, b), ties[-2:])
         total += S
     assert total > 276
