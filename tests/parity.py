@@ -47,30 +47,51 @@ def order_is_reference_like(out: dict, k_limited: bool):
         assert bool((lin[:-1] < lin[1:]).all())
 
 
-def compare_lightglue(out: dict, ref: dict, score_tol: float = 1e-3, dense_ref=None, dense_out=None, dense_tol: float = 1e-3):
+def compare_lightglue(out: dict, ref: dict, score_tol: float = 1e-3, dense_ref=None, dense_out=None, dense_tol: float = 1e-3,
+                      tie_tol: float = 1e-4, max_ties: int = 2, filter_threshold=None):
     """out/ref: reference-style dicts for one pair (CPU tensors; ref from the oracle or the golden
     file).  Integer outputs (stop, prune, matches) must be identical except where the oracle's own
-    decision is a numerical near-tie (two assignment scores closer than 1e-4), which is reported."""
+    decision is a numerical near-tie (two assignment scores closer than tie_tol), which is reported:
+    that exception needs the oracle's dense log-assignment (dense_ref) — without it any difference fails —
+    and is bounded (at most max_ties matches, each checked by match_list_difference_is_a_tie)."""
     res = {}
     assert int(out["stop"]) == int(ref["stop"]), (int(out["stop"]), int(ref["stop"]))
     for k in ("prune0", "prune1"):
         assert torch.equal(out[k].reshape(-1).long(), torch.as_tensor(ref[k]).reshape(-1).long()), k
-    for k in ("matching_scores0", "matching_scores1"):
-        d = (out[k].reshape(-1) - torch.as_tensor(ref[k]).reshape(-1)).abs().max().item() if out[k].numel() else 0.0
-        res["max_" + k + "_diff"] = d
-        assert d <= score_tol, (k, d)
-    for k in ("matches0", "matches1"):
-        a, b = out[k].reshape(-1).long(), torch.as_tensor(ref[k]).reshape(-1).long()
-        bad = (a != b).nonzero().reshape(-1)
-        res["n_" + k + "_mismatch"] = int(bad.numel())
-        assert bad.numel() == 0, (k, bad.tolist()[:10], a[bad][:10].tolist(), b[bad][:10].tolist())
+    a0, b0 = out["matches0"].reshape(-1).long(), torch.as_tensor(ref["matches0"]).reshape(-1).long()
+    a1, b1 = out["matches1"].reshape(-1).long(), torch.as_tensor(ref["matches1"]).reshape(-1).long()
+    res["n_matches0_mismatch"], res["n_matches1_mismatch"] = int((a0 != b0).sum()), int((a1 != b1).sum())
     mo = out["matches"][0] if isinstance(out["matches"], (list, tuple)) else out["matches"]
     mr = ref["matches"][0] if isinstance(ref["matches"], (list, tuple)) else torch.as_tensor(ref["matches"])
-    assert torch.equal(mo.long().cpu(), mr.long()), "compact match list"
+    mo, mr = mo.long().cpu(), mr.long()
     so = out["scores"][0] if isinstance(out["scores"], (list, tuple)) else out["scores"]
     sr = ref["scores"][0] if isinstance(ref["scores"], (list, tuple)) else torch.as_tensor(ref["scores"])
-    if so.numel():
-        assert (so.cpu() - sr).abs().max().item() <= score_tol
+    same = res["n_matches0_mismatch"] == 0 and res["n_matches1_mismatch"] == 0
+    if same:
+        assert torch.equal(mo, mr), "compact match list"
+        common0, common1 = torch.ones_like(a0, dtype=torch.bool), torch.ones_like(a1, dtype=torch.bool)
+        if so.numel():
+            assert (so.cpu() - sr).abs().max().item() <= score_tol
+    else:
+        assert dense_ref is not None and dense_ref.numel(), ("integer outputs differ and no log-assignment was given to explain it",
+                                                             (a0 != b0).nonzero().reshape(-1).tolist()[:10], (a1 != b1).nonzero().reshape(-1).tolist()[:10])
+        # the two sides' mutual matches as (i, j) sets, each side consistent in itself (matches0 and matches1 say the same)
+        pairs_of = lambda m0: torch.stack([(m0 >= 0).nonzero().reshape(-1), m0[m0 >= 0]], 1)
+        po, pr = pairs_of(a0), pairs_of(b0)
+        assert {(int(j), int(i)) for i, j in po.tolist()} == {(int(j), int(i)) for j, i in pairs_of(a1).tolist()}, "matches0 / matches1 disagree"
+        ties = match_list_difference_is_a_tie(po, pr, dense_ref, 0.0 if filter_threshold is None else filter_threshold, tie_tol)
+        assert len(ties) <= 2 * max_ties, ties
+        res["explained_near_ties"] = ties
+        touched0 = {t["match"][0] for t in ties}; touched1 = {t["match"][1] for t in ties}
+        common0 = torch.tensor([i not in touched0 for i in range(a0.numel())], dtype=torch.bool)
+        common1 = torch.tensor([j not in touched1 for j in range(a1.numel())], dtype=torch.bool)
+        assert torch.equal(a0[common0], b0[common0]) and torch.equal(a1[common1], b1[common1])
+        assert {tuple(x) for x in mo.tolist()} ^ {tuple(x) for x in mr.tolist()} <= {tuple(t["match"]) for t in ties}, "compact match list"
+    for k, common in (("matching_scores0", common0), ("matching_scores1", common1)):
+        x, y = out[k].reshape(-1), torch.as_tensor(ref[k]).reshape(-1)
+        d = (x[common] - y[common]).abs().max().item() if int(common.sum()) else 0.0
+        res["max_" + k + "_diff"] = d
+        assert d <= score_tol, (k, d)
     if dense_ref is not None and dense_ref.numel():
         m, n = dense_ref.shape[0] - 1, dense_ref.shape[1] - 1
         d = (dense_out[:m, :n] - dense_ref[:m, :n]).abs().max().item()
