@@ -31,6 +31,17 @@ def encoder(img, conv):
     cPa = torch.relu(conv(x, sd['convPa.weight'], sd['convPa.bias']))
     logits = F.conv2d(cPa.to(torch.float64), sd['convPb.weight'].double(), sd['convPb.bias'].double())
     return logits
+def wino1d_conv(x, w, b, dtype):
+    # F(2, 3) along x only: 4 transform positions x 3 kernel rows (12 instead of 18 products per 2 outputs)
+    x = x.to(dtype); w = w.to(dtype); Gd, Btd, Atd = G.to(dtype), Bt.to(dtype), At.to(dtype)
+    U = torch.einsum('ij,ocrj->ocri', Gd, w)                    # [O,C,3 rows,4]
+    xp = F.pad(x, (1,1,1,1))
+    H, W = x.shape[2], x.shape[3]
+    tiles = xp.unfold(3,4,2)                                    # [1,C,H+2,W/2,4]
+    V = torch.einsum('ij,nchwj->nchwi', Btd, tiles)             # [1,C,H+2,tw,4]
+    M = sum(torch.einsum('oci,nchwi->nohwi', U[:, :, r], V[:, :, r:r + H]) for r in range(3))   # [1,O,H,tw,4]
+    Y = torch.einsum('ij,nohwj->nohwi', Atd, M)                 # [1,O,H,tw,2]
+    return Y.reshape(1, w.shape[0], H, W) + b.to(dtype).view(1,-1,1,1)
 direct = lambda dt: (lambda x,w,b: F.conv2d(x.to(dt), w.to(dt), b.to(dt), padding=1))
 img = torch.rand(1,1,256,256)
 ref64 = encoder(img, direct(torch.float64))
@@ -42,6 +53,10 @@ print("logit scale", ref64.abs().max().item())
 print("winograd fp64 vs direct fp64 (algebra check):", (w64 - ref64).abs().max().item())
 print("direct fp32  vs fp64: logits", (d32 - ref64).abs().max().item(), " scores", (sc(d32) - sc(ref64)).abs().max().item())
 print("winograd fp32 vs fp64: logits", (w32 - ref64).abs().max().item(), " scores", (sc(w32) - sc(ref64)).abs().max().item())
+w1 = encoder(img, lambda x,w,b: wino1d_conv(x,w,b,torch.float32) if w.shape[1] > 1 else F.conv2d(x, w, b, padding=1))
+w1d = encoder(img, lambda x,w,b: wino1d_conv(x,w,b,torch.float64) if w.shape[1] > 1 else F.conv2d(x.double(), w.double(), b.double(), padding=1))
+print("1-D winograd fp64 vs direct fp64 (algebra check):", (w1d - ref64).abs().max().item())
+print("1-D winograd fp32 vs fp64: logits", (w1 - ref64).abs().max().item(), " scores", (sc(w1) - sc(ref64)).abs().max().item())
 # range growth of the transformed activations
 x = torch.relu(F.conv2d(img, sd['conv1a.weight'], sd['conv1a.bias'], padding=1))
 tiles = F.pad(x,(1,1,1,1)).unfold(2,4,2).unfold(3,4,2)
