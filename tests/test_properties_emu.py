@@ -12,7 +12,7 @@ from oracle import superpoint_ref
 
 tiling = importlib.import_module("deep-image-matching_amd.tiling")
 p = lambda t: ctypes.c_void_p(t.data_ptr())
-SET = dict(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+SET = dict(max_examples=25, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 
 
 @settings(**SET)
