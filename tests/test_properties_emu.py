@@ -68,3 +68,45 @@ def test_match_rows_round_trip(emu_lib, seed, P, NK):
         assert torch.equal(rows[q, :k, :2].long(), m[q, :k])
         assert torch.equal(rows[q, :k, 2].view(torch.float32), sc[q, :k])
         assert bool((rows[q, k:] == 0).all())
+
+
+from oracle import tile_ref
+
+
+def _resize(lib, fn, img, h, w):
+    src = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))
+    dst = torch.empty(h, w, dtype=torch.float32)
+    assert getattr(lib, fn)(p(src), img.shape[0], img.shape[1], p(dst), h, w, 0, None) == 0, lib.dim_last_error()
+    return dst.numpy()
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), H=st.integers(2, 70), W=st.integers(2, 70), h=st.integers(1, 90), w=st.integers(1, 90))
+def test_resize_kernels_equal_the_restated_opencv_tables(emu_lib, seed, H, W, h, w):
+    """dim_op_resize_area_f32 (shrinking and enlarging) and dim_op_resize_linear_f32 on arbitrary size pairs, bit for bit against
+    oracle/tile_ref.py's restatement of cv2.INTER_AREA / INTER_LINEAR (utils/image.py:47-65)."""
+    img = (np.random.default_rng(seed).random((H, W)) * 255).astype(np.float32)
+    assert np.array_equal(_resize(emu_lib, "dim_op_resize_area_f32", img, h, w), tile_ref.resize_area(img, (w, h)))
+    assert np.array_equal(_resize(emu_lib, "dim_op_resize_linear_f32", img, h, w), tile_ref.resize_linear(img, (w, h)))
+
+
+@settings(**SET)
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(0, 60), T0=st.integers(1, 6), T1=st.integers(1, 6), tw=st.integers(4, 40), th=st.integers(4, 40))
+def test_tile_pair_votes_equal_the_reference_helpers(emu_lib, seed, n, T0, T1, tw, th):
+    rng = np.random.default_rng(seed)
+    k0, k1 = (rng.random((80, 2)) * 100).astype(np.float32), (rng.random((70, 2)) * 100).astype(np.float32)
+    k0[::5] = np.round(k0[::5])          # points exactly on tile borders: the strict inequalities of points_in_rect decide
+    m = np.stack([rng.integers(0, 80, n), rng.integers(0, 70, n)], 1).astype(np.int64).reshape(n, 2)
+    s0, s1 = np.float32(rng.choice([1.0, 0.5, 0.37])), np.float32(rng.choice([1.0, 2.0, 0.81]))
+    o0 = rng.integers(-5, 180, (T0, 2)).astype(np.int32); o1 = rng.integers(-5, 180, (T1, 2)).astype(np.int32)
+    o0[0] = (np.round(k0[0] / s0)).astype(np.int32)   # a tile whose corner coincides with a (scaled) keypoint
+    v = torch.full((T0, T1), -7, dtype=torch.int32)
+    mt = torch.zeros(max(n, 1), 2, dtype=torch.int64); mt[:n] = torch.from_numpy(m)      # (capacity >= 1 row: the entry point rejects a null table)
+    kt0, kt1, nt = torch.from_numpy(k0), torch.from_numpy(k1), torch.tensor([n], dtype=torch.int32)
+    ot0, ot1 = torch.from_numpy(o0).contiguous(), torch.from_numpy(o1).contiguous()
+    rc = emu_lib.dim_op_tile_pair_votes(p(kt0), p(kt1), p(mt), p(nt), max(n, 1), ctypes.c_float(float(s0)), ctypes.c_float(float(s1)), p(ot0), T0,
+                                        p(ot1), T1, tw, th, p(v), None)
+    assert rc == 0, emu_lib.dim_last_error()
+    a, b = k0[m[:, 0]] / s0, k1[m[:, 1]] / s1
+    ref = tile_ref.tile_pair_votes(a, b, {i: tuple(x) for i, x in enumerate(o0)}, {i: tuple(x) for i, x in enumerate(o1)}, (tw, th))
+    assert np.array_equal(v.numpy(), ref)
