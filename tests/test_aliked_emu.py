@@ -33,9 +33,9 @@ def compare_aliked(out, ref, kp_tol=1e-3, desc_tol=1e-3, score_tol=1e-3, max_mis
     res = {"n_out": len(ko), "n_ref": len(kr), "common": len(pairs)}
     ia = torch.tensor([p[0] for p in pairs], dtype=torch.long); ib = torch.tensor([p[1] for p in pairs], dtype=torch.long)
     only_out = sorted(set(range(len(ko))) - {p[0] for p in pairs}); only_ref = sorted(set(range(len(kr))) - {p[1] for p in pairs})
-    res["kp"] = (out["keypoints"][ia] - ref["keypoints"][ib]).abs().max().item()
-    res["score"] = (out["scores"][ia] - ref["scores"][ib]).abs().max().item()
-    res["desc"] = (out["descriptors"][:, ia] - ref["descriptors"][:, ib]).abs().max().item()
+    res["kp"] = (out["keypoints"][ia] - ref["keypoints"][ib]).abs().max().item() if pairs else 0.0       # (an image without detections: nothing to compare)
+    res["score"] = (out["scores"][ia] - ref["scores"][ib]).abs().max().item() if pairs else 0.0
+    res["desc"] = (out["descriptors"][:, ia] - ref["descriptors"][:, ib]).abs().max().item() if pairs else 0.0
     if label is not None:
         import json
         d = Path(__file__).resolve().parents[1] / "gpurun_out"
