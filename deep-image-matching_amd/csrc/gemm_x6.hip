@@ -42,11 +42,15 @@ constexpr int KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
 // PROBE (timing experiments only, scripts/gpu_gemm_probe.py; 0 in every product instantiation): bit 0 = the activation rows of all
 // workgroups come from the first 2048 rows (cache-resident), bit 1 = every chunk re-reads the weight fragments of chunk 0 (L1 hits),
 // bit 2 = no MFMAs, bit 3 = the weight fragments are loaded once, before the K loop.  Results are wrong by design.
-template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false>
+// KCH: K values per staged chunk.  32 everywhere in the product; 64 (prototype, dim_tune_set key 14, pipelined wide blocks only) halves the
+// number of barrier pairs and staging round trips per MFMA for 16 more prefetch registers and a 36-dword row stride (also conflict-free).
+template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32>
 __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, int by) {
   using S = SplitMma<MODE>;
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
-  constexpr int NPL = S::NPL, NLD = BM / 32;        // float4 loads per thread and chunk
+  constexpr int NPL = S::NPL, NLD = BM * KCH / 1024;  // float4 loads per thread and chunk
+  constexpr int KC = KCH, RS = KCH / 2 + 4, Q4_SHIFT = KCH == 32 ? 3 : 4, KSTEPS = KCH / 16;   // (shadow the file-level 32-wide constants)
+  static_assert(KCH == 32 || (KCH == 64 && PIPE && PROBE == 0), "64-wide chunks exist for the pipelined K loop");
   constexpr int BN = 32 * NT * WN;
   static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
   static_assert(KV != 4 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4 && NT == 4), "the fused ffn exists for the fp16x3 64 x 512 block");
@@ -82,7 +86,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     else { src = A1; ld = a.lda1; kk0 = k0 - a.ksplit; }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
+      const int idx = t + 256 * i, row = idx >> Q4_SHIFT, q = idx & ((1 << Q4_SHIFT) - 1);
       // rows past the ragged end re-read the last valid row (always mapped): GEMM rows are independent and the
       // epilogue never stores them, so they need no zeroing — no branch, and no VALU touching the prefetch
       // registers before the split (anything earlier would drag the wait for them into the MFMA phase)
@@ -92,7 +96,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
+      const int idx = t + 256 * i, row = idx >> Q4_SHIFT, q = idx & ((1 << Q4_SHIFT) - 1);
       unsigned p0[NPL], p1[NPL];
       S::split(ra[i].x, ra[i].y, S::act_scale(), p0);
       S::split(ra[i].z, ra[i].w, S::act_scale(), p1);
@@ -161,6 +165,16 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       if (!(PROBE & 8)) load_b(min(kst + 2, KS - 2), fb0);   // the last chunk harmlessly re-reads its own first step
       __builtin_amdgcn_sched_barrier(0);
       mma_step(1, (PROBE & 8) ? fb0 : fb1);
+      if (KSTEPS == 4) {   // 64-wide chunk: two more steps, same alternation (step 2 from fb0, step 3 from fb1)
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(min(kst + 3, KS - 1), fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(2, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(min(kst + 4, KS - 4), fb0);                   // the next chunk's first step
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(3, fb1);
+      }
       __syncthreads();
     }
   } else
@@ -710,6 +724,19 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : 2)) void gemm_x6_nt_kernel(Ge
     }
   }
 }
+// ---- prototypes with 64-wide K chunks (dim_tune_set key 14 = 64; measured in round 4): the plain 128 x 256 block and the q|k|v kernel ----
+constexpr int RS64 = 64 / 2 + 4;
+__global__ __launch_bounds__(256, 2) void gemm_x6_wide_kc64_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 128 * RS64];
+  gemm_x6_body<2, 128, 2, 0, 4, 0, true, 64>(a, Ap, (int)blockIdx.y);
+}
+__global__ __launch_bounds__(256, 2) void gemm_x6_qkv_kc64_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 128 * RS64];
+  const int by = (int)blockIdx.y;
+  if (by == a.kv_kblock) gemm_x6_body<2, 128, 2, 1, 4, 0, true, 64>(a, Ap, by);
+  else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4, 0, true, 64>(a, Ap, by);
+  else gemm_x6_body<2, 128, 2, 0, 4, 0, true, 64>(a, Ap, by);
+}
 // LightGlue's ffn.0 -> LayerNorm -> GELU -> ffn.3 (+ residual) in one kernel: 64 rows per workgroup, the hidden tensor stays on the CU
 constexpr int FFN_LDS_DWORDS = 2 * 64 * RS + 2048 + 512 + 4 * 3 * 4 * 64 * 4;
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_kernel(GemmArgs a) {
@@ -802,7 +829,8 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     if (a.kv_img != nullptr) {
       DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
       DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == (int)grid.y - 1, "gemm_x6: the K and V blocks must be the last two");
-      hipLaunchKernelGGL(gemm_x6_qkv_kernel, grid, dim3(256), 0, s, a);
+      if (dim_gemm_kc() == 64 && a.K % 64 == 0) hipLaunchKernelGGL(gemm_x6_qkv_kc64_kernel, grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(gemm_x6_qkv_kernel, grid, dim3(256), 0, s, a);
     } else switch (dim_gemm_probe()) {
       case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<1>), grid, dim3(256), 0, s, a); break;
       case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<2>), grid, dim3(256), 0, s, a); break;
@@ -815,7 +843,9 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
       case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<48>), grid, dim3(256), 0, s, a); break;
       case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<32>), grid, dim3(256), 0, s, a); break;
       case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<16>), grid, dim3(256), 0, s, a); break;
-      default: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);
+      default:
+        if (dim_gemm_kc() == 64 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(gemm_x6_wide_kc64_kernel, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);
     }
   } else {
     dim3 grid(cdiv(a.M, 128), cdiv(a.N, BN), batch);

@@ -50,7 +50,7 @@ int dim_device_synchronize(void);
  * key 9 = 1 (default) ALIKED BatchNorm + SELU applied while the consumer stages its input, 0 = separate pass; key 10 = ALIKED fp16x3
  * convolution tile rows (16 default, 8, 17 = 16 with streamed weights); key 11 = LightGlue's feed-forward: 3 (default) ffn.0 +
  * LayerNorm + GELU + ffn.3 + residual as one kernel when the launch fills the GPU, 4 = always (tests), 1 / 2 = LayerNorm + GELU in
- * ffn.0's epilogue only (when large / always), 0 = separate kernels; key 12 = cross-attention timing probes
+ * ffn.0's epilogue only (when large / always), 0 = separate kernels; key 14 = K-chunk width of the wide fp16x3 GEMM blocks (32 default; 64 = unmeasured prototype); key 12 = cross-attention timing probes
  * (scripts/gpu_attn_probe.py; 0 in the product — 1 and 3 give wrong results by design). */
 int dim_tune_set(int key, int value);
 
