@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="(default since round 1) kept for compatibility")
     ap.add_argument("--main-region-only", action="store_true", help="skip the second (other-schedule) region: used for the rocprofv3 passes")
     ap.add_argument("--cpu-sample-pairs", type=int, default=4)
+    ap.add_argument("--no-strong-scaling", action="store_true", help="skip the strong_scaling sub-record (the config-4 job run after the timed region)")
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 20 if a.workload == "configs2" else 1
@@ -179,23 +180,27 @@ def cpu_baseline(n_pairs: int):
                       f"9-layer forwards) after 1 warm-up pair, {what} on torch CPU, {cores} threads"}
 
 
-def run_config4(a, rank, world, dev, dist, lib):
+def measure_config4(a, rank, world, dev, dist, lib, steps, warmup):
     """BASELINE configs[3] (SURVEY 8(d) "config 4"): `--images` synthetic 1024^2 images -> the first `--job-pairs` exhaustive
     pairs (pairs_generator.py:37-38 order) through pipeline.PairMatchingPipeline: images sharded i mod world, ONE all-gather of
     the feature tables, pairs sharded round-robin, ONE all-gather of the match tables.  STRONG scaling: the job is fixed.  A
-    "step" is one pass over the whole job; per-phase wall times are the max over ranks."""
+    "step" is one pass over the whole job; per-phase wall times are the max over ranks.  The images are crops of one canvas
+    (workloads.shifted_crops) and LightGlue runs the matching-capable synthetic weights at the reference's default threshold 0.1,
+    so the match tables that cross xGMI are filled with hundreds of true correspondences per pair.
+    Returns the record (rank 0) or None."""
     sp = importlib.import_module(PKG + ".superpoint_hip")
     lg = importlib.import_module(PKG + ".lightglue_hip")
     pl = importlib.import_module(PKG + ".pipeline")
     weights = importlib.import_module(PKG + ".weights")
+    workloads = importlib.import_module(PKG + ".workloads")
     capi = importlib.import_module(PKG + ".capi")
-    B, K, W = a.pairs, a.steps, a.warmup
+    B, K, W = a.pairs, steps, warmup
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
     conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
     ext = sp.SuperPointHIP(weights.synthetic_superpoint_state_dict(1234), cfg, max_batch=B, max_hw=(1024, 1024), capacity=2048, device=dev)
-    mat = lg.LightGlueHIP(weights.synthetic_lightglue_state_dict(0, 256), conf, max_pairs=B, max_kpts=2048, device=dev)
+    mat = lg.LightGlueHIP(weights.synthetic_lightglue_matching_state_dict(0, 256), conf, max_pairs=B, max_kpts=2048, device=dev)
     pipe = pl.PairMatchingPipeline(ext, mat, rank, world)
-    imgs = torch.stack([torch.rand(1024, 1024, generator=torch.Generator().manual_seed(s)) for s in range(a.images)]).to(dev)
+    imgs = workloads.shifted_crops(a.images, 1024, 1024, max_shift=256, seed=7)[0].to(dev)
     pairs = pl.exhaustive_pairs(a.images, a.job_pairs)
     P = int(pairs.shape[0])
 
@@ -223,34 +228,51 @@ def run_config4(a, rank, world, dev, dist, lib):
     tot_ms, launches = ctypes.c_double(), ctypes.c_int()
     capi.check(lib, lib.dim_profile_stop(ctypes.byref(tot_ms), ctypes.byref(launches)))
     total_matches = int(cnt.sum().item())
+    pairs_with_100 = int((cnt >= 100).sum().item())
     tt = torch.tensor([dt] + [phases[k] for k in phases], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt[0].item())
     sat_total, sat_sites = capi.saturation(lib, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), reset=True)
+    del ext, mat, pipe, imgs, table, mt, ms
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    per_rank_pairs = (P + world - 1) // world
+    attn_ms = tot_ms.value / max(1, launches.value)
+    # one self-attention launch = 2B items x 4 heads: QK^T + AV = 77.3 GFLOP per pair over 9 layers; the last
+    # batch of a shard may be smaller, so the algorithmic work per launch is averaged over the launches actually made
+    gflop_per_launch = 77.3 * per_rank_pairs * K / max(1, launches.value)
+    return {
+        "metric": "image-pairs/s (SuperPoint+LightGlue, 1024^2, 2048 kpts)", "value": K * P / dt, "unit": "image-pairs/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[3] (config 4): {a.images} synthetic 1024x1024 images (crops of one canvas: true correspondences) -> first {P} "
+                               "exhaustive pairs, extraction amortised over the images + 1 LightGlue match per pair (fixed-work, 9 layers, matching-capable "
+                               "synthetic weights, threshold 0.1), through PairMatchingPipeline phases 1-4",
+                   "images": a.images, "job_pairs": P, "pair_batch": B, "gflop_per_pair": LG_GFLOP_PER_PAIR + SP_GFLOP_PER_IMAGE * a.images / P,
+                   "sharding": f"images i mod {world}, ONE all-gather of feature tables ({pipe_bytes(a.images, world)[0] / 1e6:.0f} MB), pairs "
+                               f"round-robin, ONE all-gather of match tables ({pipe_bytes(P, world)[1] / 1e6:.0f} MB)"},
+        "phases_s_max_over_ranks": {k: float(v) / K for k, v in zip(phases, tt[1:].tolist())},
+        "matches_total": total_matches, "matches_per_pair_mean": total_matches / max(1, P), "pairs_with_at_least_100_matches": pairs_with_100,
+        "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
+        "roofline": {"kernel": "attn_x6_kernel<2> self-attention launches (flash attention, fp16x3 on the fp16 MFMA)", "bound": "mfma",
+                     "achieved": gflop_per_launch / attn_ms, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": gflop_per_launch / attn_ms / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": attn_ms,
+                     "launches": launches.value, "algorithmic_gflop_per_launch": gflop_per_launch},
+        "cpu_baseline": None,
+    }
+
+
+def pipe_bytes(n_items, world, cap=2048, D=256, NK=2048):
+    """(feature gather bytes for n_items images, match gather bytes for n_items pairs): the flat buffers of pipeline.py x world"""
+    per = (n_items + world - 1) // world
+    return (per * cap * (2 + 1 + D) + per) * 4 * world, (per * 2 + per * NK * 3) * 4 * world
+
+
+def run_config4(a, rank, world, dev, dist, lib):
+    line = measure_config4(a, rank, world, dev, dist, lib, a.steps, a.warmup)
     if rank == 0:
-        per_rank_pairs = (P + world - 1) // world
-        attn_ms = tot_ms.value / max(1, launches.value)
-        # one self-attention launch = 2B items x 4 heads: QK^T + AV = 77.3 GFLOP per pair over 9 layers; the last
-        # batch of a shard may be smaller, so the algorithmic work per launch is averaged over the launches actually made
-        gflop_per_launch = 77.3 * per_rank_pairs * K / max(1, launches.value)
-        line = {
-            "metric": "image-pairs/s (SuperPoint+LightGlue, 1024^2, 2048 kpts)", "value": K * P / dt, "unit": "image-pairs/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[3] (config 4): {a.images} synthetic 1024x1024 images -> first {P} exhaustive pairs, extraction amortised over "
-                                   "the images + 1 LightGlue match per pair (fixed-work, 9 layers), through PairMatchingPipeline phases 1-4",
-                       "images": a.images, "job_pairs": P, "pair_batch": B, "gflop_per_pair": LG_GFLOP_PER_PAIR + SP_GFLOP_PER_IMAGE * a.images / P,
-                       "sharding": f"images i mod {world}, ONE all-gather of feature tables ({pipe.timings['feature_gather_bytes'] / 1e6:.0f} MB), pairs "
-                                   f"round-robin, ONE all-gather of match tables ({pipe.timings['match_gather_bytes'] / 1e6:.0f} MB)"},
-            "phases_s_max_over_ranks": {k: float(v) / K for k, v in zip(phases, tt[1:].tolist())},
-            "matches_total": total_matches, "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
-            "roofline": {"kernel": "attn_x6_kernel<2> self-attention launches (flash attention, fp16x3 on the fp16 MFMA)", "bound": "mfma",
-                         "achieved": gflop_per_launch / attn_ms, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gflop_per_launch / attn_ms / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": attn_ms,
-                         "launches": launches.value, "algorithmic_gflop_per_launch": gflop_per_launch},
-            "cpu_baseline": None,
-        }
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
@@ -409,6 +431,21 @@ def main():
     clock_mhz = (ck[2] - ck[0]) / max(1, ck[3] - ck[1]) * 100.0
     sat_total, sat_sites = capi.saturation(lib, stream_ptr, reset=True)  # fp16x3 range guard over the whole run: must be 0
 
+    # strong scaling where the driver's 1/2/4/8 command sees it: the FIXED config-4 job (150 images -> 10 000
+    # exhaustive pairs, images and pairs sharded over the ranks, two all-gathers) after the headline region; `value` stays the headline
+    strong = None
+    flat_numel = flat.numel()
+    if not a.no_strong_scaling and not a.main_region_only:
+        flat_numel = flat.numel()
+        del pool, feats, flat, outs
+        torch.cuda.empty_cache()
+        rec = measure_config4(a, rank, world, dev, dist, lib, steps=1, warmup=1)
+        if rec is not None:
+            strong = {k: rec[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "phases_s_max_over_ranks", "matches_total",
+                                          "matches_per_pair_mean", "pairs_with_at_least_100_matches", "fp16x3_range_guard")}
+            strong["workload"] = rec["config"]["workload"]
+            strong["sharding"] = rec["config"]["sharding"]
+
     if rank == 0:
         pairs_total = world * K * P
         value = pairs_total / dt
@@ -433,7 +470,7 @@ def main():
                                    "seeded synthetic weights", "pairs_per_step_per_gpu": P, "image": "1024x1024",
                        "keypoints": 2048, "all_2048_kpts": n_kpts_ok, "gflop_per_pair": 2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR,
                        "sharding": f"pairs sharded over {world} rank(s); ONE RCCL all-gather of the match tables at the end "
-                                   f"(flat int32: counts + (idx0, idx1, score) rows, {flat.numel() * 4 / 1e6:.1f} MB per rank)",
+                                   f"(flat int32: counts + (idx0, idx1, score) rows, {flat_numel * 4 / 1e6:.1f} MB per rank)",
                        "streams": "extraction of batch i+1 overlaps matching of batch i (2 HIP streams)" if overlap else "single stream"},
             ("single_stream" if overlap else "two_stream_overlap"): None if a.main_region_only else {
                 "value": pairs_total / dt2, "unit": "image-pairs/s", "ms_per_step": dt2 / K * 1e3,
@@ -441,6 +478,7 @@ def main():
             "end_to_end_tflops_per_gpu": (2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR) * value / world / 1e3,
             "timed_region_s": dt, "pairs_total": pairs_total, "sustained_clock_mhz": clock_mhz,
             "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
+            "strong_scaling": strong,
             "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1,true,2> (SuperPoint conv1a 1->64 evaluated in the halo staging + conv1b 64->64 3x3 "
                                    "+ bias + ReLU + 2x2 max-pool, fp32-accurate on the fp16 MFMA (fp16x3); 1024^2 images)", "bound": "mfma",
                          "achieved": conv_tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -450,6 +488,8 @@ def main():
                                       "split-precision passes are not credited, so frac <= 1/3); mfma_pipe_util = x 3 passes = what the "
                                       "MFMA-busy counter shows (profiles/r03_pmc_mfma_summary.txt)",
                          "frac_of_fp32_mfma_peak": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_note": "CITED, not measured by this run: HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                         "of the same kernel (profiles/conv1b_hbm_bytes.json names the pass), scaled to this run's images per launch",
                          "isolated": {"note": "same kernel, same launches, timed again right after the timed region in two extraction-only batches "
                                               "(the main region is single-stream, so the two agree unless --overlap is given)",
                                       "avg_launch_ms": iso_ms.value / max(1, iso_n.value),

@@ -62,13 +62,22 @@ class _Ring:
         self._made = 0
         self._lock = threading.Lock()
 
-    def acquire(self, shapes_dtypes):
-        """-> list of host tensors matching ``shapes_dtypes`` = [(shape, dtype), ...] (re-used when the sizes still fit)."""
+    def acquire(self, shapes_dtypes, failed=None):
+        """-> list of host tensors matching ``shapes_dtypes`` = [(shape, dtype), ...] (re-used when the sizes still fit).
+        Blocks while all ``count`` buffers are with the writers; ``failed()`` (the exporter's error check, raises) is polled
+        meanwhile, so a producer that is ahead of a writer which died cannot wait forever."""
         with self._lock:
             make = self._free.empty() and self._made < self._count
             if make:
                 self._made += 1
-        bufs = None if make else self._free.get()
+        bufs = None
+        while not make:
+            try:
+                bufs = self._free.get(timeout=0.5)
+                break
+            except queue.Empty:
+                if failed is not None:
+                    failed()
         out = []
         for i, (shape, dtype) in enumerate(shapes_dtypes):
             need = int(np.prod(shape))
@@ -194,7 +203,7 @@ class AsyncExporter:
         with ctx:
             capi.check(self.lib, self.lib.dim_op_pack_features_f16(capi.ptr(kpts.contiguous()), capi.ptr(scores.contiguous()), capi.ptr(desc.contiguous()),
                                                                    capi.ptr(n.contiguous()), capi.ptr(ti), B, cap, D, capi.ptr(packed), self._stream()))
-        host = self._fring.acquire([((B * slot,), torch.float16), ((B,), torch.int32)])
+        host = self._fring.acquire([((B * slot,), torch.float16), ((B,), torch.int32)], self._check)
         ev = self._d2h(0, idx, [(packed[: B * slot], host[0]), (n.to(torch.int32), host[1])])
         left = [len(names)]
         for b, name in enumerate(names):
@@ -222,7 +231,7 @@ class AsyncExporter:
                                                                     self.min_inliers, ctypes.c_double(self.min_ratio), capi.ptr(ver), capi.ptr(n_ver),
                                                                     self._stream()))
             srcs += [ver, n_ver]
-        host = self._mring.acquire([((t.numel(),), t.dtype) for t in srcs])
+        host = self._mring.acquire([((t.numel(),), t.dtype) for t in srcs], self._check)
         ev = self._d2h(1, idx, list(zip(srcs, host)))
         self._q.put(("matches", ev, host, list(pair_names), P, NK, mask is not None))
 
@@ -233,21 +242,23 @@ class AsyncExporter:
             if item is None:
                 self._fq.task_done()
                 return
+            ev, host, left, b, name, hw, cap, D, slot = item
             try:
                 t0 = time.perf_counter()
-                ev, host, left, b, name, hw, cap, D, slot = item
                 if ev is not None:
                     ev.synchronize()
-                self._write_features(store, host, b, name, hw, cap, D, slot)
+                if self._err is None:     # after a failure the remaining jobs only hand their buffers back
+                    self._write_features(store, host, b, name, hw, cap, D, slot)
                 with self._lock:
                     self.busy_s += time.perf_counter() - t0
+            except BaseException as e:  # noqa: BLE001 - surfaced on the producer side (_check / close)
+                self._err = self._err or e
+            finally:
+                with self._lock:          # the batch's pinned buffer goes back to the ring whether or not the write succeeded
                     left[0] -= 1
                     done = left[0] == 0
                 if done:
                     self._fring.release(host)
-            except BaseException as e:  # noqa: BLE001 - surfaced on the producer side
-                self._err = e
-            finally:
                 self._fq.task_done()
 
     def _write_features(self, store, host, b, name, hw, cap, D, slot):
@@ -287,14 +298,17 @@ class AsyncExporter:
                     self._db_image(*item[1:])
                 else:
                     _, ev, host, pair_names, P, NK, verified = item
-                    if ev is not None:
-                        ev.synchronize()
-                    self._write_matches(host, pair_names, P, NK, verified)
-                    self._mring.release(host)
+                    try:
+                        if ev is not None:
+                            ev.synchronize()
+                        if self._err is None:
+                            self._write_matches(host, pair_names, P, NK, verified)
+                    finally:
+                        self._mring.release(host)
                 with self._lock:
                     self.busy_s += time.perf_counter() - t0
             except BaseException as e:  # noqa: BLE001
-                self._err = e
+                self._err = self._err or e
             finally:
                 self._q.task_done()
 
@@ -350,7 +364,12 @@ class AsyncExporter:
         self._q.put(None)             # the match writer commits and closes its database connection on the way out
         for th in self._threads:
             th.join()
-        if self._err is not None:
+        if self._err is not None:     # close the containers first (what was written stays readable), then report
+            for st in self._fstores + [self.raw, self.verified]:
+                try:
+                    st.close()
+                except BaseException:  # noqa: BLE001 - the first error is the one reported
+                    pass
             raise RuntimeError("a writer thread failed") from self._err
         for st in self._fstores:
             st.close()

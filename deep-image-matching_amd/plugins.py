@@ -287,7 +287,7 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
     """matchers/lightglue.py:77 — LightGlue on the gfx950 library."""
 
     _default_conf = {
-        "flash": True,   # accepted for compatibility; attention here is always the fp32 MFMA kernel
+        "flash": True,   # accepted for compatibility; attention here is always the flash-attention kernel of lg_attn_x6.hip (fp16x3 / bf16x6 split arithmetic, lg_attn.hip in fp32 MFMA mode)
         "mp": False,
         "depth_confidence": 0.95,
         "width_confidence": 0.99,

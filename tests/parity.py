@@ -101,7 +101,7 @@ def compare_lightglue(out: dict, ref: dict, score_tol: float = 1e-3, dense_ref=N
 
 
 def match_list_difference_is_a_tie(got: torch.Tensor, want: torch.Tensor, log_assignment: torch.Tensor, filter_threshold: float = 0.0,
-                                   tie_tol: float = 1e-4):
+                                   tie_tol: float = 1e-4, ind0=None, ind1=None):
     """The near-tie rule of compare_lightglue's docstring, for compact match lists: every match that only one side reports must
     be within tie_tol — IN THE ORACLE'S OWN log-assignment — of being the mutual best of its row and column (or of the filter
     threshold), and the decision it lost / won must itself be that close (top-2 margin of the row or column <= tie_tol).
@@ -111,8 +111,14 @@ def match_list_difference_is_a_tie(got: torch.Tensor, want: torch.Tensor, log_as
     g = {tuple(int(v) for v in x) for x in got.tolist()}
     w = {tuple(int(v) for v in x) for x in want.tolist()}
     la = log_assignment
+    # with point pruning the oracle's log-assignment lives in the PRUNED index space: ind0 / ind1 (its taps) list the surviving
+    # keypoints; a match on a pruned keypoint cannot be explained
+    pos0 = {int(v): k for k, v in enumerate(ind0.tolist())} if ind0 is not None else None
+    pos1 = {int(v): k for k, v in enumerate(ind1.tolist())} if ind1 is not None else None
     explained = []
-    for (i, j) in sorted(g ^ w):
+    for (gi, gj) in sorted(g ^ w):
+        assert (pos0 is None or gi in pos0) and (pos1 is None or gj in pos1), ("match on a keypoint the oracle pruned", (gi, gj))
+        i, j = (pos0[gi] if pos0 is not None else gi), (pos1[gj] if pos1 is not None else gj)
         row, col = la[i, :-1], la[:-1, j]
         v = float(la[i, j])
         near_best = float(row.max()) - v <= tie_tol and float(col.max()) - v <= tie_tol
@@ -121,7 +127,7 @@ def match_list_difference_is_a_tie(got: torch.Tensor, want: torch.Tensor, log_as
         col_margin = float(top2c[0] - top2c[-1]) if col.numel() > 1 else float("inf")
         near_thr = abs(float(torch.exp(la[i, j])) - filter_threshold) <= tie_tol
         ok = near_best and (min(row_margin, col_margin) <= tie_tol or near_thr)
-        assert ok, ("unexplained match difference", (i, j), "only_out" if (i, j) in g else "only_ref", v, row_margin, col_margin)
-        explained.append({"match": (i, j), "side": "only_out" if (i, j) in g else "only_ref", "log_assignment": v,
+        assert ok, ("unexplained match difference", (gi, gj), "only_out" if (gi, gj) in g else "only_ref", v, row_margin, col_margin)
+        explained.append({"match": (gi, gj), "side": "only_out" if (gi, gj) in g else "only_ref", "log_assignment": v,
                           "row_top2_margin": row_margin, "col_top2_margin": col_margin})
     return explained

@@ -98,13 +98,13 @@ def test_aliked_emulated_vs_oracle_and_golden(emu_lib, name):
     compare_aliked(out, gold)
 
 
-REAL_ALIKED = Path("/root/reference/src/deep_image_matching/thirdparty/ALIKED/models/aliked-n16rot.pth")
+REAL_ALIKED = Path(__file__).parent / "assets" / "aliked-n16rot.pth"   # byte copy of the reference's thirdparty/ALIKED/models/aliked-n16rot.pth
 
 
-@pytest.mark.skipif(not REAL_ALIKED.exists(), reason="the reference tree (with its aliked-n16rot.pth) is not present")
+@pytest.mark.skipif(not REAL_ALIKED.exists(), reason="aliked-n16rot.pth asset not present")
 def test_aliked_real_checkpoint_through_the_hip_sources(emu_lib):
-    """The REAL aliked-n16rot.pth that ships inside the reference tree (read in place, never copied — so this runs in the
-    build container only; the checkpoint cannot travel to the GPU box) through the HIP sources on the emulator, vs the
+    """The REAL aliked-n16rot.pth that ships inside the reference tree (tests/assets holds a byte copy: a data file, md5
+    bfec5e8086e9f6bf68ffeb90ca7a793a, so that the GPU tests can use it too) through the HIP sources on the emulator, vs the
     oracle that oracle/make_golden.py pins bit-exact against the reference's aliked.py with the same file.  Real weights
     have the trained dynamic range (BatchNorm scales, score head) that the seeded synthetic ones lack."""
     weights = importlib.import_module("deep-image-matching_amd.weights")

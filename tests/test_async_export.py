@@ -187,3 +187,44 @@ def test_h5py_path_precompressed_chunks_read_back_by_the_reference(emu_lib, tmp_
         refstubs.uninstall(added)
         importlib.reload(export)
         assert not export.HAVE_H5PY
+
+
+def test_writer_failure_surfaces_instead_of_hanging_the_producer(tmp_path, emu_lib):
+    """a writer thread that raises (disk full ...) must not leak its pinned ring buffer — with max_pending
+    buffers leaked the producer used to block forever in _Ring.acquire.  Now the buffers come back in a finally block, acquire
+    polls the error flag, and close() closes the containers before it reports the first error."""
+    import threading
+    rng = np.random.default_rng(1)
+    names = [f"im{i}.jpg" for i in range(8)]
+    ex = aexp.AsyncExporter(tmp_path / "fail", device="cpu", max_pending=1, lib=emu_lib, feature_workers=2, image_names=names)
+    boom = OSError(28, "No space left on device")
+
+    def failing(*a, **k):
+        raise boom
+
+    ex._write_features = failing
+    ex._write_matches = failing
+    outcome = {}
+
+    def producer():
+        try:
+            for rep in range(6):       # far more batches than ring buffers: every one needs a buffer a failed writer must have returned
+                kp, sc, de, n = _fake_batch(rng, 2, 16)
+                ex.put_features(names[:2], kp, sc, de, n, [(48, 64)] * 2)
+                m = torch.zeros(2, 8, 2, dtype=torch.int64)
+                ex.put_matches([(names[0], names[1]), (names[1], names[2])], m, torch.tensor([3, 4], dtype=torch.int32))
+            outcome["producer"] = "finished"
+        except RuntimeError as e:
+            outcome["producer"] = e
+        try:
+            ex.close()
+            outcome["close"] = "no error"
+        except RuntimeError as e:
+            outcome["close"] = e
+
+    th = threading.Thread(target=producer, daemon=True)
+    th.start()
+    th.join(timeout=60)
+    assert not th.is_alive(), "the producer hangs behind a failed writer"
+    assert isinstance(outcome["producer"], RuntimeError) and outcome["producer"].__cause__ is boom     # surfaced by _check, not swallowed
+    assert isinstance(outcome["close"], RuntimeError) and outcome["close"].__cause__ is boom

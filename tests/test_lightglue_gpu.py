@@ -165,3 +165,39 @@ def test_ffn_fused_op_at_production_rows(hip_lib):
         err = (C1.double() - ref).abs().max(1).values
         assert int((err > 2e-5).sum()) == 0, (M, float(err.max()), (err > 2e-5).nonzero().reshape(-1)[:8].tolist())
         assert torch.equal(C1, C2), M
+
+
+def test_match_list_flip_rate_at_2048_within_the_measured_fp32_envelope(hip_lib):
+    """BASELINE size (2048 x 2048 keypoints, fixed work): the first 8 pairs of the 200-pair study (scripts/study/lg_flip_rate.py;
+    inputs with true correspondences, 124 .. 439 matches per pair), HIP vs the fp32 oracle at threshold 0 AND 0.1.  The bound is not
+    a constant picked after a failure: it is the flip rate / decision margin the reference's own arithmetic shows against its fp64
+    evaluation in that study (tests/test_configs_gpu.py::flip_rate_basis reads profiles/r04_flip_rate_summary.json)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "scripts" / "study"))
+    import lg_flip_rate as study
+    from tests.parity import match_list_difference_is_a_tie
+    from tests.test_configs_gpu import _record, flip_rate_basis
+    basis = flip_rate_basis()
+    lg = importlib.import_module("deep-image-matching_amd.lightglue_hip")
+    total = {0.0: 0, 0.1: 0}
+    flips = {0.0: [], 0.1: []}
+    mats = {}
+    for p in range(8):
+        c = study.case_of(p)
+        sd, f = gc.lg_weights(c), gc.lg_inputs(c)
+        if c["wseed"] not in mats:
+            mats[c["wseed"]] = lg.LightGlueHIP(sd, study.CONF, max_pairs=1, max_kpts=2048)
+        res = mats[c["wseed"]]({"image0": {"keypoints": f[0]["kpts"][None], "descriptors": f[0]["desc"][None], "image_size": f[0]["size"][None]},
+                                "image1": {"keypoints": f[1]["kpts"][None], "descriptors": f[1]["desc"][None], "image_size": f[1]["size"][None]}})
+        ref = lightglue_ref.lightglue_forward(f[0]["kpts"], f[0]["desc"], f[0]["size"], f[1]["kpts"], f[1]["desc"], f[1]["size"], sd, study.CONF, taps=True)
+        mo, so = res["matches"][0].cpu(), res["scores"][0].cpu()
+        for th in (0.0, 0.1):
+            got, want = mo[so > th], ref["matches"][ref["scores"] > th]
+            total[th] += int(want.shape[0])
+            if not torch.equal(got, want):
+                flips[th] += match_list_difference_is_a_tie(got, want, ref["log_assignment"], th, tie_tol=basis["tie_tol"])
+    assert total[0.0] >= 8 * 100
+    for th in (0.0, 0.1):
+        assert len(flips[th]) <= 3 * basis["rate"] * total[th] + 1, (th, flips[th], basis)
+    _record({"test": "lg_flip_rate_2048_first_8_pairs", "matches": total, "flips": flips, "basis": basis})
