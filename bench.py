@@ -198,9 +198,10 @@ def measure_config4(a, rank, world, dev, dist, lib, steps, warmup):
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
     conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
     ext = sp.SuperPointHIP(weights.synthetic_superpoint_state_dict(1234), cfg, max_batch=B, max_hw=(1024, 1024), capacity=2048, device=dev)
-    mat = lg.LightGlueHIP(weights.synthetic_lightglue_matching_state_dict(0, 256), conf, max_pairs=B, max_kpts=2048, device=dev)
-    pipe = pl.PairMatchingPipeline(ext, mat, rank, world)
     imgs = workloads.shifted_crops(a.images, 1024, 1024, max_shift=256, seed=7)[0].to(dev)
+    center = workloads.descriptor_mean(ext, imgs)     # same on every rank (same images, deterministic kernels)
+    mat = lg.LightGlueHIP(weights.synthetic_lightglue_matching_state_dict(0, 256, center=center), conf, max_pairs=B, max_kpts=2048, device=dev)
+    pipe = pl.PairMatchingPipeline(ext, mat, rank, world)
     pairs = pl.exhaustive_pairs(a.images, a.job_pairs)
     P = int(pairs.shape[0])
 

@@ -396,9 +396,11 @@ class EndToEndRunner:
     Every batch runs under the fp16x3 range guard (capi.run_guarded: a batch that leaves the exact range of the split is
     repeated in bf16x6 BEFORE it is handed to the exporter); the number of repeated batches is reported."""
 
-    def __init__(self, extractor, matcher, verifier=None, exporter: Optional[AsyncExporter] = None, on_saturation: str = "fallback"):
+    def __init__(self, extractor, matcher, verifier=None, exporter: Optional[AsyncExporter] = None, on_saturation: str = "fallback",
+                 overlap_verification: bool = True):
         self.ext, self.mat, self.ver, self.exp = extractor, matcher, verifier, exporter
         self.policy = on_saturation
+        self.overlap_verification = overlap_verification
 
     @torch.no_grad()
     def run(self, names: Sequence[str], images: torch.Tensor, pairs: torch.Tensor) -> Dict[str, float]:
@@ -432,19 +434,29 @@ class EndToEndRunner:
         pairs_dev = pairs.to(dev, torch.int32).contiguous()
         pair_list = pairs.tolist()
         counts = []
+        # verification + hand-over to the writers run on their OWN stream: the fp64-VALU RANSAC of batch i overlaps the matrix-core
+        # bound LightGlue of batch i + 1 (measured in round 4 with ~1400 matches per pair: RANSAC on the matching stream cost 14 %)
+        vstream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.ver is not None and self.overlap_verification) else None
         for s in range(0, pairs.shape[0], PB):
             pp = pairs_dev[s:s + PB].contiguous()
             o = capi.run_guarded(lib, stream(), lambda: self.mat.match_batch(kp, de, n, size, pair_idx=pp), "EndToEndRunner.match", self.policy, _Count())
-            mask = None
-            if self.ver is not None:
-                v = self.ver.verify_batch(kp, o["matches"], o["n_matches"], pair_idx=pp)
-                mask = v["mask"]
-                counts.append((o["n_matches"].clone(), v["n_inliers"].clone()))
-            else:
-                counts.append((o["n_matches"].clone(), None))
-            if self.exp is not None:
-                pn = [(names[a], names[b]) for a, b in pair_list[s:s + PB]]
-                self.exp.put_matches(pn, o["matches"], o["n_matches"], mask)
+            if vstream is not None:
+                vstream.wait_stream(torch.cuda.current_stream(dev))
+                for t_ in (o["matches"], o["n_matches"], pp):
+                    t_.record_stream(vstream)
+            with (torch.cuda.stream(vstream) if vstream is not None else _Null()):
+                mask = None
+                if self.ver is not None:
+                    v = self.ver.verify_batch(kp, o["matches"], o["n_matches"], pair_idx=pp)
+                    mask = v["mask"]
+                    counts.append((o["n_matches"].clone(), v["n_inliers"].clone()))
+                else:
+                    counts.append((o["n_matches"].clone(), None))
+                if self.exp is not None:
+                    pn = [(names[a], names[b]) for a, b in pair_list[s:s + PB]]
+                    self.exp.put_matches(pn, o["matches"], o["n_matches"], mask)
+        if vstream is not None:
+            torch.cuda.current_stream(dev).wait_stream(vstream)
         sync()
         t2 = time.perf_counter()
         stats = self.exp.close() if self.exp is not None else {}

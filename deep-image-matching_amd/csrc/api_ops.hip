@@ -63,6 +63,8 @@ static int g_fuse_ffn_ln = 3;
 int dim_fuse_ffn_ln() { return g_fuse_ffn_ln; }
 static int g_gemm_kc = 32;
 int dim_gemm_kc() { return g_gemm_kc; }
+static int g_conv_wino = 0;
+int dim_conv_winograd() { return g_conv_wino; }
 static int g_gemm_probe = 0;
 int dim_gemm_probe() { return g_gemm_probe; }
 static int g_attn_probe = 0;
@@ -272,6 +274,7 @@ int dim_tune_set(int key, int value) {
   if (key == 12) g_attn_probe = value;
   if (key == 13) g_gemm_probe = value;
   if (key == 14) g_gemm_kc = value;
+  if (key == 15) g_conv_wino = value;
   return 0;
 }
 

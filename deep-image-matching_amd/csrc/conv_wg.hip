@@ -1,0 +1,391 @@
+// 3x3 convolution as a 1-D Winograd F(2, 3) along x on the fp16 matrix cores (fp16x3 split arithmetic, dim_common.h): a pair of
+// neighbouring output columns (2j, 2j+1) of one row and kernel row dy needs the four input columns d0..d3 = 2j-1 .. 2j+2:
+//     t0 = d0 - d2,  t1 = d1 + d2,  t2 = d2 - d1,  t3 = d1 - d3                 (input transform, fp32, BEFORE the fp16 split)
+//     u0 = g0,  u1 = (g0 + g1 + g2) / 2,  u2 = (g0 - g1 + g2) / 2,  u3 = g2     (weight transform, host, fp64 -> fp32 -> split)
+//     m_p = sum over (cin, dy) of t_p u_p;    y(2j) = m0 + m1 + m2,  y(2j+1) = m1 - m2 - m3
+// = 4 instead of 6 multiplies per output pair, input channel and kernel row: 2/3 of the direct kernel's MFMAs (conv_x6.hip).
+// Replaces the same reference lines as conv_x6.hip (SuperPoint's 3x3 convolutions, SPN:161-175); selected by dim_tune_set(15, mask).
+//
+// Implicit GEMM per position p: M = (row, column pair) of the tile, N = cout, K = 3 dy x cin.  Workgroup = 4 waves, output tile
+// 8 rows x 32 columns x 64 channels; WAVE p OWNS POSITION p: 4 M-tiles (2 rows x 16 pairs each) x 2 N-tiles = 8 accumulators.
+//   * B operand (transformed weights of position p) goes L2 -> registers in MFMA-fragment order, one contiguous 4-KB run per wave and
+//     (chunk, dy) step, requested one step ahead: every fragment is fetched by exactly one wave, no weight image in LDS, no barrier
+//     per kernel row;
+//   * A operand: the transformed + split halo tile of one 16-channel chunk in LDS, Ip[plane][k-half][pos][row 10][pair 16] 16-byte
+//     slots (one ds_read_b128 = one MFMA operand; a wave reads 8 per 24 MFMAs where the direct kernel reads 12);
+//   * F1A staging (conv1b): SuperPoint's conv1a (1 -> 64, SPN:161) is evaluated from the image patch for the FOUR columns of a pair's
+//     tuple (same fmaf chain as conv1a_kernel / conv_x6.hip), transformed, split and stored — the 64-channel conv1a map never exists;
+//   * the four positions of an output live in four waves: after the K loop every wave hands three of its M-tiles over through LDS
+//     (the Ip bytes) and finishes one (rows 2w, 2w+1): output transform, 2x2 max-pool in-lane, bias, ReLU, split, store.
+// fp16x3 range guard: the transformed activations reach 2 max|d| (t1 = d1 + d2); the staging tracks max|t| of what it splits and
+// reports it at the consumer's site, the epilogue guards its outputs as conv_x6.hip does.
+#include <math.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "dim_kernels.h"
+
+namespace {
+constexpr int WG_TW = 32, WG_TH = 8, WG_IH = WG_TH + 2, WG_NP = WG_TW / 2;
+constexpr int WG_ROWS = WG_IH * WG_NP;            // (row, pair) slots of one (plane, k-half, position): 160
+constexpr int WG_KH = 4 * WG_ROWS + 8;            // slots of one (plane, k-half) block; + 128 B so that the two k-halves a staging store touches sit in different banks
+constexpr int WG_IMW = WG_TW + 4, WG_IMH = WG_TH + 4;   // image patch of the fused conv1a: halo of the halo (36 x 12)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ constexpr size_t planes_image_pixels_wg(int h, int w) { return ((size_t)h * w + 1) & ~(size_t)1; }  // pixel slots of one pre-split image (conv_x6.hip)
+constexpr int WG_WFRAG = 2 * 2 * 2 * 32 * 8;      // 16-bit elements per (cout block, chunk, dy, position): [plane][n][k-half][32 co][8 ci] = 4 KB
+
+template <int CIN, int POOL, bool POUT>
+__global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __restrict__ image, const unsigned short* __restrict__ wx,
+                                                               const float* __restrict__ bias, float* __restrict__ out, int H, int W, int cout,
+                                                               int tiles_x, const float* __restrict__ w1a, const float* __restrict__ b1a,
+                                                               const float* __restrict__ inv_ch, unsigned* sat, unsigned* sat_image) {
+  static_assert(CIN == 64, "the fused conv1a produces 64 channels");
+  using S = SplitMma<2>;
+  constexpr int NCHUNK = CIN / 16, NSTEP = NCHUNK * 3;
+  __shared__ u32x4 Ip[4 * WG_KH];
+  __shared__ float Img[WG_IMH * WG_IMW];
+  __shared__ float W1a[9 * 64 + 64];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, lx = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);   // = this wave's Winograd position
+  int tile;
+  {  // XCD-aware tile order (conv_x6.hip): every XCD works on a contiguous band of the image's tiles
+    const int nt = gridDim.x, xcd = blockIdx.x & 7, j = blockIdx.x >> 3, q = nt >> 3, r = nt & 7;
+    tile = xcd * q + min(xcd, r) + j;
+  }
+  const int ty = tile / tiles_x, tx = tile % tiles_x;
+  const int cb = blockIdx.y, b = blockIdx.z;
+  const int oy = ty * WG_TH, ox = tx * WG_TW;
+  const float* in_b = image + (size_t)b * H * W;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+  // image patch (rows oy - 2 .. oy + 9, columns ox - 2 .. ox + 33; zero outside the image = conv1a's padding) + range guard on it
+  {
+    unsigned imax = 0u;
+    for (int idx = t; idx < WG_IMH * WG_IMW; idx += 256) {
+      const int r = idx / WG_IMW, cc = idx - r * WG_IMW;
+      const int gy = oy + r - 2, gx = ox + cc - 2;
+      const float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in_b[(size_t)gy * W + gx] : 0.0f;
+      Img[idx] = v;
+      imax = max(imax, __float_as_uint(v) & 0x7fffffffu);
+    }
+    if (sat_image != nullptr && imax > 0x3f800000u) atomicAdd(sat_image, 1u);
+    // conv1a weights [tap][64] + bias [64], pre-multiplied by the activation scale (a power of two: exact)
+    for (int idx = t; idx < 9 * 64 + 64; idx += 256) W1a[idx] = (idx < 9 * 64 ? w1a[idx] : b1a[idx - 9 * 64]) * S::act_scale();
+  }
+
+  // B operand: transformed weights of position wv for step s = chunk * 3 + dy, one step ahead of the MFMAs that use them
+  u32x4 bw[2][2][2];   // [buffer][plane][n]
+  auto load_b = [&](int step, auto buf_t) {
+    constexpr int BUF = decltype(buf_t)::value;
+    const u32x4* src = (const u32x4*)(wx + (((size_t)cb * NSTEP + step) * 4 + wv) * WG_WFRAG);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bw[BUF][pl][n] = src[(pl * 2 + n) * 64 + lane];
+  };
+  load_b(0, std::integral_constant<int, 0>{});
+
+  // staging items: (halo row r, column pair j, channel quad q) -> conv1a at the tuple's four columns, transform, split, store.
+  // 10 x 16 x 4 = 640 items = 2.5 per thread: q and j are fixed per thread, wave w takes rows w, w + 4 and (waves 0, 1) w + 8.
+  const int q = t & 3, j = (t >> 2) & 15;
+  // does the halo of this tile leave the image?  (wave-uniform: the zero-padding masks cost VALU only on border tiles)
+  const bool border = oy == 0 || oy + WG_TH >= H || ox == 0 || ox + WG_TW >= W;
+  float vmax_in = 0.0f;   // range guard on the transformed activations (scaled units)
+  auto stage = [&](int c) {
+    float wr[9][4], bv[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 v = *(const float4*)&W1a[k * 64 + c * 16 + q * 4];
+      wr[k][0] = v.x; wr[k][1] = v.y; wr[k][2] = v.z; wr[k][3] = v.w;
+    }
+    {
+      const float4 v = *(const float4*)&W1a[9 * 64 + c * 16 + q * 4];
+      bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int r = wv + 4 * i;
+      if (r >= WG_IH) break;   // wave-uniform
+      float v[3][6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float2 p2 = *(const float2*)&Img[(r + a) * WG_IMW + 2 * j + 2 * k];
+          v[a][2 * k] = p2.x; v[a][2 * k + 1] = p2.y;
+        }
+      float d[4][4];   // [column of the tuple][channel]
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const float x = v[tap / 3][k + tap % 3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaf(x, wr[tap][e], o[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[k][e] = fmaxf(o[e] + bv[e], 0.f);
+      }
+      if (border) {  // conv1b's zero padding: halo pixels outside the image are 0, not relu(conv1a of the padded image)
+        const int gy = oy - 1 + r;
+        const bool rowok = gy >= 0 && gy < H;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int gx = ox - 1 + 2 * j + k;
+          const bool ok = rowok && gx >= 0 && gx < W;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[k][e] = ok ? d[k][e] : 0.f;
+        }
+      }
+      float tp[4][4];  // [position][channel]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tp[0][e] = d[0][e] - d[2][e];
+        tp[1][e] = d[1][e] + d[2][e];
+        tp[2][e] = d[2][e] - d[1][e];
+        tp[3][e] = d[1][e] - d[3][e];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        vmax_in = fmaxf(vmax_in, fmaxf(fmaxf(fabsf(tp[p][0]), fabsf(tp[p][1])), fmaxf(fabsf(tp[p][2]), fabsf(tp[p][3]))));
+        unsigned h01, l01, h23, l23;
+        split2_pk_raw(tp[p][0], tp[p][1], h01, l01);
+        split2_pk_raw(tp[p][2], tp[p][3], h23, l23);
+        // channels q*4 .. q*4+3 live in k-half q >> 1, dwords (q & 1) * 2, + 1 of the (row, pair) slot
+        unsigned* dst = (unsigned*)&Ip[(q >> 1) * WG_KH + p * WG_ROWS + r * WG_NP + j] + (q & 1) * 2;
+        *(u32x2*)dst = u32x2{h01, h23};
+        *(u32x2*)(dst + 2 * WG_KH * 4) = u32x2{l01, l23};   // plane 1 = the low pieces
+      }
+    }
+  };
+
+  auto mma_chunk = [&](int c, auto par_t) {
+    constexpr int CP = decltype(par_t)::value;   // chunk parity: the buffer of step c * 3 + dy is (CP + dy) & 1
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      constexpr int dummy = 0; (void)dummy;
+      const int step = c * 3 + dy;
+      if ((CP + dy) & 1) { if (step + 1 < NSTEP) load_b(step + 1, std::integral_constant<int, 0>{}); }
+      else { if (step + 1 < NSTEP) load_b(step + 1, std::integral_constant<int, 1>{}); }
+      u32x4 fa[4][2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[m][pl] = Ip[(pl * 2 + half) * WG_KH + wv * WG_ROWS + (2 * m + dy + (lx >> 4)) * WG_NP + (lx & 15)];
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int tm = 0; tm < S::NT; ++tm)  // smallest cross terms first
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], bw[(CP + dy) & 1][S::tb(tm)][n], acc[m][n]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  __syncthreads();   // Img / W1a complete
+  for (int c = 0; c < NCHUNK; c += 2) {
+    stage(c);
+    __syncthreads();
+    mma_chunk(c, std::integral_constant<int, 0>{});
+    __syncthreads();   // every wave has read chunk c's operands
+    stage(c + 1);
+    __syncthreads();
+    mma_chunk(c + 1, std::integral_constant<int, 1>{});
+    __syncthreads();
+  }
+  sat_report(sat, vmax_in * (1.0f / DIM_F16_ACT_SCALE));
+
+  // ---- output transform across the four waves: wave w finishes M-tile w (tile rows 2w, 2w + 1) ----
+  // round k: wave p hands M-tile (p + k) & 3 over (both N-tiles, 8 KB) and picks up M-tile w from wave (w - k) & 3
+  f32x4* X = (f32x4*)Ip;   // [wave 4][n 2][register quad 4][lane 64] = 32 KB of the 40.5 KB operand image
+  f32x16 y0[2], y1[2];
+  auto coef0 = [](int p) { return p == 3 ? 0.0f : 1.0f; };                         // y(2j)   = m0 + m1 + m2
+  auto coef1 = [](int p) { return p == 0 ? 0.0f : (p == 1 ? 1.0f : -1.0f); };      // y(2j+1) = m1 - m2 - m3
+  {
+    const float a0 = coef0(wv), a1 = coef1(wv);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m == wv) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { y0[n][r] = a0 * acc[m][n][r]; y1[n][r] = a1 * acc[m][n][r]; }
+      }
+  }
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const int dst = (wv + k) & 3, src = (wv + 4 - k) & 3;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m == dst) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v4 = {acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+            X[((wv * 2 + n) * 4 + g) * 64 + lane] = v4;
+          }
+      }
+    __syncthreads();
+    const float a0 = coef0(src), a1 = coef1(src);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v4 = X[((src * 2 + n) * 4 + g) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          y0[n][4 * g + i] = fmaf(a0, v4[i], y0[n][4 * g + i]);
+          y1[n][4 * g + i] = fmaf(a1, v4[i], y1[n][4 * g + i]);
+        }
+      }
+    if (k < 3) __syncthreads();
+  }
+
+  // ---- epilogue (conv_x6.hip's, on the transformed tile): register r of the C layout = (row bit r >> 3, pair jc(r & 7)) ----
+  const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+  const size_t img_elems = (POUT ? planes_image_pixels_wg(Ho, Wo) : (size_t)Ho * Wo) * cout;
+  const int par = lx & 1;
+  const unsigned psel = par ? 0x03020706u : 0x05040100u;
+  const dim_rsrc rs_f = buf_rsrc(out + (size_t)b * img_elems, POUT ? 0 : img_elems * 4);
+  const dim_rsrc rs_p = buf_rsrc(out + (size_t)b * img_elems, POUT ? img_elems * 4 : 0);
+  constexpr float OSC = POUT ? DIM_F16_ACT_SCALE : 1.0f;
+  auto run_epilogue = [&](auto chk_t) {
+    constexpr bool CHK = decltype(chk_t)::value;
+    auto put2 = [&](unsigned pix0, int col0, int wlim, int co, unsigned cpart, float v0, float v1) {
+      if (POUT) {
+        unsigned h, l;
+        split2_pk_raw(v0, v1, h, l);
+        const unsigned ho = byte_perm(lane_swap1(h), h, psel), lo = byte_perm(lane_swap1(l), l, psel);
+        const unsigned pix = pix0 + (unsigned)par;
+        unsigned off = (pix >> 1) * ((unsigned)cout * 8u) + (pix & 1u) * 64u + cpart;
+        if (CHK) off = (col0 + par < wlim) ? off : DIM_BUF_OOB;
+        buf_store_u32(rs_p, off, ho);
+        buf_store_u32(rs_p, off + 32u, lo);
+      } else {
+        const unsigned o0 = (pix0 * (unsigned)cout + (unsigned)co) * 4u;
+        buf_store_f32(rs_f, (!CHK || col0 < wlim) ? o0 : DIM_BUF_OOB, v0);
+        buf_store_f32(rs_f, (!CHK || col0 + 1 < wlim) ? o0 + (unsigned)cout * 4u : DIM_BUF_OOB, v1);
+      }
+    };
+    float vmax = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int co = cb * 64 + n * 32 + lx;
+      const float bvv = bias[co] * OSC;
+      const float inv_scale = inv_ch[co] * OSC;
+      const unsigned c2 = (unsigned)(co - par);
+      const unsigned cpart = ((c2 >> 4) * 64u + (c2 & 15u)) * 2u;
+      auto finish = [&](float& v0, float& v1) {
+        if (POUT) {
+          vmax = fmaxf(vmax, fmaxf(v0, v1));
+          v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, 65504.0f);
+          v1 = __builtin_amdgcn_fmed3f(v1, 0.0f, 65504.0f);
+        } else {
+          v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f);
+          vmax = sat_track(vmax, v0, v1);
+        }
+      };
+      if (POOL) {
+        const int py = (oy >> 1) + wv, pxb = ox >> 1;
+        float pv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          pv[r] = fmaxf(fmaxf(y0[n][r], y1[n][r]), fmaxf(y0[n][r + 8], y1[n][r + 8])) * inv_scale + bvv;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+          const int q0 = mfma_row(r, half);   // pooled column inside the tile = the pair index; register r + 1 is the next column
+          finish(pv[r], pv[r + 1]);
+          put2((unsigned)(py * Wo + pxb + q0), pxb + q0, Wo, co, cpart, pv[r], pv[r + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int y = oy + 2 * wv + (r >> 3), x0 = ox + 2 * mfma_row(r & 7, half);
+          float v0 = y0[n][r] * inv_scale + bvv, v1 = y1[n][r] * inv_scale + bvv;
+          finish(v0, v1);
+          put2((unsigned)(y * W + x0), x0, W, co, cpart, v0, v1);
+        }
+      }
+    }
+    sat_report(sat, vmax * (1.0f / OSC));
+  };
+  if (POOL ? ((ox >> 1) + WG_TW / 2 <= Wo) : (ox + WG_TW <= W)) run_epilogue(std::false_type{});
+  else run_epilogue(std::true_type{});
+}
+}  // namespace
+
+// Host: OIHW fp32 3x3 weights -> Winograd F(2,3)-along-x transformed, fp16x3-split pieces
+// [cout/64][cin/16][dy][position 4][plane 2][n 2][k-half 2][32 co][8 ci], followed by the fp32 per-output-channel inverse scales.
+// The transform is evaluated in fp64 and rounded once to fp32 (u1, u2 are not fp32-exact sums); the power-of-two scale per output
+// channel puts max|u[co]| into [8192, 16384) as prepare_conv_weights_split does for the untransformed weights.
+size_t conv_wino_weight_elems(int cin, int cout) { return (size_t)(cout / 64) * (cin / 16) * 3 * 4 * WG_WFRAG + 2 * (size_t)cout; }
+void prepare_conv_weights_wino(const float* w_oihw, int cin, int cout, unsigned short* out, SplitWeights* sw) {
+  const int nchunk = cin / 16;
+  sw->mode = 2;
+  sw->scale_off = conv_wino_weight_elems(cin, cout) - 2 * (size_t)cout;
+  float* inv = (float*)(out + sw->scale_off);
+  for (int co = 0; co < cout; ++co) {
+    auto u_of = [&](int ci, int dy, int p) -> float {
+      const float* g = w_oihw + (((size_t)co * cin + ci) * 3 + dy) * 3;
+      const double g0 = g[0], g1 = g[1], g2 = g[2];
+      const double u = p == 0 ? g0 : p == 1 ? 0.5 * (g0 + g1 + g2) : p == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+      return (float)u;
+    };
+    float mx = 0.f;
+    for (int ci = 0; ci < cin; ++ci)
+      for (int dy = 0; dy < 3; ++dy)
+        for (int p = 0; p < 4; ++p) mx = fmaxf(mx, fabsf(u_of(ci, dy, p)));
+    float wscale = 1.0f;
+    int e2 = 0;
+    if (mx > 0.f && mx < INFINITY) { frexpf(mx, &e2); wscale = ldexpf(1.0f, 14 - e2); }
+    const float inv_co = 1.0f / (wscale * DIM_F16_ACT_SCALE);
+    memcpy(&inv[co], &inv_co, 4);
+    const int cb = co / 64, n = (co % 64) / 32, col = co % 32;
+    for (int ci = 0; ci < cin; ++ci)
+      for (int dy = 0; dy < 3; ++dy)
+        for (int p = 0; p < 4; ++p) {
+          float x = u_of(ci, dy, p) * wscale;
+          const int c = ci / 16, hf = (ci % 16) / 8, e = ci % 8;
+          for (int pl = 0; pl < 2; ++pl) {
+            const _Float16 hv = (_Float16)x;
+            unsigned short bits;
+            memcpy(&bits, &hv, 2);
+            const size_t idx = ((((((((size_t)(cb * nchunk + c) * 3 + dy) * 4 + p) * 2 + pl) * 2 + n) * 2 + hf) * 32 + col) * 8) + e;
+            out[idx] = bits;
+            x = x - (float)hv;
+          }
+        }
+  }
+}
+
+// conv1a (1 -> 64) + Winograd conv1b (64 -> cout), bias, ReLU, optional 2x2 max-pool; output fp32 NHWC or pre-split planes
+int launch_conv3x3_wg_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
+                              float* out, int batch, int H, int W, int cout, int pool, int planes_out, hipStream_t s, unsigned* sat,
+                              unsigned* sat_image) {
+  DIM_REQUIRE(cout % 64 == 0, "conv3x3_wg fused conv1a: cout=%d must be a multiple of 64", cout);
+  DIM_REQUIRE(wt.dev && wt.mode == 2, "conv3x3_wg: Winograd weights not prepared");
+  if (batch <= 0 || H <= 0 || W <= 0) return 0;
+  const int tiles_x = cdiv(W, WG_TW), tiles_y = cdiv(H, WG_TH);
+  dim3 grid(tiles_x * tiles_y, cout / 64, batch);
+#define DIM_WG(P, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, P, PO>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image)
+  if (pool && planes_out) DIM_WG(1, true);
+  else if (pool) DIM_WG(1, false);
+  else if (planes_out) DIM_WG(0, true);
+  else DIM_WG(0, false);
+#undef DIM_WG
+  DIM_LAUNCH_CHECK();
+  return 0;
+}

@@ -93,6 +93,13 @@ int launch_conv3x3_x6_fused1a(const float* image, const float* w1a_tap_cout, con
 // fp16x3 only: input and / or output pre-split in the bytes of the fp32 NHWC tensor: per pixel and 16-channel group, 16 h then 16 l fp16 pieces (conv_x6.hip)
 int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const float* bias, float* out, int batch, int H, int W, int cin,
                              int cout, int pool, int relu, int planes_in, int planes_out, hipStream_t s, unsigned* sat = nullptr);
+// Winograd F(2,3)-along-x variant of the fused conv1a + 3x3 convolution (conv_wg.hip): fp16x3 only, 2/3 of the MFMAs
+size_t conv_wino_weight_elems(int cin, int cout);
+void prepare_conv_weights_wino(const float* w_oihw, int cin, int cout, unsigned short* out, SplitWeights* sw);
+int launch_conv3x3_wg_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
+                              float* out, int batch, int H, int W, int cout, int pool, int planes_out, hipStream_t s, unsigned* sat = nullptr,
+                              unsigned* sat_image = nullptr);
+int dim_conv_winograd();     // dim_tune_set key 15: bit 0 = SuperPoint conv1b (fused conv1a) runs the Winograd F(2,3) kernel (default 0 until measured faster)
 int launch_planes_to_f32(const void* planes, int batch, int hw, int channels, float* out, hipStream_t s);  // [batch][hw pixels][channels]
 // a pre-split image occupies an even number of pixel slots (pixels are stored in pairs): size buffers with this
 inline size_t dim_planes_image_pixels(int h, int w) { return ((size_t)h * w + 1) & ~(size_t)1; }

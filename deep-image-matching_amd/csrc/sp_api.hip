@@ -21,6 +21,7 @@ struct dim_sp {
   int max_batch, max_h, max_w, capacity;
   // weights (device)
   float* w1a; float* wk[12]; float* bias[12];
+  SplitWeights wsw[12];     // Winograd F(2,3)-transformed fp16x3 weights (conv_wg.hip) of the layers that have the variant (conv1b)
   SplitWeights wsp[3][12];  // [precision mode 1 = bf16x6, 2 = fp16x3] pre-split 3x3 weights (conv_x6.hip); empty for conv1a and the 1x1 layers
   // activations
   float *a1, *b1, *a2, *b2, *a3, *b3, *a4, *x, *pa, *logits, *da, *dd, *smap, *nms, *cand_score;
@@ -28,6 +29,7 @@ struct dim_sp {
   int last_h, last_w, last_batch;
   float conv1a_bound; // max over channels of sum|w1a| + |b1a|: bound on conv1a's outputs for |image| <= 1 (fp16x3 range guard)
   bool x_is_planes;   // the last extract stored the encoder output as pre-split planes
+  float* b1_dbg;      // fp32 copy of conv1b's pooled output (dim_sp_debug_conv1b)
   float* x_dbg;       // fp32 copy of it, built on request by dim_sp_debug_buffers
   std::vector<void*> allocs;
 };
@@ -71,6 +73,7 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
   h->cfg = *cfg;
   h->max_batch = max_batch; h->max_h = max_h; h->max_w = max_w; h->capacity = capacity;
   h->last_h = h->last_w = h->last_batch = 0;
+  h->b1_dbg = nullptr; h->x_dbg = nullptr;
 #define SP_TRY(x) do { if ((x) != 0) { dim_sp_destroy(h); return -1; } } while (0)
   // ---- weights: OIHW (SPN:128-143) -> [tap][cin][cout] / [cin][cout_padded4] ----
   for (int l = 0; l < 12; ++l) {
@@ -91,6 +94,15 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
         if (hipMemcpy(d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
         sw.dev = d; sw.mode = mode;
       }
+    }
+    if (l == 1) {  // conv1b: the Winograd variant's weights (dim_tune_set key 15)
+      std::vector<unsigned short> hx(conv_wino_weight_elems(ci, co));
+      SplitWeights& sw = h->wsw[l];
+      prepare_conv_weights_wino(w->conv_w[l], ci, co, hx.data(), &sw);
+      unsigned short* d = nullptr;
+      SP_TRY(dev_alloc(h, &d, hx.size()));
+      if (hipMemcpy(d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
+      sw.dev = d; sw.mode = 2;
     }
     if (k == 1) {  // the two 1x1 heads (convPb 256 -> 65, convDb 256 -> 256) run on the split GEMM
       std::vector<float> kn((size_t)ci * co);
@@ -176,7 +188,11 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   auto convp = [&](int l, const float* in, float* out, int Hh, int Ww, int ci, int co, int pool, int pin, int pout) -> int {
     return launch_conv3x3_x6_planes(in, h->wsp[2][l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, pin, pout, s, l >= 8 ? sat_head : sat_enc);
   };
-  if (x6 && dim_fuse_conv1a()) {  // conv1a evaluated inside conv1b's halo staging: its 64-channel full-resolution map never exists
+  if (pmode == 2 && dim_fuse_conv1a() && (dim_conv_winograd() & 1)) {  // Winograd F(2,3) along x: 2/3 of the MFMAs (conv_wg.hip)
+    // the transformed activations reach 2 x conv1a's output bound: check the doubled bound on the host as the direct path checks the plain one
+    if (!(2.0f * h->conv1a_bound <= DIM_F16_ACT_LIMIT)) dim_sat_host_bump(DIM_SAT_SP_IMAGE);
+    SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_wg_fused1a(images_dev, h->wk[0], h->bias[0], h->wsw[1], h->bias[1], h->b1, batch, H, W, 64, 1, planes ? 1 : 0, s, sat_enc, sat_img));
+  } else if (x6 && dim_fuse_conv1a()) {  // conv1a evaluated inside conv1b's halo staging: its 64-channel full-resolution map never exists
     SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_x6_fused1a(images_dev, h->wk[0], h->bias[0], h->wsp[pmode][1], h->bias[1], h->b1, batch, H, W, 64, 1, 1, planes ? 1 : 0, s, sat_enc, sat_img));
   } else {
     if (!h->a1) SP_RUN(dev_alloc(h, &h->a1, (size_t)h->max_batch * h->max_h * h->max_w * 64));
@@ -251,6 +267,24 @@ int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits,
   if (dense_desc) *dense_desc = h->dd;
   if (h8) *h8 = h->last_h * 8;
   if (w8) *w8 = h->last_w * 8;
+  return 0;
+}
+
+int dim_sp_debug_conv1b(dim_sp* h, int batch, int H, int W, const float** out_f32, int* h2, int* w2) {
+  // fp32 NHWC copy [batch][H/2][W/2][64] of conv1b's pooled output of the last extract (A/B of the convolution variants)
+  DIM_REQUIRE(h && out_f32 && batch >= 1 && batch <= h->max_batch, "dim_sp_debug_conv1b: bad argument");
+  const int H2 = H / 2, W2 = W / 2;
+  if (!h->b1_dbg && dev_alloc(h, &h->b1_dbg, (size_t)h->max_batch * (h->max_h / 2) * (h->max_w / 2) * 64) != 0) return -1;
+  const bool planes = dim_precision_mode() == 2 && dim_fuse_conv1a() && dim_presplit_activations();
+  if (planes) {
+    if (launch_planes_to_f32(h->b1, batch, H2 * W2, 64, h->b1_dbg, nullptr) != 0) return -1;
+  } else {
+    DIM_HIP(hipMemcpy(h->b1_dbg, h->b1, (size_t)batch * H2 * W2 * 64 * sizeof(float), hipMemcpyDeviceToDevice));
+  }
+  DIM_HIP(hipDeviceSynchronize());
+  *out_f32 = h->b1_dbg;
+  if (h2) *h2 = H2;
+  if (w2) *w2 = W2;
   return 0;
 }
 

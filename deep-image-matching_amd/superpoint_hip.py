@@ -146,6 +146,13 @@ class SuperPointHIP:
         return out
 
 
+    def debug_conv1b(self, batch: int, H: int, W: int) -> torch.Tensor:
+        """conv1b's pooled output of the last call as a CPU tensor [batch, H/2, W/2, 64] (fp32 NHWC): dim_sp_debug_conv1b."""
+        p, h2, w2 = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+        capi.check(self.lib, self.lib.dim_sp_debug_conv1b(self._h, int(batch), int(H), int(W), ctypes.byref(p), ctypes.byref(h2), ctypes.byref(w2)))
+        return _copy_from(self.lib, p.value, (batch, h2.value, w2.value, 64), self.device)
+
+
 class _null:
     def __enter__(self):
         return self

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import math
 from pathlib import Path
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
@@ -112,12 +112,15 @@ def synthetic_lightglue_state_dict(seed: int = 0, input_dim: int = 256, n_layers
 
 
 def synthetic_lightglue_matching_state_dict(seed: int = 0, input_dim: int = 256, n_layers: int = 9, dim: int = 256,
-                                            residual: float = 0.003, sharpness: float = 320.0, matchability_bias: float = 5.0
-                                            ) -> Dict[str, torch.Tensor]:
+                                            residual: float = 0.003, sharpness: float = 220.0, matchability_bias: float = 5.0,
+                                            center: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """Seeded synthetic LightGlue weights (official key layout) that MATCH: the transformer blocks are near-identity (`ffn.3`
     scaled by ``residual``, so a keypoint's state stays close to its input descriptor), every `final_proj` is
-    ``sharpness`` x identity (an orthogonal map: the similarity is sharpness^2 / 16 x the descriptors' cosine, which a random
-    `final_proj` does not preserve) and the matchability heads say "matchable".  On two views that share keypoints with equal
+    ``sharpness`` x (identity - ``center``) (an orthogonal map: the similarity is sharpness^2 / 16 x the inner product of the CENTRED
+    descriptors, which a random `final_proj` does not preserve; ``center`` = the mean descriptor of the workload, passed as
+    `final_proj.bias` = -sharpness x center — the seeded SuperPoint's descriptors have a pairwise cosine of 0.98, so without centring
+    the logits would have to be ~6000 to separate them and the REFERENCE's own fp32 evaluation of the matching scores would carry
+    1e-3 of noise) and the matchability heads say "matchable".  On two views that share keypoints with equal
     descriptors (workloads.shifted_crops) the mutual-NN assignment then returns the true correspondences — several hundred
     matches per pair with scores above the reference's default threshold 0.1 — so that verification, the match writers and the
     multi-GPU match gather of the benchmarks carry real work (VERDICT r3 weak #3).  Same arithmetic, same FLOPs as any other weights."""
@@ -128,7 +131,7 @@ def synthetic_lightglue_matching_state_dict(seed: int = 0, input_dim: int = 256,
         elif k.endswith("final_proj.weight"):
             sd[k] = torch.eye(dim) * sharpness
         elif k.endswith("final_proj.bias"):
-            sd[k] = torch.zeros_like(sd[k])
+            sd[k] = torch.zeros_like(sd[k]) if center is None else (-sharpness * center.detach().float().cpu().reshape(-1)).contiguous()
         elif k.endswith("matchability.weight"):
             sd[k] = sd[k] * 0.1
         elif k.endswith("matchability.bias"):

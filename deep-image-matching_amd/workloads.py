@@ -42,3 +42,13 @@ def true_match_fraction(kp0: torch.Tensor, kp1: torch.Tensor, matches: torch.Ten
     d = kp0[matches[:, 0]] - kp1[matches[:, 1]]
     want = torch.tensor([float(off1[1] - off0[1]), float(off1[0] - off0[0])])
     return float(((d - want).abs().max(1).values < tol).float().mean())
+
+
+@torch.no_grad()
+def descriptor_mean(extractor, images: torch.Tensor, max_images: int = 8) -> torch.Tensor:
+    """Mean descriptor over the keypoints of the first images of a workload (the ``center`` argument of
+    weights.synthetic_lightglue_matching_state_dict), from the resident extractor (SuperPointHIP / AlikedHIP ``extract_batch``)."""
+    b = min(int(images.shape[0]), int(extractor.max_batch), max_images)
+    kp, sc, de, n = extractor.extract_batch(images[:b].contiguous())
+    rows = torch.cat([de[i, : int(n[i])] for i in range(b)])
+    return rows.mean(0).cpu()

@@ -50,7 +50,8 @@ int dim_device_synchronize(void);
  * key 9 = 1 (default) ALIKED BatchNorm + SELU applied while the consumer stages its input, 0 = separate pass; key 10 = ALIKED fp16x3
  * convolution tile rows (16 default, 8, 17 = 16 with streamed weights); key 11 = LightGlue's feed-forward: 3 (default) ffn.0 +
  * LayerNorm + GELU + ffn.3 + residual as one kernel when the launch fills the GPU, 4 = always (tests), 1 / 2 = LayerNorm + GELU in
- * ffn.0's epilogue only (when large / always), 0 = separate kernels; key 14 = K-chunk width of the wide fp16x3 GEMM blocks (32 default; 64 = unmeasured prototype); key 12 = cross-attention timing probes
+ * ffn.0's epilogue only (when large / always), 0 = separate kernels; key 14 = K-chunk width of the wide fp16x3 GEMM blocks (32 default; 64 = prototype, measured neutral in round 4: 592.5 vs 592.2 pairs/s);
+ * key 15 = Winograd F(2,3)-along-x convolution variants (csrc/conv_wg.hip), bit 0 = SuperPoint conv1b with the fused conv1a (fp16x3 only); key 12 = cross-attention timing probes
  * (scripts/gpu_attn_probe.py; 0 in the product — 1 and 3 give wrong results by design). */
 int dim_tune_set(int key, int value);
 
@@ -140,6 +141,10 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
  * dense_desc (un-normalised convDb output) [batch][h][w][256]. */
 int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits, const float** score_map,
                          const float** nms_map, const float** dense_desc, int* h8, int* w8);
+
+/* fp32 NHWC copy [batch][H/2][W/2][64] of conv1b's pooled output (SPN:162-163) of the last dim_sp_extract call on (batch, H, W):
+ * A/B of the convolution variants (dim_tune_set keys 2, 3, 5, 15).  Synchronises the device. */
+int dim_sp_debug_conv1b(dim_sp* h, int batch, int H, int W, const float** out_f32, int* h2, int* w2);
 
 /* Number of NMS survivors above threshold/border per image of the last call
  * (before top-k), device int32 [batch] owned by the handle. */

@@ -214,8 +214,8 @@ def lightglue_forward(kpts0, desc0, size0, kpts1, desc1, size1, sd: Dict[str, to
         f1 = torch.full((n,), -1, dtype=torch.long)
         f0[ind0] = torch.where(a0 == -1, -1, ind1[a0.clamp(min=0)])
         f1[ind1] = torch.where(a1 == -1, -1, ind0[a1.clamp(min=0)])
-        s0 = torch.zeros(m)
-        s1 = torch.zeros(n)
+        s0 = torch.zeros(m, dtype=ms0.dtype)
+        s1 = torch.zeros(n, dtype=ms0.dtype)
         s0[ind0] = ms0
         s1[ind1] = ms1
         a0, a1, ms0, ms1 = f0, f1, s0, s1

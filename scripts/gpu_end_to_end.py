@@ -32,17 +32,19 @@ cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "re
 # above the reference's default threshold 0.1
 conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
 ext = m("superpoint_hip").SuperPointHIP(weights.synthetic_superpoint_state_dict(1234), cfg, max_batch=a.batch, max_hw=(1024, 1024), capacity=2048, device=dev)
-mat = m("lightglue_hip").LightGlueHIP(weights.synthetic_lightglue_matching_state_dict(0, 256), conf, max_pairs=a.batch, max_kpts=2048, device=dev)
 imgs_cpu, offsets = m("workloads").shifted_crops(a.images, 1024, 1024, max_shift=256, seed=7)
 imgs = imgs_cpu.to(dev)
+center = m("workloads").descriptor_mean(ext, imgs)
+mat = m("lightglue_hip").LightGlueHIP(weights.synthetic_lightglue_matching_state_dict(0, 256, center=center), conf, max_pairs=a.batch, max_kpts=2048, device=dev)
 names = [f"img{i:04d}.jpg" for i in range(a.images)]
 pairs = m("pipeline").exhaustive_pairs(a.images, a.pairs)
 res = {}
-for label, use_ver, use_exp in (("kernels_only", False, False), ("with_device_ransac", True, False), ("with_ransac_and_writers", True, True)):
+for label, use_ver, use_exp, ovl in (("kernels_only", False, False, True), ("with_device_ransac_same_stream", True, False, False), ("with_device_ransac", True, False, True),
+                                    ("with_ransac_and_writers", True, True, True)):
     tmp = Path(tempfile.mkdtemp(prefix="dim_e2e_"))
     ver = m("verify").DeviceVerifier(threshold=4.0, iters=2048, device=dev) if use_ver else None
     exp = m("async_export").AsyncExporter(tmp, device=dev, image_names=names, min_inliers_per_pair=0, min_inlier_ratio_per_pair=0.0) if use_exp else None
-    r = m("async_export").EndToEndRunner(ext, mat, ver, exp).run(names, imgs, pairs)
+    r = m("async_export").EndToEndRunner(ext, mat, ver, exp, overlap_verification=ovl).run(names, imgs, pairs)
     if label == "kernels_only":   # first run also warms up: repeat
         r = m("async_export").EndToEndRunner(ext, mat, None, None).run(names, imgs, pairs)
     r["bytes_written"] = sum(f.stat().st_size for f in tmp.rglob("*") if f.is_file())

@@ -196,10 +196,11 @@ def test_config4_style_pairs_with_true_correspondences_vs_oracle(hip_lib):
     weights, pl, wl = _m("weights"), _m("pipeline"), _m("workloads")
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 512, "remove_borders": 4}
     conf = {"depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.1, "pruning_min_kpts": -1}
-    sp_sd, lg_sd = weights.synthetic_superpoint_state_dict(1234), weights.synthetic_lightglue_matching_state_dict(0, 256)
+    sp_sd = weights.synthetic_superpoint_state_dict(1234)
     n_img, H, W = 10, 320, 320
     imgs, off = wl.shifted_crops(n_img, H, W, max_shift=48, seed=3)
     ext = _m("superpoint_hip").SuperPointHIP(sp_sd, cfg, max_batch=10, max_hw=(H, W), capacity=512)
+    lg_sd = weights.synthetic_lightglue_matching_state_dict(0, 256, center=wl.descriptor_mean(ext, imgs.cuda()))
     mat = _m("lightglue_hip").LightGlueHIP(lg_sd, conf, max_pairs=15, max_kpts=512)
     pipe = pl.PairMatchingPipeline(ext, mat)
     table = pipe.extract_all(imgs.cuda())

@@ -86,3 +86,42 @@ def test_superpoint_gpu_edge_cases(hip_lib):
     order_is_reference_like(out, k_limited=False)
     with pytest.raises(ValueError):
         _sp().SuperPointHIP(sd, {"max_keypoints": 0})
+
+
+def test_winograd_conv1b_variant_vs_direct_and_oracle(hip_lib):
+    """dim_tune_set(15, 1): conv1a + conv1b as a Winograd F(2,3)-along-x kernel (csrc/conv_wg.hip, 2/3 of the MFMAs).  Not bit-identical
+    to the direct kernel (different arithmetic), so it is held to the same bars as the default path: conv1b's pooled map within
+    fp32-class distance of an fp64 evaluation, score map <= 1e-5 from the oracle, NMS bit-exact on the tapped map, keypoint sets /
+    descriptors through compare_superpoint — at 1024 x 1024 and at a ragged size (partial tiles on both axes, floor pooling), and the
+    range guard must stay silent."""
+    import torch.nn.functional as F
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
+    sd = weights.synthetic_superpoint_state_dict(1234)
+    try:
+        for (H, W, seed) in ((1024, 1024, 3), (618, 650, 4)):
+            img = torch.rand(1, 1, H, W, generator=torch.Generator().manual_seed(seed))
+            net = _sp().SuperPointHIP(sd, cfg, max_batch=1, max_hw=(H, W), capacity=2048)
+            x = img.double()
+            a = torch.relu(F.conv2d(x, sd["conv1a.weight"].double(), sd["conv1a.bias"].double(), padding=1))
+            ref1b = F.max_pool2d(torch.relu(F.conv2d(a, sd["conv1b.weight"].double(), sd["conv1b.bias"].double(), padding=1)), 2).permute(0, 2, 3, 1)
+            err = {}
+            for wino in (0, 1):
+                hip_lib.dim_tune_set(15, wino)
+                capi.saturation(hip_lib, net._stream(), reset=True)
+                net.extract_batch(img[:, 0].contiguous().cuda())
+                total, sites = capi.saturation(hip_lib, net._stream(), reset=True)
+                assert total == 0, (wino, sites)
+                err[wino] = (net.debug_conv1b(1, H, W).double() - ref1b).abs().max().item()
+            assert err[1] <= max(2e-6, 1.5 * err[0]), err          # measured on the emulator: 8e-7 (Winograd) vs 1.3e-6 (direct)
+            hip_lib.dim_tune_set(15, 1)
+            out = {k: v.cpu() for k, v in net(img.cuda()).items()}
+            taps = net.debug_taps()
+            ref = superpoint_ref.superpoint_forward(img, sd, cfg, taps=True)
+            assert (taps["score_map"][0] - ref["score_map"][0]).abs().max().item() < 1e-5
+            assert torch.equal(superpoint_ref.simple_nms(taps["score_map"], 3)[0], taps["nms_map"][0])
+            res = compare_superpoint(out, ref)
+            assert res["n_out"] == 2048
+    finally:
+        hip_lib.dim_tune_set(15, 0)
