@@ -27,25 +27,36 @@
 #include "dim_kernels.h"
 
 namespace {
-constexpr int WG_TW = 32, WG_TH = 8, WG_IH = WG_TH + 2, WG_NP = WG_TW / 2;
-constexpr int WG_ROWS = WG_IH * WG_NP;            // (row, pair) slots of one (plane, k-half, position): 160
-constexpr int WG_KH = 4 * WG_ROWS + 8;            // slots of one (plane, k-half) block; + 128 B so that the two k-halves a staging store touches sit in different banks
-constexpr int WG_IMW = WG_TW + 4, WG_IMH = WG_TH + 4;   // image patch of the fused conv1a: halo of the halo (36 x 12)
+constexpr int WG_TW = 32, WG_NP = WG_TW / 2;
+constexpr int WG_IMW = WG_TW + 4;                 // image patch of the fused conv1a: halo of the halo (36 columns)
+// MT = M-tiles per position = tile rows / 2 (template parameter): 4 = 8-row tiles (halo 10 rows = 2.5 staging rounds per wave),
+// 3 = 6-row tiles (8 halo rows = 2 rounds exactly, 6 accumulators, 3 workgroups per CU; wave 3 finishes no M-tile)
+constexpr int wg_th(int mt) { return 2 * mt; }
+constexpr int wg_rows(int mt) { return (wg_th(mt) + 2) * WG_NP; }     // (row, pair) slots of one (plane, k-half, position)
+// slots of one (plane, k-half) block, padded so that the block stride is 16 banks (mod 32): a ds_write_b64 lane group (16 lanes = 4 pairs x
+// 4 channel quads) touches both k-halves, and LDS stores are banked (a / 4) mod 32 (MI355X_MICROARCH.md, LDS) — measured before the
+// padding: SQ_LDS_BANK_CONFLICT = 18 % of the LDS cycles, all of it the staging stores
+constexpr int wg_kh(int mt) { return 4 * wg_rows(mt) + ((4 * wg_rows(mt)) % 8 == 0 ? 4 : 0); }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr size_t planes_image_pixels_wg(int h, int w) { return ((size_t)h * w + 1) & ~(size_t)1; }  // pixel slots of one pre-split image (conv_x6.hip)
 constexpr int WG_WFRAG = 2 * 2 * 2 * 32 * 8;      // 16-bit elements per (cout block, chunk, dy, position): [plane][n][k-half][32 co][8 ci] = 4 KB
 
-template <int CIN, int POOL, bool POUT>
+template <int CIN, int POOL, bool POUT, int MT, bool PROBE = false, int STG = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __restrict__ image, const unsigned short* __restrict__ wx,
                                                                const float* __restrict__ bias, float* __restrict__ out, int H, int W, int cout,
                                                                int tiles_x, const float* __restrict__ w1a, const float* __restrict__ b1a,
-                                                               const float* __restrict__ inv_ch, unsigned* sat, unsigned* sat_image) {
+                                                               const float* __restrict__ inv_ch, unsigned* sat, unsigned* sat_image, int stagger) {
   static_assert(CIN == 64, "the fused conv1a produces 64 channels");
   using S = SplitMma<2>;
   constexpr int NCHUNK = CIN / 16, NSTEP = NCHUNK * 3;
+  constexpr int WG_TH = wg_th(MT), WG_IH = WG_TH + 2, WG_ROWS = wg_rows(MT), WG_KH = wg_kh(MT), WG_IMH = WG_TH + 4;
   __shared__ u32x4 Ip[4 * WG_KH];
   __shared__ float Img[WG_IMH * WG_IMW];
   __shared__ float W1a[9 * 64 + 64];
+  // STG 1: conv1a's outputs of one chunk for the halo tile, fp32 [pixel (IH x 34)][16 channels + 4 pad] (80-byte pixel stride:
+  // 16-byte aligned float4 reads, neighbouring pixel pairs 40 banks apart)
+  constexpr int SPS = 20, NHP = WG_IH * (WG_TW + 2);
+  __shared__ float Sx[STG == 1 ? NHP * SPS : 1];
 
   const int t = threadIdx.x;
   const int lane = t & 63, lx = lane & 31, half = lane >> 5;
@@ -60,9 +71,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
   const int oy = ty * WG_TH, ox = tx * WG_TW;
   const float* in_b = image + (size_t)b * H * W;
 
-  f32x16 acc[4][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
       bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < (WG_IH + 3) / 4; ++i) {
       const int r = wv + 4 * i;
       if (r >= WG_IH) break;   // wave-uniform
       float v[3][6];
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
       for (int k = 0; k < 4; ++k) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < (PROBE ? 1 : 9); ++tap) {   // PROBE (timing only, wrong results): one tap instead of nine
           const float x = v[tap / 3][k + tap % 3];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = fmaf(x, wr[tap][e], o[e]);
@@ -170,6 +181,84 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
     }
   };
 
+  // ---- STG 1: two-phase staging.  Phase 1: conv1a ONCE per halo pixel (the fused form evaluates every column twice: the tuples of
+  // neighbouring pairs overlap) on packed fp32 FMAs (v_pk_fma_f32: two channels per instruction; every VALU instruction of this kernel
+  // costs ~4 cycles of a SIMD that cannot issue MFMAs meanwhile — measured: 8/9 of the conv1a FMAs removed = -16 % kernel time), into Sx.
+  // Phase 2: per (row, pair, channel quad) four float4 reads, input transform, split (v_fma_mix residuals), store. ----
+  constexpr int N1 = (NHP * 4 + 255) / 256;
+  int s1_img[STG == 1 ? N1 : 1];     // Img offset of the item's pixel, -1 = no such item
+  bool s1_ok[STG == 1 ? N1 : 1];     // pixel inside the image (conv1b's zero padding otherwise)
+  if (STG == 1) {
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int idx = t + 256 * i, p = idx >> 2;
+      const int py = p / (WG_TW + 2), px = p - py * (WG_TW + 2);
+      const int gy = oy + py - 1, gx = ox + px - 1;
+      s1_img[i] = idx < NHP * 4 ? py * WG_IMW + px : -1;
+      s1_ok[i] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    }
+  }
+  auto stage1 = [&](int c) {
+    f32x2 wr2[9][2], bv2[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 v = *(const float4*)&W1a[k * 64 + c * 16 + q * 4];
+      wr2[k][0] = f32x2{v.x, v.y}; wr2[k][1] = f32x2{v.z, v.w};
+    }
+    {
+      const float4 v = *(const float4*)&W1a[9 * 64 + c * 16 + q * 4];
+      bv2[0] = f32x2{v.x, v.y}; bv2[1] = f32x2{v.z, v.w};
+    }
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+      const int io = s1_img[i];
+      if (io < 0) continue;
+      f32x2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < (PROBE ? 1 : 9); ++tap) {
+        const float x = Img[io + (tap / 3) * WG_IMW + tap % 3];
+        const f32x2 x2 = {x, x};
+        o0 = __builtin_elementwise_fma(x2, wr2[tap][0], o0);
+        o1 = __builtin_elementwise_fma(x2, wr2[tap][1], o1);
+      }
+      o0 = o0 + bv2[0]; o1 = o1 + bv2[1];
+      float4 d = make_float4(fmaxf(o0[0], 0.f), fmaxf(o0[1], 0.f), fmaxf(o1[0], 0.f), fmaxf(o1[1], 0.f));
+      if (border && !s1_ok[i]) d = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int p = (t + 256 * i) >> 2;
+      *(float4*)&Sx[p * SPS + q * 4] = d;
+    }
+  };
+  auto stage2 = [&](int c) {
+    (void)c;
+#pragma unroll
+    for (int i = 0; i < (WG_IH + 3) / 4; ++i) {
+      const int r = wv + 4 * i;
+      if (r >= WG_IH) break;   // wave-uniform
+      float4 d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = *(const float4*)&Sx[(r * (WG_TW + 2) + 2 * j + k) * SPS + q * 4];
+      const float dd[4][4] = {{d[0].x, d[0].y, d[0].z, d[0].w}, {d[1].x, d[1].y, d[1].z, d[1].w}, {d[2].x, d[2].y, d[2].z, d[2].w}, {d[3].x, d[3].y, d[3].z, d[3].w}};
+      float tp[4][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tp[0][e] = dd[0][e] - dd[2][e];
+        tp[1][e] = dd[1][e] + dd[2][e];
+        tp[2][e] = dd[2][e] - dd[1][e];
+        tp[3][e] = dd[1][e] - dd[3][e];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        vmax_in = fmaxf(vmax_in, fmaxf(fmaxf(fabsf(tp[p][0]), fabsf(tp[p][1])), fmaxf(fabsf(tp[p][2]), fabsf(tp[p][3]))));
+        unsigned h01, l01, h23, l23;
+        split2_pk_raw(tp[p][0], tp[p][1], h01, l01);
+        split2_pk_raw(tp[p][2], tp[p][3], h23, l23);
+        unsigned* dst = (unsigned*)&Ip[(q >> 1) * WG_KH + p * WG_ROWS + r * WG_NP + j] + (q & 1) * 2;
+        *(u32x2*)dst = u32x2{h01, h23};
+        *(u32x2*)(dst + 2 * WG_KH * 4) = u32x2{l01, l23};
+      }
+    }
+  };
+
   auto mma_chunk = [&](int c, auto par_t) {
     constexpr int CP = decltype(par_t)::value;   // chunk parity: the buffer of step c * 3 + dy is (CP + dy) & 1
 #pragma unroll
@@ -178,23 +267,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
       const int step = c * 3 + dy;
       if ((CP + dy) & 1) { if (step + 1 < NSTEP) load_b(step + 1, std::integral_constant<int, 0>{}); }
       else { if (step + 1 < NSTEP) load_b(step + 1, std::integral_constant<int, 1>{}); }
-      u32x4 fa[4][2];
+      u32x4 fa[MT][2];
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) fa[m][pl] = Ip[(pl * 2 + half) * WG_KH + wv * WG_ROWS + (2 * m + dy + (lx >> 4)) * WG_NP + (lx & 15)];
+        for (int m = 0; m < MT; ++m) fa[m][pl] = Ip[(pl * 2 + half) * WG_KH + wv * WG_ROWS + (2 * m + dy + (lx >> 4)) * WG_NP + (lx & 15)];
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tm = 0; tm < S::NT; ++tm)  // smallest cross terms first
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < 2; ++n) acc[m][n] = S::mma(fa[m][S::ta(tm)], bw[(CP + dy) & 1][S::tb(tm)][n], acc[m][n]);
       __builtin_amdgcn_s_setprio(0);
     }
   };
 
+  // experiment (dim_tune_set(15, .. | 256)): the workgroups that the dispatcher places second on each CU at kernel start wait half a
+  // chunk period once, so that the co-resident workgroups alternate staging (VALU) and MFMA phases instead of running them in lockstep
+  if (stagger && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512 && blockIdx.y == 0 && blockIdx.z == 0) {
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   __syncthreads();   // Img / W1a complete
+  if (STG == 1) {
+    // phase 1 of chunk c + 1 shares a barrier interval with the MFMAs of chunk c (Sx is free once phase 2 has read it): 2 barriers per chunk
+    stage1(0);
+    __syncthreads();
+    for (int c = 0; c < NCHUNK; c += 2) {
+      stage2(c);
+      __syncthreads();
+      mma_chunk(c, std::integral_constant<int, 0>{});
+      stage1(c + 1);
+      __syncthreads();
+      stage2(c + 1);
+      __syncthreads();
+      mma_chunk(c + 1, std::integral_constant<int, 1>{});
+      if (c + 2 < NCHUNK) stage1(c + 2);
+      __syncthreads();
+    }
+  } else
   for (int c = 0; c < NCHUNK; c += 2) {
     stage(c);
     __syncthreads();
@@ -216,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
   {
     const float a0 = coef0(wv), a1 = coef1(wv);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
       if (m == wv) {
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -228,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
   for (int k = 1; k < 4; ++k) {
     const int dst = (wv + k) & 3, src = (wv + 4 - k) & 3;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
       if (m == dst) {
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -240,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
       }
     __syncthreads();
     const float a0 = coef0(src), a1 = coef1(src);
+    if (wv < MT)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -322,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
     }
     sat_report(sat, vmax * (1.0f / OSC));
   };
+  if (wv >= MT) return;   // (6-row tiles: the fourth wave owns a position but no output rows)
   if (POOL ? ((ox >> 1) + WG_TW / 2 <= Wo) : (ox + WG_TW <= W)) run_epilogue(std::false_type{});
   else run_epilogue(std::true_type{});
 }
@@ -375,16 +488,26 @@ void prepare_conv_weights_wino(const float* w_oihw, int cin, int cout, unsigned 
 int launch_conv3x3_wg_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
                               float* out, int batch, int H, int W, int cout, int pool, int planes_out, hipStream_t s, unsigned* sat,
                               unsigned* sat_image) {
+  const int var = dim_conv_winograd();
+  const int mt = ((var >> 4) & 3) == 1 ? 3 : 4, stagger = (var >> 8) & 255;
   DIM_REQUIRE(cout % 64 == 0, "conv3x3_wg fused conv1a: cout=%d must be a multiple of 64", cout);
   DIM_REQUIRE(wt.dev && wt.mode == 2, "conv3x3_wg: Winograd weights not prepared");
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
-  const int tiles_x = cdiv(W, WG_TW), tiles_y = cdiv(H, WG_TH);
+  const int tiles_x = cdiv(W, WG_TW), tiles_y = cdiv(H, wg_th(mt));
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-#define DIM_WG(P, PO) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, P, PO>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image)
-  if (pool && planes_out) DIM_WG(1, true);
-  else if (pool) DIM_WG(1, false);
-  else if (planes_out) DIM_WG(0, true);
-  else DIM_WG(0, false);
+#define DIM_WG(P, PO, MTV) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, P, PO, MTV>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger)
+#define DIM_WG_MT(P, PO) { if (mt == 3) DIM_WG(P, PO, 3); else DIM_WG(P, PO, 4); }
+  if (pool && planes_out && (var & 2)) {   // two-phase staging (Sx scratch, packed fp32 conv1a, fma_mix splits)
+    if (var & 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, true, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger);   // timing probe
+    else if (mt == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 3, false, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger);
+  } else
+  if (pool && planes_out && (var & 4)) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger);   // timing probe
+  else if (pool && planes_out) DIM_WG_MT(1, true)
+  else if (pool) DIM_WG_MT(1, false)
+  else if (planes_out) DIM_WG_MT(0, true)
+  else DIM_WG_MT(0, false)
+#undef DIM_WG_MT
 #undef DIM_WG
   DIM_LAUNCH_CHECK();
   return 0;

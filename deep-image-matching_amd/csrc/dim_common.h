@@ -66,18 +66,32 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {  // round-to-
   f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
+// The residual x - (float)h is taken by v_fma_mix_f32, which reads an fp16 half directly (fma(h, -1, x): exact, the same value as the
+// convert-and-subtract form the host-compiled test emulator uses): 4 instead of 6 VALU per pair of values.  Every VALU instruction
+// of the matrix-core kernels costs ~4 cycles of a SIMD that issues no MFMA meanwhile (round-4 counters: MFMA-busy + VALU-active ~ 1).
+__device__ __forceinline__ void split2_residual(float x0, float x1, unsigned h, float& r0, float& r1) {
+#if defined(__AMDGCN__)
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
+#else
+  const f16x2 hv = __builtin_bit_cast(f16x2, h);
+  r0 = x0 - (float)hv[0]; r1 = x1 - (float)hv[1];
+#endif
+}
 __device__ __forceinline__ void split2_pk(float x0, float x1, float scale, unsigned& h, unsigned& l) {
   x0 = __builtin_amdgcn_fmed3f(x0 * scale, -65504.0f, 65504.0f);
   x1 = __builtin_amdgcn_fmed3f(x1 * scale, -65504.0f, 65504.0f);
   h = cvt_pk_f16(x0, x1);
-  const f16x2 hv = __builtin_bit_cast(f16x2, h);
-  l = cvt_pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+  float r0, r1;
+  split2_residual(x0, x1, h, r0, r1);
+  l = cvt_pk_f16(r0, r1);
 }
 // the same split for a value that is already scaled and known to lie inside +-65504 (no multiply, no clamp)
 __device__ __forceinline__ void split2_pk_raw(float x0, float x1, unsigned& h, unsigned& l) {
   h = cvt_pk_f16(x0, x1);
-  const f16x2 hv = __builtin_bit_cast(f16x2, h);
-  l = cvt_pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+  float r0, r1;
+  split2_residual(x0, x1, h, r0, r1);
+  l = cvt_pk_f16(r0, r1);
 }
 // Split policy shared by conv_x6 / gemm_x6 / lg_attn_x6: MODE 1 = three bf16 planes, six cross terms;
 // MODE 2 = two fp16 planes, three cross terms.  Cross terms are issued smallest first.

@@ -266,6 +266,7 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma_32x32x16_f16((a), (b), (c))
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(fmaxf(a, b), c), fminf(a, b)); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4((a), (b), (c))
