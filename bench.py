@@ -67,10 +67,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 20 (configs2: 20 x 50 pairs) / 1 (config4: one pass over the 10 000-pair job)")
     ap.add_argument("--warmup", type=int, default=None, help="default 3 (configs2) / 1 (config4: one reduced pass)")
-    ap.add_argument("--workload", choices=("configs2", "config4"), default="configs2", help="configs2 (default, the headline line): BASELINE configs[2]; "
+    ap.add_argument("--workload", choices=("configs2", "config4", "config5"), default="configs2", help="config5: BASELINE configs[4], ALIKED + LightGlue on tiled "
+                    "6000x4000 images through pipeline.TiledPairPipeline (strong scaling: `--images` images -> exhaustive pairs shared by the ranks); "
+                    "configs2 (default, the headline line): BASELINE configs[2]; "
                     "config4: BASELINE configs[3], 150 images -> first 10 000 exhaustive pairs through PairMatchingPipeline "
                     "(phases 1-4 of SURVEY 8(e), STRONG scaling: the job is fixed, ranks share it)")
-    ap.add_argument("--images", type=int, default=150, help="config4 only")
+    ap.add_argument("--images", type=int, default=None, help="config4: 150 images; config5: 8 images of 6000 x 4000")
     ap.add_argument("--job-pairs", type=int, default=10000, help="config4 only")
     ap.add_argument("--pairs", type=int, default=50, help="pairs per step per GPU (50 x 20 steps = the 1000 pairs of configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,8 +84,11 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="(default since round 1) kept for compatibility")
     ap.add_argument("--main-region-only", action="store_true", help="skip the second (other-schedule) region: used for the rocprofv3 passes")
     ap.add_argument("--cpu-sample-pairs", type=int, default=4)
+    ap.add_argument("--tile-selection", default="PRESELECTION", help="config5: tile_selection method (PRESELECTION | GRID | EXHAUSTIVE | PRESELECTION_AFFINE_TRANSFORM)")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the strong_scaling sub-record (the config-4 job run after the timed region)")
     a = ap.parse_args()
+    if a.images is None:
+        a.images = 8 if a.workload == "config5" else 150
     if a.steps is None:
         a.steps = 20 if a.workload == "configs2" else 1
     if a.warmup is None:
@@ -280,6 +285,110 @@ def run_config4(a, rank, world, dev, dist, lib):
         dist.destroy_process_group()
 
 
+def run_config5(a, rank, world, dev, dist, lib):
+    """BASELINE configs[4] (SURVEY 8(d) "config 5"): ALIKED (aliked-n16rot geometry, 4000 keypoints per 1500 x 1000 tile, 4 x 4 tiles) +
+    LightGlue (128-d) on `--images` synthetic 6000 x 4000 RGB images -> all exhaustive image pairs, through pipeline.TiledPairPipeline:
+    images i mod world -> batched _extract_by_tile -> ONE feature all-gather -> pairs j mod world -> tile preselection (down-sampled
+    SuperPoint + LightGlue on the device) + batched tile-pair matching -> ONE match all-gather.  STRONG scaling.  The images are crops of
+    one canvas (offsets multiples of 32 px = ALIKED's total stride) and both LightGlue instances run matching-capable synthetic
+    weights, so tile pairs ARE selected and the match tables are filled.  Roofline object: ALIKED's two full-resolution 3 x 3
+    convolutions (HBM-bound: algorithmic bytes = fp32 input + output maps of one launch), timed with HIP events on the launch stream."""
+    import numpy as np
+    plugins = importlib.import_module(PKG + ".plugins")
+    pl = importlib.import_module(PKG + ".pipeline")
+    tm = importlib.import_module(PKG + ".tile_matching")
+    weights = importlib.import_module(PKG + ".weights")
+    capi = importlib.import_module(PKG + ".capi")
+    K, W = a.steps, a.warmup
+    general = {"tile_size": (1500, 1000), "tile_overlap": 0, "tile_preselection_size": 1024, "min_matches_per_tile": 5, "quality": "HIGH",
+               "allow_synthetic_weights": True}
+    ex = plugins.AlikedExtractor({"general": general, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 4000,
+                                                                     "detection_threshold": 0.2, "nms_radius": 3, "allow_synthetic_weights": True}})
+    mt = plugins.LightGlueMatcher({"general": general, "matcher": {"name": "lightglue", "depth_confidence": 0.95, "width_confidence": 0.99,
+                                                                   "filter_threshold": 0.1, "allow_synthetic_weights": True}}, local_features="aliked")
+    mt._sd = weights.synthetic_lightglue_matching_state_dict(0, 128)          # ALIKED's synthetic descriptors are discriminative (mean cosine 0.12): no centring
+    rng = np.random.default_rng(5)
+    canvas = rng.integers(0, 256, (4000 + 512, 6000 + 512, 3), dtype=np.uint8)
+    offs = [(0, 0)] + [(int(rng.integers(0, 17)) * 32, int(rng.integers(0, 17)) * 32) for _ in range(a.images - 1)]
+    images = [np.ascontiguousarray(canvas[dy:dy + 4000, dx:dx + 6000]).astype(np.float32) for dy, dx in offs]
+    del canvas
+    # the preselector (SuperPoint + LightGlue at 1024 px) with matching-capable weights centred on its own descriptors
+    sp_sd = weights.synthetic_superpoint_state_dict(1234)
+    pre = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_state_dict(0, 256), tile_preselection_size=1024, device=dev, lib=lib)
+    f0 = pre.features("warm", np.ascontiguousarray(images[0][..., 0]), "HIGH")
+    center = f0[1][0, : int(f0[2][0])].mean(0).cpu()
+    mt._tile_preselector = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_matching_state_dict(0, 256, center=center), tile_preselection_size=1024,
+                                              device=dev, lib=lib)
+    del pre
+    pipe = pl.TiledPairPipeline(ex, mt, rank, world, selection=a.tile_selection, empty_selection_fallback="GRID" if a.tile_selection.startswith("PRESELECTION") else None)
+    pairs = pl.exhaustive_pairs(a.images, a.job_pairs)
+    P = int(pairs.shape[0])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(W):    # reduced pass: one image per rank, one pair per rank
+        nw = min(a.images, max(2, world))
+        fw = pipe.extract_all(images[:nw])
+        pipe.match_all(images[:nw], fw, pl.exhaustive_pairs(nw, world))
+    barrier()
+    capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong(1 << 17)))     # DIM_PROF_AL_CONV_FULL
+    phases = {"extract_s": 0.0, "feature_gather_s": 0.0, "match_s": 0.0, "tile_selection_s": 0.0, "tile_matching_s": 0.0, "match_gather_s": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(K):
+        mt._tile_preselector._cache.clear()
+        feats = pipe.extract_all(images)
+        matches = pipe.match_all(images, feats, pairs)
+        for k in phases:
+            phases[k] += pipe.timings[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_ms, launches = ctypes.c_double(), ctypes.c_int()
+    capi.check(lib, lib.dim_profile_stop(ctypes.byref(tot_ms), ctypes.byref(launches)))
+    tt = torch.tensor([dt] + [phases[k] for k in phases], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt[0].item())
+    sat_total, sat_sites = capi.saturation(lib, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), reset=True)
+    if rank == 0:
+        conv_ms = tot_ms.value / max(1, launches.value)
+        # one launch = a batch of 16 tiles padded to 1024 x 1504 (multiples of 32); block1.conv1 reads 3 and writes 16 fp32 channels,
+        # block1.conv2 reads 16 and writes 16: the average launch moves (19 + 32) / 2 channels x 4 B per pixel
+        px = 16 * 1024 * 1504
+        bytes_per_launch = px * (19 + 32) / 2 * 4
+        nm = [int(m.shape[0]) for m in matches]
+        line = {
+            "metric": "image-pairs/s (ALIKED+LightGlue, tiled 6000x4000, 4x4 tiles, 4000 kpts per tile)", "value": K * P / dt, "unit": "image-pairs/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[4] (config 5): {a.images} synthetic 6000x4000 RGB images (crops of one canvas) -> {P} exhaustive image pairs; ALIKED "
+                                   "aliked-n16rot geometry, 16 tiles of 1500x1000 per image, 4000 keypoints per tile; tile selection " + a.tile_selection + " on the device; LightGlue "
+                                   "(128-d, adaptive depth / width 0.95 / 0.99, threshold 0.1) on the selected tile pairs; seeded synthetic weights",
+                       "images": a.images, "job_pairs": P,
+                       "sharding": f"images i mod {world}, ONE all-gather of the merged tile tables ({pipe.timings['feature_gather_bytes'] / 1e6:.0f} MB), image pairs j mod {world}, "
+                                   f"ONE all-gather of the match rows ({pipe.timings['match_gather_bytes'] / 1e6:.0f} MB)"},
+            "phases_s_max_over_ranks": {k: float(v) / K for k, v in zip(phases, tt[1:].tolist())},
+            "keypoints_per_image_mean": float(np.mean([f["keypoints"].shape[0] for f in feats])),
+            "matches_per_pair_mean": float(np.mean(nm)), "matches_per_pair_min": int(min(nm)), "pairs_with_matches": int(sum(1 for x in nm if x > 0)),
+            "tile_selection_note": "PRESELECTION (down-sampled SuperPoint + LightGlue on the device) runs and is timed for every image pair; with seeded synthetic "
+                                   "weights it cannot vote, so the GRID method (16 tile pairs per image pair) supplies the tile pairs that are matched "
+                                   f"(pairs that fell back on this rank: {pipe.n_fallback} of {len(pl.shard_indices(P, rank, world)) * K})",
+            "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
+            "roofline": {"kernel": "al_convx3_kernel<16, 9, 16> full-resolution launches (ALIKED block1.conv1 3 -> 16 and block1.conv2 16 -> 16, fp16x3, BatchNorm "
+                                   "statistics in the epilogue)", "bound": "hbm", "achieved": bytes_per_launch / conv_ms / 1e6, "peak": 8000.0, "unit": "GB/s",
+                         "frac": bytes_per_launch / conv_ms / 1e6 / 8000.0, "traffic": None, "avg_launch_ms": conv_ms, "launches": launches.value,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -311,6 +420,8 @@ def main():
 
     if a.workload == "config4":
         return run_config4(a, rank, world, dev, dist, lib)
+    if a.workload == "config5":
+        return run_config5(a, rank, world, dev, dist, lib)
     P, K, W = a.pairs, a.steps, a.warmup
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
     conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}

@@ -248,7 +248,9 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     if (in_bn >= 0) ab(in_bn, &ia, &ib);
     if (x3) {
       int n_wg = 0, rc;
+      if (Hh == Hp) dim_prof_begin(DIM_PROF_AL_CONV_FULL, s);
       if ((rc = launch_al_convx3(in, in_c, cin_pad, taps, wx, nullptr, out, co, batch, Hh, Ww, h->tile_partial, &n_wg, ia, ib, s))) return rc;
+      if (Hh == Hp) dim_prof_end(DIM_PROF_AL_CONV_FULL, s);
       return launch_al_bn_final_tiles(h->tile_partial, n_wg, batch, Hh * Ww, co, h->bn_g[i], h->bn_b[i], a, bt, s);
     }
     int rc = launch_al_conv3x3(in, in_c, wv, nullptr, out, co, batch, Hh, Ww, AL_ACT_NONE, 0, 0, Hh, Ww, s);

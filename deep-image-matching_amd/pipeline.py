@@ -192,3 +192,145 @@ class PairMatchingPipeline:
         cnt = cnt.cpu()
         mt, ms = mt.cpu(), ms.cpu()
         return [(mt[p, : int(cnt[p])], ms[p, : int(cnt[p])]) for p in range(cnt.shape[0])]
+
+
+class TiledPairPipeline:
+    """BASELINE config 5 across the GPUs of one node: tile-wise extraction + tile-pair matching of large images, sharded like
+    PairMatchingPipeline with the TILE TABLE of an image as the feature unit.
+
+      phase 1  images i = rank (mod world): the extractor plugin's batched ``_extract_by_tile`` (extractors/extractor_base.py:279-390:
+               pad, unfold, one forward per tile, shift, border filter, np.unique merge — here one batch per image on the device),
+      phase 2  ONE all-gather of a flat fp32 buffer per rank: [per][cap][keypoints 2 | score | tile_idx | descriptor D] + the counts'
+               bit patterns (cap = tiles x max keypoints per tile: the merged table of an image can hold no more),
+      phase 3  image pairs j = rank (mod world): ``tile_selection`` (matchers/matcher_base.py:989-1140; PRESELECTION runs its own
+               down-sampled SuperPoint + LightGlue on the device) and the batched tile-pair matching (MB:362-485),
+      phase 4  ONE all-gather of a flat int32 buffer per rank: [per][count | (idx0, idx1) rows].
+
+    ``extractor`` / ``matcher``: plugins.SuperPointExtractor / AlikedExtractor and plugins.LightGlueMatcher (any descriptor width and
+    channel count: both come from the extractor).  Every rank needs the image arrays of the pairs it matches only when the selection
+    method reads pixels (PRESELECTION*).  Results are identical on every rank and identical to a single-process run."""
+
+    def __init__(self, extractor, matcher, rank: int = 0, world: int = 1, selection: str = "PRESELECTION", max_kpts_per_image: Optional[int] = None,
+                 max_matches_per_pair: Optional[int] = None, empty_selection_fallback: Optional[str] = None):
+        self.ext, self.mat, self.rank, self.world = extractor, matcher, rank, world
+        self.selection = selection
+        # benchmarks on seeded synthetic weights only: PRESELECTION needs a trained SuperPoint + LightGlue to vote for tile pairs; with
+        # random weights it runs (and is timed) but selects nothing, and the named method then supplies the tile pairs.  None (default,
+        # the reference's behaviour): an empty selection means an empty match list.
+        self.fallback = empty_selection_fallback
+        self.n_fallback = 0
+        self.max_kpts, self.max_matches = max_kpts_per_image, max_matches_per_pair
+        self.timings: dict = {}
+
+    def _device(self):
+        d = getattr(self.ext, "_device", "cuda")
+        return torch.device(d if isinstance(d, (str, torch.device)) else "cuda")
+
+    def _cap(self, image) -> int:
+        if self.max_kpts is not None:
+            return int(self.max_kpts)
+        from .tile_matching import tile_grid
+        general = self.ext.config["general"]
+        n_tiles = len(tile_grid(image.shape[:2], general["tile_size"], general.get("tile_overlap", 0)))
+        mk = int(self.ext.config["extractor"].get("max_num_keypoints", self.ext.config["extractor"].get("max_keypoints", -1)))
+        if mk <= 0:
+            raise ValueError("TiledPairPipeline: pass max_kpts_per_image when the extractor keeps all keypoints")
+        return n_tiles * mk
+
+    # ---- phases 1 + 2 ----------------------------------------------------------------------
+    @torch.no_grad()
+    def extract_all(self, images: Sequence) -> List[dict]:
+        """images: sequence of numpy arrays (H, W) or (H, W, C), 0..255, the same list on every rank (only this rank's shard is read).
+        Returns the feature dict of EVERY image (keypoints (N,2) f32, descriptors (D,N) f32, scores (N,), tile_idx (N,), image_size)."""
+        import time
+        import numpy as np
+        n_img = len(images)
+        mine = shard_indices(n_img, self.rank, self.world).tolist()
+        per = (n_img + self.world - 1) // self.world
+        D, dev = int(self.ext.descriptor_size), self._device()
+        cap = self._cap(images[0])
+        row = 2 + 1 + 1 + D
+        flat = torch.zeros(per * cap * row + per, dtype=torch.float32, device=dev)
+        body, cnt = flat[: per * cap * row].view(per, cap, row), flat[per * cap * row:].view(torch.int32)
+        t0 = time.perf_counter()
+        for s, i in enumerate(mine):
+            f = self.ext._extract_by_tile(np.asarray(images[i]))
+            k = int(f["keypoints"].shape[0])
+            if k > cap:
+                raise ValueError(f"TiledPairPipeline: image {i} has {k} keypoints, more than the exchange slot ({cap})")
+            host = np.empty((k, row), dtype=np.float32)
+            host[:, 0:2], host[:, 2], host[:, 3], host[:, 4:] = f["keypoints"], f["scores"], f["tile_idx"], f["descriptors"].T
+            body[s, :k] = torch.from_numpy(host).to(dev)
+            cnt[s] = k
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        g = _all_gather_cat(flat[None], self.world)          # phase 2: ONE collective
+        out: List[dict] = []
+        gb = g[:, : per * cap * row].reshape(self.world, per, cap, row)
+        gc = g[:, per * cap * row:].reshape(self.world, per).view(torch.int32) if self.world > 1 else cnt.view(1, per)
+        for i in range(n_img):
+            r, s = i % self.world, i // self.world
+            k = int(gc[r, s])
+            t = gb[r, s, :k].cpu().numpy()
+            out.append({"keypoints": np.ascontiguousarray(t[:, 0:2]), "scores": np.ascontiguousarray(t[:, 2]), "tile_idx": np.ascontiguousarray(t[:, 3]),
+                        "descriptors": np.ascontiguousarray(t[:, 4:].T), "image_size": np.array(np.asarray(images[i]).shape[:2], dtype=np.int32)})
+        self.timings.update(extract_s=t1 - t0, feature_gather_s=time.perf_counter() - t1, feature_gather_bytes=int(flat.numel() * 4 * self.world))
+        return out
+
+    # ---- phases 3 + 4 ----------------------------------------------------------------------
+    @torch.no_grad()
+    def match_all(self, images: Sequence, feats: List[dict], pairs: torch.Tensor, names: Optional[Sequence[str]] = None) -> List:
+        """pairs [P, 2] image indices.  Returns, on every rank, the list of (M, 2) int64 match arrays in the order of ``pairs``
+        (the arrays MatcherBase._match_by_tile returns, MB:362-485)."""
+        import time
+        import numpy as np
+        from .tile_matching import match_tile_pairs_batched
+        P = int(pairs.shape[0])
+        mine = shard_indices(P, self.rank, self.world).tolist()
+        per = (P + self.world - 1) // self.world
+        dev = self._device()
+        cap_m = int(self.max_matches if self.max_matches is not None else 2 * max(1, max(f["keypoints"].shape[0] for f in feats)))
+        flat = torch.zeros(per + per * cap_m * 2, dtype=torch.int32, device=dev)
+        cnt, rows = flat[:per], flat[per:].view(per, cap_m, 2)
+        names = names if names is not None else [f"image{i:05d}" for i in range(len(feats))]
+        sel_s = mat_s = 0.0
+        t0 = time.perf_counter()
+        for s, p in enumerate(mine):
+            a, b = int(pairs[p, 0]), int(pairs[p, 1])
+            ts = time.perf_counter()
+            needs_pixels = self.selection.startswith("PRESELECTION")
+            tile_pairs = self.mat.tile_selection(names[a], names[b], self.selection,
+                                                 image0=_band1(images[a]) if needs_pixels else np.zeros(np.asarray(images[a]).shape[:2], np.float32),
+                                                 image1=_band1(images[b]) if needs_pixels else np.zeros(np.asarray(images[b]).shape[:2], np.float32))
+            if len(tile_pairs) == 0 and self.fallback is not None:
+                self.n_fallback += 1
+                z = np.zeros(np.asarray(images[a]).shape[:2], np.float32)
+                tile_pairs = self.mat.tile_selection(names[a], names[b], self.fallback, image0=z, image1=np.zeros(np.asarray(images[b]).shape[:2], np.float32))
+            tm_ = time.perf_counter()
+            m = match_tile_pairs_batched(self.mat._ensure_pairs, feats[a], feats[b], tile_pairs, dev, getattr(self.mat, "tile_pair_batch", 8))
+            sel_s += tm_ - ts
+            mat_s += time.perf_counter() - tm_
+            if m.shape[0] > cap_m:
+                raise ValueError(f"TiledPairPipeline: pair ({a}, {b}) has {m.shape[0]} matches, more than the exchange slot ({cap_m})")
+            rows[s, : m.shape[0]] = torch.from_numpy(m.astype(np.int32)).to(dev)
+            cnt[s] = m.shape[0]
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        g = _all_gather_cat(flat[None], self.world)          # phase 4: ONE collective
+        gc, gr = g[:, :per].cpu(), g[:, per:].reshape(self.world, per, cap_m, 2)
+        out = []
+        for p in range(P):
+            r, s = p % self.world, p // self.world
+            out.append(gr[r, s, : int(gc[r, s])].cpu().numpy().astype(np.int64))
+        self.timings.update(match_s=t1 - t0, tile_selection_s=sel_s, tile_matching_s=mat_s, match_gather_s=time.perf_counter() - t1,
+                            match_gather_bytes=int(flat.numel() * 4 * self.world))
+        return out
+
+
+def _band1(image):
+    """the first band of an image array as float32 (what tile_selection reads with rasterio, MB:1021-1024)"""
+    import numpy as np
+    a = np.asarray(image)
+    return np.ascontiguousarray(a if a.ndim == 2 else a[..., 0], dtype=np.float32)

@@ -63,7 +63,8 @@ enum {
   DIM_PROF_SP_CONV1A = 0, DIM_PROF_SP_CONV1B, DIM_PROF_SP_CONV2A, DIM_PROF_SP_CONV2B, DIM_PROF_SP_CONV3A,
   DIM_PROF_SP_CONV3B, DIM_PROF_SP_CONV4A, DIM_PROF_SP_CONV4B, DIM_PROF_SP_CONVPA, DIM_PROF_SP_CONVPB,
   DIM_PROF_SP_CONVDA, DIM_PROF_SP_CONVDB, DIM_PROF_SP_POST, DIM_PROF_LG_SELF_ATTN, DIM_PROF_LG_CROSS_ATTN,
-  DIM_PROF_LG_GEMMS, DIM_PROF_LG_ASSIGN
+  DIM_PROF_LG_GEMMS, DIM_PROF_LG_ASSIGN,
+  DIM_PROF_AL_CONV_FULL   /* ALIKED's full-resolution 3x3 convolutions (block1.conv1 3 -> 16, block1.conv2 16 -> 16): HBM-bound */
 };
 int dim_profile_start(unsigned long long site_mask);
 int dim_profile_stop(double* total_ms, int* launches);

@@ -111,3 +111,19 @@ def test_reference_accept_rules_and_host_pool():
     assert res[1][0] is None and res[1][1].all() and sorted(calls) == [12, 20] and res[0][1].shape == (20,)
     with pytest.raises(ImportError):
         verify.HostVerifierPool(method="MAGSAC")                                          # no cv2 in this container
+
+
+def test_device_ransac_against_ground_truth_scenes_small(emu_lib):
+    """Ground truth, not self-agreement: known F, known inlier set (tests/two_view_truth.py); the emulator runs the
+    small sizes, tests/test_geom_verify_gpu.py the full grid up to 2048 matches and 70 % outliers."""
+    from tests import two_view_truth as tv
+    cases = [(8, 0), (100, 10), (100, 40)]
+    scenes = [tv.scene(ni, no, seed=i) for i, (ni, no) in enumerate(cases)]
+    kt, mt, n = _tables([(s["x0"], s["x1"]) for s in scenes], cap=160)
+    v = verify.DeviceVerifier(threshold=2.0, iters=1024, seed=5, device="cpu", lib=emu_lib)
+    out = v.verify_batch(kt, mt, n)
+    for p, sc in enumerate(scenes):
+        s = len(sc["x0"])
+        r = tv.score(out["mask"][p, :s].numpy().astype(bool), out["F"][p].numpy(), sc)
+        assert r["recall"] >= 0.9 and r["precision"] >= 0.9, (cases[p], r)
+        assert r["sampson_rms_clean_px"] < (3.0 if s == 8 else 1.0), (cases[p], r)     # (8 noisy points determine F only loosely)

@@ -127,3 +127,49 @@ def test_device_ransac_vs_the_reference_estimator_iou(hip_lib):
     with open(out_dir / "parity_measured.jsonl", "a") as f:
         f.write(json.dumps({"case": "device RANSAC vs cv2 USAC_MAGSAC inlier IoU", "iou": ious}) + "\n")
     assert min(ious) >= 0.9, ious
+
+
+def test_device_ransac_against_ground_truth_scenes(hip_lib):
+    """f3 against GROUND TRUTH (VERDICT r3 weak #4 / next #8b): synthetic two-view scenes with a known F and a known inlier set
+    (tests/two_view_truth.py — independent of geom_verify.hip and of oracle/geom_ref.py), 8 / 100 / 2048 matches x 0 - 70 % outliers:
+    recall and precision of the device inlier mask, and the Sampson RMS of the CLEAN true correspondences under the returned F.
+    cv2's USAC_MAGSAC (utils/geometric_verification.py:136-152) is not importable here, so parity with it stays unpinned; this is the
+    contract it is called for.  Measured numbers go to gpurun_out/parity_measured.jsonl."""
+    import json
+    from pathlib import Path
+    from tests import two_view_truth as tv
+    verify = importlib.import_module("deep-image-matching_amd.verify")
+    grid = [(8, 0.0), (8, 0.12), (100, 0.1), (100, 0.4), (100, 0.7), (2048, 0.1), (2048, 0.4), (2048, 0.7)]
+    scenes = []
+    for i, (n, rho) in enumerate(grid):
+        no = int(round(n * rho))
+        scenes.append(tv.scene(n - no, no, seed=50 + i))
+    P, S = len(scenes), 2048
+    kt = torch.zeros(2 * P, S, 2); mt = torch.zeros(P, S, 2, dtype=torch.int64); cnt = torch.zeros(P, dtype=torch.int32)
+    for p, sc in enumerate(scenes):
+        s = len(sc["x0"])
+        kt[2 * p, :s], kt[2 * p + 1, :s] = torch.from_numpy(sc["x0"]), torch.from_numpy(sc["x1"])
+        mt[p, :s, 0] = mt[p, :s, 1] = torch.arange(s)
+        cnt[p] = s
+    rows = []
+    for iters in (4096, 32768):      # the reference's USAC budget is adaptive; 0.3^7 = 2.2e-4: 70 % outliers need the larger budget
+        v = verify.DeviceVerifier(threshold=2.0, iters=iters, seed=9)
+        out = v.verify_batch(kt.cuda(), mt.cuda(), cnt.cuda())
+        mask, Fs = out["mask"].cpu().numpy().astype(bool), out["F"].cpu().numpy()
+        for p, sc in enumerate(scenes):
+            s = len(sc["x0"])
+            r = tv.score(mask[p, :s], Fs[p], sc)
+            rows.append({"test": "f3_ground_truth", "matches": grid[p][0], "outlier_ratio": grid[p][1], "iters": iters, **r})
+            n, rho = grid[p]
+            if n == 8 and rho > 0:       # 7 inliers + 1 outlier: only one all-inlier sample exists; report, assert the mask is sane
+                assert mask[p, :s].sum() >= 7
+                continue
+            if rho >= 0.7 and iters < 32768:
+                continue                 # reported, not asserted: too few hypotheses for a clean 7-sample
+            assert r["recall"] >= 0.9 and r["precision"] >= (0.85 if rho >= 0.7 else 0.9), (grid[p], iters, r)
+            assert r["sampson_rms_clean_px"] < (3.0 if n == 8 else 1.0), (grid[p], iters, r)
+    d = Path(__file__).resolve().parents[1] / "gpurun_out"
+    d.mkdir(exist_ok=True)
+    with open(d / "parity_measured.jsonl", "a") as f:
+        for r in rows:
+            f.write(json.dumps(r) + "\n")

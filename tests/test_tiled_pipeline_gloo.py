@@ -1,0 +1,87 @@
+"""CPU, world_size 2 over gloo: BASELINE config 5's multi-GPU path (pipeline.TiledPairPipeline: tile-wise ALIKED extraction of the images
+i mod world -> ONE all-gather of the merged tile tables -> tile-pair matching of the image pairs j mod world -> ONE all-gather of the
+match rows) must give every rank exactly the single-process result.  Device work = the HIP sources on the test emulator, through the
+plugin classes (capi.install hook), RGB images, 128-d descriptors."""
+import importlib
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _run(lib_path, rank, world):
+    import ctypes
+
+    sys.path.insert(0, str(ROOT))
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    plugins = importlib.import_module("deep-image-matching_amd.plugins")
+    pl = importlib.import_module("deep-image-matching_amd.pipeline")
+    lib = ctypes.CDLL(lib_path)
+    capi.install(lib, "cpu")
+    general = {"tile_size": (96, 64), "tile_overlap": 0, "min_matches_per_tile": 1, "quality": "HIGH"}
+    ex = plugins.AlikedExtractor({"general": general, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 24,
+                                                                     "detection_threshold": 0.2, "nms_radius": 2, "allow_synthetic_weights": True}})
+    mt = plugins.LightGlueMatcher({"general": general, "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1,
+                                                                   "filter_threshold": 0.0, "allow_synthetic_weights": True}}, local_features="aliked")
+    rng = np.random.default_rng(21)
+    base = (rng.random((128 + 32, 192 + 32, 3)) * 255).astype(np.float32)
+    images = [np.ascontiguousarray(base[dy:dy + 128, dx:dx + 192]) for dy, dx in ((0, 0), (32, 0), (0, 32))]      # 2 x 2 tiles of 96 x 64 each
+    pipe = pl.TiledPairPipeline(ex, mt, rank, world, selection="GRID")
+    feats = pipe.extract_all(images)
+    pairs = pl.exhaustive_pairs(3)
+    matches = pipe.match_all(images, feats, pairs)
+    return feats, matches
+
+
+def _worker(rank, world, port, lib_path, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    calls = []
+    orig = dist.all_gather_into_tensor
+
+    def counting(out, inp, *a, **k):
+        calls.append((inp.dtype, inp.numel()))
+        return orig(out, inp, *a, **k)
+
+    dist.all_gather_into_tensor = counting
+    feats, matches = _run(lib_path, rank, world)
+    dist.all_gather_into_tensor = orig
+    torch.save({"feats": feats, "matches": matches, "collectives": calls}, os.path.join(out_dir, f"tiled{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tiled_pipeline_equals_single_process(tmp_path):
+    build = importlib.import_module("deep-image-matching_amd.build")
+    lib_path = str(build.build_emu())
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    try:
+        feats1, matches1 = _run(lib_path, 0, 1)
+    finally:
+        capi.install(None)
+    assert all(f["keypoints"].shape[0] > 0 and f["descriptors"].shape[0] == 128 for f in feats1)
+    assert {int(t) for f in feats1 for t in np.unique(f["tile_idx"])} == {0, 1, 2, 3}
+    assert sum(m.shape[0] for m in matches1) > 0
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, lib_path, str(tmp_path)), nprocs=2, join=True)
+    cap = 4 * 24                                     # 4 tiles x 24 keypoints: the exchange slot of one image
+    for r in range(2):
+        got = torch.load(tmp_path / f"tiled{r}.pt", weights_only=False)
+        for a, b in zip(got["feats"], feats1):
+            assert set(a) == set(b) and all(np.array_equal(a[k], b[k]) for k in a)
+        assert len(got["matches"]) == 3 and all(np.array_equal(a, b) and a.dtype == np.int64 for a, b in zip(got["matches"], matches1))
+        # phase 2: one fp32 buffer of 2 image slots x cap x (2 + 1 + 1 + 128) + 2 counts; phase 4: one int32 buffer of 2 pair slots
+        assert got["collectives"] == [(torch.float32, 2 * cap * 132 + 2), (torch.int32, 2 + 2 * (2 * max(f["keypoints"].shape[0] for f in feats1)) * 2)], got["collectives"]
