@@ -41,11 +41,13 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr size_t planes_image_pixels_wg(int h, int w) { return ((size_t)h * w + 1) & ~(size_t)1; }  // pixel slots of one pre-split image (conv_x6.hip)
 constexpr int WG_WFRAG = 2 * 2 * 2 * 32 * 8;      // 16-bit elements per (cout block, chunk, dy, position): [plane][n][k-half][32 co][8 ci] = 4 KB
 
-template <int CIN, int POOL, bool POUT, int MT, bool PROBE = false, int STG = 0>
+__device__ unsigned long long g_wg_phase[16];   // TIMING builds: summed s_memtime deltas of wave 0 per phase (dim_conv_wg_phase_read)
+
+template <int CIN, int POOL, bool POUT, int MT, bool PROBE = false, int STG = 0, bool TIMING = false, int NTILE = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __restrict__ image, const unsigned short* __restrict__ wx,
                                                                const float* __restrict__ bias, float* __restrict__ out, int H, int W, int cout,
                                                                int tiles_x, const float* __restrict__ w1a, const float* __restrict__ b1a,
-                                                               const float* __restrict__ inv_ch, unsigned* sat, unsigned* sat_image, int stagger) {
+                                                               const float* __restrict__ inv_ch, unsigned* sat, unsigned* sat_image, int stagger, int n_tiles) {
   static_assert(CIN == 64, "the fused conv1a produces 64 channels");
   using S = SplitMma<2>;
   constexpr int NCHUNK = CIN / 16, NSTEP = NCHUNK * 3;
@@ -61,16 +63,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
   const int t = threadIdx.x;
   const int lane = t & 63, lx = lane & 31, half = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);   // = this wave's Winograd position
-  int tile;
-  {  // XCD-aware tile order (conv_x6.hip): every XCD works on a contiguous band of the image's tiles
+  int tile0;   // first tile of this workgroup (NTILE consecutive tiles of the XCD-banded order: a persistent workgroup keeps the conv1a
+               // weights in LDS and fetches the next tile's image patch behind the current tile's work — the per-tile start-up chain
+               // global load -> LDS -> barrier -> phase 1 -> barrier was 22 % of a workgroup's time in the phase-timer build)
+  {  // XCD-aware order (conv_x6.hip): every XCD works on a contiguous band of the image's tile groups
     const int nt = gridDim.x, xcd = blockIdx.x & 7, j = blockIdx.x >> 3, q = nt >> 3, r = nt & 7;
-    tile = xcd * q + min(xcd, r) + j;
+    tile0 = (xcd * q + min(xcd, r) + j) * NTILE;
   }
-  const int ty = tile / tiles_x, tx = tile % tiles_x;
   const int cb = blockIdx.y, b = blockIdx.z;
-  const int oy = ty * WG_TH, ox = tx * WG_TW;
+  int oy = (tile0 / tiles_x) * WG_TH, ox = (tile0 % tiles_x) * WG_TW;
   const float* in_b = image + (size_t)b * H * W;
 
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = TIMING ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long tstart = tlast;
+  auto tick = [&](int ph) {   // TIMING: charge the cycles since the previous tick to phase ph
+    if (TIMING) { const unsigned long long now = __builtin_readcyclecounter(); tph[ph] += now - tlast; tlast = now; }
+  };
   f32x16 acc[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -79,20 +87,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-  // image patch (rows oy - 2 .. oy + 9, columns ox - 2 .. ox + 33; zero outside the image = conv1a's padding) + range guard on it
-  {
+  // image patch (rows oy - 2 .. oy + TH + 1, columns ox - 2 .. ox + 33; zero outside the image = conv1a's padding): global -> registers
+  // (load_img, issued one tile ahead) -> LDS (put_img, with the range guard on the values)
+  constexpr int NIMG = (WG_IMH * WG_IMW + 255) / 256;
+  float pimg[NIMG];
+  auto load_img = [&](int toy, int tox) {
+#pragma unroll
+    for (int i = 0; i < NIMG; ++i) {
+      const int idx = t + 256 * i, r = idx / WG_IMW, cc = idx - r * WG_IMW;
+      const int gy = toy + r - 2, gx = tox + cc - 2;
+      pimg[i] = (idx < WG_IMH * WG_IMW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? in_b[(size_t)gy * W + gx] : 0.0f;
+    }
+  };
+  auto put_img = [&]() {
     unsigned imax = 0u;
-    for (int idx = t; idx < WG_IMH * WG_IMW; idx += 256) {
-      const int r = idx / WG_IMW, cc = idx - r * WG_IMW;
-      const int gy = oy + r - 2, gx = ox + cc - 2;
-      const float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in_b[(size_t)gy * W + gx] : 0.0f;
-      Img[idx] = v;
-      imax = max(imax, __float_as_uint(v) & 0x7fffffffu);
+#pragma unroll
+    for (int i = 0; i < NIMG; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < WG_IMH * WG_IMW) Img[idx] = pimg[i];
+      imax = max(imax, __float_as_uint(pimg[i]) & 0x7fffffffu);
     }
     if (sat_image != nullptr && imax > 0x3f800000u) atomicAdd(sat_image, 1u);
-    // conv1a weights [tap][64] + bias [64], pre-multiplied by the activation scale (a power of two: exact)
-    for (int idx = t; idx < 9 * 64 + 64; idx += 256) W1a[idx] = (idx < 9 * 64 ? w1a[idx] : b1a[idx - 9 * 64]) * S::act_scale();
-  }
+  };
+  load_img(oy, ox);
+  // conv1a weights [tap][64] + bias [64], pre-multiplied by the activation scale (a power of two: exact); once per workgroup
+  for (int idx = t; idx < 9 * 64 + 64; idx += 256) W1a[idx] = (idx < 9 * 64 ? w1a[idx] : b1a[idx - 9 * 64]) * S::act_scale();
 
   // B operand: transformed weights of position wv for step s = chunk * 3 + dy, one step ahead of the MFMAs that use them
   u32x4 bw[2][2][2];   // [buffer][plane][n]
@@ -110,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
   // 10 x 16 x 4 = 640 items = 2.5 per thread: q and j are fixed per thread, wave w takes rows w, w + 4 and (waves 0, 1) w + 8.
   const int q = t & 3, j = (t >> 2) & 15;
   // does the halo of this tile leave the image?  (wave-uniform: the zero-padding masks cost VALU only on border tiles)
-  const bool border = oy == 0 || oy + WG_TH >= H || ox == 0 || ox + WG_TW >= W;
+  bool border = false;   // set per tile
   float vmax_in = 0.0f;   // range guard on the transformed activations (scaled units)
   auto stage = [&](int c) {
     float wr[9][4], bv[4];
@@ -188,16 +207,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
   constexpr int N1 = (NHP * 4 + 255) / 256;
   int s1_img[STG == 1 ? N1 : 1];     // Img offset of the item's pixel, -1 = no such item
   bool s1_ok[STG == 1 ? N1 : 1];     // pixel inside the image (conv1b's zero padding otherwise)
-  if (STG == 1) {
+  auto setup_tile = [&]() {   // per tile: border flag, phase-1 item tables
+    border = oy == 0 || oy + WG_TH >= H || ox == 0 || ox + WG_TW >= W;
+    if (STG == 1) {
 #pragma unroll
-    for (int i = 0; i < N1; ++i) {
-      const int idx = t + 256 * i, p = idx >> 2;
-      const int py = p / (WG_TW + 2), px = p - py * (WG_TW + 2);
-      const int gy = oy + py - 1, gx = ox + px - 1;
-      s1_img[i] = idx < NHP * 4 ? py * WG_IMW + px : -1;
-      s1_ok[i] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      for (int i = 0; i < N1; ++i) {
+        const int idx = t + 256 * i, p = idx >> 2;
+        const int py = p / (WG_TW + 2), px = p - py * (WG_TW + 2);
+        const int gy = oy + py - 1, gx = ox + px - 1;
+        s1_img[i] = idx < NHP * 4 ? py * WG_IMW + px : -1;
+        s1_ok[i] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      }
     }
-  }
+  };
   auto stage1 = [&](int c) {
     f32x2 wr2[9][2], bv2[2];
 #pragma unroll
@@ -283,40 +305,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
     }
   };
 
-  // experiment (dim_tune_set(15, .. | 256)): the workgroups that the dispatcher places second on each CU at kernel start wait half a
-  // chunk period once, so that the co-resident workgroups alternate staging (VALU) and MFMA phases instead of running them in lockstep
-  if (stagger && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512 && blockIdx.y == 0 && blockIdx.z == 0) {
-    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  (void)stagger;
+  for (int it = 0; it < NTILE; ++it) {
+  const int tile = tile0 + it;
+  if (tile >= n_tiles) break;   // workgroup-uniform
+  oy = (tile / tiles_x) * WG_TH; ox = (tile % tiles_x) * WG_TW;
+  setup_tile();
+  if (it > 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
   }
+  put_img();   // (every wave has left the previous tile's phase 1 long ago: the exchange barriers lie in between)
   __syncthreads();   // Img / W1a complete
+  if (NTILE > 1 && it + 1 < NTILE && tile + 1 < n_tiles) load_img(((tile + 1) / tiles_x) * WG_TH, ((tile + 1) % tiles_x) * WG_TW);
+  tick(0);
   if (STG == 1) {
     // phase 1 of chunk c + 1 shares a barrier interval with the MFMAs of chunk c (Sx is free once phase 2 has read it): 2 barriers per chunk
     stage1(0);
     __syncthreads();
+    tick(0);
     for (int c = 0; c < NCHUNK; c += 2) {
-      stage2(c);
-      __syncthreads();
-      mma_chunk(c, std::integral_constant<int, 0>{});
-      stage1(c + 1);
-      __syncthreads();
-      stage2(c + 1);
-      __syncthreads();
-      mma_chunk(c + 1, std::integral_constant<int, 1>{});
+      stage2(c); tick(1);
+      __syncthreads(); tick(2);
+      mma_chunk(c, std::integral_constant<int, 0>{}); tick(3);
+      stage1(c + 1); tick(4);
+      __syncthreads(); tick(5);
+      stage2(c + 1); tick(1);
+      __syncthreads(); tick(2);
+      mma_chunk(c + 1, std::integral_constant<int, 1>{}); tick(3);
       if (c + 2 < NCHUNK) stage1(c + 2);
-      __syncthreads();
+      tick(4);
+      __syncthreads(); tick(5);
     }
   } else
   for (int c = 0; c < NCHUNK; c += 2) {
-    stage(c);
-    __syncthreads();
-    mma_chunk(c, std::integral_constant<int, 0>{});
-    __syncthreads();   // every wave has read chunk c's operands
-    stage(c + 1);
-    __syncthreads();
-    mma_chunk(c + 1, std::integral_constant<int, 1>{});
-    __syncthreads();
+    stage(c); tick(1);
+    __syncthreads(); tick(2);
+    mma_chunk(c, std::integral_constant<int, 0>{}); tick(3);
+    __syncthreads(); tick(5);   // every wave has read chunk c's operands
+    stage(c + 1); tick(1);
+    __syncthreads(); tick(2);
+    mma_chunk(c + 1, std::integral_constant<int, 1>{}); tick(3);
+    __syncthreads(); tick(5);
   }
-  sat_report(sat, vmax_in * (1.0f / DIM_F16_ACT_SCALE));
 
   // ---- output transform across the four waves: wave w finishes M-tile w (tile rows 2w, 2w + 1) ----
   // round k: wave p hands M-tile (p + k) & 3 over (both N-tiles, 8 KB) and picks up M-tile w from wave (w - k) & 3
@@ -366,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
     if (k < 3) __syncthreads();
   }
 
+  tick(6);
   // ---- epilogue (conv_x6.hip's, on the transformed tile): register r of the C layout = (row bit r >> 3, pair jc(r & 7)) ----
   const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
   const size_t img_elems = (POUT ? planes_image_pixels_wg(Ho, Wo) : (size_t)Ho * Wo) * cout;
@@ -434,9 +470,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
     }
     sat_report(sat, vmax * (1.0f / OSC));
   };
-  if (wv >= MT) return;   // (6-row tiles: the fourth wave owns a position but no output rows)
-  if (POOL ? ((ox >> 1) + WG_TW / 2 <= Wo) : (ox + WG_TW <= W)) run_epilogue(std::false_type{});
-  else run_epilogue(std::true_type{});
+  if (wv < MT) {   // (6-row tiles: the fourth wave owns a position but no output rows)
+    if (POOL ? ((ox >> 1) + WG_TW / 2 <= Wo) : (ox + WG_TW <= W)) run_epilogue(std::false_type{});
+    else run_epilogue(std::true_type{});
+  }
+  tick(7);
+  if (NTILE > 1 && it + 1 < NTILE && tile + 1 < n_tiles) load_b(0, std::integral_constant<int, 0>{});   // step 0 of the next tile: in flight during its phase 1
+  }   // tile loop
+  sat_report(sat, vmax_in * (1.0f / DIM_F16_ACT_SCALE));
+  if (TIMING) {
+    if (t == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(&g_wg_phase[i], tph[i]);
+      atomicAdd(&g_wg_phase[8], __builtin_readcyclecounter() - tstart);
+      atomicAdd(&g_wg_phase[9], 1ull);
+    }
+  }
 }
 }  // namespace
 
@@ -494,15 +543,32 @@ int launch_conv3x3_wg_fused1a(const float* image, const float* w1a_tap_cout, con
   DIM_REQUIRE(wt.dev && wt.mode == 2, "conv3x3_wg: Winograd weights not prepared");
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int tiles_x = cdiv(W, WG_TW), tiles_y = cdiv(H, wg_th(mt));
-  dim3 grid(tiles_x * tiles_y, cout / 64, batch);
-#define DIM_WG(P, PO, MTV) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, P, PO, MTV>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger)
+  const int n_tiles = tiles_x * tiles_y;
+  const int ntile = (var & 32) ? 8 : ((var & 64) ? 4 : 1);   // persistent workgroups: consecutive tiles per workgroup
+  dim3 grid(cdiv(n_tiles, ntile), cout / 64, batch);
+  if (pool && planes_out && ntile > 1 && mt == 4) {
+    if (ntile == 8) {
+      if (var & 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1, true, 8>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+      else if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1, false, 8>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 0, false, 8>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+    } else {
+      if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1, false, 4>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 0, false, 4>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+    }
+    DIM_LAUNCH_CHECK();
+    return 0;
+  }
+#define DIM_WG(P, PO, MTV) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, P, PO, MTV>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles)
 #define DIM_WG_MT(P, PO) { if (mt == 3) DIM_WG(P, PO, 3); else DIM_WG(P, PO, 4); }
-  if (pool && planes_out && (var & 2)) {   // two-phase staging (Sx scratch, packed fp32 conv1a, fma_mix splits)
-    if (var & 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, true, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger);   // timing probe
-    else if (mt == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 3, false, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger);
+  if (pool && planes_out && (var & 8) && mt == 4) {   // phase timers (s_memtime deltas of wave 0, dim_conv_wg_phase_read)
+    if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 0, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+  } else if (pool && planes_out && (var & 2)) {   // two-phase staging (Sx scratch, packed fp32 conv1a, fma_mix splits)
+    if (var & 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, true, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);   // timing probe
+    else if (mt == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 3, false, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
   } else
-  if (pool && planes_out && (var & 4)) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger);   // timing probe
+  if (pool && planes_out && (var & 4)) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);   // timing probe
   else if (pool && planes_out) DIM_WG_MT(1, true)
   else if (pool) DIM_WG_MT(1, false)
   else if (planes_out) DIM_WG_MT(0, true)
@@ -510,5 +576,17 @@ int launch_conv3x3_wg_fused1a(const float* image, const float* w1a_tap_cout, con
 #undef DIM_WG_MT
 #undef DIM_WG
   DIM_LAUNCH_CHECK();
+  return 0;
+}
+
+// TIMING builds (dim_tune_set(15, .. | 8)): phase cycles of wave 0 summed over the workgroups since the last reset:
+// [0] prologue, [1] staging (fused) / phase 2, [2] barrier after it, [3] MFMA steps, [4] phase 1 of the next chunk, [5] barrier after the
+// MFMA interval, [6] output transform across the waves, [7] epilogue, [8] whole workgroup, [9] workgroups
+extern "C" int dim_conv_wg_phase_read(unsigned long long* host16, int reset) {
+  DIM_HIP(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_wg_phase), 16 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    DIM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_phase), z, sizeof(z)));
+  }
   return 0;
 }

@@ -147,6 +147,9 @@ int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits,
  * A/B of the convolution variants (dim_tune_set keys 2, 3, 5, 15).  Synchronises the device. */
 int dim_sp_debug_conv1b(dim_sp* h, int batch, int H, int W, const float** out_f32, int* h2, int* w2);
 
+/* Developer probe: summed per-phase cycles of the Winograd convolution's timing build (dim_tune_set(15, .. | 8); csrc/conv_wg.hip). */
+int dim_conv_wg_phase_read(unsigned long long* host16, int reset);
+
 /* Number of NMS survivors above threshold/border per image of the last call
  * (before top-k), device int32 [batch] owned by the handle. */
 int dim_sp_candidate_counts(dim_sp* h, const int32_t** ncand_dev);
