@@ -43,7 +43,7 @@ constexpr int WG_WFRAG = 2 * 2 * 2 * 32 * 8;      // 16-bit elements per (cout b
 
 __device__ unsigned long long g_wg_phase[16];   // TIMING builds: summed s_memtime deltas of wave 0 per phase (dim_conv_wg_phase_read)
 
-template <int CIN, int POOL, bool POUT, int MT, bool PROBE = false, int STG = 0, bool TIMING = false, int NTILE = 1>
+template <int CIN, int POOL, bool POUT, int MT, int PROBE = 0, int STG = 0, bool TIMING = false, int NTILE = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __restrict__ image, const unsigned short* __restrict__ wx,
                                                                const float* __restrict__ bias, float* __restrict__ out, int H, int W, int cout,
                                                                int tiles_x, const float* __restrict__ w1a, const float* __restrict__ b1a,
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
       for (int k = 0; k < 4; ++k) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tap = 0; tap < (PROBE ? 1 : 9); ++tap) {   // PROBE (timing only, wrong results): one tap instead of nine
+        for (int tap = 0; tap < (PROBE == 1 ? 1 : 9); ++tap) {   // PROBE 1 (timing only, wrong results): one tap instead of nine
           const float x = v[tap / 3][k + tap % 3];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = fmaf(x, wr[tap][e], o[e]);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
       if (io < 0) continue;
       f32x2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
 #pragma unroll
-      for (int tap = 0; tap < (PROBE ? 1 : 9); ++tap) {
+      for (int tap = 0; tap < (PROBE == 1 ? 1 : 9); ++tap) {
         const float x = Img[io + (tap / 3) * WG_IMW + tap % 3];
         const f32x2 x2 = {x, x};
         o0 = __builtin_elementwise_fma(x2, wr2[tap][0], o0);
@@ -287,7 +287,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wg_f1a_kernel(const float* __r
     for (int dy = 0; dy < 3; ++dy) {
       constexpr int dummy = 0; (void)dummy;
       const int step = c * 3 + dy;
-      if ((CP + dy) & 1) { if (step + 1 < NSTEP) load_b(step + 1, std::integral_constant<int, 0>{}); }
+      if (PROBE == 2) {   // timing probe (wrong results): the weight fragments of step 0 / 1 serve every step — no L2 round trip per step
+        if (step == 0) load_b(1, std::integral_constant<int, 1>{});
+      } else if ((CP + dy) & 1) { if (step + 1 < NSTEP) load_b(step + 1, std::integral_constant<int, 0>{}); }
       else { if (step + 1 < NSTEP) load_b(step + 1, std::integral_constant<int, 1>{}); }
       u32x4 fa[MT][2];
 #pragma unroll
@@ -548,27 +550,30 @@ int launch_conv3x3_wg_fused1a(const float* image, const float* w1a_tap_cout, con
   dim3 grid(cdiv(n_tiles, ntile), cout / 64, batch);
   if (pool && planes_out && ntile > 1 && mt == 4) {
     if (ntile == 8) {
-      if (var & 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1, true, 8>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
-      else if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1, false, 8>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 0, false, 8>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+      if (var & 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 0, 1, true, 8>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+      else if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 0, 1, false, 8>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 0, 0, false, 8>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
     } else {
-      if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1, false, 4>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 0, false, 4>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+      if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 0, 1, false, 4>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 0, 0, false, 4>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
     }
     DIM_LAUNCH_CHECK();
     return 0;
   }
 #define DIM_WG(P, PO, MTV) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, P, PO, MTV>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles)
 #define DIM_WG_MT(P, PO) { if (mt == 3) DIM_WG(P, PO, 3); else DIM_WG(P, PO, 4); }
-  if (pool && planes_out && (var & 8) && mt == 4) {   // phase timers (s_memtime deltas of wave 0, dim_conv_wg_phase_read)
-    if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 0, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+  if (pool && planes_out && (var & 128) && mt == 4) {   // timing probe 2: no weight-fragment reloads
+    if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 2, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 2, 0>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+  } else if (pool && planes_out && (var & 8) && mt == 4) {   // phase timers (s_memtime deltas of wave 0, dim_conv_wg_phase_read)
+    if (var & 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 0, 1, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 0, 0, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
   } else if (pool && planes_out && (var & 2)) {   // two-phase staging (Sx scratch, packed fp32 conv1a, fma_mix splits)
-    if (var & 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, true, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);   // timing probe
-    else if (mt == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 3, false, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, false, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+    if (var & 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 1, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);   // timing probe
+    else if (mt == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 3, 0, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 0, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);
   } else
-  if (pool && planes_out && (var & 4)) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, true>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);   // timing probe
+  if (pool && planes_out && (var & 4)) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wg_f1a_kernel<64, 1, true, 4, 1>), grid, dim3(256), 0, s, image, wt.dev, bias, out, H, W, cout, tiles_x, w1a_tap_cout, b1a, wt.inv_ch(), sat, sat_image, stagger, n_tiles);   // timing probe
   else if (pool && planes_out) DIM_WG_MT(1, true)
   else if (pool) DIM_WG_MT(1, false)
   else if (planes_out) DIM_WG_MT(0, true)

@@ -19,6 +19,9 @@ struct AreaTaps {
   bool head, tail;
   __device__ float weight(int i) const { return (head && i == 0) ? a_head : ((tail && i == n - 1) ? a_tail : a_mid); }
 };
+// cv::resize computes inv_scale = (double)dsize / ssize first and scale = 1. / inv_scale from it (resize.cpp): that is NOT always the
+// double nearest to ssize / dsize (1 ulp apart for some non-power-of-two ratios), and a floor / weight can depend on it
+__device__ __forceinline__ double cv_scale(int ssize, int dsize) { return 1.0 / ((double)dsize / (double)ssize); }
 __device__ __forceinline__ AreaTaps area_taps(int d, int ssize, double scale) {
   const double f1 = d * scale, f2 = f1 + scale;
   const double cell = fmin(scale, (double)ssize - f1);
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const float* __restric
       for (int x = 0; x < sx; ++x) sum += src[(size_t)(dy * sy + y) * W + dx * sx + x];
     out = sum * (float)(1.0 / (double)(sx * sy));
   } else {
-    const AreaTaps tx = area_taps(dx, W, (double)W / (double)w), ty = area_taps(dy, H, (double)H / (double)h);
+    const AreaTaps tx = area_taps(dx, W, cv_scale(W, w)), ty = area_taps(dy, H, cv_scale(H, h));
     float sum = 0.f;
     for (int j = 0; j < ty.n; ++j) {
       const float* row = src + (size_t)(ty.first + j) * W + tx.first;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const float* __restric
 // resize_max / tile_preselection_size this way (pairs_generator.py:141-146, matcher_base.py:1062-1069).
 struct LinTap { int s; float f; };
 __device__ __forceinline__ LinTap area_linear_tap(int d, int ssize, int dsize) {
-  const double scale = (double)ssize / (double)dsize, inv_scale = (double)dsize / (double)ssize;
+  const double inv_scale = (double)dsize / (double)ssize, scale = 1.0 / inv_scale;   // OpenCV's order (cv_scale)
   LinTap t;
   t.s = (int)floor(d * scale);
   float f = (float)((double)(d + 1) - (double)(t.s + 1) * inv_scale);
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void resize_area_linear_kernel(const float* __
 // (the vertical weights keep their fraction).  This is what utils/image.py:52-57 resize_image switches to when the
 // requested size ENLARGES the image (quality HIGHEST, extractor_base.py:392-412 / matcher_base.py:1026-1034).
 __device__ __forceinline__ LinTap linear_tap(int d, int ssize, int dsize) {
-  const double scale = (double)ssize / (double)dsize;
+  const double scale = cv_scale(ssize, dsize);
   float fx = (float)(((double)d + 0.5) * scale - 0.5);
   LinTap t;
   t.s = (int)floorf(fx);

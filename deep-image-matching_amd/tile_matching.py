@@ -135,20 +135,27 @@ def _similarity_ransac(kp0: np.ndarray, kp1: np.ndarray, threshold: float = 4.0,
 
     best, best_mask, iters, it = -1, None, int(max_iters), 0
     thr2 = threshold * threshold
+    az, bz = a[:, 0] + 1j * a[:, 1], b[:, 0] + 1j * b[:, 1]       # points as complex numbers: a similarity is z -> r z + t
     while it < iters:
         batch = min(256, iters - it)
         i0 = rng.integers(0, n, batch)
         i1 = (i0 + 1 + rng.integers(0, n - 1, batch)) % n
-        for u, v in zip(i0, i1):
+        # all samples of the batch at once (the per-sample Python loop was the slow part): the 2-point fit is exact,
+        # r = (q1 - q0) / (p1 - p0), t = q0 - r p0; residuals of every point under every sample as one (batch, n) array
+        dp = az[i1] - az[i0]
+        ok = dp != 0
+        r = np.where(ok, (bz[i1] - bz[i0]) / np.where(ok, dp, 1.0), 0.0)
+        tt = bz[i0] - r * az[i0]
+        res = r[:, None] * az[None, :] + tt[:, None] - bz[None, :]
+        masks = (res.real ** 2 + res.imag ** 2) <= thr2
+        counts = masks.sum(axis=1)
+        for k in range(batch):           # the sequential part: best-so-far and the adaptive stopping rule, in sample order
             it += 1
-            M = fit(a[[u, v]], b[[u, v]])
-            if M is None:
+            if not ok[k]:
                 continue
-            r = a @ M[:, :2].T + M[:, 2] - b
-            mask = np.sum(r * r, axis=1) <= thr2
-            c = int(mask.sum())
+            c = int(counts[k])
             if c > best:
-                best, best_mask = c, mask
+                best, best_mask = c, masks[k]
                 w = min(max(c / n, 1e-9), 1 - 1e-9)
                 need = np.log(1 - confidence) / np.log(1 - w * w)
                 iters = min(iters, int(np.ceil(need)) if np.isfinite(need) else iters)
@@ -157,6 +164,9 @@ def _similarity_ransac(kp0: np.ndarray, kp1: np.ndarray, threshold: float = 4.0,
     if best < 2:
         return None
     return fit(a[best_mask], b[best_mask])
+
+
+_WARNED_NO_CV2 = False
 
 
 def estimate_affine_from_matches(kp0: np.ndarray, kp1: np.ndarray) -> np.ndarray:
@@ -170,6 +180,11 @@ def estimate_affine_from_matches(kp0: np.ndarray, kp1: np.ndarray) -> np.ndarray
         if cv2 is not None:
             M, _ = cv2.estimateAffinePartial2D(kp0, kp1, method=cv2.RANSAC, ransacReprojThreshold=4.0, confidence=0.999, maxIters=10000)
         else:
+            global _WARNED_NO_CV2
+            if not _WARNED_NO_CV2:
+                logger.warning("OpenCV is not importable: PRESELECTION_AFFINE_TRANSFORM uses the built-in 2-point similarity RANSAC instead of "
+                               "cv2.estimateAffinePartial2D (same model, threshold and stopping rule; tile selection can differ near rectangle borders)")
+                _WARNED_NO_CV2 = True
             M = _similarity_ransac(kp0, kp1)
         if M is None:
             M = _affine_total_least_squares(kp0, kp1)

@@ -90,6 +90,9 @@ def merge_tile_features(per_tile: Dict[int, dict], origins: Dict[int, Tuple[int,
     return {"keypoints": kpts, "descriptors": desc, "scores": scores, "tile_idx": tidx}
 
 
+DEVICE_MERGE_MAX_SLOTS = 1 << 18   # 262 144 slots = 6.9e10 rank compares (~10 ms); above it the host merge is faster
+
+
 def merge_tile_features_device(lib, dev, stream, tables, origins_xy, tile_ids, image_shape, select_unique: bool = True) -> dict:
     """merge_tile_features on the device (csrc/tile_merge.hip: shift, border filter, np.unique's lexicographic order and
     first-occurrence rule, descriptor transpose) from the extractor's per-chunk device tables (kp [T,cap,2], scores [T,cap],
@@ -112,6 +115,14 @@ def merge_tile_features_device(lib, dev, stream, tables, origins_xy, tile_ids, i
     kp, sc, de, n = kp.contiguous(), sc.contiguous(), de.contiguous(), n.to(torch.int32).contiguous()
     T, cap, D = int(de.shape[0]), int(de.shape[1]), int(de.shape[2])
     assert T == len(tile_ids) == len(origins_xy)
+    if T * cap > DEVICE_MERGE_MAX_SLOTS:
+        # tm_rank_kernel ranks all T * cap slots against each other (O(n^2) compares, dead padding slots included): fine at 16 tiles x
+        # 4096 slots (~1 ms), quadratic beyond — keep-all capacities or images with hundreds of tiles go through the host merge
+        # (the reference's own numpy statements), which only touches the live keypoints
+        n_h = n.cpu().numpy()
+        kp_h, sc_h, de_h = kp.cpu().numpy(), sc.cpu().numpy(), de.cpu().numpy()
+        per_tile = {tid: {"keypoints": kp_h[i, :n_h[i]], "scores": sc_h[i, :n_h[i]], "descriptors": de_h[i, :n_h[i]].T} for i, tid in enumerate(tile_ids)}
+        return merge_tile_features(per_tile, {tid: tuple(origins_xy[i]) for i, tid in enumerate(tile_ids)}, image_shape, D, select_unique)
     og = torch.tensor(origins_xy, dtype=torch.int32, device=dev).reshape(T, 2).contiguous()
     ids = torch.tensor([float(i) for i in tile_ids], dtype=torch.float32, device=dev)
     lib.dim_op_merge_tiles_workspace_bytes.restype = ctypes.c_size_t

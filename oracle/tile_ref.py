@@ -90,7 +90,7 @@ def match_by_tile(features0: dict, features1: dict, tile_pairs, match_pairs: Cal
 # ---------------------------------------------------------------------------------------------------
 def _area_table(ssize: int, dsize: int):
     """computeResizeAreaTab: per destination index a list of (source index, fp32 weight)."""
-    scale = ssize / dsize
+    scale = 1.0 / (dsize / ssize)      # cv::resize: inv_scale = dsize / ssize, scale = 1. / inv_scale (not always == ssize / dsize in double)
     tab = []
     for d in range(dsize):
         f1 = d * scale
@@ -119,7 +119,8 @@ def resize_area(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
     w, h = int(size_wh[0]), int(size_wh[1])
     if h > H or w > W:
         def taps(ssize, dsize):
-            scale, inv = ssize / dsize, dsize / ssize
+            inv = dsize / ssize
+            scale = 1.0 / inv
             d = np.arange(dsize)
             s = np.floor(d * scale).astype(np.int64)
             f = ((d + 1) - (s + 1) * inv).astype(np.float32)
@@ -185,7 +186,7 @@ def resize_linear(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
     one = np.float32(1)
 
     def taps(ssize, dsize):
-        scale = ssize / dsize
+        scale = 1.0 / (dsize / ssize)
         f = ((np.arange(dsize) + 0.5) * scale - 0.5).astype(np.float32)
         s = np.floor(f).astype(np.int64)
         return s, (f - s.astype(np.float32)).astype(np.float32)

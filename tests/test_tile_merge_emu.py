@@ -62,3 +62,17 @@ def test_device_merge_of_chunked_tables_and_empty_result(emu_lib):
     z = tiling.merge_tile_features_device(emu_lib, torch.device("cpu"), None, [(torch.zeros(2, 8, 2), torch.ones(2, 8), torch.ones(2, 8, 24), torch.full((2,), 8, dtype=torch.int32))],
                                           [(0, 0), (0, 0)], [0, 1], (H, W), True)
     assert z["keypoints"].shape == (0, 2) and z["descriptors"].shape == (24, 0) and z["scores"].shape == (0,) and z["tile_idx"].shape == (0,)
+
+
+def test_large_merges_take_the_host_path_with_the_same_result(emu_lib, monkeypatch):
+    """the device rank sort is O((tiles x capacity)^2); above tiling.DEVICE_MERGE_MAX_SLOTS the merge runs the reference's numpy
+    statements on the host (only the live keypoints).  Same result either way: the threshold is lowered so that this case crosses it."""
+    H, W = 90, 120
+    kp, sc, de, n, origins = _case(77, 6, 48, 32, 24, H, W)
+    ids = list(range(6))
+    tables = [(torch.from_numpy(kp), torch.from_numpy(sc), torch.from_numpy(de), torch.from_numpy(n))]
+    dev_res = tiling.merge_tile_features_device(emu_lib, torch.device("cpu"), None, tables, origins, ids, (H, W), True)
+    monkeypatch.setattr(tiling, "DEVICE_MERGE_MAX_SLOTS", 6 * 48 - 1)
+    host_res = tiling.merge_tile_features_device(None, torch.device("cpu"), None, tables, origins, ids, (H, W), True)    # lib=None: the device must not be touched
+    for k in dev_res:
+        assert host_res[k].dtype == dev_res[k].dtype and np.array_equal(host_res[k], dev_res[k]), k
