@@ -45,11 +45,45 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* __restric
 // the column pass over x.  Every stage covers only the region its inputs are exact on (T shrinks by 2R per
 // pool: 62 -> 56 -> 50 -> 44 -> 38 -> 32 for R = 3, TILE = 32): a third less work than full-tile passes.  Arrays: s (scores, -inf outside the image), t (row-pass scratch),
 // rest (suppressed scores; sign bit marks "near a kept maximum"), kp / t8 (keep mask, bytes).
+// window maximum as v_max3 chains.  `a > b ? a : b` on floats compiles to v_cmp_gt_f32 + v_cndmask_b32 (+ an s_nop for the VCC hazard)
+// per step — ~15 issue slots per output of a 7-wide window, and every instruction of this VALU-bound kernel is time (round-4
+// counters: the float passes were ~2/3 of its 16 us per 1024^2 map); fmaxf nests become v_max3_f32.  Scores are finite or -inf
+// (never NaN: a softmax of finite logits), so fmaxf == the comparison form.  t3[k] = max(v[k], v[k+1], v[k+2]) is shared by the
+// outputs: a 7-wide window is max3(t3[o], t3[o+3], v[o+6]) = 2.25 instructions per output.
+__device__ __forceinline__ float nms_mx3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ unsigned char nms_mx3(unsigned char a, unsigned char b, unsigned char c) {
+  const unsigned char m = a > b ? a : b;
+  return m > c ? m : c;
+}
+template <int R, int SEG, typename T>
+__device__ __forceinline__ void nms_window_max(const T (&v)[SEG + 2 * R], T (&out)[SEG]) {
+  constexpr int W = 2 * R + 1;
+  if (R == 0) {
+#pragma unroll
+    for (int o = 0; o < SEG; ++o) out[o] = v[o];
+    return;
+  }
+  T t3[SEG + 2 * R - 2 > 0 ? SEG + 2 * R - 2 : 1];
+#pragma unroll
+  for (int k = 0; k < SEG + 2 * R - 2; ++k) t3[k] = nms_mx3(v[k], v[k + 1], v[k + 2]);
+#pragma unroll
+  for (int o = 0; o < SEG; ++o) {
+    T m = t3[o];
+    // the remaining W - 3 elements o+3 .. o+W-1: whole t3 blocks while they fit, single elements for the rest, two terms per max3
+    if (W == 5) m = nms_mx3(m, v[o + 3], v[o + 4]);
+    if (W == 7) m = nms_mx3(m, t3[o + 3], v[o + 6]);
+    if (W == 9) m = nms_mx3(m, t3[o + 3], t3[o + 6]);
+    if (W == 11) { m = nms_mx3(m, t3[o + 3], t3[o + 6]); m = nms_mx3(m, v[o + 9], v[o + 10]); }
+    if (W == 13) { m = nms_mx3(m, t3[o + 3], t3[o + 6]); m = nms_mx3(m, t3[o + 9], v[o + 12]); }
+    out[o] = m;
+  }
+}
 template <int R, int SEG, int NMS_THREADS, typename T, bool ROW, typename Emit>
 __device__ __forceinline__ void nms_line_max(const T* src, int TS, int l0, int l1, int p0, int p1, Emit emit) {
   // lines l0..l1-1, window maxima at positions p0..p1-1 (the window p-R..p+R always lies inside the array: every
   // stage only covers the region its inputs are valid on, which shrinks by R per pool).  SEG outputs per item: chosen
   // with the thread count so that one pass of the tile is a single, well-filled round of items
+  static_assert(R <= 6, "window forms up to 13 wide");
   const int nl = l1 - l0, nseg = (p1 - p0 + SEG - 1) / SEG;
   for (int item = threadIdx.x; item < nl * nseg; item += NMS_THREADS) {
     const int line = l0 + item % nl, seg = item / nl;
@@ -57,18 +91,23 @@ __device__ __forceinline__ void nms_line_max(const T* src, int TS, int l0, int l
     const int stride = ROW ? 1 : TS;
     const int off = ROW ? line * TS : line;
     T v[SEG + 2 * R];
+    if (base + SEG + 2 * R - 1 <= p1 - 1 + R) {   // whole segment inside the line: constant offsets from one base address
+      const T* p = src + off + base * stride;
 #pragma unroll
-    for (int k = 0; k < SEG + 2 * R; ++k) {
-      const int q = min(base + k, p1 - 1 + R);  // the last segment may be short: re-read the last needed element
-      v[k] = src[off + q * stride];
+      for (int k = 0; k < SEG + 2 * R; ++k) v[k] = p[k * stride];
+    } else {
+#pragma unroll
+      for (int k = 0; k < SEG + 2 * R; ++k) {
+        const int q = min(base + k, p1 - 1 + R);  // the last segment may be short: re-read the last needed element
+        v[k] = src[off + q * stride];
+      }
     }
+    T mo[SEG];
+    nms_window_max<R, SEG, T>(v, mo);
 #pragma unroll
     for (int o = 0; o < SEG; ++o) {
-      T m = v[o];
-#pragma unroll
-      for (int k = 1; k <= 2 * R; ++k) m = v[o + k] > m ? v[o + k] : m;
       const int q = p0 + seg * SEG + o;
-      if (q < p1) emit(off + q * stride, m);
+      if (q < p1) emit(off + q * stride, mo[o]);
     }
   }
 }
