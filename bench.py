@@ -335,6 +335,7 @@ def run_config5(a, rank, world, dev, dist, lib):
         fw = pipe.extract_all(images[:nw])
         pipe.match_all(images[:nw], fw, pl.exhaustive_pairs(nw, world))
     barrier()
+    pipe.n_fallback = 0
     capi.check(lib, lib.dim_profile_start(ctypes.c_ulonglong(1 << 17)))     # DIM_PROF_AL_CONV_FULL
     phases = {"extract_s": 0.0, "feature_gather_s": 0.0, "match_s": 0.0, "tile_selection_s": 0.0, "tile_matching_s": 0.0, "match_gather_s": 0.0}
     t0 = time.perf_counter()
