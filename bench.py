@@ -341,7 +341,7 @@ def run_config5(a, rank, world, dev, dist, lib):
     t0 = time.perf_counter()
     for _ in range(K):
         mt._tile_preselector._cache.clear()
-        feats = pipe.extract_all(images)
+        feats = pipe.extract_all(images, as_numpy=False)
         matches = pipe.match_all(images, feats, pairs)
         for k in phases:
             phases[k] += pipe.timings[k]
@@ -372,7 +372,7 @@ def run_config5(a, rank, world, dev, dist, lib):
                        "sharding": f"images i mod {world}, ONE all-gather of the merged tile tables ({pipe.timings['feature_gather_bytes'] / 1e6:.0f} MB), image pairs j mod {world}, "
                                    f"ONE all-gather of the match rows ({pipe.timings['match_gather_bytes'] / 1e6:.0f} MB)"},
             "phases_s_max_over_ranks": {k: float(v) / K for k, v in zip(phases, tt[1:].tolist())},
-            "keypoints_per_image_mean": float(np.mean([f["keypoints"].shape[0] for f in feats])),
+            "keypoints_per_image_mean": float(np.mean([int(f["keypoints"].shape[0]) for f in feats])),
             "matches_per_pair_mean": float(np.mean(nm)), "matches_per_pair_min": int(min(nm)), "pairs_with_matches": int(sum(1 for x in nm if x > 0)),
             "tile_selection_note": "PRESELECTION (down-sampled SuperPoint + LightGlue on the device) runs and is timed for every image pair; with seeded synthetic "
                                    "weights it cannot vote, so the GRID method (16 tile pairs per image pair) supplies the tile pairs that are matched "

@@ -222,6 +222,15 @@ class TiledPairPipeline:
         self.max_kpts, self.max_matches = max_kpts_per_image, max_matches_per_pair
         self.timings: dict = {}
 
+    def _band(self, images, i):
+        """first band of image i as a contiguous float32 array, cached (extracting 1 of 3 interleaved channels of a 6000 x 4000 image
+        costs ~40 ms; every image takes part in n - 1 pairs)"""
+        c = self.__dict__.setdefault("_band_cache", {})
+        key = (id(images), i)
+        if key not in c:
+            c[key] = _band1(images[i])
+        return c[key]
+
     def _device(self):
         d = getattr(self.ext, "_device", "cuda")
         return torch.device(d if isinstance(d, (str, torch.device)) else "cuda")
@@ -239,9 +248,11 @@ class TiledPairPipeline:
 
     # ---- phases 1 + 2 ----------------------------------------------------------------------
     @torch.no_grad()
-    def extract_all(self, images: Sequence) -> List[dict]:
+    def extract_all(self, images: Sequence, as_numpy: bool = True) -> List[dict]:
         """images: sequence of numpy arrays (H, W) or (H, W, C), 0..255, the same list on every rank (only this rank's shard is read).
-        Returns the feature dict of EVERY image (keypoints (N,2) f32, descriptors (D,N) f32, scores (N,), tile_idx (N,), image_size)."""
+        Returns the feature dict of EVERY image (keypoints (N,2) f32, descriptors (D,N) f32, scores (N,), tile_idx (N,), image_size) as
+        numpy arrays; with ``as_numpy=False`` the device views of the exchange buffer that match_all uses anyway (keypoints [N,2],
+        descriptors_nd [N,D], tile_idx, scores: no device-to-host copy of 34 MB per image)."""
         import time
         import numpy as np
         n_img = len(images)
@@ -254,13 +265,15 @@ class TiledPairPipeline:
         body, cnt = flat[: per * cap * row].view(per, cap, row), flat[per * cap * row:].view(torch.int32)
         t0 = time.perf_counter()
         for s, i in enumerate(mine):
-            f = self.ext._extract_by_tile(np.asarray(images[i]))
+            # the merged tile table never leaves HBM: merge_tile_features_device -> views of the exchange buffer
+            f = self.ext._extract_by_tile(np.asarray(images[i]), as_device=True)
             k = int(f["keypoints"].shape[0])
             if k > cap:
                 raise ValueError(f"TiledPairPipeline: image {i} has {k} keypoints, more than the exchange slot ({cap})")
-            host = np.empty((k, row), dtype=np.float32)
-            host[:, 0:2], host[:, 2], host[:, 3], host[:, 4:] = f["keypoints"], f["scores"], f["tile_idx"], f["descriptors"].T
-            body[s, :k] = torch.from_numpy(host).to(dev)
+            body[s, :k, 0:2] = f["keypoints"]
+            body[s, :k, 2] = f["scores"]
+            body[s, :k, 3] = f["tile_idx"]
+            body[s, :k, 4:] = f["descriptors"].t()
             cnt[s] = k
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
@@ -268,13 +281,20 @@ class TiledPairPipeline:
         g = _all_gather_cat(flat[None], self.world)          # phase 2: ONE collective
         out: List[dict] = []
         gb = g[:, : per * cap * row].reshape(self.world, per, cap, row)
-        gc = g[:, per * cap * row:].reshape(self.world, per).view(torch.int32) if self.world > 1 else cnt.view(1, per)
+        gc = (g[:, per * cap * row:].reshape(self.world, per).view(torch.int32) if self.world > 1 else cnt.view(1, per)).cpu()
+        self._dev_feats = []
         for i in range(n_img):
             r, s = i % self.world, i // self.world
             k = int(gc[r, s])
-            t = gb[r, s, :k].cpu().numpy()
-            out.append({"keypoints": np.ascontiguousarray(t[:, 0:2]), "scores": np.ascontiguousarray(t[:, 2]), "tile_idx": np.ascontiguousarray(t[:, 3]),
-                        "descriptors": np.ascontiguousarray(t[:, 4:].T), "image_size": np.array(np.asarray(images[i]).shape[:2], dtype=np.int32)})
+            size = np.array(np.asarray(images[i]).shape[:2], dtype=np.int32)
+            t = gb[r, s, :k]
+            self._dev_feats.append({"keypoints": t[:, 0:2], "descriptors_nd": t[:, 4:], "tile_idx": t[:, 3], "scores": t[:, 2], "image_size": size})
+            if as_numpy:
+                h = t.cpu().numpy()
+                out.append({"keypoints": np.ascontiguousarray(h[:, 0:2]), "scores": np.ascontiguousarray(h[:, 2]), "tile_idx": np.ascontiguousarray(h[:, 3]),
+                            "descriptors": np.ascontiguousarray(h[:, 4:].T), "image_size": size})
+            else:
+                out.append(self._dev_feats[-1])
         self.timings.update(extract_s=t1 - t0, feature_gather_s=time.perf_counter() - t1, feature_gather_bytes=int(flat.numel() * 4 * self.world))
         return out
 
@@ -285,12 +305,14 @@ class TiledPairPipeline:
         (the arrays MatcherBase._match_by_tile returns, MB:362-485)."""
         import time
         import numpy as np
-        from .tile_matching import match_tile_pairs_batched
+        from .tile_matching import match_tile_pairs_batched, match_tile_pairs_batched_device
         P = int(pairs.shape[0])
+        dev_feats = getattr(self, "_dev_feats", None)
+        use_dev = dev_feats is not None and len(dev_feats) == len(feats)      # tables of the last extract_all are still in HBM
         mine = shard_indices(P, self.rank, self.world).tolist()
         per = (P + self.world - 1) // self.world
         dev = self._device()
-        cap_m = int(self.max_matches if self.max_matches is not None else 2 * max(1, max(f["keypoints"].shape[0] for f in feats)))
+        cap_m = int(self.max_matches if self.max_matches is not None else 2 * max(1, max(int(f["keypoints"].shape[0]) for f in feats)))
         flat = torch.zeros(per + per * cap_m * 2, dtype=torch.int32, device=dev)
         cnt, rows = flat[:per], flat[per:].view(per, cap_m, 2)
         names = names if names is not None else [f"image{i:05d}" for i in range(len(feats))]
@@ -300,20 +322,22 @@ class TiledPairPipeline:
             a, b = int(pairs[p, 0]), int(pairs[p, 1])
             ts = time.perf_counter()
             needs_pixels = self.selection.startswith("PRESELECTION")
-            tile_pairs = self.mat.tile_selection(names[a], names[b], self.selection,
-                                                 image0=_band1(images[a]) if needs_pixels else np.zeros(np.asarray(images[a]).shape[:2], np.float32),
-                                                 image1=_band1(images[b]) if needs_pixels else np.zeros(np.asarray(images[b]).shape[:2], np.float32))
+            shape_only = lambda i: np.broadcast_to(np.float32(0), np.asarray(images[i]).shape[:2])     # the grid methods read the shape only
+            band = lambda i: self._band(images, i) if needs_pixels else shape_only(i)
+            tile_pairs = self.mat.tile_selection(names[a], names[b], self.selection, image0=band(a), image1=band(b))
             if len(tile_pairs) == 0 and self.fallback is not None:
                 self.n_fallback += 1
-                z = np.zeros(np.asarray(images[a]).shape[:2], np.float32)
-                tile_pairs = self.mat.tile_selection(names[a], names[b], self.fallback, image0=z, image1=np.zeros(np.asarray(images[b]).shape[:2], np.float32))
+                tile_pairs = self.mat.tile_selection(names[a], names[b], self.fallback, image0=shape_only(a), image1=shape_only(b))
             tm_ = time.perf_counter()
-            m = match_tile_pairs_batched(self.mat._ensure_pairs, feats[a], feats[b], tile_pairs, dev, getattr(self.mat, "tile_pair_batch", 8))
+            if use_dev:
+                m = match_tile_pairs_batched_device(self.mat._ensure_pairs, dev_feats[a], dev_feats[b], tile_pairs, getattr(self.mat, "tile_pair_batch", 8))
+            else:
+                m = torch.from_numpy(match_tile_pairs_batched(self.mat._ensure_pairs, feats[a], feats[b], tile_pairs, dev, getattr(self.mat, "tile_pair_batch", 8))).to(dev)
             sel_s += tm_ - ts
             mat_s += time.perf_counter() - tm_
             if m.shape[0] > cap_m:
                 raise ValueError(f"TiledPairPipeline: pair ({a}, {b}) has {m.shape[0]} matches, more than the exchange slot ({cap_m})")
-            rows[s, : m.shape[0]] = torch.from_numpy(m.astype(np.int32)).to(dev)
+            rows[s, : m.shape[0]] = m.to(torch.int32)
             cnt[s] = m.shape[0]
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)

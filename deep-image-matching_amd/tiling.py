@@ -93,7 +93,7 @@ def merge_tile_features(per_tile: Dict[int, dict], origins: Dict[int, Tuple[int,
 DEVICE_MERGE_MAX_SLOTS = 1 << 18   # 262 144 slots = 6.9e10 rank compares (~10 ms); above it the host merge is faster
 
 
-def merge_tile_features_device(lib, dev, stream, tables, origins_xy, tile_ids, image_shape, select_unique: bool = True) -> dict:
+def merge_tile_features_device(lib, dev, stream, tables, origins_xy, tile_ids, image_shape, select_unique: bool = True, as_device: bool = False) -> dict:
     """merge_tile_features on the device (csrc/tile_merge.hip: shift, border filter, np.unique's lexicographic order and
     first-occurrence rule, descriptor transpose) from the extractor's per-chunk device tables (kp [T,cap,2], scores [T,cap],
     desc [T,cap,D], n [T]); ONE device-to-host copy of the final arrays.  EB:330-390."""
@@ -122,7 +122,8 @@ def merge_tile_features_device(lib, dev, stream, tables, origins_xy, tile_ids, i
         n_h = n.cpu().numpy()
         kp_h, sc_h, de_h = kp.cpu().numpy(), sc.cpu().numpy(), de.cpu().numpy()
         per_tile = {tid: {"keypoints": kp_h[i, :n_h[i]], "scores": sc_h[i, :n_h[i]], "descriptors": de_h[i, :n_h[i]].T} for i, tid in enumerate(tile_ids)}
-        return merge_tile_features(per_tile, {tid: tuple(origins_xy[i]) for i, tid in enumerate(tile_ids)}, image_shape, D, select_unique)
+        res = merge_tile_features(per_tile, {tid: tuple(origins_xy[i]) for i, tid in enumerate(tile_ids)}, image_shape, D, select_unique)
+        return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in res.items()} if as_device else res
     og = torch.tensor(origins_xy, dtype=torch.int32, device=dev).reshape(T, 2).contiguous()
     ids = torch.tensor([float(i) for i in tile_ids], dtype=torch.float32, device=dev)
     lib.dim_op_merge_tiles_workspace_bytes.restype = ctypes.c_size_t
@@ -138,6 +139,8 @@ def merge_tile_features_device(lib, dev, stream, tables, origins_xy, tile_ids, i
                                                int(image_shape[0]), int(image_shape[1]), int(bool(select_unique)), capi.ptr(ws),
                                                capi.ptr(o_kp), capi.ptr(o_sc), capi.ptr(o_ti), capi.ptr(o_de), capi.ptr(n_out), stream))
     N = int(n_out.item())
+    if as_device:   # the merged table stays in HBM (pipeline.TiledPairPipeline packs it into its exchange buffer there)
+        return {"keypoints": o_kp[:N], "descriptors": o_de[:D * N].reshape(D, N), "scores": o_sc[:N], "tile_idx": o_ti[:N]}
     return {"keypoints": o_kp[:N].cpu().numpy(), "descriptors": o_de[:D * N].reshape(D, N).cpu().numpy(),
             "scores": o_sc[:N].cpu().numpy(), "tile_idx": o_ti[:N].cpu().numpy()}
 
@@ -150,7 +153,7 @@ class BatchedTilingMixin:
     tile_batch = 16
 
     @torch.no_grad()
-    def _extract_by_tile(self, image: np.ndarray, select_unique: bool = True) -> dict:
+    def _extract_by_tile(self, image: np.ndarray, select_unique: bool = True, as_device: bool = False) -> dict:
         """The image goes to the device ONCE (one H2D copy of the caller's array); zero padding, tile slicing and
         _frame2tensor's /255 happen there (IEEE fp32 division: bit-identical to the host's), so no host pass touches
         the 288 MB of a 6000x4000 RGB float image."""
@@ -193,4 +196,4 @@ class BatchedTilingMixin:
                 net = self._ensure_batch(th, tw, self.tile_batch)
                 kp, sc, de, n = getattr(net, "extract_batch_guarded", net.extract_batch)(t)
             tables.append((kp, sc, de, n))
-        return merge_tile_features_device(lib, dev, stream, tables, [origins[i] for i in idxs], idxs, image.shape, select_unique)
+        return merge_tile_features_device(lib, dev, stream, tables, [origins[i] for i in idxs], idxs, image.shape, select_unique, as_device)

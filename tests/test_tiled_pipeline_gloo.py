@@ -85,3 +85,38 @@ def test_two_rank_tiled_pipeline_equals_single_process(tmp_path):
         assert len(got["matches"]) == 3 and all(np.array_equal(a, b) and a.dtype == np.int64 for a, b in zip(got["matches"], matches1))
         # phase 2: one fp32 buffer of 2 image slots x cap x (2 + 1 + 1 + 128) + 2 counts; phase 4: one int32 buffer of 2 pair slots
         assert got["collectives"] == [(torch.float32, 2 * cap * 132 + 2), (torch.int32, 2 + 2 * (2 * max(f["keypoints"].shape[0] for f in feats1)) * 2)], got["collectives"]
+
+
+def test_device_resident_tile_matching_equals_the_numpy_path():
+    """pipeline.TiledPairPipeline keeps the merged tile tables in HBM and matches from there (tile_matching.match_tile_pairs_batched_device);
+    the array it returns must be the one the numpy path (match_tile_pairs_batched = the reference's loop MB:414-460, batched) returns."""
+    import ctypes
+    build = importlib.import_module("deep-image-matching_amd.build")
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    tm = importlib.import_module("deep-image-matching_amd.tile_matching")
+    pl = importlib.import_module("deep-image-matching_amd.pipeline")
+    plugins = importlib.import_module("deep-image-matching_amd.plugins")
+    lib = ctypes.CDLL(str(build.build_emu()))
+    capi.install(lib, "cpu")
+    try:
+        general = {"tile_size": (96, 64), "tile_overlap": 0, "min_matches_per_tile": 1, "quality": "HIGH"}
+        ex = plugins.AlikedExtractor({"general": general, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 24,
+                                                                         "detection_threshold": 0.2, "nms_radius": 2, "allow_synthetic_weights": True}})
+        mt = plugins.LightGlueMatcher({"general": general, "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1,
+                                                                       "filter_threshold": 0.0, "allow_synthetic_weights": True}}, local_features="aliked")
+        rng = np.random.default_rng(22)
+        base = (rng.random((128 + 32, 192 + 32, 3)) * 255).astype(np.float32)
+        images = [np.ascontiguousarray(base[dy:dy + 128, dx:dx + 192]) for dy, dx in ((0, 0), (32, 32))]
+        pipe = pl.TiledPairPipeline(ex, mt, 0, 1, selection="GRID")
+        feats = pipe.extract_all(images)                       # numpy dicts; pipe._dev_feats = the same tables in "device" memory
+        # the device-returning merge equals the numpy-returning one
+        direct = ex._extract_by_tile(images[0])
+        assert all(np.array_equal(direct[k], feats[0][k]) for k in ("keypoints", "descriptors", "scores", "tile_idx"))
+        pairs = tm.select_tile_pairs("GRID", range(4), range(4)) + [(0, 3), (2, 1), (1, 1)]
+        want = tm.match_tile_pairs_batched(mt._ensure_pairs, feats[0], feats[1], pairs, "cpu", 3)
+        got = tm.match_tile_pairs_batched_device(mt._ensure_pairs, pipe._dev_feats[0], pipe._dev_feats[1], pairs, 3)
+        assert want.shape[0] > 0 and got.dtype == torch.int64 and np.array_equal(got.numpy(), want)
+        none = tm.match_tile_pairs_batched_device(mt._ensure_pairs, pipe._dev_feats[0], pipe._dev_feats[1], [], 3)
+        assert none.shape == (0, 2)
+    finally:
+        capi.install(None)
