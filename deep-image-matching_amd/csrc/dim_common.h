@@ -70,7 +70,7 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {  // round-to-
 // convert-and-subtract form the host-compiled test emulator uses): 4 instead of 6 VALU per pair of values.  Every VALU instruction
 // of the matrix-core kernels costs ~4 cycles of a SIMD that issues no MFMA meanwhile (round-4 counters: MFMA-busy + VALU-active ~ 1).
 __device__ __forceinline__ void split2_residual(float x0, float x1, unsigned h, float& r0, float& r1) {
-#if defined(__AMDGCN__)
+#if defined(__AMDGCN__) && !defined(DIM_SPLIT_NO_MIX)   // (DIM_SPLIT_NO_MIX: the pre-round-4 form, for A/B builds)
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
 #else
