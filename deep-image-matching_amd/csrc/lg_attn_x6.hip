@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
 
 // fp16x3: 16 KB of LDS and <= 128 VGPRs -> 4 workgroups per CU, so the 1024 workgroups of a 16-item batch
 // (16 query blocks x 4 heads x 16 items) run as ONE round on 256 CUs instead of 1.33 rounds at 3 per CU
-template <int MODE>
+// PROBE: the round-3 timing probes (dim_tune_set key 12) as a TEMPLATE parameter: as a run-time test around the score MFMAs they forced the
+// product kernel to materialise the zeroed score accumulator (16 v_mov per key tile; every VALU instruction is time)
+template <int MODE, int PROBE = 0>
 __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnArgs6 a) {
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, TILE_SLOTS = tile_slots(NPL), KSL = NPL * 256, NCP = TILE_SLOTS / 256;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
     // (probe 1 — timing only, results wrong: every second key tile of a cross launch runs WITHOUT its score MFMAs = the 25 % of the
     // launch's MFMAs a score tile shared by the two directions would not execute.  Every second TILE rather than every second
     // item: the XCD-aware mapping above sends the odd items to XCDs 4..7, which would idle while 0..3 set the launch time.)
-    if (!(a.probe == 1 && (kt & 32))) {
+    if (!(PROBE == 1 && (kt & 32))) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         u32x4 kf[NPL];
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
     // (probe 3 — timing only: the second direction of a shared score tile cannot keep its output across query blocks; per
     // 32-key tile the workgroup would write a 32 x (64 + m + l) partial record.  Every second tile writes a record of that size
     // here: the volume of one direction, spread over all XCDs.)
-    if (a.probe == 3 && (kt & 32)) {
+    if (PROBE == 3 && (kt & 32)) {
       float* pp = a.part + (((((size_t)item * 4 + head) * ((a.tiles + 1) >> 1) + (kt >> 6)) * (a.qblocks / a.splits) + qb) * 256 + t) * 8;
       *(float4*)pp = make_float4(oacc[0][0], oacc[0][1], oacc[0][2], oacc[0][3]);
       *(float4*)(pp + 4) = make_float4(oacc[1][0], oacc[1][1], oacc[1][2], oacc[1][3]);
@@ -352,7 +354,9 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
   dim3 grid((unsigned)(cdiv(a.groups, 8) * 8 * a.qblocks));  // whole rounds of 8 groups, one per XCD (surplus workgroups exit)
   if (dim_precision_mode() == 2) {
     if (!kv_ready) hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<2>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2>), grid, dim3(256), 0, s, a);
+    if (a.probe == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2, 1>), grid, dim3(256), 0, s, a);
+    else if (a.probe == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2, 3>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2>), grid, dim3(256), 0, s, a);
   } else {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<1>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<1>), grid, dim3(256), 0, s, a);
