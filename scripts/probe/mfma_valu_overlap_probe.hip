@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int periods) {
   for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 0.01f + i;
   const float m1 = 1.0001f, m2 = 0.0003f;
   // which workgroup of the CU am I?  the first 256 workgroups fill slot 0 of every CU, the next 256 slot 1 (dispatch order)
-  const bool second = (blockIdx.x >> 8) & 1;
+  const bool second = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 8) & 1)) != 0;   // scalar: a real branch, not EXEC masking of both paths
   auto mfmas = [&]() {
 #pragma unroll
     for (int i = 0; i < NM; ++i) c[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[i & 7], 0, 0, 0);
