@@ -57,6 +57,54 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int periods) {
   if (s == 12345.678f) out[0] = s;
 }
 
+// the same with 4 accumulators (<= 128 registers) and 4 workgroups per CU = 4 waves per SIMD: VAR 0 phased lockstep, 2 interleaved
+template <int VAR>
+__global__ __launch_bounds__(256, 4) void k4(float* out, int periods) {
+  f16x8 a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(threadIdx.x * 0.001f + e); b[e] = (_Float16)(e * 0.5f); }
+  f32x16 c[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 0.01f + i;
+  const float m1 = 1.0001f, m2 = 0.0003f;
+  for (int p = 0; p < periods; ++p) {
+    if (VAR == 0) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) c[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[i & 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i & 15] = __builtin_fmaf(v[i & 15], m1, m2);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        c[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c[i & 3], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NV / NM; ++j) v[(i * (NV / NM) + j) & 15] = __builtin_fmaf(v[(i * (NV / NM) + j) & 15], m1, m2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float s = 0;
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += c[i][r];
+  for (int i = 0; i < 16; ++i) s += v[i];
+  if (s == 12345.678f) out[0] = s;
+}
+template <int VAR>
+float run4(float* d, int periods) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k4<VAR>, dim3(1024), dim3(256), 0, 0, d, 10);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k4<VAR>, dim3(1024), dim3(256), 0, 0, d, periods);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms;
+}
+
 template <int VAR>
 float run(float* d, int periods) {
   hipEvent_t e0, e1;
@@ -79,5 +127,9 @@ int main() {
   float ms[5] = {run<0>(d, P), run<1>(d, P), run<2>(d, P), run<3>(d, P), run<4>(d, P)};
   for (int i = 0; i < 5; ++i)
     printf("{\"variant\": \"%s\", \"ns_per_period\": %.1f, \"mfma_per_period\": %d, \"valu_per_period\": %d}\n", names[i], ms[i] * 1e6 / P, i == 4 ? 0 : NM, i == 3 ? 0 : NV);
+  // 4 waves per SIMD (twice the work per SIMD and period: compare ns_per_period / 2 with the rows above)
+  const float a4 = run4<0>(d, P), b4 = run4<2>(d, P);
+  printf("{\"variant\": \"4 waves per SIMD, phased lockstep\", \"ns_per_period_per_2_waves\": %.1f}\n", a4 * 1e6 / P / 2);
+  printf("{\"variant\": \"4 waves per SIMD, interleaved in-wave\", \"ns_per_period_per_2_waves\": %.1f}\n", b4 * 1e6 / P / 2);
   return 0;
 }
