@@ -58,6 +58,10 @@ LG_GFLOP_PER_PAIR = 229.8         # 2048 x 2048, 9 layers, fixed work
 CONV1A_GFLOP_PER_IMAGE = 2 * 0.604   # Appendix B: 3x3, 1->64 @1024^2 (+ReLU), fused into the conv1b kernel
 CONV1B_GFLOP_PER_IMAGE = 2 * 38.655  # Appendix B: 3x3, 64->64 @1024^2 (+ReLU+pool)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+# What the matrix cores of an MI355X SUSTAIN on non-zero operands under the package power limit (scripts/probe/mfma_power_probe.hip,
+# profiles/r04_mfma_power_probe.jsonl: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD, operands distributed like the fp16x3 kernels' —
+# pieces of post-ReLU activations and of scaled weights; 1314 W, 1.65 GHz; 2450 with all-zero operands, 1580 with one ds_read_b128 per MFMA)
+SUSTAINED_FP16_MFMA_TFLOPS = 1727.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 X6_PASSES = 3                     # fp16 MFMA terms per fp32-accurate product step (lh, hl, hh)
 
@@ -600,7 +604,14 @@ def main():
                          "peak_note": "frac = ALGORITHMIC fp32 FLOP/s / dense fp16 MFMA peak (2500 TFLOP/s, the precision issued; the 3 "
                                       "split-precision passes are not credited, so frac <= 1/3); mfma_pipe_util = x 3 passes = what the "
                                       "MFMA-busy counter shows (profiles/r03_pmc_mfma_summary.txt)",
-                         "frac_of_fp32_mfma_peak": conv_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "frac_of_fp32_mfma_peak": conv_tflops / PEAK_FP32_MFMA_TFLOPS,
+                         "power_limited": {"sustained_peak": SUSTAINED_FP16_MFMA_TFLOPS, "mfma_issue_rate": conv_tflops * X6_PASSES,
+                                           "frac_of_sustained": conv_tflops * X6_PASSES / SUSTAINED_FP16_MFMA_TFLOPS,
+                                           "note": "CITED, not measured by this run: the rate back-to-back fp16 MFMAs sustain on every SIMD with operands "
+                                                   "like this kernel's, held at 1.65 GHz by the 1314 W package power limit "
+                                                   "(profiles/r04_mfma_power_probe.jsonl; 2450 TFLOP/s only with all-zero operands); mfma_issue_rate = "
+                                                   "achieved x 3 split passes"},
+                         "traffic": traffic,
                          "traffic_note": "CITED, not measured by this run: HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                          "of the same kernel (profiles/conv1b_hbm_bytes.json names the pass), scaled to this run's images per launch",
                          "isolated": {"note": "same kernel, same launches, timed again right after the timed region in two extraction-only batches "

@@ -44,13 +44,18 @@ constexpr int KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
 // bit 2 = no MFMAs, bit 3 = the weight fragments are loaded once, before the K loop.  Results are wrong by design.
 // KCH: K values per staged chunk.  32 everywhere in the product; 64 (prototype, dim_tune_set key 14, pipelined wide blocks only) halves the
 // number of barrier pairs and staging round trips per MFMA for 16 more prefetch registers and a 36-dword row stride (also conflict-free).
-template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32>
+// DB (prototype, dim_tune_set key 14 = 33, pipelined blocks only): the staged activation tile is double-buffered in LDS — chunk c + 1 is split and
+// written into the other half BEFORE the MFMAs of chunk c, one barrier per chunk instead of two, and the store -> barrier -> fragment-read
+// latency chain leaves the critical path.
+template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32, bool DB = false>
 __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, int by) {
   using S = SplitMma<MODE>;
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
   constexpr int NPL = S::NPL, NLD = BM * KCH / 1024;  // float4 loads per thread and chunk
   constexpr int KC = KCH, RS = KCH / 2 + 4, Q4_SHIFT = KCH == 32 ? 3 : 4, KSTEPS = KCH / 16;   // (shadow the file-level 32-wide constants)
   static_assert(KCH == 32 || (KCH == 64 && PIPE && PROBE == 0), "64-wide chunks exist for the pipelined K loop");
+  static_assert(!DB || (PIPE && KCH == 32 && PROBE == 0), "the double-buffered tile exists for the pipelined 32-wide K loop");
+  constexpr int ABUF = NPL * BM * RS;   // dwords of one staged activation tile
   constexpr int BN = 32 * NT * WN;
   static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
   static_assert(KV != 4 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4 && NT == 4), "the fused ffn exists for the fp16x3 64 x 512 block");
@@ -93,26 +98,28 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       ra[i] = *(const float4*)(src + (size_t)((PROBE & 1) ? ((m0 + row) & 2047) : min(m0 + row, rows - 1)) * ld + kk0 + q * 4);
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int abuf = 0) {
+    unsigned* const Ab = Ap + abuf * ABUF;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = t + 256 * i, row = idx >> Q4_SHIFT, q = idx & ((1 << Q4_SHIFT) - 1);
       unsigned p0[NPL], p1[NPL];
       S::split(ra[i].x, ra[i].y, S::act_scale(), p0);
       S::split(ra[i].z, ra[i].w, S::act_scale(), p1);
-      unsigned* d = &Ap[row * RS + q * 2];
+      unsigned* d = &Ab[row * RS + q * 2];
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) { d[pl * BM * RS] = p0[pl]; d[pl * BM * RS + 1] = p1[pl]; }
     }
   };
 
   // one 16-wide k-step of the chunk staged in LDS against the weight fragments fbk[n][plane]
-  auto mma_step = [&](int ks, const u32x4 (&fbk)[NT][NPL]) {
+  auto mma_step = [&](int ks, const u32x4 (&fbk)[NT][NPL], int abuf = 0) {
+    const unsigned* const Ab = Ap + abuf * ABUF;
     u32x4 fa[MT][NPL];
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * (32 * MT) + m * 32 + lx) * RS + ks * 8 + half * 4];
+      for (int m = 0; m < MT; ++m) fa[m][p] = *(const u32x4*)&Ab[(p * BM + wm * (32 * MT) + m * 32 + lx) * RS + ks * 8 + half * 4];
     // cross terms smallest first; the accumulators interleave so no MFMA waits on its predecessor
     if (PROBE & 4) {  // no MFMAs: keep the operands alive
 #pragma unroll
@@ -144,7 +151,29 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 
   load_chunk(0);
   const int k_end = (PROBE & 32) ? KC : a.K;   // probe bit 5: one K chunk only
-  if (PIPE) {
+  if (PIPE && DB) {
+    u32x4 fb0[NT][NPL], fb1[NT][NPL];
+    store_chunk(0);
+    load_chunk(min(KC, a.K - KC));
+    load_b(0, fb0);
+    __syncthreads();
+    int abuf = 0;
+    for (int k0 = 0; k0 < a.K; k0 += KC, abuf ^= 1) {
+      const int kst = k0 >> 4;
+      load_b(kst + 1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk(abuf ^ 1);                      // chunk c + 1 (held in ra since the previous iteration) into the other half
+      __builtin_amdgcn_sched_barrier(0);
+      load_chunk(min(k0 + 2 * KC, a.K - KC));     // chunk c + 2 (the tail harmlessly re-reads the last chunk)
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(0, fb0, abuf);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(min(kst + 2, KS - 2), fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(1, fb1, abuf);
+      __syncthreads();   // everyone has read this half and written the other
+    }
+  } else if (PIPE) {
     // Weight fragments double-buffered per k-STEP: the fragments of step s + 1 are requested before the MFMAs of step s, so the
     // (L2) latency of every request hides behind 3 * MT * NT MFMAs instead of standing in front of them twice per chunk, in the
     // registers the one-chunk-at-a-time form already used (2 steps x NT x NPL).  Vector-memory loads retire in order: the next
@@ -737,6 +766,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_qkv_kc64_kernel(GemmArgs a) {
   else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4, 0, true, 64>(a, Ap, by);
   else gemm_x6_body<2, 128, 2, 0, 4, 0, true, 64>(a, Ap, by);
 }
+// ---- prototypes with the activation tile double-buffered in LDS (dim_tune_set key 14 = 33) ----
+__global__ __launch_bounds__(256, 2) void gemm_x6_wide_db_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 2 * 128 * RS];
+  gemm_x6_body<2, 128, 2, 0, 4, 0, true, 32, true>(a, Ap, (int)blockIdx.y);
+}
+__global__ __launch_bounds__(256, 2) void gemm_x6_qkv_db_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 2 * 128 * RS];
+  const int by = (int)blockIdx.y;
+  if (by == a.kv_kblock) gemm_x6_body<2, 128, 2, 1, 4, 0, true, 32, true>(a, Ap, by);
+  else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4, 0, true, 32, true>(a, Ap, by);
+  else gemm_x6_body<2, 128, 2, 0, 4, 0, true, 32, true>(a, Ap, by);
+}
 // LightGlue's ffn.0 -> LayerNorm -> GELU -> ffn.3 (+ residual) in one kernel: 64 rows per workgroup, the hidden tensor stays on the CU
 constexpr int FFN_LDS_DWORDS = 2 * 64 * RS + 2048 + 512 + 4 * 3 * 4 * 64 * 4;
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_kernel(GemmArgs a) {
@@ -829,7 +870,8 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     if (a.kv_img != nullptr) {
       DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
       DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == (int)grid.y - 1, "gemm_x6: the K and V blocks must be the last two");
-      if (dim_gemm_kc() == 64 && a.K % 64 == 0) hipLaunchKernelGGL(gemm_x6_qkv_kc64_kernel, grid, dim3(256), 0, s, a);
+      if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_qkv_db_kernel, grid, dim3(256), 0, s, a);
+      else if (dim_gemm_kc() == 64 && a.K % 64 == 0) hipLaunchKernelGGL(gemm_x6_qkv_kc64_kernel, grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL(gemm_x6_qkv_kernel, grid, dim3(256), 0, s, a);
     } else switch (dim_gemm_probe()) {
       case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<1>), grid, dim3(256), 0, s, a); break;
@@ -844,7 +886,8 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
       case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<32>), grid, dim3(256), 0, s, a); break;
       case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<16>), grid, dim3(256), 0, s, a); break;
       default:
-        if (dim_gemm_kc() == 64 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(gemm_x6_wide_kc64_kernel, grid, dim3(256), 0, s, a);
+        if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_wide_db_kernel, grid, dim3(256), 0, s, a);
+        else if (dim_gemm_kc() == 64 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(gemm_x6_wide_kc64_kernel, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);
     }
   } else {

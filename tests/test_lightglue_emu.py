@@ -196,20 +196,22 @@ def test_swapping_the_images_transposes_the_result(emu_lib):
 
 
 def test_wide_gemm_blocks_with_64_wide_k_chunks_are_bit_identical(emu_lib):
-    """dim_tune_set(14, 64): the pipelined 128 x 256 GEMM block and the q|k|v kernel stage 64 instead of 32 K values per barrier pair
-    (a default-off prototype).  Same k-step order, same MFMA sequence per accumulator: every output bit for bit, with the large-batch
-    kernels forced (6 = 2) on two golden cases."""
+    """dim_tune_set(14, 64): the pipelined 128 x 256 GEMM block and the q|k|v kernel stage 64 instead of 32 K values per barrier pair;
+    dim_tune_set(14, 33): the staged activation tile is double-buffered in LDS, one barrier per chunk (default-off prototypes).  Same
+    k-step order, same MFMA sequence per accumulator: every output bit for bit, with the large-batch kernels forced (6 = 2) on two
+    golden cases."""
     for name in ("default", "fixed"):
         case = gc.LG_CASES[name]
         outs = []
         try:
             emu_lib.dim_tune_set(6, 2)
-            for kc in (32, 64):
+            for kc in (32, 64, 33):
                 emu_lib.dim_tune_set(14, kc)
                 out, ref = run_case(emu_lib, case)
                 compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
                 outs.append(out)
         finally:
             emu_lib.dim_tune_set(6, 1); emu_lib.dim_tune_set(14, 32)
-        a, b = outs
-        assert torch.equal(a["dense"], b["dense"]) and torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matching_scores0"], b["matching_scores0"]), name
+        a = outs[0]
+        for b in outs[1:]:
+            assert torch.equal(a["dense"], b["dense"]) and torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matching_scores0"], b["matching_scores0"]), name
