@@ -84,6 +84,22 @@ def build_hip(verbose: bool = False) -> Path:
     return out
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> Path:
+    """The same sources with extra -D flags -> lib/libdim_hip_<name>.so (measurement builds for scripts/: A/B of a code path that is a
+    compile-time choice, instrumented kernels).  Never loaded by the package."""
+    out = LIBDIR / f"libdim_hip_{name}.so"
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", *defines]
+    objs, changed = _compile_all(
+        PKG / "build" / f"hip_{name}", lambda s, o: [HIPCC, *flags, "-c", str(s), "-o", str(o)], _sources(), "hip" + " ".join(flags)
+    )
+    if changed or not out.exists():
+        LIBDIR.mkdir(exist_ok=True)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *map(str, objs)])
+    if verbose:
+        print("built", out)
+    return out
+
+
 def build_emu(verbose: bool = False) -> Path:
     """Host-clang build of the same sources against tests/hipemu (CPU tests only)."""
     emu = ROOT / "tests" / "hipemu"

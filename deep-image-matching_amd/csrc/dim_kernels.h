@@ -109,7 +109,7 @@ int dim_aliked_tile_rows();  // dim_tune_set key 10: tile rows (16 | 8) of ALIKE
 int dim_aliked_fuse_bn();   // dim_tune_set key 9: ALIKED folds BatchNorm + SELU into the consuming convolution's staging (default 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
 int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)
-int dim_gemm_kc();           // 32 (product); 64 = prototype: 64-wide K chunks in the pipelined wide GEMM blocks (dim_tune_set key 14)
+int dim_gemm_kc();           // dim_tune_set key 14: 32 (product); 64 / 33 = prototypes of the wide GEMM blocks, 36 = the fused feed-forward's previous K loop, 35 = timing probe
 int dim_gemm_probe();        // 0 (product); timing probes of the wide fp16x3 GEMM blocks (dim_tune_set key 13; gemm_x6.hip PROBE)
 int dim_attn_probe();        // 0 (product); 1 / 2 / 3: timing probes of cross attention (dim_tune_set key 12; lg_attn_x6.hip)
 int dim_fuse_ffn_ln();       // dim_tune_set key 11.  3 (default): LightGlue's whole feed-forward (ffn.0, LayerNorm, GELU, ffn.3, residual) is one kernel when the

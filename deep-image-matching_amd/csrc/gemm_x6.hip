@@ -44,10 +44,36 @@ constexpr int KC = 32, RS = 20;  // RS: row stride in dwords (40 bf16)
 // bit 2 = no MFMAs, bit 3 = the weight fragments are loaded once, before the K loop.  Results are wrong by design.
 // KCH: K values per staged chunk.  32 everywhere in the product; 64 (prototype, dim_tune_set key 14, pipelined wide blocks only) halves the
 // number of barrier pairs and staging round trips per MFMA for 16 more prefetch registers and a 36-dword row stride (also conflict-free).
+#ifdef DIM_FFN_TIMERS
+// Instrumented build only (build.build_variant("ffntime", ["-DDIM_FFN_TIMERS"]); scripts/gpu_ffn_phases.py): s_memtime stamps (100 MHz; gfx950 has
+// no SHADER_CYCLES register; the stamp's lgkmcnt(0) wait sits where a barrier or a consumed LDS read waits anyway) at the phase boundaries of the
+// fused feed-forward, summed over every wave of every workgroup.
+__device__ unsigned long long g_ffn_phase[24];
+__device__ __forceinline__ unsigned ft_now() {
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned v = (unsigned)__builtin_readcyclecounter();
+  __builtin_amdgcn_sched_barrier(0);
+  return v;
+}
+#define FT_DECL unsigned ft_ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned ft_last = ft_now(); const unsigned long long ft_t0 = __builtin_readcyclecounter(), ft_r0 = __builtin_amdgcn_s_memrealtime();
+#define FT_TICK(p) do { if (KV == 4) { const unsigned ft_n = ft_now(); ft_ph[p] += ft_n - ft_last; ft_last = ft_n; } } while (0)
+// one workgroup in 16 reports (230 000 waves adding to the same 18 words would stretch the kernel)
+#define FT_FLUSH() do { if (KV == 4 && (threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) { \
+    const unsigned long long ft_t1 = __builtin_readcyclecounter() - ft_t0, ft_r1 = __builtin_amdgcn_s_memrealtime() - ft_r0; \
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_ffn_phase[i], (unsigned long long)ft_ph[i]); \
+    atomicAdd(&g_ffn_phase[16], ft_t1); atomicAdd(&g_ffn_phase[17], 1ull); atomicAdd(&g_ffn_phase[18], ft_r1); } } while (0)
+#else
+#define FT_DECL
+#define FT_TICK(p)
+#define FT_FLUSH()
+#endif
 // DB (prototype, dim_tune_set key 14 = 33, pipelined blocks only): the staged activation tile is double-buffered in LDS — chunk c + 1 is split and
 // written into the other half BEFORE the MFMAs of chunk c, one barrier per chunk instead of two, and the store -> barrier -> fragment-read
 // latency chain leaves the critical path.
-template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32, bool DB = false>
+// ROLL (the fused feed-forward's K loop since round 4; dim_tune_set key 14 = 36 selects the previous one-k-step-at-a-time loop): the weight fragments of column tile n are
+// re-requested for the NEXT k-step right after this step's MFMAs on tile n have been issued — every request has the other tiles' MFMAs (3/4 of a
+// step) in front of its use, in the same 32 registers; the activation prefetch goes out between the chunk's two steps (requests retire in order).
+template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32, bool DB = false, bool ROLL = false>
 __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, int by) {
   using S = SplitMma<MODE>;
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
@@ -55,6 +81,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   constexpr int KC = KCH, RS = KCH / 2 + 4, Q4_SHIFT = KCH == 32 ? 3 : 4, KSTEPS = KCH / 16;   // (shadow the file-level 32-wide constants)
   static_assert(KCH == 32 || (KCH == 64 && PIPE && PROBE == 0), "64-wide chunks exist for the pipelined K loop");
   static_assert(!DB || (PIPE && KCH == 32 && PROBE == 0), "the double-buffered tile exists for the pipelined 32-wide K loop");
+  static_assert(!ROLL || ((KV == 3 || KV == 4) && !PIPE && (PROBE & ~1) == 0), "rolling fragment requests exist for the 64 x 512 blocks");
   constexpr int ABUF = NPL * BM * RS;   // dwords of one staged activation tile
   constexpr int BN = 32 * NT * WN;
   static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
@@ -84,6 +111,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  FT_DECL
   float4 ra[NLD];
   auto load_chunk = [&](int k0) {
     const float* src; int ld, kk0;
@@ -149,6 +177,28 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       for (int n = 0; n < NT; ++n) fbk[n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + kstep) * 2 + half) * 32 + lx];
   };
 
+  // ROLL: one k-step with the column tiles outermost; tile n's fragments are replaced by those of k-step `next` as soon as its MFMAs are issued
+  // (per accumulator the cross terms keep their order: lh, hl, hh of step s, then of step s + 1 — bit-identical results)
+  auto mma_roll = [&](int ks, u32x4 (&fbk)[NT][NPL], int next) {
+    u32x4 fa[MT][NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fa[m][p] = *(const u32x4*)&Ap[(p * BM + wm * (32 * MT) + m * 32 + lx) * RS + ks * 8 + half * 4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+      for (int tm = 0; tm < S::NT; ++tm)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][n] = kblk ? S::mma(fbk[n][S::tb(tm)], fa[m][S::ta(tm)], acc[m][n]) : S::mma(fa[m][S::ta(tm)], fbk[n][S::tb(tm)], acc[m][n]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) fbk[n][p] = Bf[((((size_t)p * NB + nb0 + n) * KS + next) * 2 + half) * 32 + lx];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   load_chunk(0);
   const int k_end = (PROBE & 32) ? KC : a.K;   // probe bit 5: one K chunk only
   if (PIPE && DB) {
@@ -206,10 +256,36 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       }
       __syncthreads();
     }
+  } else if (ROLL) {
+    // (rotated: the split + store of chunk c + 1 closes the iteration, so that the wait in front of it is sized in straight-line code — it
+    // leaves the eight fragment requests of the second step in flight; at a loop header the compiler waits for everything)
+    u32x4 fbr[NT][NPL];
+    load_b(0, fbr);
+    FT_TICK(13);
+    store_chunk();
+    FT_TICK(0);
+    for (int k0 = 0; k0 < a.K; k0 += KC) {
+      __syncthreads();
+      FT_TICK(1);
+      const int kst = k0 >> 4;
+      mma_roll(0, fbr, kst + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_chunk(min(k0 + KC, a.K - KC));
+      __builtin_amdgcn_sched_barrier(0);
+      mma_roll(1, fbr, min(kst + 2, KS - 1));   // the last step harmlessly re-reads its own fragments
+      FT_TICK(2);
+      __syncthreads();
+      FT_TICK(3);
+      if (k0 + KC < a.K) store_chunk();
+      FT_TICK(0);
+    }
   } else
   for (int k0 = 0; k0 < k_end; k0 += KC) {
+    if (k0 == 0) FT_TICK(13);
     store_chunk();
+    FT_TICK(0);
     __syncthreads();
+    FT_TICK(1);
     // Issue order matters: vector-memory loads retire in order, so the weight fragments this chunk's MFMAs
     // need are requested BEFORE the next chunk's activation prefetch — the wait in front of the first MFMA
     // then covers the (L2-resident) fragments only and the HBM latency of the prefetch hides behind the MFMAs.
@@ -232,7 +308,9 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       if ((lng || ffn) && ks == 1 && !(PROBE & 8)) load_b(kf0 + 1, fb[0]);
       mma_step(ks, fb[(lng || ffn) ? 0 : ks]);
     }
+    FT_TICK(2);
     __syncthreads();
+    FT_TICK(3);
   }
 
   if constexpr (ffn) {
@@ -290,6 +368,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     token_total(part, red + 256, rstd);
 #pragma unroll
     for (int m = 0; m < MT; ++m) rstd[m] = 1.0f / sqrtf(rstd[m] * (1.0f / 512.0f) + 1e-5f);
+    FT_TICK(4);
     // ---- normalise, GELU, range guard, split: tile (m, n) -> hq[m][n][plane][q] (q = which 8 registers = which k-step) ----
     u32x4 hq[MT][NT][NPL][2];
     float vmax = 0.0f;
@@ -319,6 +398,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
         }
       }
     sat_report(a.sat, vmax);
+    FT_TICK(5);
     // ---- ffn.3 over this wave's 128 hidden units (8 k-steps: step ks = tile n = ks / 2, registers 8 (ks & 1) ..), 64 output
     // columns per round; weight fragments one k-step ahead ----
     const u32x4* const Bf2 = (const u32x4*)a.B2x3;
@@ -366,6 +446,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
         __builtin_amdgcn_sched_barrier(0);
         { const u32x4 h0[NPL] = {hq[0][n][0][1], hq[0][n][1][1]}, h1[NPL] = {hq[1][n][0][1], hq[1][n][1][1]}; step2(h0, h1, fb2); }
       }
+      FT_TICK(6);
       // the residual of the tile this wave will own (tile wn: rows 32 (wn >> 1) .., columns 64 grp + 32 (wn & 1) ..), requested
       // before the exchange so that its latency hides behind it
       const int ocol = 64 * grp + 32 * (wn & 1) + lx;
@@ -386,7 +467,9 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
             *(float4*)(xbuf + ((((t4 * 3 + src) * 4 + rq) * 64 + lane) << 2)) =
                 make_float4(acc2[t4 >> 1][t4 & 1][4 * rq], acc2[t4 >> 1][t4 & 1][4 * rq + 1], acc2[t4 >> 1][t4 & 1][4 * rq + 2], acc2[t4 >> 1][t4 & 1][4 * rq + 3]);
         }
+      FT_TICK(7);
       __syncthreads();
+      FT_TICK(8);
       float own[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -410,9 +493,12 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
         const int k = (r & 3) + 8 * (r >> 2);
         if (orow + k < rows) buf_store_f32_s(Cr, obase, goff + (unsigned)k * (unsigned)a.ldc * 4u, v);
       }
+      FT_TICK(9);
       __syncthreads();   // the exchange buffer is rewritten by the next round
+      FT_TICK(10);
     }
     sat_report(a.sat2, vmax2);
+    FT_FLUSH();
     return;
   }
 
@@ -786,7 +872,23 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_kernel(GemmArgs a) {
   for (int i = threadIdx.x; i < 512; i += 256) {
     prm[i] = a.inv_ch[i]; prm[512 + i] = a.bias[i]; prm[1024 + i] = a.ln_gamma[i]; prm[1536 + i] = a.ln_beta[i];
   }   // (visible to every wave after the K loop's barriers)
-  gemm_x6_body<2, 64, 4, 4, 4, 0, false>(a, Ap, 0);   // (the k-step-pipelined loop needs 32 more registers here: measured slower, 613 vs 592 us)
+  gemm_x6_body<2, 64, 4, 4, 4, 0, false, 32, false, true>(a, Ap, 0);   // rolling fragment requests (round 4: 593 -> 576 us; the k-step-pipelined
+}                                                                       // loop needs 32 more registers here: measured slower, 613 vs 592 us)
+__global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_step_kernel(GemmArgs a) {   // round 3's loop (one k-step's fragments at a time), kept for A/B: dim_tune_set(14, 36)
+  __shared__ unsigned Ap[FFN_LDS_DWORDS];
+  float* const prm = (float*)(Ap + 2 * 64 * RS);
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    prm[i] = a.inv_ch[i]; prm[512 + i] = a.bias[i]; prm[1024 + i] = a.ln_gamma[i]; prm[1536 + i] = a.ln_beta[i];
+  }
+  gemm_x6_body<2, 64, 4, 4, 4, 0, false>(a, Ap, 0);
+}
+__global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_roll_probe_kernel(GemmArgs a) {   // timing probe (14 = 35): activations from 2048 cached rows, results wrong
+  __shared__ unsigned Ap[FFN_LDS_DWORDS];
+  float* const prm = (float*)(Ap + 2 * 64 * RS);
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    prm[i] = a.inv_ch[i]; prm[512 + i] = a.bias[i]; prm[1024 + i] = a.ln_gamma[i]; prm[1536 + i] = a.ln_beta[i];
+  }
+  gemm_x6_body<2, 64, 4, 4, 4, 1, false, 32, false, true>(a, Ap, 0);
 }
 // LightGlue's q|k|v projection in ONE launch: blockIdx.y selects the column block and with it the code path (plain fp32 /
 // transposed K image / V image — three inlined bodies, one register allocation each), so that the 2 or 3 column blocks of
@@ -837,7 +939,9 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     DIM_REQUIRE(a.split_mode == 2 && a.N == 512 && a.n_pad == 512 && a.K % KC == 0 && a.ln_beta && a.bias && a.bias2 && a.inv_ch2 && a.R && a.C && a.relu == 0 &&
                 a.kv_img == nullptr && a.ldr == a.ldc && a.strideR == a.strideC,
                 "gemm_x6: the fused feed-forward needs the fp16x3 512 -> 256 shapes, a residual laid out like the output and both bias vectors");
-    hipLaunchKernelGGL(gemm_x6_ffn_fused_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    if (dim_gemm_kc() == 35) hipLaunchKernelGGL(gemm_x6_ffn_fused_roll_probe_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    else if (dim_gemm_kc() == 36) hipLaunchKernelGGL(gemm_x6_ffn_fused_step_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gemm_x6_ffn_fused_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
     DIM_LAUNCH_CHECK();
     return 0;
   }
@@ -952,3 +1056,15 @@ void split_weights(const float* w_kn, int K, int N, int n_pad, int mode, unsigne
       }
     }
 }
+
+#ifdef DIM_FFN_TIMERS
+// instrumented build only: [0..15] summed s_memtime ticks (100 MHz) per phase over all waves, [16] the same for the whole wave, [17] waves that reported (one workgroup in 16), [18] s_memrealtime ticks (100 MHz) for the whole wave
+extern "C" int dim_ffn_phase_read(unsigned long long* host24, int reset) {
+  DIM_HIP(hipMemcpyFromSymbol(host24, HIP_SYMBOL(g_ffn_phase), 24 * sizeof(unsigned long long)));
+  if (reset) {
+    const unsigned long long z[24] = {};
+    DIM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ffn_phase), z, sizeof(z)));
+  }
+  return 0;
+}
+#endif
