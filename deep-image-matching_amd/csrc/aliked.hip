@@ -595,21 +595,22 @@ __global__ __launch_bounds__(256) void al_sddh_patches_kernel(AlFeat F, const fl
     dst[(lane * 2 + 1) * 9 + c] = v.y;
   }
 }
-// wave per keypoint: offsets = clamp(W2 * selu(hidden) + b2), then 16 bilinear samples of the normalised feature map ->
-// feats [kpt][16][128]; the 8 cells of two samples are in flight together
+// wave per keypoint: offsets = clamp(W2 * selu(hidden) + b2), then M (16: aliked-n16 / n16rot, 32: aliked-n32) bilinear samples of the
+// normalised feature map -> feats [kpt][M][128]; the 8 cells of two samples are in flight together
+template <int M>
 __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const float* __restrict__ kpts_norm,
                                                              const int* __restrict__ n_kpts, const float* __restrict__ hidden,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
                                                              float* __restrict__ feats, int H, int W, int pad_t, int pad_l, int capacity) {
-  __shared__ float offs[4][32];
+  __shared__ float offs[4][2 * M];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wv, b = blockIdx.y;
   const bool live = i < n_kpts[b];
   const size_t k = (size_t)b * capacity + (live ? i : 0);
   const float max_off = (float)max(H, W) / 4.0f;
-  if (lane < 32) {  // offset_conv.2 (1x1, 32->32) on selu(hidden); w2 is [in][out]
+  if (lane < 2 * M) {  // offset_conv.2 (1x1, 2M -> 2M) on selu(hidden); w2 is [in][out]
     float o = b2[lane];
-    for (int c = 0; c < 32; ++c) o = fmaf(selu_(hidden[k * 32 + c]), w2[c * 32 + lane], o);
+    for (int c = 0; c < 2 * M; ++c) o = fmaf(selu_(hidden[k * (2 * M) + c]), w2[c * (2 * M) + lane], o);
     offs[wv][lane] = fminf(fmaxf(o, -max_off), max_off);
   }
   __syncthreads();
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const flo
   const float wx = (float)(W - 1), wy = (float)(H - 1);
   const float kwx = (kpts_norm[k * 2] / 2.f + 0.5f) * wx, kwy = (kpts_norm[k * 2 + 1] / 2.f + 0.5f) * wy;
   constexpr int SB = 2;   // samples per round: 8 cells in flight (104 VGPRs), 3 waves per SIMD
-  for (int p0 = 0; p0 < 16; p0 += SB) {
+  for (int p0 = 0; p0 < M; p0 += SB) {
     FeatCell cell[SB][4];
     float wts[SB][4];
     bool in[SB][4];
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const flo
     for (int j = 0; j < SB; ++j) {
       const int p = p0 + j;
       // offset[:, :, 0, 0].view(N, 2, M): channel p = x offset, channel M + p = y offset (ALN:540)
-      const float gx = 2.0f * (kwx + offs[wv][p]) / wx - 1.f, gy = 2.0f * (kwy + offs[wv][16 + p]) / wy - 1.f;
+      const float gx = 2.0f * (kwx + offs[wv][p]) / wx - 1.f, gy = 2.0f * (kwy + offs[wv][M + p]) / wy - 1.f;
       const float ix = ((gx + 1.f) / 2.f) * wx, iy = ((gy + 1.f) / 2.f) * wy;
       const float fx = floorf(ix), fy = floorf(iy);
       const int xa = (int)fx, ya = (int)fy;
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const flo
         const float2 v = feat_finish(cell[j][c], w1r, lane);
         if (in[j][c]) { o0 += v.x * wts[j][c]; o1 += v.y * wts[j][c]; }
       }
-      *(float2*)(feats + (k * 16 + p0 + j) * 128 + lane * 2) = make_float2(o0, o1);
+      *(float2*)(feats + (k * M + p0 + j) * 128 + lane * 2) = make_float2(o0, o1);
     }
   }
 }
@@ -803,8 +804,10 @@ int launch_al_sddh_patches(const AlFeat& F, const float* kpts_norm, const int* n
   return 0;
 }
 int launch_al_sddh_sample(const AlFeat& F, const float* kpts_norm, const int* n_kpts, const float* off_hidden, const float* w2,
-                          const float* b2, float* feats, int batch, int H, int W, int pad_t, int pad_l, int capacity, hipStream_t s) {
-  hipLaunchKernelGGL(al_sddh_sample_kernel, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, off_hidden, w2, b2, feats, H, W, pad_t, pad_l, capacity);
+                          const float* b2, float* feats, int M, int batch, int H, int W, int pad_t, int pad_l, int capacity, hipStream_t s) {
+  DIM_REQUIRE(M == 16 || M == 32, "al_sddh_sample: M = %d sample positions (16 or 32)", M);
+  if (M == 16) hipLaunchKernelGGL(al_sddh_sample_kernel<16>, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, off_hidden, w2, b2, feats, H, W, pad_t, pad_l, capacity);
+  else hipLaunchKernelGGL(al_sddh_sample_kernel<32>, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, off_hidden, w2, b2, feats, H, W, pad_t, pad_l, capacity);
   DIM_LAUNCH_CHECK();
   return 0;
 }

@@ -106,8 +106,9 @@ void dim_aliked_destroy(dim_aliked* h) {
 int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg, int max_batch, int max_h, int max_w,
                       int capacity, dim_aliked** out) {
   DIM_REQUIRE(w && cfg && out, "dim_aliked_create: null argument");
-  DIM_REQUIRE(cfg->c1 == 16 && cfg->c2 == 32 && cfg->c3 == 64 && cfg->c4 == 128 && cfg->dim == 128 && cfg->K == 3 && cfg->M == 16,
-              "dim_aliked_create: only the aliked-n16 / aliked-n16rot geometry (16,32,64,128,128,3,16) is built in this round");
+  DIM_REQUIRE(cfg->c1 == 16 && cfg->c2 == 32 && cfg->c3 == 64 && cfg->c4 == 128 && cfg->dim == 128 && cfg->K == 3 && (cfg->M == 16 || cfg->M == 32),
+              "dim_aliked_create: the aliked-n16 / n16rot / n32 geometries (16,32,64,128,128,3,16|32) are built; aliked-t16 is not");
+  const int M = cfg->M, M2 = 2 * cfg->M;   // SDDH sample positions; offset channels (ALN:503-519)
   DIM_REQUIRE(cfg->detection_threshold > 0, "dim_aliked_create: detection_threshold must be > 0 (top-k-only mode not built)");
   DIM_REQUIRE(cfg->nms_radius >= 1 && cfg->nms_radius <= 6, "dim_aliked_create: nms_radius %d", cfg->nms_radius);
   DIM_REQUIRE(capacity > 0 && capacity <= 4096 && cfg->max_num_keypoints <= capacity, "dim_aliked_create: capacity %d (<= 4096) must cover max_num_keypoints %d", capacity, cfg->max_num_keypoints);
@@ -145,11 +146,11 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
     AL_TRY(upload_x3g(h, &h->g_hc2, kn(w->conv2, 32, 32, 1).data(), 32, 32)); AL_TRY(upload_x3g(h, &h->g_hc3, kn(w->conv3, 32, 64, 1).data(), 64, 32));
     AL_TRY(upload_x3g(h, &h->g_hc4, kn(w->conv4, 32, 128, 1).data(), 128, 32));
     AL_TRY(upload_x3g(h, &h->g_sf, kn(w->desc_sf, 128, 128, 1).data(), 128, 128));
-    AL_TRY(upload_x3g(h, &h->g_agg, w->desc_agg, 2048, 128));
-    std::vector<float> o0((size_t)1152 * 32);
-    for (int co = 0; co < 32; ++co)
-      for (int k = 0; k < 1152; ++k) o0[(size_t)k * 32 + co] = w->desc_off0_w[(size_t)co * 1152 + k];
-    AL_TRY(upload_x3g(h, &h->g_o0, o0.data(), 1152, 32));
+    AL_TRY(upload_x3g(h, &h->g_agg, w->desc_agg, M * 128, 128));
+    std::vector<float> o0((size_t)1152 * M2);
+    for (int co = 0; co < M2; ++co)
+      for (int k = 0; k < 1152; ++k) o0[(size_t)k * M2 + co] = w->desc_off0_w[(size_t)co * 1152 + k];
+    AL_TRY(upload_x3g(h, &h->g_o0, o0.data(), 1152, M2));
   }
   {
     const std::vector<float> w1 = relayout(w->conv1, 32, 16, 1, 16, 32), ws0 = relayout(w->score0, 8, 128, 1, 128, 8);
@@ -169,14 +170,14 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
   AL_TRY(upload(h, &h->hc3, relayout(w->conv3, 32, 64, 1, 64, 32))); AL_TRY(upload(h, &h->hc4, relayout(w->conv4, 32, 128, 1, 128, 32)));
   AL_TRY(upload(h, &h->sh0, relayout(w->score0, 8, 128, 1, 128, 8))); AL_TRY(upload(h, &h->sh2, relayout(w->score2, 4, 8, 3, 8, 4)));
   AL_TRY(upload(h, &h->sh4, relayout(w->score4, 4, 4, 3, 4, 4))); AL_TRY(upload(h, &h->sh6, relayout(w->score6, 1, 4, 3, 4, 4)));
-  {  // SDDH: offset_conv.0 (32,128,3,3) -> GEMM operand [ci*9+tap][32]; offset_conv.2 (32,32,1,1) -> [in][out]
-    std::vector<float> o0((size_t)1152 * 32);
-    for (int co = 0; co < 32; ++co)
-      for (int k = 0; k < 1152; ++k) o0[(size_t)k * 32 + co] = w->desc_off0_w[(size_t)co * 1152 + k];
-    AL_TRY(upload(h, &h->dh_o0_w, o0)); AL_TRY(upload(h, &h->dh_o0_b, padvec(w->desc_off0_b, 32, 32)));
-    AL_TRY(upload(h, &h->dh_o2_w, relayout(w->desc_off2_w, 32, 32, 1, 32, 32))); AL_TRY(upload(h, &h->dh_o2_b, padvec(w->desc_off2_b, 32, 32)));
+  {  // SDDH: offset_conv.0 (2M,128,3,3) -> GEMM operand [ci*9+tap][2M]; offset_conv.2 (2M,2M,1,1) -> [in][out]
+    std::vector<float> o0((size_t)1152 * M2);
+    for (int co = 0; co < M2; ++co)
+      for (int k = 0; k < 1152; ++k) o0[(size_t)k * M2 + co] = w->desc_off0_w[(size_t)co * 1152 + k];
+    AL_TRY(upload(h, &h->dh_o0_w, o0)); AL_TRY(upload(h, &h->dh_o0_b, padvec(w->desc_off0_b, M2, M2)));
+    AL_TRY(upload(h, &h->dh_o2_w, relayout(w->desc_off2_w, M2, M2, 1, M2, M2))); AL_TRY(upload(h, &h->dh_o2_b, padvec(w->desc_off2_b, M2, M2)));
     AL_TRY(upload(h, &h->dh_sf, relayout(w->desc_sf, 128, 128, 1, 128, 128)));
-    AL_TRY(upload(h, &h->dh_agg, padvec(w->desc_agg, 16 * 128 * 128, 16 * 128 * 128)));  // [p][c][d] == GEMM operand [p*128+c][d]
+    AL_TRY(upload(h, &h->dh_agg, padvec(w->desc_agg, M * 128 * 128, M * 128 * 128)));  // [p][c][d] == GEMM operand [p*128+c][d]
   }
   const size_t B = max_batch;
   const size_t Hp = ((size_t)max_h + 31) / 32 * 32, Wp = ((size_t)max_w + 31) / 32 * 32, NP = Hp * Wp, cap = capacity;
@@ -192,8 +193,8 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
   AL_TRY(dev_alloc(h, &h->cand_score, B * NP)); AL_TRY(dev_alloc(h, &h->cand_idx, B * NP)); AL_TRY(dev_alloc(h, &h->rowcount, B * Hp));
   AL_TRY(dev_alloc(h, &h->rowoff, B * Hp)); AL_TRY(dev_alloc(h, &h->ncand, B)); AL_TRY(dev_alloc(h, &h->kpts_px, B * cap * 2));
   AL_TRY(dev_alloc(h, &h->sc_tmp, B * cap)); AL_TRY(dev_alloc(h, &h->kpts_norm, B * cap * 2)); AL_TRY(dev_alloc(h, &h->kscore, B * cap));
-  AL_TRY(dev_alloc(h, &h->patches, B * cap * 1152)); AL_TRY(dev_alloc(h, &h->hidden, B * cap * 32)); AL_TRY(dev_alloc(h, &h->feats, B * cap * 2048));
-  AL_TRY(dev_alloc(h, &h->feats2, B * cap * 2048)); AL_TRY(dev_alloc(h, &h->bn_alpha, 2 * B * 128)); AL_TRY(dev_alloc(h, &h->bn_beta, 2 * B * 128));   // two slots: a conv's input and output BatchNorm
+  AL_TRY(dev_alloc(h, &h->patches, B * cap * 1152)); AL_TRY(dev_alloc(h, &h->hidden, B * cap * M2)); AL_TRY(dev_alloc(h, &h->feats, B * cap * M * 128));
+  AL_TRY(dev_alloc(h, &h->feats2, B * cap * M * 128)); AL_TRY(dev_alloc(h, &h->bn_alpha, 2 * B * 128)); AL_TRY(dev_alloc(h, &h->bn_beta, 2 * B * 128));   // two slots: a conv's input and output BatchNorm
   AL_TRY(dev_alloc(h, &h->mean, B)); AL_TRY(dev_alloc(h, &h->thr_eff, B)); AL_TRY(dev_alloc(h, &h->partial, B * 256 * 128 * 2));
   AL_TRY(dev_alloc(h, &h->tile_partial, al_convx3_partial_doubles((int)B, (int)Hp, (int)Wp)));
 #undef AL_TRY
@@ -335,24 +336,25 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   AL_RUN(launch_al_dkd_refine(h->score, h->kpts_px, n_kpts_dev, h->kpts_norm, scores_dev, h->kscore, kpts_xy_dev, batch, H, W, cap, r, s));
   // SDDH (ALN:503-558)
   AL_RUN(launch_al_sddh_patches(F, h->kpts_norm, n_kpts_dev, h->patches, batch, H, W, pad_t, pad_l, cap, s));
+  const int M = h->cfg.M, M2 = 2 * M;
   {
     GemmArgs g;
-    g.A0 = h->patches; g.lda0 = 1152; g.strideA0 = (long long)cap * 1152; g.B = h->dh_o0_w; g.ldb = 32; g.bias = h->dh_o0_b;
-    g.C = h->hidden; g.ldc = 32; g.strideC = (long long)cap * 32; g.M = cap; g.N = 32; g.K = 1152; g.rows = n_kpts_dev;
+    g.A0 = h->patches; g.lda0 = 1152; g.strideA0 = (long long)cap * 1152; g.B = h->dh_o0_w; g.ldb = M2; g.bias = h->dh_o0_b;
+    g.C = h->hidden; g.ldc = M2; g.strideC = (long long)cap * M2; g.M = cap; g.N = M2; g.K = 1152; g.rows = n_kpts_dev;
     AL_RUN(gemm(g, h->g_o0, batch));
   }
-  AL_RUN(launch_al_sddh_sample(F, h->kpts_norm, n_kpts_dev, h->hidden, h->dh_o2_w, h->dh_o2_b, h->feats, batch, H, W, pad_t, pad_l, cap, s));
+  AL_RUN(launch_al_sddh_sample(F, h->kpts_norm, n_kpts_dev, h->hidden, h->dh_o2_w, h->dh_o2_b, h->feats, M, batch, H, W, pad_t, pad_l, cap, s));
   {
-    GemmArgs g;  // sf_conv 1x1 (128 -> 128) + SELU over the 16 sampled positions of every keypoint
-    g.A0 = h->feats; g.lda0 = 128; g.strideA0 = (long long)cap * 2048; g.B = h->dh_sf; g.ldb = 128;
-    g.C = h->feats2; g.ldc = 128; g.strideC = (long long)cap * 2048; g.M = cap * 16; g.N = 128; g.K = 128;
-    g.rows = n_kpts_dev; g.rows_scale = 16; g.relu = 2;
+    GemmArgs g;  // sf_conv 1x1 (128 -> 128) + SELU over the M sampled positions of every keypoint
+    g.A0 = h->feats; g.lda0 = 128; g.strideA0 = (long long)cap * M * 128; g.B = h->dh_sf; g.ldb = 128;
+    g.C = h->feats2; g.ldc = 128; g.strideC = (long long)cap * M * 128; g.M = cap * M; g.N = 128; g.K = 128;
+    g.rows = n_kpts_dev; g.rows_scale = M; g.relu = 2;
     AL_RUN(gemm(g, h->g_sf, batch));
   }
   {
     GemmArgs g;  // einsum("ncp,pcd->nd") with agg_weights [p][c][d] == [n][p*128+c] x [p*128+c][d]
-    g.A0 = h->feats2; g.lda0 = 2048; g.strideA0 = (long long)cap * 2048; g.B = h->dh_agg; g.ldb = 128;
-    g.C = desc_dev; g.ldc = 128; g.strideC = (long long)cap * 128; g.M = cap; g.N = 128; g.K = 2048; g.rows = n_kpts_dev;
+    g.A0 = h->feats2; g.lda0 = M * 128; g.strideA0 = (long long)cap * M * 128; g.B = h->dh_agg; g.ldb = 128;
+    g.C = desc_dev; g.ldc = 128; g.strideC = (long long)cap * 128; g.M = cap; g.N = 128; g.K = M * 128; g.rows = n_kpts_dev;
     AL_RUN(gemm(g, h->g_agg, batch));
   }
   AL_RUN(launch_al_normalize_rows(desc_dev, n_kpts_dev, batch, cap, 128, s));

@@ -40,7 +40,7 @@ struct AlFeat { const float *x1, *f2, *f3, *f4, *w1; int Hp, Wp; };
 int launch_al_sddh_patches(const AlFeat& F, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H, int W,
                            int pad_t, int pad_l, int capacity, hipStream_t s);
 int launch_al_sddh_sample(const AlFeat& F, const float* kpts_norm, const int* n_kpts, const float* off_hidden, const float* w2,
-                          const float* b2, float* feats, int batch, int H, int W, int pad_t, int pad_l, int capacity, hipStream_t s);
+                          const float* b2, float* feats, int M, int batch, int H, int W, int pad_t, int pad_l, int capacity, hipStream_t s);
 int launch_al_normalize_rows(float* x, const int* n_rows, int batch, int capacity, int C, hipStream_t s);
 int launch_al_mean(const float* x, int batch, int n, double* partial, float* mean, hipStream_t s);
 int launch_al_pick_threshold(const int* ncand, const float* mean, float thr, float* thr_out, int batch, hipStream_t s);

@@ -176,7 +176,7 @@ typedef struct dim_aliked_weights {
 
 /* ALIKED._default_conf (ALN:562-567) + the geometry row of ALIKED.cfgs (ALN:573-579). */
 typedef struct dim_aliked_config {
-  int c1, c2, c3, c4, dim, K, M;   /* aliked-n16 / n16rot: 16,32,64,128,128,3,16 */
+  int c1, c2, c3, c4, dim, K, M;   /* ALN:573-579: aliked-n16 / n16rot 16,32,64,128,128,3,16; aliked-n32 the same with M = 32 */
   int max_num_keypoints;           /* n_limit of DKD; -1 = capacity */
   double detection_threshold;      /* > 0 */
   int nms_radius;

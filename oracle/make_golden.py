@@ -174,17 +174,19 @@ def main_aliked():
         np.savez_compressed(out_dir / f"al_{name}.npz", keypoints=ref["keypoints"][0].numpy(),
                             descriptors=ref["descriptors"][0].t().contiguous().numpy(), scores=ref["keypoint_scores"][0].numpy())
         print(f"al_{name}: N={ref['keypoints'].shape[1]} ok (oracle == reference, bit-exact)")
-    # also pin with the REAL aliked-n16rot.pth that ships inside the reference tree (not copied; not a golden)
-    real = REF / "ALIKED/models/aliked-n16rot.pth"
-    if real.exists():
-        sd = {k: v for k, v in torch.load(str(real), map_location="cpu").items()}
-        cfg = gc.AL_CASES["rgb_pad"]["cfg"]
-        img = gc.al_image(gc.AL_CASES["rgb_pad"])
-        with torch.no_grad():
-            ref = reference_aliked(sd, cfg)({"image": img})
-        mine = aliked_ref.aliked_forward(img, sd, cfg)
-        assert torch.equal(ref["keypoints"][0], mine["keypoints"]) and torch.equal(ref["keypoint_scores"][0], mine["scores"])
-        print(f"aliked real weights: N={mine['keypoints'].shape[0]} ok (oracle == reference, bit-exact)")
+    # also pin with the REAL checkpoints that ship inside the reference tree (not goldens; tests/assets holds byte copies for the HIP tests)
+    for model, case_name in (("aliked-n16rot", "rgb_pad"), ("aliked-n32", "n32")):
+        real = REF / f"ALIKED/models/{model}.pth"
+        if real.exists():
+            sd = {k: v for k, v in torch.load(str(real), map_location="cpu").items()}
+            cfg = {**gc.AL_CASES[case_name]["cfg"], "model_name": model}
+            img = gc.al_image(gc.AL_CASES[case_name])
+            with torch.no_grad():
+                ref = reference_aliked(sd, cfg)({"image": img})
+            mine = aliked_ref.aliked_forward(img, sd, cfg)
+            assert torch.equal(ref["keypoints"][0], mine["keypoints"]) and torch.equal(ref["keypoint_scores"][0], mine["scores"])
+            assert torch.equal(ref["descriptors"][0].t(), mine["descriptors"])
+            print(f"{model} real weights: N={mine['keypoints'].shape[0]} ok (oracle == reference, bit-exact)")
 
 
 def reference_tile_helpers():

@@ -116,11 +116,14 @@ AL_CASES = {
     # gray input repeated to RGB, n_limit binding (more maxima than max_num_keypoints), radius 3
     "gray_limit": {"seed": 22, "H": 64, "W": 96, "C": 1, "wseed": 8,
                    "cfg": {"model_name": "aliked-n16rot", "max_num_keypoints": 60, "detection_threshold": 0.2, "nms_radius": 3}},
+    # aliked-n32 (ALN:577): 32 instead of 16 deformable sample positions in the descriptor head
+    "n32": {"seed": 23, "H": 72, "W": 88, "C": 3, "wseed": 9,
+            "cfg": {"model_name": "aliked-n32", "max_num_keypoints": 300, "detection_threshold": 0.2, "nms_radius": 2}},
 }
 
 
 def al_weights(case):
-    return weights.synthetic_aliked_state_dict(case["wseed"])
+    return weights.synthetic_aliked_state_dict(case["wseed"], case["cfg"]["model_name"])
 
 
 def al_image(case) -> torch.Tensor:
