@@ -71,6 +71,7 @@ class AlikedHIP:
             w.bn_weight[i] = host(b + ".weight")
             w.bn_bias[i] = host(b + ".bias")
         geo = ALIKED_CFGS[self.cfg["model_name"]]
+        self.dim = int(geo[4])     # descriptor length: 128, or 64 for aliked-t16
         mk = int(self.cfg["max_num_keypoints"])
         self.capacity = int(capacity if capacity is not None else (mk if mk > 0 else 4096))
         c = _AlConfig(*geo, mk, float(self.cfg["detection_threshold"]), int(self.cfg["nms_radius"]))
@@ -100,13 +101,13 @@ class AlikedHIP:
     @torch.no_grad()
     def extract_batch(self, images: torch.Tensor):
         """images [B,H,W,C] float32 in [0,1] (HWC, C = 3 or 1) on self.device -> device tensors
-        (kpts [B,cap,2], scores [B,cap], desc [B,cap,128], n [B] int32); no host sync."""
+        (kpts [B,cap,2], scores [B,cap], desc [B,cap,dim], n [B] int32); no host sync."""
         assert images.dim() == 4 and images.dtype == torch.float32 and images.is_contiguous()
         B, H, W, C = images.shape
         dev = images.device
         kp = torch.empty(B, self.capacity, 2, dtype=torch.float32, device=dev)
         sc = torch.empty(B, self.capacity, dtype=torch.float32, device=dev)
-        de = torch.empty(B, self.capacity, 128, dtype=torch.float32, device=dev)
+        de = torch.empty(B, self.capacity, self.dim, dtype=torch.float32, device=dev)
         n = torch.zeros(B, dtype=torch.int32, device=dev)
         with self._ctx():
             capi.check(self.lib, self.lib.dim_aliked_extract(self._h, capi.ptr(images), B, H, W, C, capi.ptr(kp), capi.ptr(sc), capi.ptr(de),
@@ -123,7 +124,7 @@ class AlikedHIP:
     @torch.no_grad()
     def __call__(self, image: torch.Tensor) -> dict:
         """image [1,C,H,W] (the reference's input).  Returns DIM's feature dict for one image (device
-        tensors): keypoints (N,2), descriptors (128,N), scores (N,) (= dispersities, Q8)."""
+        tensors): keypoints (N,2), descriptors (dim,N), scores (N,) (= dispersities, Q8)."""
         img = image[0].permute(1, 2, 0).contiguous().to(self.device, torch.float32)[None]
         kp, sc, de, n = self.extract_batch_guarded(img)
         k = int(n[0].item())
@@ -136,5 +137,5 @@ class AlikedHIP:
         v = [ctypes.c_int() for _ in range(4)]
         capi.check(self.lib, self.lib.dim_aliked_debug_buffers(self._h, ctypes.byref(p1), ctypes.byref(p2), *[ctypes.byref(x) for x in v]))
         hp, wp, pt, pl = [x.value for x in v]
-        return {"x1234": _copy_from(self.lib, p1.value, (batch, hp, wp, 128), self.device), "pad": (pt, pl), "hp_wp": (hp, wp),
+        return {"x1234": _copy_from(self.lib, p1.value, (batch, hp, wp, self.dim), self.device), "pad": (pt, pl), "hp_wp": (hp, wp),
                 "score_ptr": p2.value}

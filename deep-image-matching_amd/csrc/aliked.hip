@@ -145,7 +145,7 @@ constexpr int BN_BLOCKS = 256;
 __global__ __launch_bounds__(256) void al_bn_partial_kernel(const float* __restrict__ x, int n_pixels, int C, double* __restrict__ partial) {
   __shared__ double red[256][2];
   const int b = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
-  const int lanes_per_c = 256 / C;  // C in {16,32,64,128} -> 16,8,4,2 pixel lanes per channel
+  const int lanes_per_c = 256 / C;  // C in {8,16,32,64,128} -> 32,16,8,4,2 pixel lanes per channel
   const int c = t % C, pl = t / C;
   const float* src = x + (size_t)b * n_pixels * C;
   double s = 0.0, q = 0.0;
@@ -242,10 +242,12 @@ __global__ __launch_bounds__(256) void al_clamp_kernel(float* __restrict__ x, si
 // GEMM: this kernel forms cols[pixel][tap * CIN + c] (the deformed im2col row, K = 9 * CIN) and the
 // product with the [9 * CIN][cout] weight runs on the matrix cores (gemm.hip).  Thread = (pixel, tap,
 // 4 channels); a wave covers consecutive channels of one tap so every corner read is one contiguous run.
+// KROW = row stride of cols: 9 * CIN rounded up to the GEMMs' 32-wide K granule (CIN = 16, aliked-t16's block3: 144 -> 160, the tail zeroed here —
+// the buffer is shared by layers of different K).
 template <int CIN>
 __global__ __launch_bounds__(256) void al_deform_gather_kernel(const float* __restrict__ in, const float* __restrict__ offs, int off_c,
                                                                float* __restrict__ cols, int H, int W, int n_rows) {
-  constexpr int C4 = CIN / 4;
+  constexpr int C4 = CIN / 4, KROW = (9 * CIN + 31) / 32 * 32;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)n_rows * 9 * C4) return;
   const int c4 = (int)(i % C4);
@@ -267,7 +269,10 @@ __global__ __launch_bounds__(256) void al_deform_gather_kernel(const float* __re
     if (y1 <= H - 1 && x0 >= 0) { const float4 v = *(const float4*)(src + ((size_t)y1 * W + x0) * CIN); s.x += w10 * v.x; s.y += w10 * v.y; s.z += w10 * v.z; s.w += w10 * v.w; }
     if (y1 <= H - 1 && x1 <= W - 1) { const float4 v = *(const float4*)(src + ((size_t)y1 * W + x1) * CIN); s.x += w11 * v.x; s.y += w11 * v.y; s.z += w11 * v.z; s.w += w11 * v.w; }
   }
-  *(float4*)(cols + gp * (9 * CIN) + tap * CIN + c4 * 4) = s;
+  *(float4*)(cols + gp * KROW + tap * CIN + c4 * 4) = s;
+  if (KROW > 9 * CIN && tap == 8) {   // (KROW - 9 CIN) / 4 <= C4 float4s of zero padding, written by the last tap's threads
+    if (c4 < (KROW - 9 * CIN) / 4) *(float4*)(cols + gp * KROW + 9 * CIN + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -291,12 +296,13 @@ __device__ __forceinline__ UpIdx up_index(int dst, int in_size, int out_size) {
 // that the 512 B/pixel feature map is written as one contiguous 32-KiB run.  The product path runs
 // STORE = false: only s8 is written; the 128-channel map (512 MB per 1024^2 image) is never materialised,
 // SDDH re-evaluates it at the cells it touches (feat_pair below).  STORE = true serves the debug tap.
-template <bool STORE>
+// C1 = channels of x1, G = dim / 4 channels per group: (16, 32) for aliked-n16 / n16rot / n32, (8, 16) for aliked-t16
+template <bool STORE, int C1, int G>
 __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restrict__ x1, const float* __restrict__ f2,
                                                           const float* __restrict__ f3, const float* __restrict__ f4,
                                                           const float* __restrict__ w1, const float* __restrict__ ws0,
                                                           float* __restrict__ x1234, float* __restrict__ s8, int Hp, int Wp) {
-  __shared__ float tile[STORE ? 64 * 132 : 4];
+  __shared__ float tile[STORE ? 64 * (4 * G + 4) : 4];
   __shared__ float spart[3][8][64];
   const int t = threadIdx.x, g = __builtin_amdgcn_readfirstlane(t >> 6), pl = t & 63, b = blockIdx.y;  // g is wave-uniform: weights come through scalar loads
   const int i = blockIdx.x * 64 + pl;
@@ -305,19 +311,19 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restric
   float sacc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) sacc[k] = 0.f;
-  float* trow = &tile[STORE ? pl * 132 + g * 32 : 0];
+  float* trow = &tile[STORE ? pl * (4 * G + 4) + g * G : 0];
   if (g == 0) {
-    const float* src = x1 + ((size_t)b * Hp * Wp + (ok ? i : 0)) * 16;
-    float a[16];
+    const float* src = x1 + ((size_t)b * Hp * Wp + (ok ? i : 0)) * C1;
+    float a[C1];
 #pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) { const float4 v = *(const float4*)(src + c4 * 4); a[c4 * 4] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w; }
+    for (int c4 = 0; c4 < C1 / 4; ++c4) { const float4 v = *(const float4*)(src + c4 * 4); a[c4 * 4] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w; }
 #pragma unroll
-    for (int co = 0; co < 32; co += 4) {
+    for (int co = 0; co < G; co += 4) {
       float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ci = 0; ci < 16; ++ci)
+      for (int ci = 0; ci < C1; ++ci)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaf(a[ci], w1[ci * 32 + co + j], o[j]);
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(a[ci], w1[ci * G + co + j], o[j]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         o[j] = selu_(o[j]);
@@ -331,13 +337,13 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restric
     const float* map = g == 1 ? f2 : (g == 2 ? f3 : f4);
     const int h = Hp / fac, w = Wp / fac;
     const UpIdx uy = up_index(y, h, Hp), ux = up_index(x, w, Wp);
-    const float* base = map + (size_t)b * h * w * 32;
-    const float* p00 = base + ((size_t)uy.i0 * w + ux.i0) * 32;
-    const float* p01 = base + ((size_t)uy.i0 * w + ux.i1) * 32;
-    const float* p10 = base + ((size_t)uy.i1 * w + ux.i0) * 32;
-    const float* p11 = base + ((size_t)uy.i1 * w + ux.i1) * 32;
+    const float* base = map + (size_t)b * h * w * G;
+    const float* p00 = base + ((size_t)uy.i0 * w + ux.i0) * G;
+    const float* p01 = base + ((size_t)uy.i0 * w + ux.i1) * G;
+    const float* p10 = base + ((size_t)uy.i1 * w + ux.i0) * G;
+    const float* p11 = base + ((size_t)uy.i1 * w + ux.i1) * G;
 #pragma unroll
-    for (int c = 0; c < 32; c += 4) {
+    for (int c = 0; c < G; c += 4) {
       const float4 a = *(const float4*)(p00 + c), bq = *(const float4*)(p01 + c), cq = *(const float4*)(p10 + c), d = *(const float4*)(p11 + c);
       float o[4];
       o[0] = uy.l0 * (ux.l0 * a.x + ux.l1 * bq.x) + uy.l1 * (ux.l0 * cq.x + ux.l1 * d.x);
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sacc[k] = fmaf(o[j], ws0[(32 * g + c + j) * 8 + k], sacc[k]);
+        for (int k = 0; k < 8; ++k) sacc[k] = fmaf(o[j], ws0[(G * g + c + j) * 8 + k], sacc[k]);
       if (STORE) *(float4*)(trow + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
@@ -366,11 +372,11 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restric
   }
   if (!STORE) return;
   const int p0 = blockIdx.x * 64;
-  float* dst = x1234 + ((size_t)b * Hp * Wp + p0) * 128;
+  float* dst = x1234 + ((size_t)b * Hp * Wp + p0) * (4 * G);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int idx = t + 256 * k, pix = idx >> 5, c4 = idx & 31;
-    if (p0 + pix < Hp * Wp) *(float4*)(dst + (size_t)pix * 128 + c4 * 4) = *(const float4*)&tile[pix * 132 + c4 * 4];
+  for (int k = 0; k < G / 4; ++k) {   // 64 pixels x G float4
+    const int idx = t + 256 * k, pix = idx / G, c4 = idx % G;
+    if (p0 + pix < Hp * Wp) *(float4*)(dst + (size_t)pix * (4 * G) + c4 * 4) = *(const float4*)&tile[pix * (4 * G + 4) + c4 * 4];
   }
 }
 
@@ -381,6 +387,7 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(const float* __restric
 // and the full-resolution pass interpolates 8 instead of 32 channels per map: 12 corner reads of 32 B and 96 FMAs per pixel
 // where the unfactored form needs 12 x 128 B and 384 + 768.  Thread = pixel: the 16 -> 32 conv of x1, SELU, its share of the
 // projection, the three 8-channel interpolations, SELU.  Rounding differs from the unfactored order by fp32 reassociation only.
+template <int C1, int G>
 __global__ __launch_bounds__(256) void al_assemble_proj_kernel(const float* __restrict__ x1, const float* __restrict__ q2,
                                                                const float* __restrict__ q3, const float* __restrict__ q4,
                                                                const float* __restrict__ w1, const float* __restrict__ ws0,
@@ -392,17 +399,17 @@ __global__ __launch_bounds__(256) void al_assemble_proj_kernel(const float* __re
 #pragma unroll
   for (int k = 0; k < 8; ++k) sacc[k] = 0.f;
   {
-    const float* src = x1 + ((size_t)b * Hp * Wp + i) * 16;
-    float a[16];
+    const float* src = x1 + ((size_t)b * Hp * Wp + i) * C1;
+    float a[C1];
 #pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) { const float4 v = *(const float4*)(src + c4 * 4); a[c4 * 4] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w; }
+    for (int c4 = 0; c4 < C1 / 4; ++c4) { const float4 v = *(const float4*)(src + c4 * 4); a[c4 * 4] = v.x; a[c4 * 4 + 1] = v.y; a[c4 * 4 + 2] = v.z; a[c4 * 4 + 3] = v.w; }
 #pragma unroll
-    for (int co = 0; co < 32; co += 4) {
+    for (int co = 0; co < G; co += 4) {
       float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ci = 0; ci < 16; ++ci)
+      for (int ci = 0; ci < C1; ++ci)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaf(a[ci], w1[ci * 32 + co + j], o[j]);
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(a[ci], w1[ci * G + co + j], o[j]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         o[j] = selu_(o[j]);
@@ -502,82 +509,68 @@ __global__ __launch_bounds__(256) void al_dkd_refine_kernel(const float* __restr
 // ---------------------------------------------------------------------------
 // SDDH (ALN:503-558).  The 128-channel map x1234 is not stored: each cell a keypoint touches is
 // re-evaluated from its sources with the arithmetic of al_assemble_kernel (lane -> channels 2*lane,
-// 2*lane+1: lanes 0-15 the 16->32 conv of x1, then one up-sampled map per 16 lanes) and L2-normalised
-// on the fly (F.normalize over the 128 channels, ALN:669).
-__device__ __forceinline__ float2 feat_pair(const AlFeat& F, int b, int Y, int X, int lane) {
-  const int g = lane >> 4, cc = (lane & 15) * 2;
-  if (g == 0) {
-    const float* src = F.x1 + (((size_t)b * F.Hp + Y) * F.Wp + X) * 16;
-    float o0 = 0.f, o1 = 0.f;
-#pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) {
-      const float4 v = *(const float4*)(src + c4 * 4);
-      const float a[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float2 w = *(const float2*)(F.w1 + (c4 * 4 + j) * 32 + cc);
-        o0 = fmaf(a[j], w.x, o0); o1 = fmaf(a[j], w.y, o1);
-      }
-    }
-    return make_float2(selu_(o0), selu_(o1));
-  }
-  const int fac = g == 1 ? 2 : (g == 2 ? 8 : 32);
-  const float* map = g == 1 ? F.f2 : (g == 2 ? F.f3 : F.f4);
-  const int h = F.Hp / fac, w = F.Wp / fac;
-  const UpIdx uy = up_index(Y, h, F.Hp), ux = up_index(X, w, F.Wp);
-  const float* base = map + (size_t)b * h * w * 32 + cc;
-  const float2 a = *(const float2*)(base + ((size_t)uy.i0 * w + ux.i0) * 32), bq = *(const float2*)(base + ((size_t)uy.i0 * w + ux.i1) * 32);
-  const float2 cq = *(const float2*)(base + ((size_t)uy.i1 * w + ux.i0) * 32), d = *(const float2*)(base + ((size_t)uy.i1 * w + ux.i1) * 32);
-  return make_float2(uy.l0 * (ux.l0 * a.x + ux.l1 * bq.x) + uy.l1 * (ux.l0 * cq.x + ux.l1 * d.x),
-                     uy.l0 * (ux.l0 * a.y + ux.l1 * bq.y) + uy.l1 * (ux.l0 * cq.y + ux.l1 * d.y));
-}
-// ---- the same evaluation, split into "issue the loads" and "finish", so that a wave can keep the gathers of MANY cells in
-// flight (the kernels below were latency-bound with one cell's loads per round trip: 1.5 ms for 2 M cells).  Lanes 0-15
-// (group 0) hold ONE input channel of x1 each — the 16 values reach all lanes through v_readlane (wave-uniform SGPRs) and the
-// lane's two columns of the 16 -> 32 conv weights stay in registers for the whole kernel; lanes 16-63 hold the four bilinear
-// corners of their up-sampled map.  9 VGPRs per cell in flight.
+// 2*lane+1: lanes 0-15 the 16->32 conv of x1, then one up-sampled map per 16 lanes; aliked-t16: one channel per lane,
+// 8 -> 16 conv) and L2-normalised on the fly (F.normalize over the 4 G channels, ALN:669).
+// ---- the evaluation is split into "issue the loads" and "finish", so that a wave can keep the gathers of MANY cells in
+// flight (the kernels below were latency-bound with one cell's loads per round trip: 1.5 ms for 2 M cells).  Lanes 0 .. C1-1
+// (group 0) hold ONE input channel of x1 each — the C1 values reach all lanes through v_readlane (wave-uniform SGPRs) and the
+// lane's CPL = G / 16 columns of the C1 -> G conv weights stay in registers for the whole kernel; lanes 16-63 hold the four bilinear
+// corners of their up-sampled map.  9 VGPRs per cell in flight.  (CPL = 1: the .y halves are zero throughout.)
 struct FeatCell { float x1v; float2 c00, c01, c10, c11; float l0y, l1y, l0x, l1x; };
+template <int CPL>
+__device__ __forceinline__ float2 feat_load(const float* p) {
+  if (CPL == 2) return *(const float2*)p;
+  return make_float2(p[0], 0.f);
+}
+template <int C1, int G>
 __device__ __forceinline__ void feat_issue(const AlFeat& F, int b, int Y, int X, int lane, FeatCell& r) {
-  const int g = lane >> 4, cc = (lane & 15) * 2;
-  r.x1v = F.x1[(((size_t)b * F.Hp + Y) * F.Wp + X) * 16 + (lane & 15)];
+  constexpr int CPL = G / 16;
+  const int g = lane >> 4, cc = (lane & 15) * CPL;
+  r.x1v = F.x1[(((size_t)b * F.Hp + Y) * F.Wp + X) * C1 + (lane & (C1 - 1))];
   const int fac = g <= 1 ? 2 : (g == 2 ? 8 : 32);
   const float* map = g <= 1 ? F.f2 : (g == 2 ? F.f3 : F.f4);
   const int h = F.Hp / fac, w = F.Wp / fac;
   const UpIdx uy = up_index(Y, h, F.Hp), ux = up_index(X, w, F.Wp);
-  const float* base = map + (size_t)b * h * w * 32 + cc;
-  r.c00 = *(const float2*)(base + ((size_t)uy.i0 * w + ux.i0) * 32); r.c01 = *(const float2*)(base + ((size_t)uy.i0 * w + ux.i1) * 32);
-  r.c10 = *(const float2*)(base + ((size_t)uy.i1 * w + ux.i0) * 32); r.c11 = *(const float2*)(base + ((size_t)uy.i1 * w + ux.i1) * 32);
+  const float* base = map + (size_t)b * h * w * G + cc;
+  r.c00 = feat_load<CPL>(base + ((size_t)uy.i0 * w + ux.i0) * G); r.c01 = feat_load<CPL>(base + ((size_t)uy.i0 * w + ux.i1) * G);
+  r.c10 = feat_load<CPL>(base + ((size_t)uy.i1 * w + ux.i0) * G); r.c11 = feat_load<CPL>(base + ((size_t)uy.i1 * w + ux.i1) * G);
   r.l0y = uy.l0; r.l1y = uy.l1; r.l0x = ux.l0; r.l1x = ux.l1;
 }
-// -> this lane's two channels of the L2-NORMALISED 128-vector of the cell (F.normalize, ALN:669), same arithmetic as feat_pair
-__device__ __forceinline__ float2 feat_finish(const FeatCell& r, const float2 (&w1r)[16], int lane) {
+// -> this lane's CPL channels of the L2-NORMALISED 4 G-vector of the cell (F.normalize, ALN:669), same arithmetic as al_assemble_kernel
+template <int C1, int G>
+__device__ __forceinline__ float2 feat_finish(const FeatCell& r, const float2 (&w1r)[C1], int lane) {
+  constexpr int CPL = G / 16;
   float o0 = 0.f, o1 = 0.f;
 #pragma unroll
-  for (int ci = 0; ci < 16; ++ci) {
+  for (int ci = 0; ci < C1; ++ci) {
     const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.x1v), ci));
     o0 = fmaf(a, w1r[ci].x, o0); o1 = fmaf(a, w1r[ci].y, o1);
   }
   float2 v;
-  if ((lane >> 4) == 0) v = make_float2(selu_(o0), selu_(o1));
+  if ((lane >> 4) == 0) v = make_float2(selu_(o0), CPL == 2 ? selu_(o1) : 0.f);
   else v = make_float2(r.l0y * (r.l0x * r.c00.x + r.l1x * r.c01.x) + r.l1y * (r.l0x * r.c10.x + r.l1x * r.c11.x),
                        r.l0y * (r.l0x * r.c00.y + r.l1x * r.c01.y) + r.l1y * (r.l0x * r.c10.y + r.l1x * r.c11.y));
   const float den = fmaxf(sqrtf(wave_sum_dpp(v.x * v.x + v.y * v.y)), 1e-12f);   // DPP reduction: no LDS round trips in the gather loop
   return make_float2(v.x / den, v.y / den);
 }
-__device__ __forceinline__ void feat_weights(const AlFeat& F, int lane, float2 (&w1r)[16]) {
-  const int cc = (lane & 15) * 2;
+template <int C1, int G>
+__device__ __forceinline__ void feat_weights(const AlFeat& F, int lane, float2 (&w1r)[C1]) {
+  constexpr int CPL = G / 16;
+  const int cc = (lane & 15) * CPL;
 #pragma unroll
-  for (int ci = 0; ci < 16; ++ci) w1r[ci] = *(const float2*)(F.w1 + ci * 32 + cc);
+  for (int ci = 0; ci < C1; ++ci) w1r[ci] = feat_load<CPL>(F.w1 + ci * G + cc);
 }
-// wave per keypoint: the 3x3 patch of normalised features -> patches [kpt][128 ci][9 cells]; all 9 cells' loads in flight
+// wave per keypoint: the 3x3 patch of normalised features -> patches [kpt][4 G ci][9 cells]; all 9 cells' loads in flight
+template <int C1, int G>
 __global__ __launch_bounds__(256) void al_sddh_patches_kernel(AlFeat F, const float* __restrict__ kpts_norm,
                                                               const int* __restrict__ n_kpts, float* __restrict__ patches, int H,
                                                               int W, int pad_t, int pad_l, int capacity) {
+  constexpr int CPL = G / 16;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wv, b = blockIdx.y;
   if (i >= n_kpts[b]) return;
-  float2 w1r[16];
-  feat_weights(F, lane, w1r);
+  float2 w1r[C1];
+  feat_weights<C1, G>(F, lane, w1r);
   const size_t k = (size_t)b * capacity + i;
   const float kwx = (kpts_norm[k * 2] / 2.f + 0.5f) * (float)(W - 1), kwy = (kpts_norm[k * 2 + 1] / 2.f + 0.5f) * (float)(H - 1);
   const int xl = (int)kwx, yl = (int)kwy;  // .long()
@@ -585,19 +578,19 @@ __global__ __launch_bounds__(256) void al_sddh_patches_kernel(AlFeat F, const fl
   cx = min(max(cx, 0), W - 1 - 3); cy = min(max(cy, 0), H - 1 - 3);
   FeatCell cell[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) feat_issue(F, b, cy + c / 3 + pad_t, cx + c % 3 + pad_l, lane, cell[c]);
-  // layout [kpt][ci][ky][kx] flattened as ci*9 + cell to match offset_conv.0.weight (32,128,3,3)
-  float* dst = patches + k * 1152;
+  for (int c = 0; c < 9; ++c) feat_issue<C1, G>(F, b, cy + c / 3 + pad_t, cx + c % 3 + pad_l, lane, cell[c]);
+  // layout [kpt][ci][ky][kx] flattened as ci*9 + cell to match offset_conv.0.weight (2M, 4G, 3, 3)
+  float* dst = patches + k * (4 * G * 9);
 #pragma unroll
   for (int c = 0; c < 9; ++c) {
-    const float2 v = feat_finish(cell[c], w1r, lane);
-    dst[(lane * 2) * 9 + c] = v.x;
-    dst[(lane * 2 + 1) * 9 + c] = v.y;
+    const float2 v = feat_finish<C1, G>(cell[c], w1r, lane);
+    dst[(lane * CPL) * 9 + c] = v.x;
+    if (CPL == 2) dst[(lane * CPL + 1) * 9 + c] = v.y;
   }
 }
 // wave per keypoint: offsets = clamp(W2 * selu(hidden) + b2), then M (16: aliked-n16 / n16rot, 32: aliked-n32) bilinear samples of the
-// normalised feature map -> feats [kpt][M][128]; the 8 cells of two samples are in flight together
-template <int M>
+// normalised feature map -> feats [kpt][M][4 G]; the 8 cells of two samples are in flight together
+template <int M, int C1, int G>
 __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const float* __restrict__ kpts_norm,
                                                              const int* __restrict__ n_kpts, const float* __restrict__ hidden,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
@@ -615,8 +608,9 @@ __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const flo
   }
   __syncthreads();
   if (!live) return;
-  float2 w1r[16];
-  feat_weights(F, lane, w1r);
+  constexpr int CPL = G / 16;
+  float2 w1r[C1];
+  feat_weights<C1, G>(F, lane, w1r);
   const float wx = (float)(W - 1), wy = (float)(H - 1);
   const float kwx = (kpts_norm[k * 2] / 2.f + 0.5f) * wx, kwy = (kpts_norm[k * 2 + 1] / 2.f + 0.5f) * wy;
   constexpr int SB = 2;   // samples per round: 8 cells in flight (104 VGPRs), 3 waves per SIMD
@@ -638,7 +632,7 @@ __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const flo
       for (int c = 0; c < 4; ++c) {
         const int xs = xa + (c & 1), ys = ya + (c >> 1);
         in[j][c] = xs >= 0 && xs < W && ys >= 0 && ys < H;  // wave-uniform
-        feat_issue(F, b, (in[j][c] ? ys : 0) + pad_t, (in[j][c] ? xs : 0) + pad_l, lane, cell[j][c]);
+        feat_issue<C1, G>(F, b, (in[j][c] ? ys : 0) + pad_t, (in[j][c] ? xs : 0) + pad_l, lane, cell[j][c]);
       }
     }
 #pragma unroll
@@ -646,10 +640,11 @@ __global__ __launch_bounds__(256) void al_sddh_sample_kernel(AlFeat F, const flo
       float o0 = 0.f, o1 = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float2 v = feat_finish(cell[j][c], w1r, lane);
+        const float2 v = feat_finish<C1, G>(cell[j][c], w1r, lane);
         if (in[j][c]) { o0 += v.x * wts[j][c]; o1 += v.y * wts[j][c]; }
       }
-      *(float2*)(feats + (k * M + p0 + j) * 128 + lane * 2) = make_float2(o0, o1);
+      if (CPL == 2) *(float2*)(feats + (k * M + p0 + j) * (4 * G) + lane * 2) = make_float2(o0, o1);
+      else feats[(k * M + p0 + j) * (4 * G) + lane] = o0;
     }
   }
 }
@@ -695,6 +690,10 @@ int launch_al_conv3x3(const float* in, int cin, const float* w, const float* bia
   dim3 grid(tx * ty, 1, batch);
 #define AL_C3(CC, CIP, CO) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_conv3x3_kernel<CC, CO>), grid, dim3(256), 0, s, in, cin, CIP, w, bias, out, cout, H, W, act, tx, crop_y, crop_x, out_h, out_w)
   if (cin == 3 && cout == 16) AL_C3(4, 4, 16);
+  else if (cin == 3 && cout == 8) AL_C3(4, 4, 8);        // aliked-t16: 8 / 16 / 32 / 64 channels
+  else if (cin == 8 && cout == 8) AL_C3(8, 8, 8);
+  else if (cin == 8 && cout == 16) AL_C3(8, 8, 16);
+  else if (cin == 16 && cout == 18) AL_C3(16, 16, 20);
   else if (cin == 16 && cout == 16) AL_C3(16, 16, 16);
   else if (cin == 16 && cout == 32) AL_C3(16, 16, 32);
   else if (cin == 32 && cout == 32) AL_C3(32, 32, 32);
@@ -714,6 +713,11 @@ int launch_al_conv1x1(const float* in, int cin, const float* w, const float* bia
   dim3 grid(cdiv(n_pixels, 256));
 #define AL_C1(CI, CO) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_conv1x1_kernel<CI, CO>), grid, dim3(256), 0, s, in, w, bias, out, n_pixels, act)
   if (cin == 16 && cout == 32) AL_C1(16, 32);
+  else if (cin == 8 && cout == 16) AL_C1(8, 16);         // aliked-t16
+  else if (cin == 16 && cout == 16) AL_C1(16, 16);
+  else if (cin == 32 && cout == 16) AL_C1(32, 16);
+  else if (cin == 64 && cout == 16) AL_C1(64, 16);
+  else if (cin == 16 && cout == 8) AL_C1(16, 8);
   else if (cin == 32 && cout == 32) AL_C1(32, 32);
   else if (cin == 32 && cout == 64) AL_C1(32, 64);
   else if (cin == 64 && cout == 32) AL_C1(64, 32);
@@ -738,7 +742,7 @@ int launch_al_avgpool(const float* in, float* out, int batch, int H, int W, int 
 }
 int launch_al_bn_stats(const float* x, int batch, int n_pixels, int C, const float* gamma, const float* beta_w, double* partial,
                        float* alpha, float* beta, hipStream_t s) {
-  DIM_REQUIRE(C == 16 || C == 32 || C == 64 || C == 128, "aliked bn: C=%d unsupported", C);
+  DIM_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64 || C == 128, "aliked bn: C=%d unsupported", C);
   hipLaunchKernelGGL(al_bn_partial_kernel, dim3(BN_BLOCKS, batch), dim3(256), 0, s, x, n_pixels, C, partial);
   hipLaunchKernelGGL(al_bn_final_kernel, dim3(batch), dim3(128), 0, s, (const double*)partial, n_pixels, C, gamma, beta_w, alpha, beta);
   DIM_LAUNCH_CHECK();
@@ -761,15 +765,16 @@ int launch_al_bn_apply_pool(const float* x, const float* alpha, const float* bet
 }
 int launch_al_deform_conv(const float* in, int cin, const float* offsets, int off_c, const float* w, const SplitWeights* wx, unsigned* sat,
                           float* cols, float* out, int cout, int batch, int H, int W, hipStream_t s) {
-  DIM_REQUIRE(cout % 32 == 0 && (cin == 32 || cin == 64 || cin == 128), "deform conv: cin %d cout %d", cin, cout);
-  const int rows = batch * H * W;
+  DIM_REQUIRE(cout % 32 == 0 && (cin == 16 || cin == 32 || cin == 64 || cin == 128), "deform conv: cin %d cout %d", cin, cout);
+  const int rows = batch * H * W, krow = al_deform_krow(cin);
   const dim3 grid((unsigned)(((size_t)rows * 9 * (cin / 4) + 255) / 256));
-  if (cin == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_gather_kernel<32>), grid, dim3(256), 0, s, in, offsets, off_c, cols, H, W, rows);
+  if (cin == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_gather_kernel<16>), grid, dim3(256), 0, s, in, offsets, off_c, cols, H, W, rows);
+  else if (cin == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_gather_kernel<32>), grid, dim3(256), 0, s, in, offsets, off_c, cols, H, W, rows);
   else if (cin == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_gather_kernel<64>), grid, dim3(256), 0, s, in, offsets, off_c, cols, H, W, rows);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(al_deform_gather_kernel<128>), grid, dim3(256), 0, s, in, offsets, off_c, cols, H, W, rows);
   DIM_LAUNCH_CHECK();
-  GemmArgs g;
-  g.A0 = cols; g.lda0 = 9 * cin; g.B = w; g.ldb = cout; g.C = out; g.ldc = cout; g.M = rows; g.N = cout; g.K = 9 * cin;
+  GemmArgs g;   // the weight operand has krow rows (zero rows past 9 cin: al_deform_krow)
+  g.A0 = cols; g.lda0 = krow; g.B = w; g.ldb = cout; g.C = out; g.ldc = cout; g.M = rows; g.N = cout; g.K = krow;
   if (wx != nullptr) { g.set_split(*wx); g.sat = sat; return launch_gemm_x6(g, 1, s); }   // fp16x3 on the matrix cores
   return launch_gemm(g, 1, s);
 }
@@ -779,15 +784,19 @@ int launch_al_clamp(float* x, size_t n, float lim, hipStream_t s) {
   return 0;
 }
 int launch_al_assemble(const float* x1, const float* f2, const float* f3, const float* f4, const float* w1, const float* ws0,
-                       float* x1234, float* s8, int batch, int Hp, int Wp, hipStream_t s) {
-  if (x1234) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_assemble_kernel<true>), dim3(cdiv(Hp * Wp, 64), batch), dim3(256), 0, s, x1, f2, f3, f4, w1, ws0, x1234, s8, Hp, Wp);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(al_assemble_kernel<false>), dim3(cdiv(Hp * Wp, 64), batch), dim3(256), 0, s, x1, f2, f3, f4, w1, ws0, x1234, s8, Hp, Wp);
+                       float* x1234, float* s8, int c1, int batch, int Hp, int Wp, hipStream_t s) {
+  const dim3 grid(cdiv(Hp * Wp, 64), batch);
+#define AL_ASM(ST, C1, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_assemble_kernel<ST, C1, G>), grid, dim3(256), 0, s, x1, f2, f3, f4, w1, ws0, x1234, s8, Hp, Wp)
+  if (c1 == 16) { if (x1234) AL_ASM(true, 16, 32); else AL_ASM(false, 16, 32); }
+  else { if (x1234) AL_ASM(true, 8, 16); else AL_ASM(false, 8, 16); }
+#undef AL_ASM
   DIM_LAUNCH_CHECK();
   return 0;
 }
 int launch_al_assemble_proj(const float* x1, const float* q2, const float* q3, const float* q4, const float* w1, const float* ws0, float* s8,
-                            int batch, int Hp, int Wp, hipStream_t s) {
-  hipLaunchKernelGGL(al_assemble_proj_kernel, dim3(cdiv(Hp * Wp, 256), batch), dim3(256), 0, s, x1, q2, q3, q4, w1, ws0, s8, Hp, Wp);
+                            int c1, int batch, int Hp, int Wp, hipStream_t s) {
+  if (c1 == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_assemble_proj_kernel<16, 32>), dim3(cdiv(Hp * Wp, 256), batch), dim3(256), 0, s, x1, q2, q3, q4, w1, ws0, s8, Hp, Wp);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(al_assemble_proj_kernel<8, 16>), dim3(cdiv(Hp * Wp, 256), batch), dim3(256), 0, s, x1, q2, q3, q4, w1, ws0, s8, Hp, Wp);
   DIM_LAUNCH_CHECK();
   return 0;
 }
@@ -799,15 +808,20 @@ int launch_al_dkd_refine(const float* score, const float* kpts_px, const int* n_
 }
 int launch_al_sddh_patches(const AlFeat& F, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H, int W,
                            int pad_t, int pad_l, int capacity, hipStream_t s) {
-  hipLaunchKernelGGL(al_sddh_patches_kernel, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, patches, H, W, pad_t, pad_l, capacity);
+  if (F.c1 == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_sddh_patches_kernel<16, 32>), dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, patches, H, W, pad_t, pad_l, capacity);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(al_sddh_patches_kernel<8, 16>), dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, patches, H, W, pad_t, pad_l, capacity);
   DIM_LAUNCH_CHECK();
   return 0;
 }
 int launch_al_sddh_sample(const AlFeat& F, const float* kpts_norm, const int* n_kpts, const float* off_hidden, const float* w2,
                           const float* b2, float* feats, int M, int batch, int H, int W, int pad_t, int pad_l, int capacity, hipStream_t s) {
-  DIM_REQUIRE(M == 16 || M == 32, "al_sddh_sample: M = %d sample positions (16 or 32)", M);
-  if (M == 16) hipLaunchKernelGGL(al_sddh_sample_kernel<16>, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, off_hidden, w2, b2, feats, H, W, pad_t, pad_l, capacity);
-  else hipLaunchKernelGGL(al_sddh_sample_kernel<32>, dim3(cdiv(capacity, 4), batch), dim3(256), 0, s, F, kpts_norm, n_kpts, off_hidden, w2, b2, feats, H, W, pad_t, pad_l, capacity);
+  DIM_REQUIRE((M == 16 || M == 32) && (F.c1 == 16 || M == 16), "al_sddh_sample: M = %d sample positions (16 or 32; aliked-t16: 16)", M);
+  const dim3 grid(cdiv(capacity, 4), batch);
+#define AL_SMP(MM, C1, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(al_sddh_sample_kernel<MM, C1, G>), grid, dim3(256), 0, s, F, kpts_norm, n_kpts, off_hidden, w2, b2, feats, H, W, pad_t, pad_l, capacity)
+  if (F.c1 == 8) AL_SMP(16, 8, 16);
+  else if (M == 16) AL_SMP(16, 16, 32);
+  else AL_SMP(32, 16, 32);
+#undef AL_SMP
   DIM_LAUNCH_CHECK();
   return 0;
 }

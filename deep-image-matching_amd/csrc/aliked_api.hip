@@ -106,8 +106,12 @@ void dim_aliked_destroy(dim_aliked* h) {
 int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg, int max_batch, int max_h, int max_w,
                       int capacity, dim_aliked** out) {
   DIM_REQUIRE(w && cfg && out, "dim_aliked_create: null argument");
-  DIM_REQUIRE(cfg->c1 == 16 && cfg->c2 == 32 && cfg->c3 == 64 && cfg->c4 == 128 && cfg->dim == 128 && cfg->K == 3 && (cfg->M == 16 || cfg->M == 32),
-              "dim_aliked_create: the aliked-n16 / n16rot / n32 geometries (16,32,64,128,128,3,16|32) are built; aliked-t16 is not");
+  const bool normal = cfg->c1 == 16 && cfg->c2 == 32 && cfg->c3 == 64 && cfg->c4 == 128 && cfg->dim == 128 && (cfg->M == 16 || cfg->M == 32);
+  const bool tiny = cfg->c1 == 8 && cfg->c2 == 16 && cfg->c3 == 32 && cfg->c4 == 64 && cfg->dim == 64 && cfg->M == 16;
+  DIM_REQUIRE((normal || tiny) && cfg->K == 3,
+              "dim_aliked_create: geometry (%d,%d,%d,%d,%d,%d,%d) is none of ALN:573-579 (aliked-t16 / n16 / n16rot / n32)", cfg->c1, cfg->c2, cfg->c3,
+              cfg->c4, cfg->dim, cfg->K, cfg->M);
+  const int c1 = cfg->c1, c2 = cfg->c2, c3 = cfg->c3, c4 = cfg->c4, dim = cfg->dim, G = cfg->dim / 4;
   const int M = cfg->M, M2 = 2 * cfg->M;   // SDDH sample positions; offset channels (ALN:503-519)
   DIM_REQUIRE(cfg->detection_threshold > 0, "dim_aliked_create: detection_threshold must be > 0 (top-k-only mode not built)");
   DIM_REQUIRE(cfg->nms_radius >= 1 && cfg->nms_radius <= 6, "dim_aliked_create: nms_radius %d", cfg->nms_radius);
@@ -117,42 +121,52 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
   h->cfg = *cfg;
   h->max_batch = max_batch; h->max_h = max_h; h->max_w = max_w; h->capacity = capacity;
 #define AL_TRY(x) do { if ((x) != 0) { dim_aliked_destroy(h); return -1; } } while (0)
-  AL_TRY(upload(h, &h->b1c1, relayout(w->block1_conv1, 16, 3, 3, 4, 16)));
-  AL_TRY(upload(h, &h->b1c2, relayout(w->block1_conv2, 16, 16, 3, 16, 16)));
-  AL_TRY(upload(h, &h->b2c1, relayout(w->block2_conv1, 32, 16, 3, 16, 32)));
-  AL_TRY(upload(h, &h->b2c2, relayout(w->block2_conv2, 32, 32, 3, 32, 32)));
-  AL_TRY(upload(h, &h->b2ds_w, relayout(w->block2_ds_w, 32, 16, 1, 16, 32))); AL_TRY(upload(h, &h->b2ds_b, padvec(w->block2_ds_b, 32, 32)));
-  AL_TRY(upload(h, &h->b3o1_w, relayout(w->block3_off1_w, 18, 32, 3, 32, 20))); AL_TRY(upload(h, &h->b3o1_b, padvec(w->block3_off1_b, 18, 20)));
-  AL_TRY(upload(h, &h->b3r1, relayout(w->block3_reg1, 64, 32, 3, 32, 64)));
-  AL_TRY(upload(h, &h->b3o2_w, relayout(w->block3_off2_w, 18, 64, 3, 64, 20))); AL_TRY(upload(h, &h->b3o2_b, padvec(w->block3_off2_b, 18, 20)));
-  AL_TRY(upload(h, &h->b3r2, relayout(w->block3_reg2, 64, 64, 3, 64, 64)));
-  AL_TRY(upload(h, &h->b3ds_w, relayout(w->block3_ds_w, 64, 32, 1, 32, 64))); AL_TRY(upload(h, &h->b3ds_b, padvec(w->block3_ds_b, 64, 64)));
-  AL_TRY(upload(h, &h->b4o1_w, relayout(w->block4_off1_w, 18, 64, 3, 64, 20))); AL_TRY(upload(h, &h->b4o1_b, padvec(w->block4_off1_b, 18, 20)));
-  AL_TRY(upload(h, &h->b4r1, relayout(w->block4_reg1, 128, 64, 3, 64, 128)));
-  AL_TRY(upload(h, &h->b4o2_w, relayout(w->block4_off2_w, 18, 128, 3, 128, 20))); AL_TRY(upload(h, &h->b4o2_b, padvec(w->block4_off2_b, 18, 20)));
-  AL_TRY(upload(h, &h->b4r2, relayout(w->block4_reg2, 128, 128, 3, 128, 128)));
-  AL_TRY(upload(h, &h->b4ds_w, relayout(w->block4_ds_w, 128, 64, 1, 64, 128))); AL_TRY(upload(h, &h->b4ds_b, padvec(w->block4_ds_b, 128, 128)));
-  AL_TRY(upload_x3(h, &h->x_b1c1, relayout(w->block1_conv1, 16, 3, 3, 16, 16), 9 * 16, 16));
-  AL_TRY(upload_x3(h, &h->x_b1c2, relayout(w->block1_conv2, 16, 16, 3, 16, 16), 9 * 16, 16));
-  AL_TRY(upload_x3(h, &h->x_b2c1, relayout(w->block2_conv1, 32, 16, 3, 16, 32), 9 * 16, 32));
-  AL_TRY(upload_x3(h, &h->x_b2c2, relayout(w->block2_conv2, 32, 32, 3, 32, 32), 9 * 32, 32));
-  AL_TRY(upload_x3(h, &h->x_b2ds, relayout(w->block2_ds_w, 32, 16, 1, 16, 32), 16, 32));
+  // [tap][ci][co] operand of a deformable convolution's GEMM with the rows padded to the K granule (al_deform_krow: aliked-t16's 144 -> 160)
+  auto deform_w = [&](const float* w_, int co, int ci) {
+    std::vector<float> v = relayout(w_, co, ci, 3, ci, co);
+    v.resize((size_t)al_deform_krow(ci) * co, 0.0f);
+    return v;
+  };
+  AL_TRY(upload(h, &h->b1c1, relayout(w->block1_conv1, c1, 3, 3, 4, c1)));
+  AL_TRY(upload(h, &h->b1c2, relayout(w->block1_conv2, c1, c1, 3, c1, c1)));
+  AL_TRY(upload(h, &h->b2c1, relayout(w->block2_conv1, c2, c1, 3, c1, c2)));
+  AL_TRY(upload(h, &h->b2c2, relayout(w->block2_conv2, c2, c2, 3, c2, c2)));
+  AL_TRY(upload(h, &h->b2ds_w, relayout(w->block2_ds_w, c2, c1, 1, c1, c2))); AL_TRY(upload(h, &h->b2ds_b, padvec(w->block2_ds_b, c2, c2)));
+  AL_TRY(upload(h, &h->b3o1_w, relayout(w->block3_off1_w, 18, c2, 3, c2, 20))); AL_TRY(upload(h, &h->b3o1_b, padvec(w->block3_off1_b, 18, 20)));
+  AL_TRY(upload(h, &h->b3r1, deform_w(w->block3_reg1, c3, c2)));
+  AL_TRY(upload(h, &h->b3o2_w, relayout(w->block3_off2_w, 18, c3, 3, c3, 20))); AL_TRY(upload(h, &h->b3o2_b, padvec(w->block3_off2_b, 18, 20)));
+  AL_TRY(upload(h, &h->b3r2, deform_w(w->block3_reg2, c3, c3)));
+  AL_TRY(upload(h, &h->b3ds_w, relayout(w->block3_ds_w, c3, c2, 1, c2, c3))); AL_TRY(upload(h, &h->b3ds_b, padvec(w->block3_ds_b, c3, c3)));
+  AL_TRY(upload(h, &h->b4o1_w, relayout(w->block4_off1_w, 18, c3, 3, c3, 20))); AL_TRY(upload(h, &h->b4o1_b, padvec(w->block4_off1_b, 18, 20)));
+  AL_TRY(upload(h, &h->b4r1, deform_w(w->block4_reg1, c4, c3)));
+  AL_TRY(upload(h, &h->b4o2_w, relayout(w->block4_off2_w, 18, c4, 3, c4, 20))); AL_TRY(upload(h, &h->b4o2_b, padvec(w->block4_off2_b, 18, 20)));
+  AL_TRY(upload(h, &h->b4r2, deform_w(w->block4_reg2, c4, c4)));
+  AL_TRY(upload(h, &h->b4ds_w, relayout(w->block4_ds_w, c4, c3, 1, c3, c4))); AL_TRY(upload(h, &h->b4ds_b, padvec(w->block4_ds_b, c4, c4)));
+  if (normal) {   // the matrix-core forms of the full- / half-resolution convolutions and of the aggregation exist for the 16 / 32-channel geometry
+    AL_TRY(upload_x3(h, &h->x_b1c1, relayout(w->block1_conv1, 16, 3, 3, 16, 16), 9 * 16, 16));
+    AL_TRY(upload_x3(h, &h->x_b1c2, relayout(w->block1_conv2, 16, 16, 3, 16, 16), 9 * 16, 16));
+    AL_TRY(upload_x3(h, &h->x_b2c1, relayout(w->block2_conv1, 32, 16, 3, 16, 32), 9 * 16, 32));
+    AL_TRY(upload_x3(h, &h->x_b2c2, relayout(w->block2_conv2, 32, 32, 3, 32, 32), 9 * 32, 32));
+    AL_TRY(upload_x3(h, &h->x_b2ds, relayout(w->block2_ds_w, 32, 16, 1, 16, 32), 16, 32));
+  }
   {  // the same operands the fp32 GEMMs use ([K][N] row-major), split for the matrix cores
     auto kn = [&](const float* w_, int co, int ci, int k) { return relayout(w_, co, ci, k, ci, co); };
-    AL_TRY(upload_x3g(h, &h->g_b3r1, kn(w->block3_reg1, 64, 32, 3).data(), 288, 64)); AL_TRY(upload_x3g(h, &h->g_b3r2, kn(w->block3_reg2, 64, 64, 3).data(), 576, 64));
-    AL_TRY(upload_x3g(h, &h->g_b3ds, kn(w->block3_ds_w, 64, 32, 1).data(), 32, 64));
-    AL_TRY(upload_x3g(h, &h->g_b4r1, kn(w->block4_reg1, 128, 64, 3).data(), 576, 128)); AL_TRY(upload_x3g(h, &h->g_b4r2, kn(w->block4_reg2, 128, 128, 3).data(), 1152, 128));
-    AL_TRY(upload_x3g(h, &h->g_b4ds, kn(w->block4_ds_w, 128, 64, 1).data(), 64, 128));
-    AL_TRY(upload_x3g(h, &h->g_hc2, kn(w->conv2, 32, 32, 1).data(), 32, 32)); AL_TRY(upload_x3g(h, &h->g_hc3, kn(w->conv3, 32, 64, 1).data(), 64, 32));
-    AL_TRY(upload_x3g(h, &h->g_hc4, kn(w->conv4, 32, 128, 1).data(), 128, 32));
-    AL_TRY(upload_x3g(h, &h->g_sf, kn(w->desc_sf, 128, 128, 1).data(), 128, 128));
-    AL_TRY(upload_x3g(h, &h->g_agg, w->desc_agg, M * 128, 128));
-    std::vector<float> o0((size_t)1152 * M2);
+    AL_TRY(upload_x3g(h, &h->g_b3r1, deform_w(w->block3_reg1, c3, c2).data(), al_deform_krow(c2), c3)); AL_TRY(upload_x3g(h, &h->g_b3r2, deform_w(w->block3_reg2, c3, c3).data(), al_deform_krow(c3), c3));
+    AL_TRY(upload_x3g(h, &h->g_b4r1, deform_w(w->block4_reg1, c4, c3).data(), al_deform_krow(c3), c4)); AL_TRY(upload_x3g(h, &h->g_b4r2, deform_w(w->block4_reg2, c4, c4).data(), al_deform_krow(c4), c4));
+    AL_TRY(upload_x3g(h, &h->g_b4ds, kn(w->block4_ds_w, c4, c3, 1).data(), c3, c4));
+    if (normal) {
+      AL_TRY(upload_x3g(h, &h->g_b3ds, kn(w->block3_ds_w, 64, 32, 1).data(), 32, 64));
+      AL_TRY(upload_x3g(h, &h->g_hc2, kn(w->conv2, 32, 32, 1).data(), 32, 32)); AL_TRY(upload_x3g(h, &h->g_hc3, kn(w->conv3, 32, 64, 1).data(), 64, 32));
+      AL_TRY(upload_x3g(h, &h->g_hc4, kn(w->conv4, 32, 128, 1).data(), 128, 32));
+    }
+    AL_TRY(upload_x3g(h, &h->g_sf, kn(w->desc_sf, dim, dim, 1).data(), dim, dim));
+    AL_TRY(upload_x3g(h, &h->g_agg, w->desc_agg, M * dim, dim));
+    std::vector<float> o0((size_t)dim * 9 * M2);
     for (int co = 0; co < M2; ++co)
-      for (int k = 0; k < 1152; ++k) o0[(size_t)k * M2 + co] = w->desc_off0_w[(size_t)co * 1152 + k];
-    AL_TRY(upload_x3g(h, &h->g_o0, o0.data(), 1152, M2));
+      for (int k = 0; k < dim * 9; ++k) o0[(size_t)k * M2 + co] = w->desc_off0_w[(size_t)co * dim * 9 + k];
+    AL_TRY(upload_x3g(h, &h->g_o0, o0.data(), dim * 9, M2));
   }
-  {
+  if (normal) {
     const std::vector<float> w1 = relayout(w->conv1, 32, 16, 1, 16, 32), ws0 = relayout(w->score0, 8, 128, 1, 128, 8);
     std::vector<unsigned short> frag(al_assemble_x3_frag_halves());
     std::vector<float> inv1(32);
@@ -161,40 +175,40 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
     AL_TRY(upload(h, &h->asm_inv1, inv1));
     if (hipMemcpy(h->asm_frag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_aliked_destroy(h); return -1; }
   }
-  const int bnc[8] = {16, 16, 32, 32, 64, 64, 128, 128};
+  const int bnc[8] = {c1, c1, c2, c2, c3, c3, c4, c4};
   for (int i = 0; i < 8; ++i) {
     AL_TRY(upload(h, &h->bn_g[i], padvec(w->bn_weight[i], bnc[i], bnc[i])));
     AL_TRY(upload(h, &h->bn_b[i], padvec(w->bn_bias[i], bnc[i], bnc[i])));
   }
-  AL_TRY(upload(h, &h->hc1, relayout(w->conv1, 32, 16, 1, 16, 32))); AL_TRY(upload(h, &h->hc2, relayout(w->conv2, 32, 32, 1, 32, 32)));
-  AL_TRY(upload(h, &h->hc3, relayout(w->conv3, 32, 64, 1, 64, 32))); AL_TRY(upload(h, &h->hc4, relayout(w->conv4, 32, 128, 1, 128, 32)));
-  AL_TRY(upload(h, &h->sh0, relayout(w->score0, 8, 128, 1, 128, 8))); AL_TRY(upload(h, &h->sh2, relayout(w->score2, 4, 8, 3, 8, 4)));
+  AL_TRY(upload(h, &h->hc1, relayout(w->conv1, G, c1, 1, c1, G))); AL_TRY(upload(h, &h->hc2, relayout(w->conv2, G, c2, 1, c2, G)));
+  AL_TRY(upload(h, &h->hc3, relayout(w->conv3, G, c3, 1, c3, G))); AL_TRY(upload(h, &h->hc4, relayout(w->conv4, G, c4, 1, c4, G)));
+  AL_TRY(upload(h, &h->sh0, relayout(w->score0, 8, dim, 1, dim, 8))); AL_TRY(upload(h, &h->sh2, relayout(w->score2, 4, 8, 3, 8, 4)));
   AL_TRY(upload(h, &h->sh4, relayout(w->score4, 4, 4, 3, 4, 4))); AL_TRY(upload(h, &h->sh6, relayout(w->score6, 1, 4, 3, 4, 4)));
-  {  // SDDH: offset_conv.0 (2M,128,3,3) -> GEMM operand [ci*9+tap][2M]; offset_conv.2 (2M,2M,1,1) -> [in][out]
-    std::vector<float> o0((size_t)1152 * M2);
+  {  // SDDH: offset_conv.0 (2M,dim,3,3) -> GEMM operand [ci*9+tap][2M]; offset_conv.2 (2M,2M,1,1) -> [in][out]
+    std::vector<float> o0((size_t)dim * 9 * M2);
     for (int co = 0; co < M2; ++co)
-      for (int k = 0; k < 1152; ++k) o0[(size_t)k * M2 + co] = w->desc_off0_w[(size_t)co * 1152 + k];
+      for (int k = 0; k < dim * 9; ++k) o0[(size_t)k * M2 + co] = w->desc_off0_w[(size_t)co * dim * 9 + k];
     AL_TRY(upload(h, &h->dh_o0_w, o0)); AL_TRY(upload(h, &h->dh_o0_b, padvec(w->desc_off0_b, M2, M2)));
     AL_TRY(upload(h, &h->dh_o2_w, relayout(w->desc_off2_w, M2, M2, 1, M2, M2))); AL_TRY(upload(h, &h->dh_o2_b, padvec(w->desc_off2_b, M2, M2)));
-    AL_TRY(upload(h, &h->dh_sf, relayout(w->desc_sf, 128, 128, 1, 128, 128)));
-    AL_TRY(upload(h, &h->dh_agg, padvec(w->desc_agg, M * 128 * 128, M * 128 * 128)));  // [p][c][d] == GEMM operand [p*128+c][d]
+    AL_TRY(upload(h, &h->dh_sf, relayout(w->desc_sf, dim, dim, 1, dim, dim)));
+    AL_TRY(upload(h, &h->dh_agg, padvec(w->desc_agg, M * dim * dim, M * dim * dim)));  // [p][c][d] == GEMM operand [p*dim+c][d]
   }
   const size_t B = max_batch;
   const size_t Hp = ((size_t)max_h + 31) / 32 * 32, Wp = ((size_t)max_w + 31) / 32 * 32, NP = Hp * Wp, cap = capacity;
-  AL_TRY(dev_alloc(h, &h->cols, B * NP / 64 * 576));  // deformed im2col rows: block3 (1/8 res, K = 9*64) is the largest
-  AL_TRY(dev_alloc(h, &h->P, B * NP * 3)); AL_TRY(dev_alloc(h, &h->raw, B * NP * 16)); AL_TRY(dev_alloc(h, &h->act, B * NP * 16));
-  AL_TRY(dev_alloc(h, &h->x1, B * NP * 16)); AL_TRY(dev_alloc(h, &h->p2, B * NP / 4 * 16)); AL_TRY(dev_alloc(h, &h->idn, B * NP / 4 * 32));
-  AL_TRY(dev_alloc(h, &h->x2, B * NP / 4 * 32)); AL_TRY(dev_alloc(h, &h->p3, B * NP / 64 * 32)); AL_TRY(dev_alloc(h, &h->off, B * NP / 64 * 20));
-  AL_TRY(dev_alloc(h, &h->x3, B * NP / 64 * 64)); AL_TRY(dev_alloc(h, &h->p4, B * NP / 1024 * 64)); AL_TRY(dev_alloc(h, &h->x4, B * NP / 1024 * 128));
-  AL_TRY(dev_alloc(h, &h->f2, B * NP / 4 * 32)); AL_TRY(dev_alloc(h, &h->f3, B * NP / 64 * 32)); AL_TRY(dev_alloc(h, &h->f4, B * NP / 1024 * 32));
+  AL_TRY(dev_alloc(h, &h->cols, B * NP / 64 * al_deform_krow(c3)));  // deformed im2col rows: block3 (1/8 res, K = 9 * c3) is the largest
+  AL_TRY(dev_alloc(h, &h->P, B * NP * 3)); AL_TRY(dev_alloc(h, &h->raw, B * NP * c1)); AL_TRY(dev_alloc(h, &h->act, B * NP * c1));
+  AL_TRY(dev_alloc(h, &h->x1, B * NP * c1)); AL_TRY(dev_alloc(h, &h->p2, B * NP / 4 * c1)); AL_TRY(dev_alloc(h, &h->idn, B * NP / 4 * c2));
+  AL_TRY(dev_alloc(h, &h->x2, B * NP / 4 * c2)); AL_TRY(dev_alloc(h, &h->p3, B * NP / 64 * c2)); AL_TRY(dev_alloc(h, &h->off, B * NP / 64 * 20));
+  AL_TRY(dev_alloc(h, &h->x3, B * NP / 64 * c3)); AL_TRY(dev_alloc(h, &h->p4, B * NP / 1024 * c3)); AL_TRY(dev_alloc(h, &h->x4, B * NP / 1024 * c4));
+  AL_TRY(dev_alloc(h, &h->f2, B * NP / 4 * G)); AL_TRY(dev_alloc(h, &h->f3, B * NP / 64 * G)); AL_TRY(dev_alloc(h, &h->f4, B * NP / 1024 * G));
   AL_TRY(dev_alloc(h, &h->q2, B * NP / 4 * 8)); AL_TRY(dev_alloc(h, &h->q3, B * NP / 64 * 8)); AL_TRY(dev_alloc(h, &h->q4, B * NP / 1024 * 8));
   AL_TRY(dev_alloc(h, &h->s8, B * NP * 8)); AL_TRY(dev_alloc(h, &h->s4a, B * NP * 4));
   AL_TRY(dev_alloc(h, &h->s4b, B * NP * 4)); AL_TRY(dev_alloc(h, &h->score, B * NP)); AL_TRY(dev_alloc(h, &h->nms, B * NP));
   AL_TRY(dev_alloc(h, &h->cand_score, B * NP)); AL_TRY(dev_alloc(h, &h->cand_idx, B * NP)); AL_TRY(dev_alloc(h, &h->rowcount, B * Hp));
   AL_TRY(dev_alloc(h, &h->rowoff, B * Hp)); AL_TRY(dev_alloc(h, &h->ncand, B)); AL_TRY(dev_alloc(h, &h->kpts_px, B * cap * 2));
   AL_TRY(dev_alloc(h, &h->sc_tmp, B * cap)); AL_TRY(dev_alloc(h, &h->kpts_norm, B * cap * 2)); AL_TRY(dev_alloc(h, &h->kscore, B * cap));
-  AL_TRY(dev_alloc(h, &h->patches, B * cap * 1152)); AL_TRY(dev_alloc(h, &h->hidden, B * cap * M2)); AL_TRY(dev_alloc(h, &h->feats, B * cap * M * 128));
-  AL_TRY(dev_alloc(h, &h->feats2, B * cap * M * 128)); AL_TRY(dev_alloc(h, &h->bn_alpha, 2 * B * 128)); AL_TRY(dev_alloc(h, &h->bn_beta, 2 * B * 128));   // two slots: a conv's input and output BatchNorm
+  AL_TRY(dev_alloc(h, &h->patches, B * cap * dim * 9)); AL_TRY(dev_alloc(h, &h->hidden, B * cap * M2)); AL_TRY(dev_alloc(h, &h->feats, B * cap * M * dim));
+  AL_TRY(dev_alloc(h, &h->feats2, B * cap * M * dim)); AL_TRY(dev_alloc(h, &h->bn_alpha, 2 * B * 128)); AL_TRY(dev_alloc(h, &h->bn_beta, 2 * B * 128));   // two slots: a conv's input and output BatchNorm
   AL_TRY(dev_alloc(h, &h->mean, B)); AL_TRY(dev_alloc(h, &h->thr_eff, B)); AL_TRY(dev_alloc(h, &h->partial, B * 256 * 128 * 2));
   AL_TRY(dev_alloc(h, &h->tile_partial, al_convx3_partial_doubles((int)B, (int)Hp, (int)Wp)));
 #undef AL_TRY
@@ -209,6 +223,8 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   DIM_REQUIRE(in_channels == 1 || in_channels == 3, "dim_aliked_extract: in_channels %d (1 or 3)", in_channels);
   DIM_REQUIRE(H >= 16 && W >= 16 && H <= h->max_h && W <= h->max_w, "dim_aliked_extract: image %dx%d outside the handle's %dx%d", H, W, h->max_h, h->max_w);
   hipStream_t s = (hipStream_t)stream;
+  const int c1 = h->cfg.c1, c2 = h->cfg.c2, c3 = h->cfg.c3, c4 = h->cfg.c4, dim = h->cfg.dim, G = dim / 4;
+  const bool tiny = c1 == 8;   // aliked-t16: fp32 VALU kernels for the small-channel convolutions and 1x1 heads (the matrix-core forms are built for 16 / 32 channels)
   // InputPadder(div 32) (ALN:247-271,646-648)
   const int ph = (((H / 32) + 1) * 32 - H) % 32, pw = (((W / 32) + 1) * 32 - W) % 32;
   const int pad_t = ph / 2, pad_l = pw / 2, Hp = H + ph, Wp = W + pw;
@@ -218,12 +234,14 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   // 1x1 convolutions on NHWC maps are plain GEMMs over pixels (weights already [cin][cout])
   // GEMMs: fp16x3 on the matrix cores (gemm_x6.hip) under the default arithmetic, plain fp32 MFMA otherwise
   const bool x3 = dim_precision_mode() == 2;
+  const bool x3c = x3 && !tiny;
   unsigned* const sat_al = dim_sat_counter(DIM_SAT_ALIKED);
   auto gemm = [&](GemmArgs& g, const SplitWeights& wx, int nb) -> int {
     if (x3 && g.K % 32 == 0) { g.set_split(wx); g.sat = sat_al; return launch_gemm_x6(g, nb, s); }
     return launch_gemm(g, nb, s);
   };
   auto conv1x1 = [&](const float* in, int ci, const float* w1, const SplitWeights& wx, const float* bias, float* out, int co, int npx, int act) -> int {
+    if (tiny && !(ci == 32 && co == 64)) return launch_al_conv1x1(in, ci, w1, bias, out, co, npx, act, s);   // K = 16 / N = 16: below the GEMMs' granules
     GemmArgs g;
     g.A0 = in; g.lda0 = ci; g.B = w1; g.ldb = co; g.bias = bias; g.C = out; g.ldc = co; g.M = npx; g.N = co; g.K = ci;
     g.relu = act == AL_ACT_SELU ? 2 : 0;
@@ -237,17 +255,17 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   AL_RUN(launch_al_pad_replicate(images_dev, h->P, batch, H, W, Hp, Wp, pad_t, pad_l, in_channels, s));
   // Full- and half-resolution convolutions: fp16x3 on the matrix cores with the BatchNorm statistics reduced in the conv
   // epilogue (aliked_x3.hip) under the default arithmetic; the fp32 VALU kernels + a separate statistics pass otherwise
-  // (dim_tune_set(1, 0 | 1): A/B checks and the range-guard fallback).
+  // (dim_tune_set(1, 0 | 1): A/B checks and the range-guard fallback; aliked-t16).
   // conv -> train-mode BN statistics -> (alpha, beta) of BatchNorm layer i in slot `slot` of bn_alpha / bn_beta.  in_bn >= 0: the
   // input is the previous convolution's RAW output and its BatchNorm + SELU (slot in_bn) is applied while the tile is staged.
-  const bool fuse_bn = x3 && dim_aliked_fuse_bn();
+  const bool fuse_bn = x3c && dim_aliked_fuse_bn();
   auto ab = [&](int slot, float** a, float** bta) { *a = h->bn_alpha + (size_t)slot * batch * 128; *bta = h->bn_beta + (size_t)slot * batch * 128; };
   auto conv_bn = [&](const float* in, int in_c, int cin_pad, int taps, const SplitWeights& wx, const float* wv, float* out, int co,
                      int Hh, int Ww, int i, int slot, int in_bn) -> int {
     float *a, *bt, *ia = nullptr, *ib = nullptr;
     ab(slot, &a, &bt);
     if (in_bn >= 0) ab(in_bn, &ia, &ib);
-    if (x3) {
+    if (x3c) {
       int n_wg = 0, rc;
       if (Hh == Hp) dim_prof_begin(DIM_PROF_AL_CONV_FULL, s);
       if ((rc = launch_al_convx3(in, in_c, cin_pad, taps, wx, nullptr, out, co, batch, Hh, Ww, h->tile_partial, &n_wg, ia, ib, s))) return rc;
@@ -270,26 +288,26 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     return launch_al_bn_apply_pool(x, a, bt, res, dst, pooled, batch, Hh, Ww, C, k, s);
   };
   // block1 (ConvBlock, ALN:367-393)
-  AL_RUN(conv_bn(h->P, 3, 16, 9, h->x_b1c1, h->b1c1, h->raw, 16, Hp, Wp, 0, 0, -1));
+  AL_RUN(conv_bn(h->P, 3, 16, 9, h->x_b1c1, h->b1c1, h->raw, c1, Hp, Wp, 0, 0, -1));
   if (fuse_bn) {
-    AL_RUN(conv_bn(h->raw, 16, 16, 9, h->x_b1c2, h->b1c2, h->act, 16, Hp, Wp, 1, 1, 0));   // bn1 + SELU of conv1 in the staging; raw output -> act
-    AL_RUN(apply_pool(h->act, 1, nullptr, h->x1, h->p2, Hp, Wp, 16, 2));
+    AL_RUN(conv_bn(h->raw, c1, c1, 9, h->x_b1c2, h->b1c2, h->act, c1, Hp, Wp, 1, 1, 0));   // bn1 + SELU of conv1 in the staging; raw output -> act
+    AL_RUN(apply_pool(h->act, 1, nullptr, h->x1, h->p2, Hp, Wp, c1, 2));
   } else {
-    AL_RUN(apply(h->raw, 0, nullptr, h->act, NP, 16));
-    AL_RUN(conv_bn(h->act, 16, 16, 9, h->x_b1c2, h->b1c2, h->raw, 16, Hp, Wp, 1, 1, -1));
-    AL_RUN(apply_pool(h->raw, 1, nullptr, h->x1, h->p2, Hp, Wp, 16, 2));
+    AL_RUN(apply(h->raw, 0, nullptr, h->act, NP, c1));
+    AL_RUN(conv_bn(h->act, c1, c1, 9, h->x_b1c2, h->b1c2, h->raw, c1, Hp, Wp, 1, 1, -1));
+    AL_RUN(apply_pool(h->raw, 1, nullptr, h->x1, h->p2, Hp, Wp, c1, 2));
   }
   // block2 (ResBlock, plain convs); its input p2 = avgpool2(x1) was written by apply_pool
-  AL_RUN(conv_bn(h->p2, 16, 16, 9, h->x_b2c1, h->b2c1, h->raw, 32, H2, W2, 2, 0, -1));
-  if (x3) AL_RUN(launch_al_convx3(h->p2, 16, 16, 1, h->x_b2ds, h->b2ds_b, h->idn, 32, batch, H2, W2, nullptr, nullptr, nullptr, nullptr, s));
-  else AL_RUN(launch_al_conv1x1(h->p2, 16, h->b2ds_w, h->b2ds_b, h->idn, 32, batch * H2 * W2, AL_ACT_NONE, s));  // K = 16: below the GEMM's K granule
+  AL_RUN(conv_bn(h->p2, c1, c1, 9, h->x_b2c1, h->b2c1, h->raw, c2, H2, W2, 2, 0, -1));
+  if (x3c) AL_RUN(launch_al_convx3(h->p2, c1, c1, 1, h->x_b2ds, h->b2ds_b, h->idn, c2, batch, H2, W2, nullptr, nullptr, nullptr, nullptr, s));
+  else AL_RUN(launch_al_conv1x1(h->p2, c1, h->b2ds_w, h->b2ds_b, h->idn, c2, batch * H2 * W2, AL_ACT_NONE, s));  // K = 16 / 8: below the GEMM's K granule
   if (fuse_bn) {
-    AL_RUN(conv_bn(h->raw, 32, 32, 9, h->x_b2c2, h->b2c2, h->act, 32, H2, W2, 3, 1, 0));
-    AL_RUN(apply_pool(h->act, 1, h->idn, h->x2, h->p3, H2, W2, 32, 4));
+    AL_RUN(conv_bn(h->raw, c2, c2, 9, h->x_b2c2, h->b2c2, h->act, c2, H2, W2, 3, 1, 0));
+    AL_RUN(apply_pool(h->act, 1, h->idn, h->x2, h->p3, H2, W2, c2, 4));
   } else {
-    AL_RUN(apply(h->raw, 0, nullptr, h->act, H2 * W2, 32));
-    AL_RUN(conv_bn(h->act, 32, 32, 9, h->x_b2c2, h->b2c2, h->raw, 32, H2, W2, 3, 1, -1));
-    AL_RUN(apply_pool(h->raw, 1, h->idn, h->x2, h->p3, H2, W2, 32, 4));
+    AL_RUN(apply(h->raw, 0, nullptr, h->act, H2 * W2, c2));
+    AL_RUN(conv_bn(h->act, c2, c2, 9, h->x_b2c2, h->b2c2, h->raw, c2, H2, W2, 3, 1, -1));
+    AL_RUN(apply_pool(h->raw, 1, h->idn, h->x2, h->p3, H2, W2, c2, 4));
   }
   // block3 / block4 (ResBlock with DeformableConv2d, ALN:274-330)
   auto dcn_block = [&](const float* x, int Hh, int Ww, int ci, int co, const float* o1w, const float* o1b, const float* r1,
@@ -307,20 +325,26 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     if ((rc = conv1x1(x, ci, dsw, xds, dsb, h->idn, co, batch * Hh * Ww, AL_ACT_NONE))) return rc;
     return bn(h->raw, Hh * Ww, co, bni + 1, h->idn, dst);
   };
-  AL_RUN(dcn_block(h->p3, H8, W8, 32, 64, h->b3o1_w, h->b3o1_b, h->b3r1, h->b3o2_w, h->b3o2_b, h->b3r2, h->b3ds_w, h->b3ds_b, 4, h->x3, h->g_b3r1, h->g_b3r2, h->g_b3ds));
-  AL_RUN(launch_al_avgpool(h->x3, h->p4, batch, H8, W8, 64, 4, s));
-  AL_RUN(dcn_block(h->p4, H32, W32, 64, 128, h->b4o1_w, h->b4o1_b, h->b4r1, h->b4o2_w, h->b4o2_b, h->b4r2, h->b4ds_w, h->b4ds_b, 6, h->x4, h->g_b4r1, h->g_b4r2, h->g_b4ds));
+  AL_RUN(dcn_block(h->p3, H8, W8, c2, c3, h->b3o1_w, h->b3o1_b, h->b3r1, h->b3o2_w, h->b3o2_b, h->b3r2, h->b3ds_w, h->b3ds_b, 4, h->x3, h->g_b3r1, h->g_b3r2, h->g_b3ds));
+  AL_RUN(launch_al_avgpool(h->x3, h->p4, batch, H8, W8, c3, 4, s));
+  AL_RUN(dcn_block(h->p4, H32, W32, c3, c4, h->b4o1_w, h->b4o1_b, h->b4r1, h->b4o2_w, h->b4o2_b, h->b4r2, h->b4ds_w, h->b4ds_b, 6, h->x4, h->g_b4r1, h->g_b4r2, h->g_b4ds));
   // feature aggregation + score head (ALN:656-669)
-  AL_RUN(conv1x1(h->x2, 32, h->hc2, h->g_hc2, nullptr, h->f2, 32, batch * H2 * W2, AL_ACT_SELU));
-  AL_RUN(conv1x1(h->x3, 64, h->hc3, h->g_hc3, nullptr, h->f3, 32, batch * H8 * W8, AL_ACT_SELU));
-  AL_RUN(conv1x1(h->x4, 128, h->hc4, h->g_hc4, nullptr, h->f4, 32, batch * H32 * W32, AL_ACT_SELU));
-  // s8 only; x1234 stays virtual.  The 32 -> 8 projections of the three up-sampled groups run at the maps' own resolutions
-  AL_RUN(launch_al_conv1x1(h->f2, 32, h->sh0 + 32 * 8, nullptr, h->q2, 8, batch * H2 * W2, AL_ACT_NONE, s));
-  AL_RUN(launch_al_conv1x1(h->f3, 32, h->sh0 + 64 * 8, nullptr, h->q3, 8, batch * H8 * W8, AL_ACT_NONE, s));
-  AL_RUN(launch_al_conv1x1(h->f4, 32, h->sh0 + 96 * 8, nullptr, h->q4, 8, batch * H32 * W32, AL_ACT_NONE, s));
-  if (x3) AL_RUN(launch_al_assemble_x3(h->x1, h->q2, h->q3, h->q4, h->asm_frag, h->asm_inv1, h->asm_inv0, h->s8, batch, Hp, Wp, s));
-  else AL_RUN(launch_al_assemble_proj(h->x1, h->q2, h->q3, h->q4, h->hc1, h->sh0, h->s8, batch, Hp, Wp, s));
-  const AlFeat F{h->x1, h->f2, h->f3, h->f4, h->hc1, Hp, Wp};
+  if (tiny) {
+    AL_RUN(launch_al_conv1x1(h->x2, c2, h->hc2, nullptr, h->f2, G, batch * H2 * W2, AL_ACT_SELU, s));
+    AL_RUN(launch_al_conv1x1(h->x3, c3, h->hc3, nullptr, h->f3, G, batch * H8 * W8, AL_ACT_SELU, s));
+    AL_RUN(launch_al_conv1x1(h->x4, c4, h->hc4, nullptr, h->f4, G, batch * H32 * W32, AL_ACT_SELU, s));
+  } else {
+    AL_RUN(conv1x1(h->x2, 32, h->hc2, h->g_hc2, nullptr, h->f2, 32, batch * H2 * W2, AL_ACT_SELU));
+    AL_RUN(conv1x1(h->x3, 64, h->hc3, h->g_hc3, nullptr, h->f3, 32, batch * H8 * W8, AL_ACT_SELU));
+    AL_RUN(conv1x1(h->x4, 128, h->hc4, h->g_hc4, nullptr, h->f4, 32, batch * H32 * W32, AL_ACT_SELU));
+  }
+  // s8 only; x1234 stays virtual.  The G -> 8 projections of the three up-sampled groups run at the maps' own resolutions
+  AL_RUN(launch_al_conv1x1(h->f2, G, h->sh0 + G * 8, nullptr, h->q2, 8, batch * H2 * W2, AL_ACT_NONE, s));
+  AL_RUN(launch_al_conv1x1(h->f3, G, h->sh0 + 2 * G * 8, nullptr, h->q3, 8, batch * H8 * W8, AL_ACT_NONE, s));
+  AL_RUN(launch_al_conv1x1(h->f4, G, h->sh0 + 3 * G * 8, nullptr, h->q4, 8, batch * H32 * W32, AL_ACT_NONE, s));
+  if (x3c) AL_RUN(launch_al_assemble_x3(h->x1, h->q2, h->q3, h->q4, h->asm_frag, h->asm_inv1, h->asm_inv0, h->s8, batch, Hp, Wp, s));
+  else AL_RUN(launch_al_assemble_proj(h->x1, h->q2, h->q3, h->q4, h->hc1, h->sh0, h->s8, c1, batch, Hp, Wp, s));
+  const AlFeat F{h->x1, h->f2, h->f3, h->f4, h->hc1, Hp, Wp, c1};
   AL_RUN(launch_al_conv3x3(h->s8, 8, h->sh2, nullptr, h->s4a, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));
   AL_RUN(launch_al_conv3x3(h->s4a, 4, h->sh4, nullptr, h->s4b, 4, batch, Hp, Wp, AL_ACT_SELU, 0, 0, Hp, Wp, s));
   AL_RUN(launch_al_conv3x3(h->s4b, 4, h->sh6, nullptr, h->score, 1, batch, Hp, Wp, AL_ACT_SIGMOID, pad_t, pad_l, H, W, s));  // unpad (ALN:672-673)
@@ -336,28 +360,28 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   AL_RUN(launch_al_dkd_refine(h->score, h->kpts_px, n_kpts_dev, h->kpts_norm, scores_dev, h->kscore, kpts_xy_dev, batch, H, W, cap, r, s));
   // SDDH (ALN:503-558)
   AL_RUN(launch_al_sddh_patches(F, h->kpts_norm, n_kpts_dev, h->patches, batch, H, W, pad_t, pad_l, cap, s));
-  const int M = h->cfg.M, M2 = 2 * M;
+  const int M = h->cfg.M, M2 = 2 * M, PK = dim * 9;
   {
     GemmArgs g;
-    g.A0 = h->patches; g.lda0 = 1152; g.strideA0 = (long long)cap * 1152; g.B = h->dh_o0_w; g.ldb = M2; g.bias = h->dh_o0_b;
-    g.C = h->hidden; g.ldc = M2; g.strideC = (long long)cap * M2; g.M = cap; g.N = M2; g.K = 1152; g.rows = n_kpts_dev;
+    g.A0 = h->patches; g.lda0 = PK; g.strideA0 = (long long)cap * PK; g.B = h->dh_o0_w; g.ldb = M2; g.bias = h->dh_o0_b;
+    g.C = h->hidden; g.ldc = M2; g.strideC = (long long)cap * M2; g.M = cap; g.N = M2; g.K = PK; g.rows = n_kpts_dev;
     AL_RUN(gemm(g, h->g_o0, batch));
   }
   AL_RUN(launch_al_sddh_sample(F, h->kpts_norm, n_kpts_dev, h->hidden, h->dh_o2_w, h->dh_o2_b, h->feats, M, batch, H, W, pad_t, pad_l, cap, s));
   {
-    GemmArgs g;  // sf_conv 1x1 (128 -> 128) + SELU over the M sampled positions of every keypoint
-    g.A0 = h->feats; g.lda0 = 128; g.strideA0 = (long long)cap * M * 128; g.B = h->dh_sf; g.ldb = 128;
-    g.C = h->feats2; g.ldc = 128; g.strideC = (long long)cap * M * 128; g.M = cap * M; g.N = 128; g.K = 128;
+    GemmArgs g;  // sf_conv 1x1 (dim -> dim) + SELU over the M sampled positions of every keypoint
+    g.A0 = h->feats; g.lda0 = dim; g.strideA0 = (long long)cap * M * dim; g.B = h->dh_sf; g.ldb = dim;
+    g.C = h->feats2; g.ldc = dim; g.strideC = (long long)cap * M * dim; g.M = cap * M; g.N = dim; g.K = dim;
     g.rows = n_kpts_dev; g.rows_scale = M; g.relu = 2;
     AL_RUN(gemm(g, h->g_sf, batch));
   }
   {
-    GemmArgs g;  // einsum("ncp,pcd->nd") with agg_weights [p][c][d] == [n][p*128+c] x [p*128+c][d]
-    g.A0 = h->feats2; g.lda0 = M * 128; g.strideA0 = (long long)cap * M * 128; g.B = h->dh_agg; g.ldb = 128;
-    g.C = desc_dev; g.ldc = 128; g.strideC = (long long)cap * 128; g.M = cap; g.N = 128; g.K = M * 128; g.rows = n_kpts_dev;
+    GemmArgs g;  // einsum("ncp,pcd->nd") with agg_weights [p][c][d] == [n][p*dim+c] x [p*dim+c][d]
+    g.A0 = h->feats2; g.lda0 = M * dim; g.strideA0 = (long long)cap * M * dim; g.B = h->dh_agg; g.ldb = dim;
+    g.C = desc_dev; g.ldc = dim; g.strideC = (long long)cap * dim; g.M = cap; g.N = dim; g.K = M * dim; g.rows = n_kpts_dev;
     AL_RUN(gemm(g, h->g_agg, batch));
   }
-  AL_RUN(launch_al_normalize_rows(desc_dev, n_kpts_dev, batch, cap, 128, s));
+  AL_RUN(launch_al_normalize_rows(desc_dev, n_kpts_dev, batch, cap, dim, s));
 #undef AL_RUN
   h->last_hp = Hp; h->last_wp = Wp; h->last_h = H; h->last_w = W; h->last_batch = batch;
   return 0;
@@ -369,8 +393,8 @@ int dim_aliked_debug_buffers(dim_aliked* h, const float** x1234, const float** s
     DIM_REQUIRE(h->last_batch > 0, "dim_aliked_debug_buffers: no extract call yet");
     if (h->dbg_x1234) hipFree(h->dbg_x1234);
     h->dbg_x1234 = nullptr;
-    DIM_HIP(hipMalloc((void**)&h->dbg_x1234, (size_t)h->last_batch * h->last_hp * h->last_wp * 128 * sizeof(float)));
-    if (launch_al_assemble(h->x1, h->f2, h->f3, h->f4, h->hc1, h->sh0, h->dbg_x1234, h->s8, h->last_batch, h->last_hp, h->last_wp, nullptr)) return -1;
+    DIM_HIP(hipMalloc((void**)&h->dbg_x1234, (size_t)h->last_batch * h->last_hp * h->last_wp * h->cfg.dim * sizeof(float)));
+    if (launch_al_assemble(h->x1, h->f2, h->f3, h->f4, h->hc1, h->sh0, h->dbg_x1234, h->s8, h->cfg.c1, h->last_batch, h->last_hp, h->last_wp, nullptr)) return -1;
     DIM_HIP(hipDeviceSynchronize());
     *x1234 = h->dbg_x1234;
   }

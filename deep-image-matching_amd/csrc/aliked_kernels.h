@@ -28,15 +28,16 @@ int launch_al_deform_conv(const float* in, int cin, const float* offsets, int of
 int launch_al_clamp(float* x, size_t n, float lim, hipStream_t s);
 // feature aggregation + first score-head layer (ALN:657-668)
 int launch_al_assemble(const float* x1, const float* f2, const float* f3, const float* f4, const float* w1, const float* ws0,
-                       float* x1234, float* s8, int batch, int Hp, int Wp, hipStream_t s);
+                       float* x1234, float* s8, int c1, int batch, int Hp, int Wp, hipStream_t s);
 // the product form of the same stage: q_g = f_g x score_head.0[32g:32g+32] at the maps' own resolutions (8 channels), interpolated
 int launch_al_assemble_proj(const float* x1, const float* q2, const float* q3, const float* q4, const float* w1, const float* ws0, float* s8,
-                            int batch, int Hp, int Wp, hipStream_t s);
+                            int c1, int batch, int Hp, int Wp, hipStream_t s);
 // DKD sub-pixel refinement (ALN:176-216) and SDDH pieces (ALN:503-558)
 int launch_al_dkd_refine(const float* score, const float* kpts_px, const int* n_kpts, float* kpts_norm, float* disp,
                          float* kscore, float* kpts_out, int batch, int H, int W, int capacity, int radius, hipStream_t s);
 // sources of the (never materialised) 128-channel feature map x1234, padded frame Hp x Wp
-struct AlFeat { const float *x1, *f2, *f3, *f4, *w1; int Hp, Wp; };
+struct AlFeat { const float *x1, *f2, *f3, *f4, *w1; int Hp, Wp, c1; };   // c1 = channels of x1: 16 (dim 128) or 8 (aliked-t16, dim 64)
+inline int al_deform_krow(int cin) { return (9 * cin + 31) / 32 * 32; }   // row length of the deformed im2col matrix (K of its GEMM)
 int launch_al_sddh_patches(const AlFeat& F, const float* kpts_norm, const int* n_kpts, float* patches, int batch, int H, int W,
                            int pad_t, int pad_l, int capacity, hipStream_t s);
 int launch_al_sddh_sample(const AlFeat& F, const float* kpts_norm, const int* n_kpts, const float* off_hidden, const float* w2,

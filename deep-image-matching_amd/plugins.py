@@ -220,6 +220,7 @@ class AlikedExtractor(BatchedTilingMixin, _ExtractorBase):
             logger.warning("ALIKED: running on seeded SYNTHETIC weights (allow_synthetic_weights) - test / benchmark use only")
         self._sd = _weights.load_aliked_state_dict(path, model_name=self._net_cfg["model_name"],
                                                    allow_synthetic=bool(cfg.get("allow_synthetic_weights", False)))
+        self.descriptor_size = int(_weights.ALIKED_CFGS[self._net_cfg["model_name"]][4])   # 128; aliked-t16: 64 (the reference's class attribute says 128 for all)
         self._net: Optional[AlikedHIP] = None
         self._net_hw = (0, 0)
 

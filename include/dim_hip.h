@@ -176,7 +176,7 @@ typedef struct dim_aliked_weights {
 
 /* ALIKED._default_conf (ALN:562-567) + the geometry row of ALIKED.cfgs (ALN:573-579). */
 typedef struct dim_aliked_config {
-  int c1, c2, c3, c4, dim, K, M;   /* ALN:573-579: aliked-n16 / n16rot 16,32,64,128,128,3,16; aliked-n32 the same with M = 32 */
+  int c1, c2, c3, c4, dim, K, M;   /* ALN:573-579: aliked-n16 / n16rot 16,32,64,128,128,3,16; aliked-n32 the same with M = 32; aliked-t16 8,16,32,64,64,3,16 (desc_dev rows are dim floats) */
   int max_num_keypoints;           /* n_limit of DKD; -1 = capacity */
   double detection_threshold;      /* > 0 */
   int nms_radius;
@@ -188,11 +188,11 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
 void dim_aliked_destroy(dim_aliked* h);
 /* images_dev: [batch][H][W][in_channels] fp32 (HWC, as the numpy image arrives; already /255,
  *             extractors/aliked.py:66-78), in_channels 3 (RGB) or 1 (repeated to RGB, ALN:679-680).
- * Outputs as dim_sp_extract with D = 128: kpts (x, y) sub-pixel pixel coordinates (ALN:687),
- * scores = DIM's "scores" i.e. the score DISPERSITIES (quirk Q8), desc row-major (N, 128). */
+ * Outputs as dim_sp_extract with D = cfg.dim (128; aliked-t16: 64): kpts (x, y) sub-pixel pixel coordinates (ALN:687),
+ * scores = DIM's "scores" i.e. the score DISPERSITIES (quirk Q8), desc row-major (N, dim). */
 int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H, int W, int in_channels, float* kpts_xy_dev,
                        float* scores_dev, float* desc_dev, int32_t* n_kpts_dev, void* stream);
-/* Parity taps: un-normalised feature map [batch][Hp][Wp][128] in the padded frame, score map [batch][H][W]. */
+/* Parity taps: un-normalised feature map [batch][Hp][Wp][dim] in the padded frame, score map [batch][H][W]. */
 int dim_aliked_debug_buffers(dim_aliked* h, const float** x1234, const float** score_map, int* hp, int* wp, int* pad_t, int* pad_l);
 
 /* ------------------------------------------------------------------------ */

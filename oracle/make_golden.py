@@ -175,7 +175,7 @@ def main_aliked():
                             descriptors=ref["descriptors"][0].t().contiguous().numpy(), scores=ref["keypoint_scores"][0].numpy())
         print(f"al_{name}: N={ref['keypoints'].shape[1]} ok (oracle == reference, bit-exact)")
     # also pin with the REAL checkpoints that ship inside the reference tree (not goldens; tests/assets holds byte copies for the HIP tests)
-    for model, case_name in (("aliked-n16rot", "rgb_pad"), ("aliked-n32", "n32")):
+    for model, case_name in (("aliked-n16rot", "rgb_pad"), ("aliked-n32", "n32"), ("aliked-t16", "t16"), ("aliked-n16", "rgb_pad")):
         real = REF / f"ALIKED/models/{model}.pth"
         if real.exists():
             sd = {k: v for k, v in torch.load(str(real), map_location="cpu").items()}

@@ -1,4 +1,4 @@
-"""CPU sweep (no GPU): random ALIKED configurations — sides that are not multiples of 32 (replicate padding), gray / RGB, NMS radius 2-3,
+"""CPU sweep (no GPU): random ALIKED configurations — all four geometries (t16 / n16 / n16rot / n32), sides that are not multiples of 32 (replicate padding), gray / RGB, NMS radius 2-3,
 n_limit binding or not, both arithmetics (fp16x3 matrix-core path / fp32 paths) — through the HIP sources on the test emulator against the
 oracle with compare_aliked (1e-3, exact keypoint set up to explained ties).   python scripts/study/stress_aliked_emu.py SEED N"""
 import ctypes, importlib, os, random, sys, torch
@@ -14,9 +14,10 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 bad = 0
 for it in range(N):
     H, W, C = rnd.randint(40, 100), rnd.randint(40, 120), rnd.choice([1, 3])
-    cfg = {"model_name": "aliked-n16rot", "max_num_keypoints": rnd.choice([30, 200, 4000]), "detection_threshold": rnd.choice([0.2, 0.1, 0.4]),
+    model = rnd.choice(["aliked-n16rot", "aliked-n32", "aliked-t16", "aliked-n16"])
+    cfg = {"model_name": model, "max_num_keypoints": rnd.choice([30, 200, 4000]), "detection_threshold": rnd.choice([0.2, 0.1, 0.4]),
            "nms_radius": rnd.choice([2, 3])}
-    sd = weights.synthetic_aliked_state_dict(rnd.randrange(40))
+    sd = weights.synthetic_aliked_state_dict(rnd.randrange(40), model)
     img = torch.rand(1, C, H, W, generator=torch.Generator().manual_seed(rnd.randrange(10000)))
     arith = rnd.choice([2, 2, 0])
     lib.dim_tune_set(1, arith)

@@ -119,6 +119,9 @@ AL_CASES = {
     # aliked-n32 (ALN:577): 32 instead of 16 deformable sample positions in the descriptor head
     "n32": {"seed": 23, "H": 72, "W": 88, "C": 3, "wseed": 9,
             "cfg": {"model_name": "aliked-n32", "max_num_keypoints": 300, "detection_threshold": 0.2, "nms_radius": 2}},
+    # aliked-t16 (ALN:574): 8 / 16 / 32 / 64 channels, 64-d descriptors; gray input, padding on both sides
+    "t16": {"seed": 24, "H": 80, "W": 76, "C": 1, "wseed": 10,
+            "cfg": {"model_name": "aliked-t16", "max_num_keypoints": 300, "detection_threshold": 0.2, "nms_radius": 2}},
 }
 
 

@@ -102,7 +102,7 @@ REAL_ALIKED = Path(__file__).parent / "assets" / "aliked-n16rot.pth"   # byte co
 REAL_ALIKED_N32 = Path(__file__).parent / "assets" / "aliked-n32.pth"  # likewise (md5 fb7434eaaf6c52604541322d7e0fde58)
 
 
-@pytest.mark.parametrize("model", ["aliked-n16rot", "aliked-n32"])
+@pytest.mark.parametrize("model", ["aliked-n16rot", "aliked-n32", "aliked-t16"])
 def test_aliked_real_checkpoint_through_the_hip_sources(emu_lib, model):
     """The REAL aliked-n16rot.pth / aliked-n32.pth that ship inside the reference tree (tests/assets holds byte copies: data files, md5
     bfec5e8086e9f6bf68ffeb90ca7a793a / fb7434eaaf6c52604541322d7e0fde58, so that the GPU tests can use them too) through the HIP sources
