@@ -113,7 +113,8 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
               cfg->c4, cfg->dim, cfg->K, cfg->M);
   const int c1 = cfg->c1, c2 = cfg->c2, c3 = cfg->c3, c4 = cfg->c4, dim = cfg->dim, G = cfg->dim / 4;
   const int M = cfg->M, M2 = 2 * cfg->M;   // SDDH sample positions; offset channels (ALN:503-519)
-  DIM_REQUIRE(cfg->detection_threshold > 0, "dim_aliked_create: detection_threshold must be > 0 (top-k-only mode not built)");
+  // detection_threshold <= 0 selects DKD's top-k mode (ALN:602: top_k = max_num_keypoints): the max_num_keypoints highest NMS maxima
+  DIM_REQUIRE(cfg->detection_threshold > 0 || cfg->max_num_keypoints > 0, "dim_aliked_create: detection_threshold <= 0 (top-k mode) needs max_num_keypoints > 0");
   DIM_REQUIRE(cfg->nms_radius >= 1 && cfg->nms_radius <= 6, "dim_aliked_create: nms_radius %d", cfg->nms_radius);
   DIM_REQUIRE(capacity > 0 && capacity <= 4096 && cfg->max_num_keypoints <= capacity, "dim_aliked_create: capacity %d (<= 4096) must cover max_num_keypoints %d", capacity, cfg->max_num_keypoints);
   DIM_REQUIRE(max_batch > 0 && max_batch <= 64 && max_h >= 16 && max_w >= 16, "dim_aliked_create: bad sizes");
@@ -351,9 +352,16 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
   // DKD (ALN:123-244): NMS, border, threshold (mean fallback), n_limit, soft-argmax refinement
   AL_RUN(launch_nms(h->score, h->nms, batch, H, W, r, s));
   AL_RUN(launch_al_mean(h->score, batch, H * W, h->partial, h->mean, s));
-  AL_RUN(launch_select_ex(h->nms, batch, H, W, (float)h->cfg.detection_threshold, nullptr, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 1, s));
-  AL_RUN(launch_al_pick_threshold(h->ncand, h->mean, (float)h->cfg.detection_threshold, h->thr_eff, batch, s));
-  AL_RUN(launch_select_ex(h->nms, batch, H, W, 0.f, h->thr_eff, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 0, s));
+  if (h->cfg.detection_threshold > 0) {
+    AL_RUN(launch_select_ex(h->nms, batch, H, W, (float)h->cfg.detection_threshold, nullptr, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 1, s));
+    AL_RUN(launch_al_pick_threshold(h->ncand, h->mean, (float)h->cfg.detection_threshold, h->thr_eff, batch, s));
+    AL_RUN(launch_select_ex(h->nms, batch, H, W, 0.f, h->thr_eff, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 0, s));
+  } else {
+    // top-k mode (ALN:150-151: topk over the border-cleared NMS map): every maximum is a candidate (the map is zero elsewhere, scores are
+    // sigmoids > 0) and launch_topk keeps the max_num_keypoints highest.  With FEWER maxima than that the reference fills up with zero-score
+    // pixels in torch.topk's unspecified tie order; this path returns the maxima only.
+    AL_RUN(launch_select_ex(h->nms, batch, H, W, 0.f, nullptr, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 0, s));
+  }
   const int n_limit = h->cfg.max_num_keypoints > 0 ? h->cfg.max_num_keypoints : cap;
   AL_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H, W, n_limit, cap, h->kpts_px, h->sc_tmp, n_kpts_dev, s));
   // Q8: DIM's "scores" are the dispersities (ALN:682 unpacks DKD's return in the wrong order)

@@ -98,6 +98,24 @@ def test_aliked_emulated_vs_oracle_and_golden(emu_lib, name):
     compare_aliked(out, gold)
 
 
+def test_aliked_top_k_mode_vs_oracle(emu_lib):
+    """detection_threshold <= 0 = DKD's top-k mode (ALN:602, 150-151): the max_num_keypoints highest NMS maxima, whatever their score."""
+    case = gc.AL_CASES["rgb_pad"]
+    cfg = {**case["cfg"], "detection_threshold": -1.0, "max_num_keypoints": 50}
+    sd, img = gc.al_weights(case), gc.al_image(case)
+    net = al_mod.AlikedHIP(sd, cfg, max_batch=1, max_hw=(case["H"], case["W"]), capacity=64, device="cpu", lib=emu_lib)
+    out = {k: v.cpu() for k, v in net(img).items()}
+    ref = aliked_ref.aliked_forward(img, sd, cfg, taps=True)
+    assert ref["keypoints"].shape[0] == 50
+    res = compare_aliked(out, ref, ref_score_map=ref["score_map"], threshold=0.0, nms_radius=cfg["nms_radius"], n_limit=50)
+    assert res["n_out"] == 50
+    # with the default threshold the same image keeps 336 keypoints (golden rgb_pad): the 50 are its highest maxima, none below 0.2 is needed
+    thr = {**cfg, "detection_threshold": 0.2}
+    net2 = al_mod.AlikedHIP(sd, thr, max_batch=1, max_hw=(case["H"], case["W"]), capacity=64, device="cpu", lib=emu_lib)
+    out2 = {k: v.cpu() for k, v in net2(img).items()}
+    assert {tuple(r) for r in out["keypoints"].round().int().tolist()} == {tuple(r) for r in out2["keypoints"].round().int().tolist()}
+
+
 REAL_ALIKED = Path(__file__).parent / "assets" / "aliked-n16rot.pth"   # byte copy of the reference's thirdparty/ALIKED/models/aliked-n16rot.pth
 REAL_ALIKED_N32 = Path(__file__).parent / "assets" / "aliked-n32.pth"  # likewise (md5 fb7434eaaf6c52604541322d7e0fde58)
 
