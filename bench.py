@@ -44,6 +44,7 @@ import importlib
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -89,6 +90,7 @@ def parse():
     ap.add_argument("--main-region-only", action="store_true", help="skip the second (other-schedule) region: used for the rocprofv3 passes")
     ap.add_argument("--cpu-sample-pairs", type=int, default=4)
     ap.add_argument("--tile-selection", default="PRESELECTION", help="config5: tile_selection method (PRESELECTION | GRID | EXHAUSTIVE | PRESELECTION_AFFINE_TRANSFORM)")
+    ap.add_argument("--strong-timeout", type=float, default=300.0, help="seconds after which rank 0 prints the headline line without the strong_scaling sub-record and exits 3")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the strong_scaling sub-record (the config-4 job run after the timed region)")
     a = ap.parse_args()
     if a.images is None:
@@ -548,21 +550,8 @@ def main():
     clock_mhz = (ck[2] - ck[0]) / max(1, ck[3] - ck[1]) * 100.0
     sat_total, sat_sites = capi.saturation(lib, stream_ptr, reset=True)  # fp16x3 range guard over the whole run: must be 0
 
-    # strong scaling where the driver's 1/2/4/8 command sees it (VERDICT r3 next #6): the FIXED config-4 job (150 images -> 10 000
-    # exhaustive pairs, images and pairs sharded over the ranks, two all-gathers) after the headline region; `value` stays the headline
-    strong = None
     flat_numel = flat.numel()
-    if not a.no_strong_scaling and not a.main_region_only:
-        flat_numel = flat.numel()
-        del pool, feats, flat, outs
-        torch.cuda.empty_cache()
-        rec = measure_config4(a, rank, world, dev, dist, lib, steps=1, warmup=1)
-        if rec is not None:
-            strong = {k: rec[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "phases_s_max_over_ranks", "matches_total",
-                                          "matches_per_pair_mean", "pairs_with_at_least_100_matches", "fp16x3_range_guard")}
-            strong["workload"] = rec["config"]["workload"]
-            strong["sharding"] = rec["config"]["sharding"]
-
+    line = None
     if rank == 0:
         pairs_total = world * K * P
         value = pairs_total / dt
@@ -595,7 +584,7 @@ def main():
             "end_to_end_tflops_per_gpu": (2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR) * value / world / 1e3,
             "timed_region_s": dt, "pairs_total": pairs_total, "sustained_clock_mhz": clock_mhz,
             "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
-            "strong_scaling": strong,
+            "strong_scaling": None,
             "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1,true,2> (SuperPoint conv1a 1->64 evaluated in the halo staging + conv1b 64->64 3x3 "
                                    "+ bias + ReLU + 2x2 max-pool, fp32-accurate on the fp16 MFMA (fp16x3); 1024^2 images)", "bound": "mfma",
                          "achieved": conv_tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -622,6 +611,38 @@ def main():
                          "avg_launch_ms": conv_ms, "launches": launches.value,
                          "algorithmic_gflop_per_launch": gflop_per_launch},
         }
+    # strong scaling where the driver's 1/2/4/8 command sees it (VERDICT r3 next #6): the FIXED config-4 job (150 images -> 10 000
+    # exhaustive pairs, images and pairs sharded over the ranks, two all-gathers) after the headline region; `value` stays the headline.
+    # The headline line is complete before it starts: a failure of the sub-run becomes `strong_scaling.error`, and if it never returns
+    # (a rank lost inside a collective) rank 0 still prints the line after --strong-timeout seconds and exits non-zero.
+    if not a.no_strong_scaling and not a.main_region_only:
+        del pool, feats, flat, outs
+        torch.cuda.empty_cache()
+        watchdog = None
+        if rank == 0:
+            def give_up():
+                line["strong_scaling"] = {"error": f"the config-4 sub-run did not return within {a.strong_timeout} s"}
+                line["cpu_baseline"] = None
+                print(json.dumps(line), flush=True)
+                os._exit(3)
+            watchdog = threading.Timer(a.strong_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        strong = None
+        try:
+            rec = measure_config4(a, rank, world, dev, dist, lib, steps=1, warmup=1)
+            if rec is not None:
+                strong = {k: rec[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "phases_s_max_over_ranks", "matches_total",
+                                              "matches_per_pair_mean", "pairs_with_at_least_100_matches", "fp16x3_range_guard")}
+                strong["workload"] = rec["config"]["workload"]
+                strong["sharding"] = rec["config"]["sharding"]
+        except Exception as e:   # (every rank runs the same deterministic job: an exception is raised on all of them or on none)
+            strong = {"error": repr(e)[:400]}
+        if watchdog is not None:
+            watchdog.cancel()
+        if rank == 0:
+            line["strong_scaling"] = strong
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_sample_pairs)
         else:
