@@ -78,7 +78,7 @@ __device__ __forceinline__ void nms_window_max(const T (&v)[SEG + 2 * R], T (&ou
     out[o] = m;
   }
 }
-template <int R, int SEG, int NMS_THREADS, typename T, bool ROW, typename Emit>
+template <int R, int SEG, int NMS_THREADS, typename T, bool ROW, bool CLAMP0 = false, typename Emit>
 __device__ __forceinline__ void nms_line_max(const T* src, int TS, int l0, int l1, int p0, int p1, Emit emit) {
   // lines l0..l1-1, window maxima at positions p0..p1-1 (the window p-R..p+R always lies inside the array: every
   // stage only covers the region its inputs are valid on, which shrinks by R per pool).  SEG outputs per item: chosen
@@ -102,6 +102,10 @@ __device__ __forceinline__ void nms_line_max(const T* src, int TS, int l0, int l
         v[k] = src[off + q * stride];
       }
     }
+    if (CLAMP0) {   // float lines only: the values enter the pool as max(v, 0) (nms_kernel's marked scores)
+#pragma unroll
+      for (int k = 0; k < SEG + 2 * R; ++k) v[k] = (T)__builtin_fmaxf((float)v[k], 0.0f);
+    }
     T mo[SEG];
     nms_window_max<R, SEG, T>(v, mo);
 #pragma unroll
@@ -112,17 +116,20 @@ __device__ __forceinline__ void nms_line_max(const T* src, int TS, int l0, int l
   }
 }
 
-// TILE 32 / 512 threads: 54 KB of LDS, two workgroups per CU, (32 + 10 R)^2 / 32^2 = 3.75 x the tile area per pass at R = 3.
-// TILE 64 / 1024 threads: 125 KB (R = 3), one workgroup per CU, 2.16 x: 42 % less pass work per output pixel.
+// TILE 32 / 512 threads: 35 KB of LDS, (32 + 10 R)^2 / 32^2 = 3.75 x the tile area per pass at R = 3.
+// TILE 64 / 1024 threads: 80 KB (R = 3), two workgroups per CU, 2.16 x: 42 % less pass work per output pixel.
 template <int R, int TILE, int NMS_THREADS, int SEG>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ smap, float* __restrict__ out, int H8, int W8,
                                                   int tiles_x) {
   constexpr int HALO = 5 * R, T = TILE + 2 * HALO, TS = T | 1, TT = T * TS;
+  // 9 bytes per tile element (round 4; 14 before): the byte scratch of the mask passes lives in the float scratch (never live together), and the
+  // "suppressed scores" of a round are not stored — a pixel near a kept maximum carries the mark in the SIGN BIT of its score (scores are
+  // softmax outputs >= +0, or -inf outside the image), the pool input is max(s', 0) and the mark is cleared again for the next round.  80 KB
+  // instead of 125 KB for the 64 x 64 tile at R = 3: two workgroups per CU, so that one's load / store / barrier phases overlap the other's passes.
   __shared__ float s[TT];
   __shared__ float t[TT];
-  __shared__ float rest[TT];
   __shared__ unsigned char kp[TT];
-  __shared__ unsigned char t8[TT];
+  unsigned char* const t8 = (unsigned char*)t;
   const int tid = threadIdx.x, b = blockIdx.z;
   const int ty0 = (blockIdx.x / tiles_x) * TILE - HALO, tx0 = (blockIdx.x % tiles_x) * TILE - HALO;
   const float* src = smap + (size_t)b * H8 * W8;
@@ -148,18 +155,19 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     const int k = 1 + 2 * round;  // kp is exact on region k
     nms_line_max<R, SEG, NMS_THREADS, unsigned char, true>(kp, TS, lo(k), hi(k), lo(k + 1), hi(k + 1), [&](int j, unsigned char m) { t8[j] = m; });
     __syncthreads();
-    // near = dilate(keep); rest = near ? 0 : s, the sign bit of the 0 remembers "near"
+    // near = dilate(keep): marked in the sign bit of the score (-inf outside the image stays what it is; the previous round's marks are replaced)
     nms_line_max<R, SEG, NMS_THREADS, unsigned char, false>(t8, TS, lo(k + 1), hi(k + 1), lo(k + 1), hi(k + 1), [&](int j, unsigned char m) {
-      const float sv = s[j];
-      rest[j] = (sv == NEG) ? NEG : (m ? -0.0f : sv);
+      const unsigned bits = __float_as_uint(s[j]);
+      if (bits != 0xff800000u) s[j] = __uint_as_float((bits & 0x7fffffffu) | (m ? 0x80000000u : 0u));
     });
     __syncthreads();
-    nms_line_max<R, SEG, NMS_THREADS, float, true>(rest, TS, lo(k + 1), hi(k + 1), lo(k + 2), hi(k + 2), [&](int j, float m) { t[j] = m; });
+    // the suppressed scores of the round: rest = near ? 0 : s = max(s', 0) (outside the image 0 instead of -inf: a window around an in-image
+    // pixel holds that pixel's own value >= 0, so its maximum is the same)
+    nms_line_max<R, SEG, NMS_THREADS, float, true, true>(s, TS, lo(k + 1), hi(k + 1), lo(k + 2), hi(k + 2), [&](int j, float m) { t[j] = m; });
     __syncthreads();
     nms_line_max<R, SEG, NMS_THREADS, float, false>(t, TS, lo(k + 2), hi(k + 2), lo(k + 2), hi(k + 2), [&](int j, float m) {
-      const float rv = rest[j];
-      const bool near = __float_as_uint(rv) == 0x80000000u;
-      if (rv != NEG && !near && rv == m) kp[j] = 1;
+      const float sv = s[j];   // in the image: >= +0 and unmarked, or marked (sign bit) = near a kept maximum
+      if (sv != NEG && (__float_as_uint(sv) >> 31) == 0u && sv == m) kp[j] = 1;
     });
     __syncthreads();
   }
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     const int gy = ty0 + HALO + y, gx = tx0 + HALO + x;
     if (gy < H8 && gx < W8) {
       const int j = (y + HALO) * TS + x + HALO;
-      dst[(size_t)gy * W8 + gx] = kp[j] ? s[j] : 0.0f;
+      dst[(size_t)gy * W8 + gx] = kp[j] ? __uint_as_float(__float_as_uint(s[j]) & 0x7fffffffu) : 0.0f;   // (a kept maximum is near itself: clear the mark)
     }
   }
 }

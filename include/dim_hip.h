@@ -308,7 +308,8 @@ int dim_op_ffn_fused_f32(const float* A, int lda, const void* w0_x3_handle, cons
 int dim_op_conv3x3_nhwc_f32(const float* in, const float* w_tap_cin_cout, const float* bias, float* out, int batch,
                             int H, int W, int cin, int cout, int pool2x2, int relu, void* stream);
 
-/* simple_nms (SPN:47-63) on [batch][H][W] score maps, radius 0..6; non-maxima -> 0. */
+/* simple_nms (SPN:47-63) on [batch][H][W] score maps, radius 0..6; non-maxima -> 0.  Scores must be >= +0 (what the reference feeds it: softmax
+ * outputs; ALIKED: sigmoids) — the kernel keeps a per-pixel mark in the sign bit. */
 int dim_op_simple_nms_f32(const float* score_map, float* out, int batch, int H, int W, int radius, void* stream);
 
 /* The same convolution on the 16-bit matrix cores at fp32 accuracy (csrc/conv_x6.hip): weights are pre-split from
