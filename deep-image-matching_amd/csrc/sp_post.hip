@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* __restric
 // window maxima (1 LDS read + 1 write per element instead of 2R+1 reads).  Lane -> line
 // mapping keeps both passes bank-conflict free: the row pass strides lanes over y (odd TS),
 // the column pass over x.  Every stage covers only the region its inputs are exact on (T shrinks by 2R per
-// pool: 62 -> 56 -> 50 -> 44 -> 38 -> 32 for R = 3, TILE = 32): a third less work than full-tile passes.  Arrays: s (scores, -inf outside the image), t (row-pass scratch),
-// rest (suppressed scores; sign bit marks "near a kept maximum"), kp / t8 (keep mask, bytes).
+// pool: 62 -> 56 -> 50 -> 44 -> 38 -> 32 for R = 3, TILE = 32): a third less work than full-tile passes.  Arrays: s (scores, -inf outside the image; the sign bit
+// marks "near a kept maximum" during a suppress-and-recover round), t (row-pass scratch; the mask passes' byte scratch t8 lives in it), kp (keep mask, bytes).
 // window maximum as v_max3 chains.  `a > b ? a : b` on floats compiles to v_cmp_gt_f32 + v_cndmask_b32 (+ an s_nop for the VCC hazard)
 // per step — ~15 issue slots per output of a 7-wide window, and every instruction of this VALU-bound kernel is time (round-4
 // counters: the float passes were ~2/3 of its 16 us per 1024^2 map); fmaxf nests become v_max3_f32.  Scores are finite or -inf
@@ -444,7 +444,7 @@ int launch_nms(const float* smap, float* out, int batch, int H8, int W8, int rad
   switch (radius) {
     case 0: DIM_NMS(0, 32, 512, 8) break;
     case 1: if (big) DIM_NMS(1, 64, 1024, 8) else DIM_NMS(1, 32, 512, 8) break;
-    case 2: DIM_NMS(2, 32, 512, 8) break;  // 4 workgroups of 38 KB per CU beat one 64-tile workgroup of 100 KB here (measured 2.5 vs 3.1 us per 512^2 map)
+    case 2: DIM_NMS(2, 32, 512, 8) break;  // (round 2, 14-byte elements: 4 workgroups of 38 KB per CU beat one 64-tile workgroup of 100 KB: 2.5 vs 3.1 us per 512^2 map)
     case 3: if (big) DIM_NMS(3, 64, 1024, 10) else DIM_NMS(3, 32, 512, 8) break;
     case 4: if (big) DIM_NMS(4, 64, 1024, 12) else DIM_NMS(4, 32, 512, 8) break;
     case 5: DIM_NMS(5, 16, 512, 8) break;
