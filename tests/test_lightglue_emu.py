@@ -206,7 +206,7 @@ def test_wide_gemm_blocks_with_64_wide_k_chunks_are_bit_identical(emu_lib):
         outs = []
         try:
             emu_lib.dim_tune_set(6, 2)
-            for kc in (32, 64, 33, 36):
+            for kc in ((32, 64, 33, 36) if name == "fixed" else (32, 36)):   # the two prototypes on one case, the A/B loop of the product kernel on both
                 emu_lib.dim_tune_set(14, kc)
                 out, ref = run_case(emu_lib, case)
                 compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
