@@ -1,5 +1,6 @@
 #!/bin/bash
-# same-box A/B of the fp16 split's residual: v_fma_mix_f32 (product) vs convert + subtract (libdim_hip_nomix.so, built with -DDIM_SPLIT_NO_MIX)
+# same-box A/B of the fp16 split's residual: v_fma_mix_f32 (product) vs convert + subtract (libdim_hip_nomix.so: build it first, in the build container, with
+#   python -c "import importlib; importlib.import_module('deep-image-matching_amd.build').build_variant('nomix', ['-DDIM_SPLIT_NO_MIX'])")
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 for rep in 1 2; do
   for V in mix nomix; do
