@@ -207,7 +207,25 @@ __global__ __launch_bounds__(256) void count_rows_kernel(const float* __restrict
   if (thr_dev) thr = thr_dev[b];
   const float* row = nms + ((size_t)b * H8 + y) * W8;
   int c = 0;
-  for (int x = lane; x < W8; x += 64) c += sp_is_candidate(row[x], y, x, H8, W8, thr, border) ? 1 : 0;
+  if ((W8 & 3) == 0) {   // 16 bytes per lane, up to four requests in flight (one row of a 1024-wide map): the scalar loop ran at the load latency
+    for (int x0 = 0; x0 < W8; x0 += 1024) {
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = x0 + 256 * i + 4 * lane;
+        v[i] = x < W8 ? *(const float4*)(row + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = x0 + 256 * i + 4 * lane;
+        if (x < W8)
+          c += (sp_is_candidate(v[i].x, y, x, H8, W8, thr, border) ? 1 : 0) + (sp_is_candidate(v[i].y, y, x + 1, H8, W8, thr, border) ? 1 : 0) +
+               (sp_is_candidate(v[i].z, y, x + 2, H8, W8, thr, border) ? 1 : 0) + (sp_is_candidate(v[i].w, y, x + 3, H8, W8, thr, border) ? 1 : 0);
+      }
+    }
+  } else {
+    for (int x = lane; x < W8; x += 64) c += sp_is_candidate(row[x], y, x, H8, W8, thr, border) ? 1 : 0;
+  }
   c = wave_sum_i(c);
   if (lane == 0) rowcount[(size_t)b * H8 + y] = c;
 }
@@ -248,6 +266,44 @@ __global__ __launch_bounds__(256) void emit_rows_kernel(const float* __restrict_
   const float* row = nms + ((size_t)b * H8 + y) * W8;
   const size_t base_img = (size_t)b * H8 * W8;
   int base = rowoff[(size_t)b * H8 + y];
+  if ((W8 & 3) == 0) {   // the wide form of the loop below: lane l holds x .. x + 3 of every 256-column group; row-major order = lower lanes first, then the lane's own lower elements
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    for (int x0 = 0; x0 < W8; x0 += 1024) {
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = x0 + 256 * i + 4 * lane;
+        v[i] = x < W8 ? *(const float4*)(row + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = x0 + 256 * i + 4 * lane;
+        if (x0 + 256 * i >= W8) break;   // wave-uniform
+        const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        bool c[4];
+        unsigned long long m[4];
+        int before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          c[j] = x < W8 && sp_is_candidate(e[j], y, x + j, H8, W8, thr, border);
+          m[j] = __ballot(c[j]);
+          before += __popcll(m[j] & lower);
+          total += __popcll(m[j]);
+        }
+        int pos = base + before;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (c[j]) {
+            cand_score[base_img + pos] = e[j];
+            cand_idx[base_img + pos] = y * W8 + x + j;
+            ++pos;
+          }
+        }
+        base += total;
+      }
+    }
+    return;
+  }
   for (int x0 = 0; x0 < W8; x0 += 64) {
     const int x = x0 + lane;
     const float v = (x < W8) ? row[x] : 0.0f;

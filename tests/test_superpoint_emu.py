@@ -158,3 +158,19 @@ def test_range_guard_is_silent_on_ragged_odd_sized_batches(emu_lib):
         net.extract_batch(imgs)
         total, sites = capi.saturation(emu_lib, None, reset=True)
         assert total == 0, (hw, sites)
+
+
+@pytest.mark.parametrize("H,W,k", [(24, 2200, -1), (16, 264, 100)])
+def test_wide_score_rows_keep_the_reference_candidate_order(emu_lib, H, W, k):
+    """count_rows / emit_rows read 16 bytes per lane when the row length allows it: 256-column groups, 1024-column rounds (2200: two rounds, a
+    ragged last group).  The candidates must come out in torch.nonzero's row-major order (SPN:183-186) — keypoints identical INCLUDING order."""
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sp_mod = importlib.import_module("deep-image-matching_amd.superpoint_hip")
+    sd = weights.synthetic_superpoint_state_dict(5)
+    cfg = {"nms_radius": 2, "keypoint_threshold": 0.0005, "max_keypoints": k, "remove_borders": 2}
+    img = torch.rand(1, 1, H, W, generator=torch.Generator().manual_seed(H + W))
+    net = sp_mod.SuperPointHIP(sd, cfg, max_batch=1, max_hw=(H, W), capacity=8192, device="cpu", lib=emu_lib)
+    out = net(img)
+    ref = superpoint_ref.superpoint_forward(img, sd, cfg)
+    assert torch.equal(out["keypoints"].cpu(), ref["keypoints"]) and ref["keypoints"].shape[0] > 50
+    assert (out["scores"].cpu() - ref["scores"]).abs().max().item() < 1e-5
