@@ -71,6 +71,33 @@ def test_aliked_extractor_hook_contract(emu_install):
     assert len(a ^ b) <= 2
 
 
+@pytest.mark.parametrize("model,dim", [("aliked-t16", 64), ("aliked-n32", 128)])
+def test_aliked_extractor_variants_with_the_shipped_checkpoints(emu_install, model, dim):
+    """`model_name` selects the geometry (ALN:573-579) and `weights_path` the checkpoint the reference ships (tests/assets: byte copies);
+    the plugin's descriptor_size follows the model (64 for aliked-t16)."""
+    from pathlib import Path
+
+    from oracle import aliked_ref
+
+    ckpt = Path(__file__).parent / "assets" / f"{model}.pth"
+    if not ckpt.exists():
+        pytest.skip(f"{model}.pth asset not present")
+    cfg = {"general": {}, "extractor": {"name": "aliked", "model_name": model, "max_num_keypoints": 40, "nms_radius": 2, "weights_path": str(ckpt)}}
+    ex = plugins.AlikedExtractor(cfg)
+    assert ex.descriptor_size == dim
+    yy, xx = torch.meshgrid(torch.arange(48.0), torch.arange(64.0), indexing="ij")
+    img = ((0.5 + 0.3 * torch.sin(xx / 4.0) * torch.cos(yy / 5.0))[..., None].repeat(1, 1, 3) * 255
+           + 30 * torch.rand(48, 64, 3, generator=torch.Generator().manual_seed(8))).clamp(0, 255).numpy().astype(np.float32)
+    f = ex._extract(img)
+    n = f["keypoints"].shape[0]
+    assert n > 5 and f["descriptors"].shape == (dim, n) and f["scores"].shape == (n,)
+    ref = aliked_ref.aliked_forward(torch.tensor(img.transpose(2, 0, 1)[None] / 255.0, dtype=torch.float), ex._sd, ex._net_cfg)
+    assert ref["keypoints"].shape[0] == n
+    a = {tuple(np.round(k).astype(int)) for k in f["keypoints"]}
+    b = {tuple(np.round(k).astype(int)) for k in ref["keypoints"].numpy()}
+    assert len(a ^ b) <= 2
+
+
 def test_plugin_arithmetic_option_switches_the_library_mode(emu_install):
     cfg = {"general": {}, "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1,
                                       "filter_threshold": 0.0, "arithmetic": "bf16x6", "allow_synthetic_weights": True}}
