@@ -45,3 +45,20 @@ def test_batched_tile_extraction_equals_sequential(emu_install):
     kp = feats["keypoints"]
     assert (kp[:, 0] >= 2).all() and (kp[:, 0] < 70 - 2).all() and (kp[:, 1] >= 2).all() and (kp[:, 1] < 60 - 2).all()
     assert (np.lexsort((kp[:, 1], kp[:, 0])) == np.arange(len(kp))).all()  # np.unique order (x, then y)
+
+
+@pytest.mark.parametrize("model,dim", [("aliked-n16rot", 128), ("aliked-t16", 64)])
+def test_batched_tile_extraction_equals_sequential_aliked(emu_install, model, dim):
+    """the same for ALIKED (RGB tiles; 128- and 64-wide descriptor rows through gather_tiles / merge_tiles)"""
+    cfg = {"general": {"tile_size": (48, 40), "tile_overlap": 8},
+           "extractor": {"name": "aliked", "model_name": model, "max_num_keypoints": 30, "nms_radius": 2, "allow_synthetic_weights": True}}
+    ex = plugins.AlikedExtractor(cfg)
+    ex.tile_batch = 4
+    img = (torch.rand(70, 90, 3, generator=torch.Generator().manual_seed(3)) * 255).round().numpy().astype(np.float32)
+    feats = ex._extract_by_tile(img)
+    tiles, origins, _ = tiling.compute_tiles_by_size(img, cfg["general"]["tile_size"], cfg["general"]["tile_overlap"])
+    per_tile = {i: ex._extract(t) for i, t in tiles.items()}
+    ref = tiling.merge_tile_features(per_tile, origins, img.shape, dim)
+    for k in ("keypoints", "descriptors", "scores", "tile_idx"):
+        assert np.array_equal(feats[k], ref[k]), k
+    assert feats["keypoints"].shape[0] > 20 and feats["descriptors"].shape[0] == dim
