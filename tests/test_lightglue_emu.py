@@ -216,3 +216,12 @@ def test_wide_gemm_blocks_with_64_wide_k_chunks_are_bit_identical(emu_lib):
         a = outs[0]
         for b in outs[1:]:
             assert torch.equal(a["dense"], b["dense"]) and torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matching_scores0"], b["matching_scores0"]), name
+
+
+def test_lightglue_64_wide_descriptors_vs_oracle(emu_lib):
+    """input_dim 64 (aliked-t16's descriptors through input_proj, LGN:361-364 with a custom `input_dim`): no golden — the reference's feature
+    table has no 64-d entry — but the oracle (pinned on the 128- and 256-d goldens) runs the same code with any input_dim."""
+    case = {**gc.LG_CASES["aliked_dim"], "input_dim": 64, "wseed": 7}
+    out, ref = run_case(emu_lib, case)
+    compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+    assert out["matches0"].shape[-1] == case["m"]
