@@ -81,7 +81,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   constexpr int KC = KCH, RS = KCH / 2 + 4, Q4_SHIFT = KCH == 32 ? 3 : 4, KSTEPS = KCH / 16;   // (shadow the file-level 32-wide constants)
   static_assert(KCH == 32 || (KCH == 64 && PIPE && PROBE == 0), "64-wide chunks exist for the pipelined K loop");
   static_assert(!DB || (PIPE && KCH == 32 && PROBE == 0), "the double-buffered tile exists for the pipelined 32-wide K loop");
-  static_assert(!ROLL || ((KV == 3 || KV == 4) && !PIPE && (PROBE & ~1) == 0), "rolling fragment requests exist for the 64 x 512 blocks");
+  static_assert(!ROLL || (((KV == 3 || KV == 4) && !PIPE) || (PIPE && KCH == 32 && !DB)) && (PROBE & ~1) == 0, "rolling fragment requests exist for the 64 x 512 blocks and (prototype) the pipelined 32-wide K loop");
   constexpr int ABUF = NPL * BM * RS;   // dwords of one staged activation tile
   constexpr int BN = 32 * NT * WN;
   static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
@@ -201,7 +201,26 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 
   load_chunk(0);
   const int k_end = (PROBE & 32) ? KC : a.K;   // probe bit 5: one K chunk only
-  if (PIPE && DB) {
+  if (PIPE && ROLL) {
+    // prototype (dim_tune_set key 14 = 37): the two fragment sets of the pipelined loop refilled tile by tile — set 0 with step s + 2 during
+    // step s, set 1 with step s + 3 during step s + 1: every request ~1.75 steps (42 MFMAs) in front of its use instead of one (24), same 32
+    // registers; rotated like the fused feed-forward's loop (the wait in front of the split is sized in straight-line code).
+    u32x4 fb0[NT][NPL], fb1[NT][NPL];
+    load_b(0, fb0);
+    load_b(1, fb1);
+    store_chunk();
+    for (int k0 = 0; k0 < a.K; k0 += KC) {
+      __syncthreads();
+      const int kst = k0 >> 4;
+      mma_roll(0, fb0, min(kst + 2, KS - 2));   // (the last chunk harmlessly re-reads its own fragments)
+      __builtin_amdgcn_sched_barrier(0);
+      load_chunk(min(k0 + KC, a.K - KC));
+      __builtin_amdgcn_sched_barrier(0);
+      mma_roll(1, fb1, min(kst + 3, KS - 1));
+      __syncthreads();
+      if (k0 + KC < a.K) store_chunk();
+    }
+  } else if (PIPE && DB) {
     u32x4 fb0[NT][NPL], fb1[NT][NPL];
     store_chunk(0);
     load_chunk(min(KC, a.K - KC));
@@ -864,6 +883,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_qkv_db_kernel(GemmArgs a) {
   else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4, 0, true, 32, true>(a, Ap, by);
   else gemm_x6_body<2, 128, 2, 0, 4, 0, true, 32, true>(a, Ap, by);
 }
+// ---- prototypes with tile-by-tile refilled fragment sets (dim_tune_set key 14 = 37) ----
+__global__ __launch_bounds__(256, 2) void gemm_x6_wide_roll_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 128 * RS];
+  gemm_x6_body<2, 128, 2, 0, 4, 0, true, 32, false, true>(a, Ap, (int)blockIdx.y);
+}
+__global__ __launch_bounds__(256, 2) void gemm_x6_qkv_roll_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 128 * RS];
+  const int by = (int)blockIdx.y;
+  if (by == a.kv_kblock) gemm_x6_body<2, 128, 2, 1, 4, 0, true, 32, false, true>(a, Ap, by);
+  else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4, 0, true, 32, false, true>(a, Ap, by);
+  else gemm_x6_body<2, 128, 2, 0, 4, 0, true, 32, false, true>(a, Ap, by);
+}
 // LightGlue's ffn.0 -> LayerNorm -> GELU -> ffn.3 (+ residual) in one kernel: 64 rows per workgroup, the hidden tensor stays on the CU
 constexpr int FFN_LDS_DWORDS = 2 * 64 * RS + 2048 + 512 + 4 * 3 * 4 * 64 * 4;
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_kernel(GemmArgs a) {
@@ -974,7 +1005,8 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     if (a.kv_img != nullptr) {
       DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
       DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == (int)grid.y - 1, "gemm_x6: the K and V blocks must be the last two");
-      if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_qkv_db_kernel, grid, dim3(256), 0, s, a);
+      if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_qkv_roll_kernel, grid, dim3(256), 0, s, a);
+      else if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_qkv_db_kernel, grid, dim3(256), 0, s, a);
       else if (dim_gemm_kc() == 64 && a.K % 64 == 0) hipLaunchKernelGGL(gemm_x6_qkv_kc64_kernel, grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL(gemm_x6_qkv_kernel, grid, dim3(256), 0, s, a);
     } else switch (dim_gemm_probe()) {
@@ -990,7 +1022,8 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
       case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<32>), grid, dim3(256), 0, s, a); break;
       case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<16>), grid, dim3(256), 0, s, a); break;
       default:
-        if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_wide_db_kernel, grid, dim3(256), 0, s, a);
+        if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_wide_roll_kernel, grid, dim3(256), 0, s, a);
+        else if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_wide_db_kernel, grid, dim3(256), 0, s, a);
         else if (dim_gemm_kc() == 64 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(gemm_x6_wide_kc64_kernel, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);
     }

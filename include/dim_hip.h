@@ -50,7 +50,7 @@ int dim_device_synchronize(void);
  * key 9 = 1 (default) ALIKED BatchNorm + SELU applied while the consumer stages its input, 0 = separate pass; key 10 = ALIKED fp16x3
  * convolution tile rows (16 default, 8, 17 = 16 with streamed weights); key 11 = LightGlue's feed-forward: 3 (default) ffn.0 +
  * LayerNorm + GELU + ffn.3 + residual as one kernel when the launch fills the GPU, 4 = always (tests), 1 / 2 = LayerNorm + GELU in
- * ffn.0's epilogue only (when large / always), 0 = separate kernels; key 14 = variants of the fp16x3 GEMM blocks (32 default; 64 = 64-wide K chunks, 33 = activation tile double-buffered in LDS — prototypes, measured neutral in round 4; 36 = the fused feed-forward's previous K loop (one k-step's fragments at a time, 593 vs 576 us); 35 = a timing probe with wrong results);
+ * ffn.0's epilogue only (when large / always), 0 = separate kernels; key 14 = variants of the fp16x3 GEMM blocks (32 default; 64 = 64-wide K chunks, 33 = activation tile double-buffered in LDS — prototypes, measured neutral in round 4; 37 = their weight-fragment sets refilled tile by tile (prototype); 36 = the fused feed-forward's previous K loop (one k-step's fragments at a time, 593 vs 576 us); 35 = a timing probe with wrong results);
  * key 15 = Winograd F(2,3)-along-x convolution variants (csrc/conv_wg.hip), bit 0 = SuperPoint conv1b with the fused conv1a (fp16x3 only); key 12 = cross-attention timing probes
  * (scripts/gpu_attn_probe.py; 0 in the product — 1 and 3 give wrong results by design). */
 int dim_tune_set(int key, int value);
