@@ -72,7 +72,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 20 (configs2: 20 x 50 pairs) / 1 (config4: one pass over the 10 000-pair job)")
     ap.add_argument("--warmup", type=int, default=None, help="default 3 (configs2) / 1 (config4: one reduced pass)")
-    ap.add_argument("--workload", choices=("configs2", "config4", "config5"), default="configs2", help="config5: BASELINE configs[4], ALIKED + LightGlue on tiled "
+    ap.add_argument("--workload", choices=("configs2", "config4", "config5", "config1"), default="configs2", help="config1: BASELINE configs[0], the five sacre-coeur "
+                    "photographs (tests/assets/config1) -> 10 brute-force pairs with config/superpoint+lightglue.yaml's parameters, through the per-call plugin hooks and "
+                    "through BatchedImageMatcher, beside the reference's CPU path on the same inputs; config5: BASELINE configs[4], ALIKED + LightGlue on tiled "
                     "6000x4000 images through pipeline.TiledPairPipeline (strong scaling: `--images` images -> exhaustive pairs shared by the ranks); "
                     "configs2 (default, the headline line): BASELINE configs[2]; "
                     "config4: BASELINE configs[3], 150 images -> first 10 000 exhaustive pairs through PairMatchingPipeline "
@@ -91,12 +93,15 @@ def parse():
     ap.add_argument("--cpu-sample-pairs", type=int, default=4)
     ap.add_argument("--tile-selection", default="PRESELECTION", help="config5: tile_selection method (PRESELECTION | GRID | EXHAUSTIVE | PRESELECTION_AFFINE_TRANSFORM)")
     ap.add_argument("--strong-timeout", type=float, default=300.0, help="seconds after which rank 0 prints the headline line without the strong_scaling sub-record and exits 3")
+    ap.add_argument("--cpu-only", action="store_true", help="config1: run only the CPU leg (the reference modules when /root/reference exists): this is how the "
+                    "build container produces profiles/*_config1_cpu_reference.json")
+    ap.add_argument("--no-hook-path", action="store_true", help="skip the hook_path sub-record (batch-1 calls through the plugin classes)")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the strong_scaling sub-record (the config-4 job run after the timed region)")
     a = ap.parse_args()
     if a.images is None:
         a.images = 8 if a.workload == "config5" else 150
     if a.steps is None:
-        a.steps = 20 if a.workload == "configs2" else 1
+        a.steps = 20 if a.workload == "configs2" else (5 if a.workload == "config1" else 1)
     if a.warmup is None:
         a.warmup = 3 if a.workload == "configs2" else 1
     return a
@@ -396,6 +401,207 @@ def run_config5(a, rank, world, dev, dist, lib):
         dist.destroy_process_group()
 
 
+def config1_cpu_leg(repeats: int = 1):
+    """configs[0] as BASELINE.json words it: the reference's CPU path (general.force_cpu) on the five sacre-coeur photographs -> 10 brute-force
+    pairs, config/superpoint+lightglue.yaml.  The reference's SuperPoint / LightGlue modules themselves when /root/reference exists (kind
+    "reference": the build container), else the oracle (kind "port": the GPU box).  Decode (PIL) + Q5 grey + _frame2tensor + SuperPoint forward per
+    image; float16 round trip (features.h5) + featuresDict2Lightglue + LightGlue forward per pair; no file IO, no RANSAC."""
+    import numpy as np
+    from oracle import lightglue_ref, superpoint_ref
+    from tests import golden_cases as gc
+
+    weights = importlib.import_module(PKG + ".weights")
+    cores = min(16, os.cpu_count() or 16)
+    torch.set_num_threads(cores)
+    sp_sd = weights.synthetic_superpoint_state_dict(1234)
+    lg_sd = weights.synthetic_lightglue_state_dict(0, 256, gain=2.0)
+    cfg, conf = dict(gc.CONFIG1_SP), dict(gc.CONFIG1_LG)
+    ref_mods = _reference_modules()
+    if ref_mods is not None:
+        spn, lgn = ref_mods
+        orig = torch.hub.load_state_dict_from_url
+        torch.hub.load_state_dict_from_url = lambda *a_, **k_: sp_sd
+        try:
+            ref_sp = spn.SuperPoint({k: v for k, v in cfg.items() if k != "fix_sampling"}).eval()
+        finally:
+            torch.hub.load_state_dict_from_url = orig
+        ref_lg = lgn.LightGlue(features=None, input_dim=256, **conf).eval()
+        ref_lg.load_state_dict(lg_sd, strict=False)
+    grays = [gc.real_gray(n) for n in gc.SACRE_COEUR]
+
+    @torch.no_grad()
+    def job():
+        t0 = time.perf_counter()
+        feats = []
+        for g in grays:
+            img = torch.tensor(g[None][None] / 255.0, dtype=torch.float)
+            if ref_mods is not None:
+                o = ref_sp({"image": img})
+                f = {"keypoints": o["keypoints"][0].numpy(), "scores": o["scores"][0].numpy(), "descriptors": o["descriptors"][0].numpy()}
+            else:
+                o = superpoint_ref.superpoint_forward(img, sp_sd, cfg)
+                f = {k: o[k].numpy() for k in ("keypoints", "scores", "descriptors")}
+            f = gc.fp16_round_trip(f)
+            f["size"] = torch.tensor(g.shape[:2], dtype=torch.float32)
+            feats.append(f)
+        t1 = time.perf_counter()
+        n_matches = 0
+        for a, b in gc.config1_pairs():
+            fa, fb = feats[a], feats[b]
+            ka, kb = torch.tensor(fa["keypoints"]), torch.tensor(fb["keypoints"])
+            da, db = torch.tensor(fa["descriptors"]).t().contiguous(), torch.tensor(fb["descriptors"]).t().contiguous()
+            if ref_mods is not None:
+                r = ref_lg({"image0": {"keypoints": ka[None], "descriptors": da[None], "image_size": fa["size"][None]},
+                            "image1": {"keypoints": kb[None], "descriptors": db[None], "image_size": fb["size"][None]}})
+                n_matches += int(r["matches"][0].shape[0])
+            else:
+                r = lightglue_ref.lightglue_forward(ka, da, fa["size"], kb, db, fb["size"], lg_sd, conf)
+                n_matches += int(r["matches"].shape[0])
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, n_matches
+
+    job()   # warm-up
+    runs = [job() for _ in range(max(1, repeats))]
+    ext_s, match_s = min(r[0] for r in runs), min(r[1] for r in runs)
+    kind = "reference" if ref_mods is not None else "port"
+    return {"value": 10 / (ext_s + match_s), "unit": "image-pairs/s", "cores": cores, "kind": kind, "extract_s": ext_s, "match_s": match_s,
+            "ms_per_image": ext_s / 5 * 1e3, "ms_per_pair": match_s / 10 * 1e3, "matches_total": runs[0][2],
+            "sample": f"the whole config-1 job (5 SuperPoint forwards at 640x480 .. 784x784 + 10 LightGlue forwards at 2000 x 2000 keypoints, adaptive depth / width), best of "
+                      f"{max(1, repeats)} after 1 warm-up job, " + ("the reference's SuperPoint / LightGlue modules (imported from /root/reference)" if ref_mods is not None else "oracle/*.py")
+                      + f" on torch CPU, {cores} threads"}
+
+
+def run_config1(a, dev, lib):
+    """BASELINE configs[0] on its real inputs: the five photographs of assets/example_sacre_coeur (tests/assets/config1: byte copies) -> 10 brute-force
+    pairs, config/superpoint+lightglue.yaml (nms 4 / thr 0.005 / 2000 keypoints; LightGlue 0.95 / 0.99 / 0.1), seeded synthetic weights (the trained
+    files are URL downloads).  `value` = pairs/s of the whole job through the PER-CALL PLUGIN HOOKS (what the reference's own loops get when the plugins
+    are dropped in: one image / one pair per call, host arrays in and out, one guard read-back per call); sub-records: the same job through
+    BatchedImageMatcher (files -> features.h5 -> raw_matches.h5) and the CPU leg (`cpu_baseline`)."""
+    import tempfile
+    import numpy as np
+    from tests import golden_cases as gc
+
+    if a.cpu_only:
+        print(json.dumps({"metric": "image-pairs/s (SuperPoint+LightGlue, config 1: 5 sacre-coeur photographs -> 10 pairs)", "value": None, "unit": "image-pairs/s",
+                          "n_gpus": 0, "config": {"workload": "configs[0] (config 1), CPU leg only"}, "cpu_baseline": config1_cpu_leg(repeats=3)}))
+        return
+    plugins = importlib.import_module(PKG + ".plugins")
+    bm = importlib.import_module(PKG + ".batched_matcher")
+    capi = importlib.import_module(PKG + ".capi")
+    K, W = a.steps, a.warmup
+    ex = plugins.SuperPointExtractor({"general": {}, "extractor": {"name": "superpoint", **gc.CONFIG1_SP, "allow_synthetic_weights": True}})
+    mt = plugins.LightGlueMatcher({"general": {"geom_verification": "NONE"}, "matcher": {"name": "lightglue", **gc.CONFIG1_LG, "allow_synthetic_weights": True}},
+                                  local_features="superpoint")
+    mt._sd = importlib.import_module(PKG + ".weights").synthetic_lightglue_state_dict(0, 256, gain=2.0)
+    grays = [gc.real_gray(n) for n in gc.SACRE_COEUR]
+    sizes = [np.array(g.shape[:2], dtype=np.int32) for g in grays]
+
+    def hook_job():
+        t0 = time.perf_counter()
+        feats = []
+        for g, sz in zip(grays, sizes):
+            f = gc.fp16_round_trip(ex._extract(g))       # ExtractorBase.extract -> save_features_h5 -> get_features (Q6)
+            f["image_size"] = sz
+            feats.append(f)
+        t1 = time.perf_counter()
+        n = 0
+        for i, j in gc.config1_pairs():
+            n += int(mt._match_pairs(feats[i], feats[j]).shape[0])
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, n
+
+    for _ in range(max(1, W)):
+        hook_job()
+    runs = [hook_job() for _ in range(K)]
+    ext_s, match_s = float(np.median([r[0] for r in runs])), float(np.median([r[1] for r in runs]))
+    paths = [gc.REAL_DIR / n for n in gc.SACRE_COEUR]
+    pairs = [(paths[i].name, paths[j].name) for i, j in gc.config1_pairs()]
+    batched = []
+    for it in range(W + K):
+        with tempfile.TemporaryDirectory() as d:
+            shim = bm.BatchedImageMatcher(ex, mt, d, image_batch=4, pair_batch=10, verify=False)
+            t0 = time.perf_counter()
+            fpath = shim.extract_features(paths)
+            t1 = time.perf_counter()
+            shim.match_pairs(fpath, pairs)
+            t2 = time.perf_counter()
+        if it >= W:
+            batched.append((t1 - t0, t2 - t1))
+    b_ext, b_match = float(np.median([r[0] for r in batched])), float(np.median([r[1] for r in batched]))
+    sat_total, sat_sites = capi.saturation(lib, None, reset=True)
+    line = {
+        "metric": "image-pairs/s (SuperPoint+LightGlue, config 1: 5 sacre-coeur photographs -> 10 pairs)", "value": 10 / (ext_s + match_s), "unit": "image-pairs/s",
+        "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": (ext_s + match_s) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "real photographs (assets/example_sacre_coeur), seeded synthetic weights",
+        "config": {"workload": "configs[0] (config 1): 5 photographs (640x480, 618x640 x2, 640x618, 784x784) -> 10 brute-force pairs; config/superpoint+lightglue.yaml "
+                               "(SuperPoint nms 4 / thr 0.005 / 2000 keypoints; LightGlue depth 0.95 / width 0.99 / threshold 0.1); one step = the whole job through the per-call "
+                               "plugin hooks (_extract x 5, float16 round trip, _match_pairs x 10), host arrays in and out", "images": 5, "pairs": 10},
+        "hook_path": {"extract_s": ext_s, "match_s": match_s, "ms_per_image": ext_s / 5 * 1e3, "ms_per_pair": match_s / 10 * 1e3, "matches_total": runs[0][2]},
+        "batched_image_matcher": {"value": 10 / (b_ext + b_match), "unit": "image-pairs/s", "extract_features_s": b_ext, "match_pairs_s": b_match,
+                                  "note": "JPEG files -> PIL decode + Q5 grey -> batched dim_sp_extract (images bucketed by shape) -> features store (float16, deflate) -> "
+                                          "re-read -> ONE dim_lg_match of the 10 pairs -> raw_matches store; file IO included"},
+        "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
+        "roofline": None,
+        "cpu_baseline": None if a.no_cpu_baseline else config1_cpu_leg(repeats=1),
+    }
+    print(json.dumps(line))
+
+
+def measure_hook_path(dev, lib, n_img: int = 6, n_pair: int = 6):
+    """What a user who drops the plugin classes into the reference's own loops gets (image_matching.py:429-430, 467-487: one image / one pair per call):
+    SuperPointExtractor._extract on a 1024 x 1024 float32 image (numpy in, numpy out: H2D, ~25 launches, guard read-back, D2H) and
+    LightGlueMatcher._match_pairs on two 2048-keypoint numpy feature dicts, fixed work (9 layers) — batch 1, wall time per call."""
+    import numpy as np
+    plugins = importlib.import_module(PKG + ".plugins")
+    ex = plugins.SuperPointExtractor({"general": {}, "extractor": {"name": "superpoint", "nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048,
+                                                                   "remove_borders": 4, "allow_synthetic_weights": True}})
+    mt = plugins.LightGlueMatcher({"general": {}, "matcher": {"name": "lightglue", "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1,
+                                                               "allow_synthetic_weights": True}}, local_features="superpoint")
+    g = torch.Generator().manual_seed(77)
+    imgs = [(torch.rand(1024, 1024, generator=g) * 255).numpy().astype(np.float32) for _ in range(2)]
+    feats = []
+    for im in imgs:                      # warm-up + the features of the pair
+        f = ex._extract(im)
+        f["image_size"] = np.array([1024, 1024], dtype=np.int32)
+        feats.append(f)
+    mt._match_pairs(feats[0], feats[1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_img):
+        ex._extract(imgs[i % 2])
+    t1 = time.perf_counter()
+    for i in range(n_pair):
+        mt._match_pairs(feats[0], feats[1])
+    t2 = time.perf_counter()
+    # the same two calls without the host hand-over: device tensors in, device tensors out, batch 1 (kernel time of the call)
+    net, lgn = ex._net, mt._net
+    img_d = torch.from_numpy(imgs[0] / 255.0).to(dev)[None].contiguous()
+    out_sp = net.extract_batch(img_d)
+    kp, sc, de, n = out_sp
+    kt = torch.stack([kp[0], kp[0]]).contiguous(); dt_ = torch.stack([de[0], de[0]]).contiguous()
+    nt = torch.stack([n[0], n[0]]).contiguous(); st = torch.full((2, 2), 1024.0, device=dev)
+    out_lg = lgn.match_batch(kt, dt_, nt, st, n_pairs=1)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    for _ in range(n_img):
+        net.extract_batch(img_d, out=out_sp)
+    e[1].record()
+    for _ in range(n_pair):
+        lgn.match_batch(kt, dt_, nt, st, n_pairs=1, out=out_lg)
+    e[2].record()
+    torch.cuda.synchronize()
+    rec = {"ms_per_image": (t1 - t0) / n_img * 1e3, "ms_per_pair": (t2 - t1) / n_pair * 1e3,
+           "pairs_per_s_extract2_match1": 1e3 / (2 * (t1 - t0) / n_img * 1e3 + (t2 - t1) / n_pair * 1e3),
+           "device_only_ms_per_image": e[0].elapsed_time(e[1]) / n_img, "device_only_ms_per_pair": e[1].elapsed_time(e[2]) / n_pair,
+           "note": "batch-1 calls through plugins.SuperPointExtractor._extract / LightGlueMatcher._match_pairs (numpy in / out, one guard read-back per call) at the "
+                   "headline sizes (1024 x 1024, 2048 x 2048 keypoints, 9 layers); device_only_* = the same batch-1 library calls on resident tensors (HIP events). "
+                   "The calls are kernel-bound, not launch-bound: the rocprofv3 kernel times of a call add up to its wall time (profiles/r05_hook_path_*)"}
+    del ex, mt
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -404,6 +610,8 @@ def main():
         respawn_under_torchrun(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if a.workload == "config1" and a.cpu_only:
+        return run_config1(a, None, None)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -429,6 +637,9 @@ def main():
         return run_config4(a, rank, world, dev, dist, lib)
     if a.workload == "config5":
         return run_config5(a, rank, world, dev, dist, lib)
+    if a.workload == "config1":
+        assert world == 1, "config 1 is a 5-image job: one GPU"
+        return run_config1(a, dev, lib)
     P, K, W = a.pairs, a.steps, a.warmup
     cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
     conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
@@ -585,6 +796,7 @@ def main():
             "timed_region_s": dt, "pairs_total": pairs_total, "sustained_clock_mhz": clock_mhz,
             "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
             "strong_scaling": None,
+            "hook_path": None,
             "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1,true,2> (SuperPoint conv1a 1->64 evaluated in the halo staging + conv1b 64->64 3x3 "
                                    "+ bias + ReLU + 2x2 max-pool, fp32-accurate on the fp16 MFMA (fp16x3); 1024^2 images)", "bound": "mfma",
                          "achieved": conv_tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -642,6 +854,11 @@ def main():
             watchdog.cancel()
         if rank == 0:
             line["strong_scaling"] = strong
+    if rank == 0 and not a.no_hook_path and not a.main_region_only:
+        try:
+            line["hook_path"] = measure_hook_path(dev, lib)
+        except Exception as e:
+            line["hook_path"] = {"error": repr(e)[:400]}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_sample_pairs)

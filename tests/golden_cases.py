@@ -132,3 +132,60 @@ def al_weights(case):
 def al_image(case) -> torch.Tensor:
     g = torch.Generator().manual_seed(case["seed"])
     return torch.rand(1, case["C"], case["H"], case["W"], generator=g)
+
+
+# ---- BASELINE configs[0] on its REAL inputs ---------------------------------------------------------------
+# tests/assets/config1/ holds byte copies of the photographs the reference ships: assets/example_sacre_coeur/images/*.jpg (the five images of
+# configs[0]) and assets/pytest/images/DSC_646{6,7,8}.jpg (the reference's own pytest fixture, tests/conftest.py:11-37).  Decoding: the
+# reference reads with rasterio (GDAL's libjpeg); neither exists here nor on the GPU box, so PIL decodes — the goldens record a digest of the
+# decoded pixels and the tests refuse to compare against goldens made from different pixels (decoder differences are outside the parity claim,
+# SURVEY 8(c)/(d)).
+from pathlib import Path as _Path
+
+REAL_DIR = _Path(__file__).resolve().parent / "assets" / "config1"
+SACRE_COEUR = ["sacre_coeur_A.jpg", "sacre_coeur_B.jpg", "sacre_coeur_B180.jpg", "sacre_coeur_B90.jpg", "sacre_coeur_squared.jpg"]  # sorted: the reference's image list order
+PYTEST_IMAGES = ["DSC_6466.jpg", "DSC_6467.jpg", "DSC_6468.jpg"]
+CONFIG1_SP = {"nms_radius": 4, "keypoint_threshold": 0.005, "max_keypoints": 2000, "remove_borders": 4, "fix_sampling": False}   # config/superpoint+lightglue.yaml:10-16
+CONFIG1_LG = {"depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.1}                                          # ...yaml:18-24
+CONFIG1_AL = {"model_name": "aliked-n16rot", "max_num_keypoints": 4000, "detection_threshold": 0.2, "nms_radius": 3}              # config.py:197-204
+DESC_STRIDE = 16      # full descriptors are stored for every 16th keypoint, 4 fixed random projections for all of them
+
+
+def config1_pairs(names=None):
+    """pairs_from_bruteforce (pairs_generator.py:37-38): combinations of the sorted image list."""
+    from itertools import combinations
+    return list(combinations(range(len(names or SACRE_COEUR)), 2))
+
+
+def real_rgb(name: str):
+    """(H, W, 3) uint8, as rasterio's read() transposed to HWC gives it (extractor_base.py:190-196)."""
+    import numpy as np
+    from PIL import Image
+    return np.asarray(Image.open(str(REAL_DIR / name)).convert("RGB"))
+
+
+def real_gray(name: str):
+    """What ExtractorBase.extract hands to SuperPoint's _extract: cv2.cvtColor(RGB array, COLOR_BGR2GRAY) in 8-bit fixed point — quirk Q5,
+    the R / B weights end up swapped — then astype(float32), values 0..255 (extractor_base.py:197-202)."""
+    import numpy as np
+    a = real_rgb(name).astype(np.int64)
+    return ((a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + 8192) >> 14).astype(np.uint8).astype(np.float32)
+
+
+def pixel_digest(arr) -> str:
+    import hashlib
+    import numpy as np
+    a = np.ascontiguousarray(arr)
+    return hashlib.sha1(str(a.shape).encode() + a.tobytes()).hexdigest()
+
+
+def desc_projection(dim: int):
+    """(dim, 4) float64 fixed random directions of ~unit length: desc.T @ P is stored for EVERY keypoint."""
+    g = torch.Generator().manual_seed(4242 + dim)
+    return (torch.randn(dim, 4, generator=g, dtype=torch.float64) / math.sqrt(dim)).numpy()
+
+
+def fp16_round_trip(feats: dict) -> dict:
+    """save_features_h5 (extractor_base.py:56-86, quirk Q6): every float32 array is stored as float16; the matcher reads that back."""
+    import numpy as np
+    return {k: (np.asarray(v).astype(np.float16).astype(np.float32) if np.asarray(v).dtype == np.float32 else np.asarray(v)) for k, v in feats.items()}
