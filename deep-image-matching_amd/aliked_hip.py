@@ -53,6 +53,7 @@ class AlikedHIP:
                  capacity: Optional[int] = None, device="cuda", lib=None):
         self.cfg = {**self.default_config, **(cfg or {})}
         self.on_saturation = self.cfg.pop("on_saturation", "fallback")
+        self.arithmetic = self.cfg.pop("arithmetic", None)   # None: the process default; "fp16x3" | "fp32": this handle only
         self.lib = lib if lib is not None else capi.load()
         self.device = torch.device(device)
         if lib is None and self.device.type != "cuda":
@@ -80,6 +81,8 @@ class AlikedHIP:
         with self._ctx():
             capi.check(self.lib, self.lib.dim_aliked_create(ctypes.byref(w), ctypes.byref(c), self.max_batch, self.max_hw[0], self.max_hw[1],
                                                             self.capacity, ctypes.byref(self._h)))
+        if self.arithmetic is not None:
+            capi.set_handle_arithmetic(self.lib, self._h, self.arithmetic)
         del keep
 
     def __del__(self):
@@ -119,7 +122,7 @@ class AlikedHIP:
         run as fp16 splits on the matrix cores (aliked_x3.hip, gemm_x6.hip), exact for |activation| <= 4094; a call that
         leaves that range is repeated on the fp32 paths.  Synchronises."""
         with self._ctx():
-            return capi.run_guarded(self.lib, self._stream(), lambda: self.extract_batch(images), "ALIKED", self.on_saturation, logger)
+            return capi.run_guarded(self.lib, self._stream(), lambda: self.extract_batch(images), "ALIKED", self.on_saturation, logger, handle=self._h, arithmetic=self.arithmetic)
 
     @torch.no_grad()
     def __call__(self, image: torch.Tensor) -> dict:

@@ -100,18 +100,32 @@ def build_variant(name: str, defines, verbose: bool = False) -> Path:
     return out
 
 
-def build_emu(verbose: bool = False) -> Path:
-    """Host-clang build of the same sources against tests/hipemu (CPU tests only)."""
+RESEARCH_DEFINES = ["-DDIM_RESEARCH"]
+
+
+def build_research(verbose: bool = False) -> Path:
+    """lib/libdim_hip_research.so: the product sources + the default-off prototypes that lost their A/B (Winograd conv1b, 64-wide K chunks,
+    double-buffered / tile-refilled GEMM blocks, round 3's feed-forward loop) and the timing probes that give wrong results by design
+    (dim_tune_set keys 12-15).  Loaded only by the A/B scripts under scripts/ and by the tests of those variants — never by the package."""
+    return build_variant("research", RESEARCH_DEFINES, verbose)
+
+
+def build_emu(verbose: bool = False, research: bool = False) -> Path:
+    """Host-clang build of the same sources against tests/hipemu (CPU tests only).  research=True: with -DDIM_RESEARCH (the prototype
+    variants' CPU tests), a separate library next to the plain one."""
     emu = ROOT / "tests" / "hipemu"
-    out = emu / "libdim_hip_emu.so"
+    out = emu / ("libdim_hip_emu_research.so" if research else "libdim_hip_emu.so")
     flags = ["-std=c++17", "-O2", "-march=native", "-fPIC", "-ffp-contract=off", "-Wno-psabi", "-Wno-unused-value", "-I", str(emu / "include")]
+    if research:
+        flags += RESEARCH_DEFINES
     srcs = _sources()
     objs, changed = _compile_all(
-        emu / "build",
+        emu / ("build_research" if research else "build"),
         lambda s, o: [HOST_CLANG, *flags, "-x", "c++", "-c", str(s), "-o", str(o)],
         srcs,
         "emu" + " ".join(flags) + _digest([emu / "include" / "hip" / "hip_runtime.h"]),
     )
+    (emu / "build").mkdir(parents=True, exist_ok=True)
     rt = emu / "build" / "hipemu_rt.o"
     rt_stamp = emu / "build" / "hipemu_rt.sha"
     d = _digest([emu / "hipemu.cpp", emu / "include" / "hip" / "hip_runtime.h"])

@@ -71,12 +71,19 @@ def get_arithmetic(lib) -> int:
 
 
 def set_arithmetic(lib, mode) -> int:
-    """Process-wide matrix arithmetic (dim_tune_set key 1); returns the previous mode."""
+    """Process-wide DEFAULT matrix arithmetic (dim_tune_set key 1); returns the previous mode.  Handles may override it for themselves
+    (set_handle_arithmetic)."""
     mode = ARITHMETIC[mode] if isinstance(mode, str) else int(mode)
     prev = get_arithmetic(lib)
     lib.dim_tune_set(1, mode)
     _arith[id(lib)] = mode
     return prev
+
+
+def set_handle_arithmetic(lib, handle, mode) -> None:
+    """Matrix arithmetic of ONE extractor / matcher handle (dim_handle_tune_set key 1); ``None`` = back to the process default."""
+    v = -1 if mode is None else (ARITHMETIC[mode] if isinstance(mode, str) else int(mode))
+    check(lib, lib.dim_handle_tune_set(handle, 1, v))
 
 
 def saturation(lib, stream=None, reset: bool = True):
@@ -92,12 +99,15 @@ class SaturationError(DimHipError):
     pass
 
 
-def run_guarded(lib, stream, fn, what: str, policy: str = "fallback", logger=None):
+def run_guarded(lib, stream, fn, what: str, policy: str = "fallback", logger=None, handle=None, arithmetic=None):
     """Runs ``fn()`` (one extract / match call enqueued on ``stream``) under the fp16x3 range guard: when the
     default arithmetic is active and a kernel reported a value outside the exact range of the fp16 split
     (|x| > 4094), the call is repeated in bf16x6 (no range limit; policy "fallback") or a SaturationError is
-    raised (policy "raise").  Synchronises the stream.  Other arithmetic modes run unguarded."""
-    if get_arithmetic(lib) != 2 or policy == "off":
+    raised (policy "raise").  Synchronises the stream.  Other arithmetic modes run unguarded.
+    ``handle`` / ``arithmetic``: the library handle ``fn`` calls and its own arithmetic override (None = process default) — the re-run then
+    switches THAT handle to bf16x6 (dim_handle_tune_set) instead of the process-wide default, so other handles / threads are not affected."""
+    mode = get_arithmetic(lib) if arithmetic is None else (ARITHMETIC[arithmetic] if isinstance(arithmetic, str) else int(arithmetic))
+    if mode != 2 or policy == "off":
         return fn()
     saturation(lib, stream, reset=True)  # drop anything a previous unguarded call left behind
     out = fn()
@@ -108,6 +118,12 @@ def run_guarded(lib, stream, fn, what: str, policy: str = "fallback", logger=Non
         raise SaturationError(f"{what}: fp16x3 range exceeded at {sites}; set arithmetic='bf16x6'")
     if logger is not None:
         logger.warning("%s: fp16x3 range exceeded at %s - repeating the call in bf16x6", what, sites)
+    if handle is not None:
+        set_handle_arithmetic(lib, handle, 1)
+        try:
+            return fn()
+        finally:
+            set_handle_arithmetic(lib, handle, arithmetic)
     prev = set_arithmetic(lib, 1)
     try:
         return fn()

@@ -11,6 +11,7 @@
 #include "sp_kernels.h"
 
 struct dim_aliked {
+  DimHandleBase base;   // first member: dim_handle_tune_set
   dim_aliked_config cfg;
   int max_batch, max_h, max_w, capacity;
   // weights (device, kernel layouts)
@@ -220,6 +221,7 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
 int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H, int W, int in_channels, float* kpts_xy_dev,
                        float* scores_dev, float* desc_dev, int32_t* n_kpts_dev, void* stream) {
   DIM_REQUIRE(h && images_dev && kpts_xy_dev && scores_dev && desc_dev && n_kpts_dev, "dim_aliked_extract: null argument");
+  DimTuneScope tune_scope(&h->base);
   DIM_REQUIRE(batch >= 1 && batch <= h->max_batch, "dim_aliked_extract: batch %d outside [1,%d]", batch, h->max_batch);
   DIM_REQUIRE(in_channels == 1 || in_channels == 3, "dim_aliked_extract: in_channels %d (1 or 3)", in_channels);
   DIM_REQUIRE(H >= 16 && W >= 16 && H <= h->max_h && W <= h->max_w, "dim_aliked_extract: image %dx%d outside the handle's %dx%d", H, W, h->max_h, h->max_w);
@@ -397,6 +399,7 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
 
 int dim_aliked_debug_buffers(dim_aliked* h, const float** x1234, const float** score_map, int* hp, int* wp, int* pad_t, int* pad_l) {
   DIM_REQUIRE(h, "dim_aliked_debug_buffers: null handle");
+  DimTuneScope tune_scope(&h->base);
   if (x1234) {  // the product path never stores the 128-channel map: rebuild it for the last batch
     DIM_REQUIRE(h->last_batch > 0, "dim_aliked_debug_buffers: no extract call yet");
     if (h->dbg_x1234) hipFree(h->dbg_x1234);

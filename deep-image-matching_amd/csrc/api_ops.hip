@@ -51,16 +51,25 @@ void dim_sat_host_bump(int site) {
   if (site >= 0 && site < DIM_SAT_SITES) g_sat_host[site]++;
 }
 
+// process defaults (dim_tune_set) with per-handle overrides (dim_handle_tune_set): see DimTuneScope in dim_common.h
+static thread_local const DimTune* g_tune_scope = nullptr;
+void dim_tune_scope_set(const DimTune* t) { g_tune_scope = t; }
+const DimTune* dim_tune_scope_get() { return g_tune_scope; }
+static inline int tuned(int key, int process_default) {
+  const DimTune* t = g_tune_scope;
+  return (t && t->v[key] >= 0) ? t->v[key] : process_default;
+}
 static int g_precision_mode = 2;
-int dim_precision_mode() { return g_precision_mode; }
+int dim_precision_mode() { return tuned(1, g_precision_mode); }
 static int g_fuse_conv1a = 1;
-int dim_fuse_conv1a() { return g_fuse_conv1a; }
+int dim_fuse_conv1a() { return tuned(3, g_fuse_conv1a); }
 static int g_fold_out_proj = 1;
-int dim_fold_out_proj() { return g_fold_out_proj; }
+int dim_fold_out_proj() { return tuned(4, g_fold_out_proj); }
 static int g_fuse_kv = 1;
-int dim_fuse_kv() { return g_fuse_kv; }
+int dim_fuse_kv() { return tuned(8, g_fuse_kv); }
 static int g_fuse_ffn_ln = 3;
-int dim_fuse_ffn_ln() { return g_fuse_ffn_ln; }
+int dim_fuse_ffn_ln() { return tuned(11, g_fuse_ffn_ln); }
+#ifdef DIM_RESEARCH   // research build (build.build_variant("research")): prototype / timing-probe selectors, see dim_kernels.h
 static int g_gemm_kc = 32;
 int dim_gemm_kc() { return g_gemm_kc; }
 static int g_conv_wino = 0;
@@ -69,12 +78,13 @@ static int g_gemm_probe = 0;
 int dim_gemm_probe() { return g_gemm_probe; }
 static int g_attn_probe = 0;
 int dim_attn_probe() { return g_attn_probe; }
+#endif
 static int g_al_tile_rows = 16;
-int dim_aliked_tile_rows() { return g_al_tile_rows; }
+int dim_aliked_tile_rows() { return tuned(10, g_al_tile_rows); }
 static int g_al_fuse_bn = 1;
-int dim_aliked_fuse_bn() { return g_al_fuse_bn; }
+int dim_aliked_fuse_bn() { return tuned(9, g_al_fuse_bn); }
 static int g_presplit = 1;
-int dim_presplit_activations() { return g_presplit; }
+int dim_presplit_activations() { return tuned(5, g_presplit); }
 
 void dim_prof_begin(int site, hipStream_t s) {
   if (!((g_prof_mask >> site) & 1ull)) return;
@@ -271,10 +281,25 @@ int dim_tune_set(int key, int value) {
   if (key == 9) g_al_fuse_bn = value;
   if (key == 10) g_al_tile_rows = value;
   if (key == 11) g_fuse_ffn_ln = value;
+#ifdef DIM_RESEARCH
   if (key == 12) g_attn_probe = value;
   if (key == 13) g_gemm_probe = value;
   if (key == 14) g_gemm_kc = value;
   if (key == 15) g_conv_wino = value;
+#else
+  DIM_REQUIRE(key < 12 || key > 15, "dim_tune_set: key %d selects a research prototype / timing probe that the product library does not contain "
+              "(build.build_variant(\"research\", [\"-DDIM_RESEARCH\"]) -> libdim_hip_research.so)", key);
+#endif
+  DIM_REQUIRE(key >= 0 && key <= 15, "dim_tune_set: unknown key %d", key);
+  return 0;
+}
+
+int dim_handle_tune_set(void* handle, int key, int value) {
+  DimHandleBase* b = (DimHandleBase*)handle;
+  DIM_REQUIRE(b != nullptr && b->magic == DIM_HANDLE_MAGIC, "dim_handle_tune_set: not an extractor / matcher handle of this library");
+  DIM_REQUIRE(key == 1 || key == 3 || key == 4 || key == 5 || key == 8 || key == 9 || key == 10 || key == 11,
+              "dim_handle_tune_set: key %d has no per-handle form (arithmetic 1; fusion 3, 4, 5, 8, 9, 11; ALIKED tile rows 10)", key);
+  b->tune.v[key] = value < 0 ? -1 : value;
   return 0;
 }
 

@@ -19,6 +19,7 @@
 //     (the Ip bytes) and finishes one (rows 2w, 2w+1): output transform, 2x2 max-pool in-lane, bias, ReLU, split, store.
 // fp16x3 range guard: the transformed activations reach 2 max|d| (t1 = d1 + d2); the staging tracks max|t| of what it splits and
 // reports it at the consumer's site, the epilogue guards its outputs as conv_x6.hip does.
+#ifdef DIM_RESEARCH   // Winograd F(2,3) conv1b: measured at parity with the direct kernel -> research build only
 #include <math.h>
 #include <string.h>
 
@@ -595,3 +596,5 @@ extern "C" int dim_conv_wg_phase_read(unsigned long long* host16, int reset) {
   }
   return 0;
 }
+
+#endif   // DIM_RESEARCH

@@ -302,6 +302,27 @@ void dim_sat_host_bump(int site);  // a range violation established on the host 
     }                                     \
   } while (0)
 
+// ---- per-handle overrides of the dim_tune_set choices (include/dim_hip.h: dim_handle_tune_set) ----
+// Every extractor / matcher handle starts with a DimHandleBase; the C-ABI entry points open a DimTuneScope on it, and the accessors
+// (dim_precision_mode(), dim_fuse_conv1a(), ...) return the handle's override while the scope is open on this thread, else the process default.
+constexpr int DIM_TUNE_KEYS = 16;
+constexpr unsigned DIM_HANDLE_MAGIC = 0x44494d48u;   // "DIMH"
+struct DimTune {
+  int v[DIM_TUNE_KEYS];
+  DimTune() { for (int i = 0; i < DIM_TUNE_KEYS; ++i) v[i] = -1; }   // -1 = inherit the process default
+};
+struct DimHandleBase {
+  unsigned magic = DIM_HANDLE_MAGIC;
+  DimTune tune;
+};
+void dim_tune_scope_set(const DimTune* t);     // api_ops.hip (thread-local)
+const DimTune* dim_tune_scope_get();
+struct DimTuneScope {
+  const DimTune* prev;
+  explicit DimTuneScope(const DimHandleBase* h) : prev(dim_tune_scope_get()) { dim_tune_scope_set(h ? &h->tune : nullptr); }
+  ~DimTuneScope() { dim_tune_scope_set(prev); }
+};
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // weights must be finite: the range guard's reasoning (above) rests on it, and a NaN checkpoint is a caller error
 static inline bool dim_all_finite(const float* p, size_t n) {

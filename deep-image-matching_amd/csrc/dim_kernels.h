@@ -99,7 +99,14 @@ void prepare_conv_weights_wino(const float* w_oihw, int cin, int cout, unsigned 
 int launch_conv3x3_wg_fused1a(const float* image, const float* w1a_tap_cout, const float* b1a, const SplitWeights& wt, const float* bias,
                               float* out, int batch, int H, int W, int cout, int pool, int planes_out, hipStream_t s, unsigned* sat = nullptr,
                               unsigned* sat_image = nullptr);
+// Research build only (-DDIM_RESEARCH = build.build_variant("research") -> lib/libdim_hip_research.so): the default-off prototypes that lost their A/B
+// (Winograd conv1b, 64-wide K chunks, double-buffered / tile-refilled GEMM blocks, round 3's feed-forward loop) and the timing probes that give wrong
+// results by design.  The product library compiles none of them: the selectors below are constants there and dim_tune_set rejects keys 12-15.
+#ifdef DIM_RESEARCH
 int dim_conv_winograd();     // dim_tune_set key 15: bit 0 = SuperPoint conv1b (fused conv1a) runs the Winograd F(2,3) kernel (default 0 until measured faster)
+#else
+static inline int dim_conv_winograd() { return 0; }
+#endif
 int launch_planes_to_f32(const void* planes, int batch, int hw, int channels, float* out, hipStream_t s);  // [batch][hw pixels][channels]
 // a pre-split image occupies an even number of pixel slots (pixels are stored in pairs): size buffers with this
 inline size_t dim_planes_image_pixels(int h, int w) { return ((size_t)h * w + 1) & ~(size_t)1; }
@@ -109,9 +116,15 @@ int dim_aliked_tile_rows();  // dim_tune_set key 10: tile rows (16 | 8) of ALIKE
 int dim_aliked_fuse_bn();   // dim_tune_set key 9: ALIKED folds BatchNorm + SELU into the consuming convolution's staging (default 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
 int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)
+#ifdef DIM_RESEARCH
 int dim_gemm_kc();           // dim_tune_set key 14: 32 (product); 64 / 33 = prototypes of the wide GEMM blocks, 36 = the fused feed-forward's previous K loop, 35 = timing probe
 int dim_gemm_probe();        // 0 (product); timing probes of the wide fp16x3 GEMM blocks (dim_tune_set key 13; gemm_x6.hip PROBE)
 int dim_attn_probe();        // 0 (product); 1 / 2 / 3: timing probes of cross attention (dim_tune_set key 12; lg_attn_x6.hip)
+#else
+static inline int dim_gemm_kc() { return 32; }
+static inline int dim_gemm_probe() { return 0; }
+static inline int dim_attn_probe() { return 0; }
+#endif
 int dim_fuse_ffn_ln();       // dim_tune_set key 11.  3 (default): LightGlue's whole feed-forward (ffn.0, LayerNorm, GELU, ffn.3, residual) is one kernel when the
                              // launch fills the GPU with 64-row blocks, 4 = always (tests); 1 / 2: only LayerNorm + GELU in ffn.0's epilogue; 0: separate kernels
 int dim_fuse_kv();           // 1 (default): LightGlue's K | V tile images written by the projection GEMM's epilogue (dim_tune_set key 8)

@@ -761,6 +761,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 64 * RS];
   gemm_x6_body<2, 64, 4, 3, 4, 0, true>(a, Ap, 0);
 }
+#ifdef DIM_RESEARCH   // timing probes (wrong results by design): research build only
 template <int PROBE, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void gemm_x6_probe_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 128 * RS];
@@ -771,6 +772,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_probe_kernel(GemmArgs a
   __shared__ unsigned Ap[2 * 64 * RS];
   gemm_x6_body<2, 64, 4, 3, 4, PROBE, PIPE>(a, Ap, 0);
 }
+#endif
 // C[z] = A[z] * B[z]^T with BOTH operands fp32 activations (LightGlue's similarity sim = mdesc0 mdesc1^T, LGN:271; K = 256): both
 // 128 x 32 chunks are split while they are staged into LDS and both MFMA operands come from there.  128 x 128 block, waves 2 x 2,
 // each 64 x 64.  Ragged rows (a.rows) and columns (a.cols) like gemm.hip's bt mode; entries outside stay untouched.  The fp32 MFMA
@@ -858,6 +860,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : 2)) void gemm_x6_nt_kernel(Ge
     }
   }
 }
+#ifdef DIM_RESEARCH   // prototypes that lost their A/B: research build only
 // ---- prototypes with 64-wide K chunks (dim_tune_set key 14 = 64; measured in round 4): the plain 128 x 256 block and the q|k|v kernel ----
 constexpr int RS64 = 64 / 2 + 4;
 __global__ __launch_bounds__(256, 2) void gemm_x6_wide_kc64_kernel(GemmArgs a) {
@@ -895,6 +898,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_qkv_roll_kernel(GemmArgs a) {
   else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4, 0, true, 32, false, true>(a, Ap, by);
   else gemm_x6_body<2, 128, 2, 0, 4, 0, true, 32, false, true>(a, Ap, by);
 }
+#endif   // DIM_RESEARCH
 // LightGlue's ffn.0 -> LayerNorm -> GELU -> ffn.3 (+ residual) in one kernel: 64 rows per workgroup, the hidden tensor stays on the CU
 constexpr int FFN_LDS_DWORDS = 2 * 64 * RS + 2048 + 512 + 4 * 3 * 4 * 64 * 4;
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_kernel(GemmArgs a) {
@@ -905,6 +909,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_kernel(GemmArgs a) {
   }   // (visible to every wave after the K loop's barriers)
   gemm_x6_body<2, 64, 4, 4, 4, 0, false, 32, false, true>(a, Ap, 0);   // rolling fragment requests (round 4: 593 -> 576 us; the k-step-pipelined
 }                                                                       // loop needs 32 more registers here: measured slower, 613 vs 592 us)
+#ifdef DIM_RESEARCH
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_step_kernel(GemmArgs a) {   // round 3's loop (one k-step's fragments at a time), kept for A/B: dim_tune_set(14, 36)
   __shared__ unsigned Ap[FFN_LDS_DWORDS];
   float* const prm = (float*)(Ap + 2 * 64 * RS);
@@ -921,6 +926,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_roll_probe_kernel(Ge
   }
   gemm_x6_body<2, 64, 4, 4, 4, 1, false, 32, false, true>(a, Ap, 0);
 }
+#endif   // DIM_RESEARCH
 // LightGlue's q|k|v projection in ONE launch: blockIdx.y selects the column block and with it the code path (plain fp32 /
 // transposed K image / V image — three inlined bodies, one register allocation each), so that the 2 or 3 column blocks of
 // a row block run next to each other on the same XCD and the activation rows come from HBM once (as separate launches
@@ -970,9 +976,12 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     DIM_REQUIRE(a.split_mode == 2 && a.N == 512 && a.n_pad == 512 && a.K % KC == 0 && a.ln_beta && a.bias && a.bias2 && a.inv_ch2 && a.R && a.C && a.relu == 0 &&
                 a.kv_img == nullptr && a.ldr == a.ldc && a.strideR == a.strideC,
                 "gemm_x6: the fused feed-forward needs the fp16x3 512 -> 256 shapes, a residual laid out like the output and both bias vectors");
+#ifdef DIM_RESEARCH
     if (dim_gemm_kc() == 35) hipLaunchKernelGGL(gemm_x6_ffn_fused_roll_probe_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
     else if (dim_gemm_kc() == 36) hipLaunchKernelGGL(gemm_x6_ffn_fused_step_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(gemm_x6_ffn_fused_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    else
+#endif
+    hipLaunchKernelGGL(gemm_x6_ffn_fused_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
     DIM_LAUNCH_CHECK();
     return 0;
   }
@@ -981,6 +990,7 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
                 "gemm_x6: the LayerNorm + GELU epilogue needs the fp16x3 512-column ffn.0 shape");
     const dim3 lg(cdiv(a.M, 64), 1, batch);
     switch (dim_gemm_probe()) {
+#ifdef DIM_RESEARCH
       case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<1>), lg, dim3(256), 0, s, a); break;
       case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<2>), lg, dim3(256), 0, s, a); break;
       case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<4>), lg, dim3(256), 0, s, a); break;
@@ -989,6 +999,7 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
       case 100: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<0, true>), lg, dim3(256), 0, s, a); break;
       case 104: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<4, true>), lg, dim3(256), 0, s, a); break;
       case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<32>), lg, dim3(256), 0, s, a); break;
+#endif
       default: hipLaunchKernelGGL(gemm_x6_ffn_ln_kernel, lg, dim3(256), 0, s, a);
     }
     DIM_LAUNCH_CHECK();
@@ -1005,11 +1016,15 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     if (a.kv_img != nullptr) {
       DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
       DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == (int)grid.y - 1, "gemm_x6: the K and V blocks must be the last two");
+#ifdef DIM_RESEARCH
       if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_qkv_roll_kernel, grid, dim3(256), 0, s, a);
       else if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_qkv_db_kernel, grid, dim3(256), 0, s, a);
       else if (dim_gemm_kc() == 64 && a.K % 64 == 0) hipLaunchKernelGGL(gemm_x6_qkv_kc64_kernel, grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL(gemm_x6_qkv_kernel, grid, dim3(256), 0, s, a);
+      else
+#endif
+      hipLaunchKernelGGL(gemm_x6_qkv_kernel, grid, dim3(256), 0, s, a);
     } else switch (dim_gemm_probe()) {
+#ifdef DIM_RESEARCH
       case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<1>), grid, dim3(256), 0, s, a); break;
       case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<2>), grid, dim3(256), 0, s, a); break;
       case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<4>), grid, dim3(256), 0, s, a); break;
@@ -1021,11 +1036,15 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
       case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<48>), grid, dim3(256), 0, s, a); break;
       case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<32>), grid, dim3(256), 0, s, a); break;
       case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<16>), grid, dim3(256), 0, s, a); break;
+#endif
       default:
+#ifdef DIM_RESEARCH
         if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_wide_roll_kernel, grid, dim3(256), 0, s, a);
         else if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_wide_db_kernel, grid, dim3(256), 0, s, a);
         else if (dim_gemm_kc() == 64 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(gemm_x6_wide_kc64_kernel, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);
+        else
+#endif
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);
     }
   } else {
     dim3 grid(cdiv(a.M, 128), cdiv(a.N, BN), batch);

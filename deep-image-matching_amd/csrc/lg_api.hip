@@ -25,6 +25,7 @@ struct LayerW {
 }  // namespace
 
 struct dim_lg {
+  DimHandleBase base;   // first member: dim_handle_tune_set
   dim_lg_config cfg;
   int n_layers, input_dim, max_pairs, nmax;
   std::vector<LayerW> L;
@@ -206,6 +207,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
                  float* mscores_dev, int32_t* n_matches_dev, int32_t* matches01_dev, float* mscores01_dev,
                  int32_t* stop_dev, int32_t* prune01_dev, float* dense_scores_dev, void* stream) {
   DIM_REQUIRE(h && kpts_tab_dev && desc_tab_dev && n_tab_dev && size_tab_dev, "dim_lg_match: null input");
+  DimTuneScope tune_scope(&h->base);
   DIM_REQUIRE(matches_dev && mscores_dev && n_matches_dev && matches01_dev && mscores01_dev && stop_dev && prune01_dev, "dim_lg_match: null output");
   DIM_REQUIRE(n_pairs >= 1 && n_pairs <= h->max_pairs, "dim_lg_match: n_pairs %d outside [1,%d]", n_pairs, h->max_pairs);
   DIM_REQUIRE(cap > 0, "dim_lg_match: cap");

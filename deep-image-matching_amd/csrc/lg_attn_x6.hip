@@ -354,9 +354,12 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
   dim3 grid((unsigned)(cdiv(a.groups, 8) * 8 * a.qblocks));  // whole rounds of 8 groups, one per XCD (surplus workgroups exit)
   if (dim_precision_mode() == 2) {
     if (!kv_ready) hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<2>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
+#ifdef DIM_RESEARCH   // cross-attention timing probes (wrong results by design): research build only
     if (a.probe == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2, 1>), grid, dim3(256), 0, s, a);
     else if (a.probe == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2, 3>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2>), grid, dim3(256), 0, s, a);
+    else
+#endif
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2>), grid, dim3(256), 0, s, a);
   } else {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(kv_prep_kernel<1>), dim3(a.tiles, 4, st.n_items), dim3(256), 0, s, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<1>), grid, dim3(256), 0, s, a);

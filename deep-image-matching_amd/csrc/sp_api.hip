@@ -17,6 +17,7 @@
 #include "sp_kernels.h"
 
 struct dim_sp {
+  DimHandleBase base;   // first member: dim_handle_tune_set
   dim_sp_config cfg;
   int max_batch, max_h, max_w, capacity;
   // weights (device)
@@ -95,7 +96,8 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
         sw.dev = d; sw.mode = mode;
       }
     }
-    if (l == 1) {  // conv1b: the Winograd variant's weights (dim_tune_set key 15)
+#ifdef DIM_RESEARCH
+    if (l == 1) {  // conv1b: the Winograd variant's weights (dim_tune_set key 15; research build)
       std::vector<unsigned short> hx(conv_wino_weight_elems(ci, co));
       SplitWeights& sw = h->wsw[l];
       prepare_conv_weights_wino(w->conv_w[l], ci, co, hx.data(), &sw);
@@ -104,6 +106,7 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
       if (hipMemcpy(d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { dim_set_error("weight upload failed"); dim_sp_destroy(h); return -1; }
       sw.dev = d; sw.mode = 2;
     }
+#endif
     if (k == 1) {  // the two 1x1 heads (convPb 256 -> 65, convDb 256 -> 256) run on the split GEMM
       std::vector<float> kn((size_t)ci * co);
       for (int o = 0; o < co; ++o)
@@ -162,6 +165,7 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
 int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, float* kpts_xy_dev, float* scores_dev,
                    float* desc_dev, int32_t* n_kpts_dev, void* stream) {
   DIM_REQUIRE(h && images_dev && kpts_xy_dev && scores_dev && desc_dev && n_kpts_dev, "dim_sp_extract: null argument");
+  DimTuneScope tune_scope(&h->base);
   DIM_REQUIRE(batch >= 1 && batch <= h->max_batch, "dim_sp_extract: batch %d outside [1,%d]", batch, h->max_batch);
   DIM_REQUIRE(H >= 8 && W >= 8 && H <= h->max_h && W <= h->max_w && (size_t)H * W <= (size_t)h->max_h * h->max_w,
               "dim_sp_extract: image %dx%d outside the handle's %dx%d", H, W, h->max_h, h->max_w);
@@ -188,11 +192,14 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   auto convp = [&](int l, const float* in, float* out, int Hh, int Ww, int ci, int co, int pool, int pin, int pout) -> int {
     return launch_conv3x3_x6_planes(in, h->wsp[2][l], h->bias[l], out, batch, Hh, Ww, ci, co, pool, 1, pin, pout, s, l >= 8 ? sat_head : sat_enc);
   };
+#ifdef DIM_RESEARCH
   if (pmode == 2 && dim_fuse_conv1a() && (dim_conv_winograd() & 1)) {  // Winograd F(2,3) along x: 2/3 of the MFMAs (conv_wg.hip)
     // the transformed activations reach 2 x conv1a's output bound: check the doubled bound on the host as the direct path checks the plain one
     if (!(2.0f * h->conv1a_bound <= DIM_F16_ACT_LIMIT)) dim_sat_host_bump(DIM_SAT_SP_IMAGE);
     SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_wg_fused1a(images_dev, h->wk[0], h->bias[0], h->wsw[1], h->bias[1], h->b1, batch, H, W, 64, 1, planes ? 1 : 0, s, sat_enc, sat_img));
-  } else if (x6 && dim_fuse_conv1a()) {  // conv1a evaluated inside conv1b's halo staging: its 64-channel full-resolution map never exists
+  } else
+#endif
+  if (x6 && dim_fuse_conv1a()) {  // conv1a evaluated inside conv1b's halo staging: its 64-channel full-resolution map never exists
     SP_SITE(DIM_PROF_SP_CONV1B, launch_conv3x3_x6_fused1a(images_dev, h->wk[0], h->bias[0], h->wsp[pmode][1], h->bias[1], h->b1, batch, H, W, 64, 1, 1, planes ? 1 : 0, s, sat_enc, sat_img));
   } else {
     if (!h->a1) SP_RUN(dev_alloc(h, &h->a1, (size_t)h->max_batch * h->max_h * h->max_w * 64));
@@ -252,6 +259,7 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
 int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits, const float** score_map,
                          const float** nms_map, const float** dense_desc, int* h8, int* w8) {
   DIM_REQUIRE(h, "dim_sp_debug_buffers: null handle");
+  DimTuneScope tune_scope(&h->base);
   if (encoder) {
     *encoder = h->x;
     if (h->x_is_planes) {  // rebuild fp32 from the planes of the last batch
@@ -273,6 +281,7 @@ int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits,
 int dim_sp_debug_conv1b(dim_sp* h, int batch, int H, int W, const float** out_f32, int* h2, int* w2) {
   // fp32 NHWC copy [batch][H/2][W/2][64] of conv1b's pooled output of the last extract (A/B of the convolution variants)
   DIM_REQUIRE(h && out_f32 && batch >= 1 && batch <= h->max_batch, "dim_sp_debug_conv1b: bad argument");
+  DimTuneScope tune_scope(&h->base);
   const int H2 = H / 2, W2 = W / 2;
   if (!h->b1_dbg && dev_alloc(h, &h->b1_dbg, (size_t)h->max_batch * (h->max_h / 2) * (h->max_w / 2) * 64) != 0) return -1;
   const bool planes = dim_precision_mode() == 2 && dim_fuse_conv1a() && dim_presplit_activations();

@@ -54,8 +54,9 @@ class LightGlueHIP:
                     "pruning_min_kpts": -1}
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], conf: Optional[dict] = None, max_pairs: int = 1,
-                 max_kpts: int = 2048, device="cuda", lib=None, on_saturation: str = "fallback"):
+                 max_kpts: int = 2048, device="cuda", lib=None, on_saturation: str = "fallback", arithmetic=None):
         self.conf = {**self.default_conf, **(conf or {})}
+        self.arithmetic = arithmetic        # None: the process default; "fp16x3" | "bf16x6" | "fp32": this handle only
         self.on_saturation = on_saturation  # fp16x3 range guard policy of __call__: "fallback" (bf16x6 re-run) | "raise" | "off"
         self.lib = lib if lib is not None else capi.load()
         self.device = torch.device(device)
@@ -89,6 +90,8 @@ class LightGlueHIP:
         with self._ctx():
             capi.check(self.lib, self.lib.dim_lg_create(ctypes.byref(w), ctypes.byref(c), self.max_pairs, int(max_kpts), ctypes.byref(self._h)))
         self.nk = self.lib.dim_lg_max_kpts(self._h)
+        if arithmetic is not None:
+            capi.set_handle_arithmetic(self.lib, self._h, arithmetic)
         del keep
 
     def __del__(self):
@@ -110,7 +113,7 @@ class LightGlueHIP:
     def match_batch_guarded(self, *a, logger=None, **k):
         """match_batch under the fp16x3 range guard (capi.run_guarded): synchronises."""
         with self._ctx():
-            return capi.run_guarded(self.lib, self._stream(), lambda: self.match_batch(*a, **k), "LightGlue", self.on_saturation, logger)
+            return capi.run_guarded(self.lib, self._stream(), lambda: self.match_batch(*a, **k), "LightGlue", self.on_saturation, logger, handle=self._h, arithmetic=self.arithmetic)
 
     @torch.no_grad()
     def match_batch(self, kpts_tab, desc_tab, n_tab, size_tab, pair_idx=None, n_pairs=None, dense=False, out=None):

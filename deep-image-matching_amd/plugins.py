@@ -61,17 +61,18 @@ except Exception:  # noqa: BLE001
         _role = "matcher"
 
 
-def _apply_arithmetic(conf: dict, lib) -> None:
+def _apply_arithmetic(conf: dict, lib):
     """Optional plugin option ``arithmetic``: "fp16x3" (library default: 2-way fp16 splits x 3 MFMA terms; activations
     exact up to |x| = 4094 — guarded: a call that leaves the range is repeated in bf16x6, option ``on_saturation``),
     "bf16x6" (exact 3-way bf16 splits x 6 terms, no range limit) or "fp32" (plain fp32 MFMA).
-    The switch is process-wide (dim_tune_set key 1), like the reference's module-global sampler patch (Q3)."""
+    The choice belongs to THIS plugin's library handles (dim_handle_tune_set key 1, set when a handle is created); without the option
+    the handles follow the process default (capi.set_arithmetic).  Returns the validated name or None."""
     name = (conf or {}).get("arithmetic")
     if name is None:
-        return
+        return None
     if name not in capi.ARITHMETIC:
         raise ValueError(f"arithmetic must be one of {sorted(capi.ARITHMETIC)}, got {name!r}")
-    capi.set_arithmetic(lib, name)
+    return name
 
 
 def _saturation_policy(conf: dict) -> str:
@@ -117,7 +118,7 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
         self._lib = capi.load()
         self._device = _resolve_device(self._device, "SuperPointExtractor")
         cfg = self.config.get("extractor")
-        _apply_arithmetic(cfg, self._lib)
+        self._arith = _apply_arithmetic(cfg, self._lib)
         self._on_sat = _saturation_policy(cfg)
         path = cfg.get("weights_path") or os.environ.get("DIM_SUPERPOINT_WEIGHTS")
         if path is None and cfg.get("allow_synthetic_weights"):
@@ -140,7 +141,7 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
         if self._net is None or H > self._net_hw[0] or W > self._net_hw[1] or cap > self._net.capacity:
             hw = (max(H, self._net_hw[0]), max(W, self._net_hw[1]))
             self._net = SuperPointHIP(self._sd, self._net_cfg, max_batch=1, max_hw=hw, capacity=cap,
-                                      device=self._device, lib=self._lib, on_saturation=self._on_sat)
+                                      device=self._device, lib=self._lib, on_saturation=self._on_sat, arithmetic=self._arith)
             self._net_hw = hw
 
     def _ensure_batch(self, H: int, W: int, batch: int):
@@ -149,7 +150,7 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
         cap = self._capacity(H, W)
         if key is None or H > key[0] or W > key[1] or batch > key[2] or cap > self._tile_net.capacity:
             self._tile_net = SuperPointHIP(self._sd, self._net_cfg, max_batch=batch, max_hw=(H, W), capacity=cap,
-                                           device=self._device, lib=self._lib, on_saturation=self._on_sat)
+                                           device=self._device, lib=self._lib, on_saturation=self._on_sat, arithmetic=self._arith)
             self._tile_key = (H, W, batch)
         return self._tile_net
 
@@ -310,7 +311,7 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
         self._lib = capi.load()
         self._device = _resolve_device(self._device, "LightGlueMatcher")
         cfg = {**self._default_conf, **self.config.get("matcher", {})}
-        _apply_arithmetic(cfg, self._lib)
+        self._arith = _apply_arithmetic(cfg, self._lib)
         self._on_sat = _saturation_policy(cfg)
         if cfg.get("mp"):
             logger.warning("LightGlue: mixed precision ('mp') is not implemented on the MI355X path; running fp32")
@@ -334,7 +335,7 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
             self._net_n = max(256, 1 << (max(n, 1) - 1).bit_length())
             dev = self._device if isinstance(self._device, (str, torch.device)) else "cuda"
             self._net = LightGlueHIP(self._sd, self._conf, max_pairs=1, max_kpts=self._net_n, device=dev, lib=self._lib,
-                                     on_saturation=self._on_sat)
+                                     on_saturation=self._on_sat, arithmetic=self._arith)
 
     def _ensure_pairs(self, n: int, pairs: int):
         """Batched instance for tile-pair matching (tile_matching.BatchedTileMatchingMixin)."""
@@ -344,7 +345,7 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
             self._net_b_p = max(pairs, getattr(self, "_net_b_p", 0))
             dev = self._device if isinstance(self._device, (str, torch.device)) else "cuda"
             self._net_b = LightGlueHIP(self._sd, self._conf, max_pairs=self._net_b_p, max_kpts=self._net_b_n, device=dev, lib=self._lib,
-                                       on_saturation=self._on_sat)
+                                       on_saturation=self._on_sat, arithmetic=self._arith)
         return self._net_b
 
     @torch.no_grad()

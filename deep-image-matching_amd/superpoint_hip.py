@@ -37,8 +37,9 @@ class SuperPointHIP:
                       "fix_sampling": False}
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[dict] = None, max_batch: int = 1,
-                 max_hw=(1024, 1024), capacity: Optional[int] = None, device="cuda", lib=None, on_saturation: str = "fallback"):
+                 max_hw=(1024, 1024), capacity: Optional[int] = None, device="cuda", lib=None, on_saturation: str = "fallback", arithmetic=None):
         self.cfg = {**self.default_config, **(cfg or {})}
+        self.arithmetic = arithmetic        # None: the process default (capi.set_arithmetic); "fp16x3" | "bf16x6" | "fp32": this handle only
         self.on_saturation = on_saturation  # fp16x3 range guard policy of __call__: "fallback" (bf16x6 re-run) | "raise" | "off"
         mk = self.cfg["max_keypoints"]
         if mk == 0 or mk < -1:
@@ -63,6 +64,8 @@ class SuperPointHIP:
         with self._ctx():
             capi.check(self.lib, self.lib.dim_sp_create(ctypes.byref(w), ctypes.byref(c), self.max_batch, self.max_hw[0],
                                                         self.max_hw[1], self.capacity, ctypes.byref(self._h)))
+        if arithmetic is not None:
+            capi.set_handle_arithmetic(self.lib, self._h, arithmetic)
         del keep
 
     def __del__(self):
@@ -120,7 +123,7 @@ class SuperPointHIP:
         """extract_batch under the fp16x3 range guard (capi.run_guarded): synchronises."""
         with self._ctx():
             return capi.run_guarded(self.lib, self._stream(), lambda: self.extract_batch(images, out=out), "SuperPoint",
-                                    self.on_saturation, logger)
+                                    self.on_saturation, logger, handle=self._h, arithmetic=self.arithmetic)
 
     @torch.no_grad()
     def __call__(self, image: torch.Tensor) -> dict:

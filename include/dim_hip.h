@@ -36,24 +36,30 @@ extern "C" {
 const char* dim_last_error(void);
 int dim_abi_version(void);
 int dim_device_synchronize(void);
-/* Tuning hook (experiments / A-B benchmarking; process-wide): key 0 = fp32 conv3x3 kernel variant; key 1 = matrix
- * arithmetic: 2 (default) fp32-accurate products on the fp16 matrix cores ("fp16x3": 2-way splits of the
- * power-of-two-scaled operands x 3 terms; activations exact up to |x| = 4094, saturating beyond), 1 = "bf16x6" (exact
- * 3-way bf16 splits x 6 terms, no range limit), 0 = plain fp32 MFMA;
- * key 2 = split-precision conv variant: bits 0-1 prefetch variant of the bf16x6 kernels, bit 4 (default set) 16-row tiles
- * with LDS-DMA weight staging for the production fp16x3 shapes; key 3 = 1 (default) SuperPoint conv1a fused into
- * conv1b, 0 = separate kernels; key 4 = 1 (default) LightGlue out_proj folded into ffn.0 (split modes), 0 = separate GEMMs;
- * key 5 = 1 (default) SuperPoint conv-to-conv activations stored pre-split (fp16x3), 0 = fp32;
- * key 6 = split-precision GEMM block: 1 (default) 128 x 256 when the launch fills the GPU, 0 = always 128 x 128,
- * 2 = always 128 x 256 (tests); key 7 = simple_nms tiles: 1 (default) 64 x 64 on large maps, 0 = 32 x 32, 2 = always 64 x 64;
- * key 8 = 1 (default) LightGlue's K | V attention tile images written by the projection GEMM, 0 = separate pre-split pass;
- * key 9 = 1 (default) ALIKED BatchNorm + SELU applied while the consumer stages its input, 0 = separate pass; key 10 = ALIKED fp16x3
- * convolution tile rows (16 default, 8, 17 = 16 with streamed weights); key 11 = LightGlue's feed-forward: 3 (default) ffn.0 +
- * LayerNorm + GELU + ffn.3 + residual as one kernel when the launch fills the GPU, 4 = always (tests), 1 / 2 = LayerNorm + GELU in
- * ffn.0's epilogue only (when large / always), 0 = separate kernels; key 14 = variants of the fp16x3 GEMM blocks (32 default; 64 = 64-wide K chunks, 33 = activation tile double-buffered in LDS — prototypes, measured neutral in round 4; 37 = their weight-fragment sets refilled tile by tile (prototype); 36 = the fused feed-forward's previous K loop (one k-step's fragments at a time, 593 vs 576 us); 35 = a timing probe with wrong results);
- * key 15 = Winograd F(2,3)-along-x convolution variants (csrc/conv_wg.hip), bit 0 = SuperPoint conv1b with the fused conv1a (fp16x3 only); key 12 = cross-attention timing probes
- * (scripts/gpu_attn_probe.py; 0 in the product — 1 and 3 give wrong results by design). */
+/* Process-wide defaults of the choices a user may make (read at the entry of every later dim_* call; set them before the work starts —
+ * they are plain ints, not synchronised against calls running on other threads):
+ *   key 1  matrix arithmetic: 2 (default) "fp16x3" = fp32-accurate products on the fp16 matrix cores (2-way splits of the power-of-two-scaled
+ *          operands x 3 terms; activations exact up to |x| = 4094 and GUARDED beyond, dim_saturation_read), 1 = "bf16x6" (exact 3-way bf16
+ *          splits x 6 terms, no range limit), 0 = plain fp32 MFMA;
+ *   fusion on / off (every setting gives the same results to fp32 rounding; the defaults are the fast ones):
+ *   key 3  1 (default) SuperPoint conv1a evaluated inside conv1b, 0 = separate kernels;
+ *   key 4  1 (default) LightGlue out_proj folded into ffn.0 (split modes), 0 = separate GEMMs;
+ *   key 5  1 (default) SuperPoint conv-to-conv activations stored pre-split (fp16x3), 0 = fp32;
+ *   key 8  1 (default) LightGlue's K | V attention tile images written by the projection GEMM, 0 = separate pre-split pass;
+ *   key 9  1 (default) ALIKED BatchNorm + SELU applied while the consumer stages its input, 0 = separate pass;
+ *   key 11 LightGlue's feed-forward: 3 (default) ffn.0 + LayerNorm + GELU + ffn.3 + residual as one kernel when the launch fills the GPU,
+ *          4 = always, 1 / 2 = LayerNorm + GELU in ffn.0's epilogue only (when large / always), 0 = separate kernels;
+ *   kernel-shape selection (same results; the defaults pick by problem size, the other values force a shape — used by the tests to reach
+ *   the large-batch kernels with small inputs):
+ *   key 0  fp32 conv3x3 kernel variant; key 2  split-precision conv variant (bits 0-1 prefetch variant of the bf16x6 kernels, bit 4 (default
+ *          set) 16-row tiles with LDS-DMA weight staging); key 6  split-precision GEMM block (1 default: 128 x 256 when the launch fills the
+ *          GPU, 0 = always 128 x 128, 2 = always 128 x 256); key 7  simple_nms tiles (1 default: 64 x 64 on large maps, 0 = 32 x 32,
+ *          2 = always 64 x 64); key 10  ALIKED fp16x3 convolution tile rows (16 default, 8, 17 = 16 with streamed weights).
+ * Keys 12-15 do not exist in this library: they select research prototypes and timing probes that are compiled only into
+ * libdim_hip_research.so (build.build_variant("research", ["-DDIM_RESEARCH"]); csrc/dim_kernels.h) and return an error here.
+ * dim_handle_tune_set(handle, key, value) overrides a key for ONE extractor / matcher handle (value < 0: back to the process default). */
 int dim_tune_set(int key, int value);
+int dim_handle_tune_set(void* handle, int key, int value);
 
 /* Per-launch-site timing with HIP events recorded on the launch stream (bench.py's
  * roofline figure).  dim_profile_start(mask) arms the sites whose bits (1 << DIM_PROF_*) are set;
@@ -144,11 +150,8 @@ int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits,
                          const float** nms_map, const float** dense_desc, int* h8, int* w8);
 
 /* fp32 NHWC copy [batch][H/2][W/2][64] of conv1b's pooled output (SPN:162-163) of the last dim_sp_extract call on (batch, H, W):
- * A/B of the convolution variants (dim_tune_set keys 2, 3, 5, 15).  Synchronises the device. */
+ * A/B of the convolution variants (dim_tune_set keys 2, 3, 5).  Synchronises the device. */
 int dim_sp_debug_conv1b(dim_sp* h, int batch, int H, int W, const float** out_f32, int* h2, int* w2);
-
-/* Developer probe: summed per-phase cycles of the Winograd convolution's timing build (dim_tune_set(15, .. | 8); csrc/conv_wg.hip). */
-int dim_conv_wg_phase_read(unsigned long long* host16, int reset);
 
 /* Number of NMS survivors above threshold/border per image of the last call
  * (before top-k), device int32 [batch] owned by the handle. */

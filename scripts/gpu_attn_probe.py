@@ -19,7 +19,7 @@ import ctypes, importlib, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lg = importlib.import_module('deep-image-matching_amd.lightglue_hip'); weights = importlib.import_module('deep-image-matching_amd.weights')
-capi = importlib.import_module('deep-image-matching_amd.capi'); lib = capi.load()
+capi = importlib.import_module('deep-image-matching_amd.capi'); lib = capi.load(str(capi.LIB_PATH.parent / 'libdim_hip_research.so')); capi.install(lib, None)   # research build: dim_tune_set keys 12-15 (timing probes / prototypes) exist only there
 P, N = 50, 2048
 sd = weights.synthetic_lightglue_state_dict(0, 256, gain=2.0)
 conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}

@@ -1,5 +1,5 @@
 """Phase timers of the fused feed-forward kernel (gemm_x6_ffn_fused_kernel) on the bench shape: s_memtime stamps inside an INSTRUMENTED build
-(deep-image-matching_amd/lib/libdim_hip_ffntime.so = build.build_variant("ffntime", ["-DDIM_FFN_TIMERS"])), summed over every wave.
+(deep-image-matching_amd/lib/libdim_hip_ffntime.so = build.build_variant("ffntime", ["-DDIM_FFN_TIMERS", "-DDIM_RESEARCH"]) — -DDIM_RESEARCH only when a prototype loop (argument = dim_tune_set key 14 value) is timed), summed over every wave.
 Build the variant in the build container first (it is not part of build()), then on the GPU box:
 python scripts/gpu_ffn_phases.py [14=VALUE]  ->  one JSON line: average ns per wave and phase, and each phase's share."""
 import ctypes, importlib, json, sys

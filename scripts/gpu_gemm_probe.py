@@ -4,7 +4,7 @@ PROBE instantiations (dim_tune_set key 13): 0 product; 1 activations cache-resid
 4 no MFMAs; 8 weight fragments loaded once; 9 = 1 + 8.  Results of probes != 0 are wrong by design.  us per launch, HIP events."""
 import ctypes, importlib, json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-capi = importlib.import_module('deep-image-matching_amd.capi'); lib = capi.load()
+capi = importlib.import_module('deep-image-matching_amd.capi'); lib = capi.load(str(capi.LIB_PATH.parent / 'libdim_hip_research.so')); capi.install(lib, None)   # research build: dim_tune_set keys 12-15 (timing probes / prototypes) exist only there
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 M, K = 204800, 512
 g = torch.Generator().manual_seed(0)

@@ -1,0 +1,25 @@
+"""Where does a per-call plugin hook spend its wall time?  cProfile of SuperPointExtractor._extract (1024 x 1024) and LightGlueMatcher._match_pairs
+(2048 x 2048 keypoints, 9 layers) on the GPU box: the device work is 0.83 / 2.05 ms per call, the hooks take 13 / 16 ms (profiles/r05 bench line)."""
+import cProfile, importlib, io, os, pstats, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+plugins = importlib.import_module('deep-image-matching_amd.plugins')
+ex = plugins.SuperPointExtractor({"general": {}, "extractor": {"name": "superpoint", "nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048,
+                                                               "remove_borders": 4, "allow_synthetic_weights": True}})
+mt = plugins.LightGlueMatcher({"general": {}, "matcher": {"name": "lightglue", "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1,
+                                                           "allow_synthetic_weights": True}}, local_features="superpoint")
+g = torch.Generator().manual_seed(77)
+imgs = [(torch.rand(1024, 1024, generator=g) * 255).numpy().astype(np.float32) for _ in range(2)]
+feats = []
+for im in imgs:
+    f = ex._extract(im); f["image_size"] = np.array([1024, 1024], dtype=np.int32); feats.append(f)
+mt._match_pairs(feats[0], feats[1])
+for name, fn in (("extract", lambda: ex._extract(imgs[0])), ("match", lambda: mt._match_pairs(feats[0], feats[1]))):
+    for _ in range(3): fn()
+    t0 = time.perf_counter()
+    for _ in range(10): fn()
+    print(name, "ms per call", (time.perf_counter() - t0) / 10 * 1e3)
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(10): fn()
+    pr.disable()
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22); print(s.getvalue()[:5000])

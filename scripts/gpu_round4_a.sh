@@ -8,7 +8,7 @@ O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; tail -c 600 $O/${TAG}_bench.err
-python bench.py --tune 14=64 --no-cpu-baseline --no-strong-scaling > $O/${TAG}_bench_kc64.json 2>> $O/${TAG}_bench.err
+python bench.py --lib deep-image-matching_amd/lib/libdim_hip_research.so --tune 14=64 --no-cpu-baseline --no-strong-scaling > $O/${TAG}_bench_kc64.json 2>> $O/${TAG}_bench.err
 python bench.py --no-cpu-baseline --no-strong-scaling > $O/${TAG}_bench_again.json 2>> $O/${TAG}_bench.err
 python scripts/study/lg_flip_rate.py gpu 200 > $O/${TAG}_flip_gpu.log 2>&1; tail -2 $O/${TAG}_flip_gpu.log
 python scripts/gpu_end_to_end.py > $O/${TAG}_end_to_end.json 2> $O/${TAG}_e2e.err; tail -c 400 $O/${TAG}_e2e.err

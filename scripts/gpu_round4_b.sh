@@ -9,13 +9,13 @@ cd $R
 timeout 600 python -m pytest tests/test_superpoint_gpu.py -m gpu -q -x -k winograd > $O/${TAG}_wino_test.log 2>&1; tail -3 $O/${TAG}_wino_test.log
 for rep in 1 2; do
   python bench.py --no-cpu-baseline --no-strong-scaling > $O/${TAG}_bench_direct$rep.json 2>> $O/${TAG}_bench.err
-  python bench.py --tune 15=1 --no-cpu-baseline --no-strong-scaling > $O/${TAG}_bench_wino$rep.json 2>> $O/${TAG}_bench.err
+  python bench.py --lib $R/deep-image-matching_amd/lib/libdim_hip_research.so --tune 15=1 --no-cpu-baseline --no-strong-scaling > $O/${TAG}_bench_wino$rep.json 2>> $O/${TAG}_bench.err
 done
 cd /tmp && export TMPDIR=/tmp
 for V in 0 1; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_w$V -o bench -- python $R/bench.py --tune 15=$V --steps 3 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_${TAG}_w${V}_MFMA -o pmc -- python $R/bench.py --tune 15=$V --steps 2 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_${TAG}_w${V}_LDS -o pmc -- python $R/bench.py --tune 15=$V --steps 2 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_w$V -o bench -- python $R/bench.py --lib $R/deep-image-matching_amd/lib/libdim_hip_research.so --tune 15=$V --steps 3 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_${TAG}_w${V}_MFMA -o pmc -- python $R/bench.py --lib $R/deep-image-matching_amd/lib/libdim_hip_research.so --tune 15=$V --steps 2 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_${TAG}_w${V}_LDS -o pmc -- python $R/bench.py --lib $R/deep-image-matching_amd/lib/libdim_hip_research.so --tune 15=$V --steps 2 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
 done
 cd $R
 python - <<'PY'

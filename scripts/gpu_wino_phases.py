@@ -7,7 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 capi = importlib.import_module("deep-image-matching_amd.capi")
 sp = importlib.import_module("deep-image-matching_amd.superpoint_hip")
 weights = importlib.import_module("deep-image-matching_amd.weights")
-lib = capi.load()
+lib = capi.load(str(capi.LIB_PATH.parent / 'libdim_hip_research.so')); capi.install(lib, None)   # research build: dim_tune_set keys 12-15 (timing probes / prototypes) exist only there
 cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
 net = sp.SuperPointHIP(weights.synthetic_superpoint_state_dict(1234), cfg, max_batch=100, max_hw=(1024, 1024), capacity=2048)
 imgs = torch.rand(100, 1024, 1024, generator=torch.Generator().manual_seed(0)).cuda()

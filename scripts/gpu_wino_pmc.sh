@@ -10,7 +10,7 @@ for V in $VARS; do
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_THREAD_CYCLES_VALU SQ_WAVES"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $G --output-format csv -d $O/pmc_${TAG}_v${V}_g$i -o pmc -- python $R/bench.py --tune 15=$V --steps 2 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc $G --output-format csv -d $O/pmc_${TAG}_v${V}_g$i -o pmc -- python $R/bench.py --lib $R/deep-image-matching_amd/lib/libdim_hip_research.so --tune 15=$V --steps 2 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
   done
 done
 cd $R

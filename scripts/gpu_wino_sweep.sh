@@ -5,7 +5,7 @@ TAG=${1:-sweep}; shift
 VARS=${1:-"0 1 17 257 273 0"}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 for V in $VARS; do
-  python bench.py --tune 15=$V --no-cpu-baseline --no-strong-scaling --main-region-only --steps 10 --warmup 2 > $O/${TAG}_v$V.json 2>> $O/${TAG}.err
+  python bench.py --lib $R/deep-image-matching_amd/lib/libdim_hip_research.so --tune 15=$V --no-cpu-baseline --no-strong-scaling --main-region-only --steps 10 --warmup 2 > $O/${TAG}_v$V.json 2>> $O/${TAG}.err
   python - <<PY
 import json
 d = json.loads(open("$O/${TAG}_v$V.json").read().strip().splitlines()[-1])

@@ -27,6 +27,30 @@ def emu_lib():
 
 
 @pytest.fixture(scope="session")
+def emu_research_lib():
+    """The emulator build WITH -DDIM_RESEARCH (the default-off prototypes of dim_tune_set keys 14 / 15: their bit-identity tests)."""
+    import ctypes
+    import importlib
+
+    build = importlib.import_module("deep-image-matching_amd.build")
+    lib = ctypes.CDLL(str(build.build_emu(research=True)))
+    lib.dim_last_error.restype = ctypes.c_char_p
+    return lib
+
+
+@pytest.fixture(scope="session")
+def hip_research_lib():
+    """lib/libdim_hip_research.so on the GPU (built by __graft_entry__.build(); travels with the snapshot): the prototype variants' GPU tests."""
+    import importlib
+
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    p = capi.LIB_PATH.parent / "libdim_hip_research.so"
+    if not p.exists():
+        pytest.skip("libdim_hip_research.so not built (python __graft_entry__.py build)")
+    return capi.load(str(p))
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     """The real gfx950 library through the package loader (fails loudly without a GPU)."""
     import importlib

@@ -208,8 +208,19 @@ def test_batched_image_matcher_on_the_jpeg_files_equals_the_hooks(hip_lib, sp_pl
     for n in gc.SACRE_COEUR:
         f = export.FeatureStore.read(fpath, n)
         h = sp_plugin._extract(gc.real_gray(n))
-        assert np.array_equal(f["keypoints"], h["keypoints"].astype(np.float16).astype(np.float32))
-        assert np.array_equal(f["descriptors"], h["descriptors"].astype(np.float16).astype(np.float32))
+        # the ORDER among keypoints of equal score is not defined (torch.topk's is not either) and real photographs have
+        # such ties (saturated regions): compare the keypoint SETS and each keypoint's descriptor
+        hk, hd = h["keypoints"].astype(np.float16).astype(np.float32), h["descriptors"].astype(np.float16).astype(np.float32)
+        ia = {tuple(k): i for i, k in enumerate(f["keypoints"].tolist())}
+        ib = {tuple(k): i for i, k in enumerate(hk.tolist())}
+        assert len(ia) == len(ib) == 2000 and set(ia) == set(ib), (n, len(set(ia) ^ set(ib)))
+        perm = np.array([ib[k] for k in f["keypoints"].tolist()])
+        assert np.array_equal(f["descriptors"], hd[:, perm]), n
+        same_order = bool(np.array_equal(f["keypoints"], hk))
+        if not same_order:
+            sc = h["scores"][perm]
+            moved = np.nonzero((f["keypoints"] != hk).any(1))[0]
+            assert all(np.isclose(h["scores"][i], sc[i], rtol=0, atol=0) for i in moved), (n, "order differs at keypoints of different score")
         assert tuple(int(v) for v in f["image_size"]) == gc.real_gray(n).shape[:2]
     raw = export.MatchStore.read_all(tmp_path / "raw_matches.h5")
     assert len(raw) == 10

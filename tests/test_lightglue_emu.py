@@ -195,8 +195,8 @@ def test_swapping_the_images_transposes_the_result(emu_lib):
     assert ma.shape[0] > 0 and {tuple(x) for x in ma.tolist()} == {(j, i) for i, j in mb.tolist()}
 
 
-def test_wide_gemm_blocks_with_64_wide_k_chunks_are_bit_identical(emu_lib):
-    """dim_tune_set(14, 64): the pipelined 128 x 256 GEMM block and the q|k|v kernel stage 64 instead of 32 K values per barrier pair;
+def test_wide_gemm_blocks_with_64_wide_k_chunks_are_bit_identical(emu_research_lib):
+    """RESEARCH build (-DDIM_RESEARCH: the product library does not contain these prototypes).  dim_tune_set(14, 64): the pipelined 128 x 256 GEMM block and the q|k|v kernel stage 64 instead of 32 K values per barrier pair;
     dim_tune_set(14, 33): the staged activation tile is double-buffered in LDS, one barrier per chunk; dim_tune_set(14, 37): their fragment sets refilled tile by tile; dim_tune_set(14, 36): the fused
     feed-forward's previous K loop (the product one re-requests a column tile's weight fragments right after its MFMAs).  Same
     k-step order, same MFMA sequence per accumulator: every output bit for bit, with the large-batch kernels forced (6 = 2) on two
@@ -204,10 +204,11 @@ def test_wide_gemm_blocks_with_64_wide_k_chunks_are_bit_identical(emu_lib):
     for name in ("default", "fixed"):
         case = gc.LG_CASES[name]
         outs = []
+        emu_lib = emu_research_lib
         try:
             emu_lib.dim_tune_set(6, 2)
             for kc in ((32, 64, 33, 36, 37) if name == "fixed" else (32, 36, 37)):   # the two prototypes on one case, the A/B loop of the product kernel on both
-                emu_lib.dim_tune_set(14, kc)
+                assert emu_lib.dim_tune_set(14, kc) == 0
                 out, ref = run_case(emu_lib, case)
                 compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
                 outs.append(out)
