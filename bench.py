@@ -91,6 +91,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="(default since round 1) kept for compatibility")
     ap.add_argument("--main-region-only", action="store_true", help="skip the second (other-schedule) region: used for the rocprofv3 passes")
     ap.add_argument("--cpu-sample-pairs", type=int, default=4)
+    ap.add_argument("--tile-pair-batch", type=int, default=16, help="config5: tile pairs per dim_lg_match call")
     ap.add_argument("--tile-selection", default="PRESELECTION", help="config5: tile_selection method (PRESELECTION | GRID | EXHAUSTIVE | PRESELECTION_AFFINE_TRANSFORM)")
     ap.add_argument("--strong-timeout", type=float, default=300.0, help="seconds after which rank 0 prints the headline line without the strong_scaling sub-record and exits 3")
     ap.add_argument("--cpu-only", action="store_true", help="config1: run only the CPU leg (the reference modules when /root/reference exists): this is how the "
@@ -199,7 +200,7 @@ def cpu_baseline(n_pairs: int):
 def measure_config4(a, rank, world, dev, dist, lib, steps, warmup):
     """BASELINE configs[3] (SURVEY 8(d) "config 4"): `--images` synthetic 1024^2 images -> the first `--job-pairs` exhaustive
     pairs (pairs_generator.py:37-38 order) through pipeline.PairMatchingPipeline: images sharded i mod world, ONE all-gather of
-    the feature tables, pairs sharded round-robin, ONE all-gather of the match tables.  STRONG scaling: the job is fixed.  A
+    the feature tables, pairs dealt by cost n0 x n1 (pipeline.balanced_shards), ONE all-gather of the match tables.  STRONG scaling: the job is fixed.  A
     "step" is one pass over the whole job; per-phase wall times are the max over ranks.  The images are crops of one canvas
     (workloads.shifted_crops) and LightGlue runs the matching-capable synthetic weights at the reference's default threshold 0.1,
     so the match tables that cross xGMI are filled with hundreds of true correspondences per pair.
@@ -269,7 +270,7 @@ def measure_config4(a, rank, world, dev, dist, lib, steps, warmup):
                                "synthetic weights, threshold 0.1), through PairMatchingPipeline phases 1-4",
                    "images": a.images, "job_pairs": P, "pair_batch": B, "gflop_per_pair": LG_GFLOP_PER_PAIR + SP_GFLOP_PER_IMAGE * a.images / P,
                    "sharding": f"images i mod {world}, ONE all-gather of feature tables ({pipe_bytes(a.images, world)[0] / 1e6:.0f} MB), pairs "
-                               f"round-robin, ONE all-gather of match tables ({pipe_bytes(P, world)[1] / 1e6:.0f} MB)"},
+                               f"dealt by cost n0 x n1 (balanced_shards; equal costs = round-robin), ONE all-gather of match tables ({pipe_bytes(P, world)[1] / 1e6:.0f} MB)"},
         "phases_s_max_over_ranks": {k: float(v) / K for k, v in zip(phases, tt[1:].tolist())},
         "matches_total": total_matches, "matches_per_pair_mean": total_matches / max(1, P), "pairs_with_at_least_100_matches": pairs_with_100,
         "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
@@ -311,7 +312,12 @@ def run_config5(a, rank, world, dev, dist, lib):
     weights = importlib.import_module(PKG + ".weights")
     capi = importlib.import_module(PKG + ".capi")
     K, W = a.steps, a.warmup
-    general = {"tile_size": (1500, 1000), "tile_overlap": 0, "tile_preselection_size": 1024, "min_matches_per_tile": 5, "quality": "HIGH",
+    # tile_preselection_size 750 (the reference's default is 1024): 6000 x 4000 images are then down-sampled by EXACTLY 8 (INTER_AREA = 8 x 8 box
+    # means), so crops of one canvas at multiples of 64 px have bit-identical down-sampled overlaps shifted by multiples of 8 px — the shifts
+    # SuperPoint is equivariant under — and the preselector's seeded SuperPoint + matching-capable LightGlue find the true correspondences:
+    # PRESELECTION votes and selects the tile pairs itself, nothing falls back to GRID
+    PRE = 750
+    general = {"tile_size": (1500, 1000), "tile_overlap": 0, "tile_preselection_size": PRE, "min_matches_per_tile": 5, "quality": "HIGH",
                "allow_synthetic_weights": True}
     ex = plugins.AlikedExtractor({"general": general, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 4000,
                                                                      "detection_threshold": 0.2, "nms_radius": 3, "allow_synthetic_weights": True}})
@@ -320,18 +326,19 @@ def run_config5(a, rank, world, dev, dist, lib):
     mt._sd = weights.synthetic_lightglue_matching_state_dict(0, 128)          # ALIKED's synthetic descriptors are discriminative (mean cosine 0.12): no centring
     rng = np.random.default_rng(5)
     canvas = rng.integers(0, 256, (4000 + 512, 6000 + 512, 3), dtype=np.uint8)
-    offs = [(0, 0)] + [(int(rng.integers(0, 17)) * 32, int(rng.integers(0, 17)) * 32) for _ in range(a.images - 1)]
+    offs = [(0, 0)] + [(int(rng.integers(0, 9)) * 64, int(rng.integers(0, 9)) * 64) for _ in range(a.images - 1)]      # multiples of 64 (and so of ALIKED's stride 32)
     images = [np.ascontiguousarray(canvas[dy:dy + 4000, dx:dx + 6000]).astype(np.float32) for dy, dx in offs]
     del canvas
     # the preselector (SuperPoint + LightGlue at 1024 px) with matching-capable weights centred on its own descriptors
     sp_sd = weights.synthetic_superpoint_state_dict(1234)
-    pre = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_state_dict(0, 256), tile_preselection_size=1024, device=dev, lib=lib)
+    pre = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_state_dict(0, 256), tile_preselection_size=PRE, device=dev, lib=lib)
     f0 = pre.features("warm", np.ascontiguousarray(images[0][..., 0]), "HIGH")
     center = f0[1][0, : int(f0[2][0])].mean(0).cpu()
-    mt._tile_preselector = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_matching_state_dict(0, 256, center=center), tile_preselection_size=1024,
+    mt._tile_preselector = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_matching_state_dict(0, 256, center=center), tile_preselection_size=PRE,
                                               device=dev, lib=lib)
     del pre
-    pipe = pl.TiledPairPipeline(ex, mt, rank, world, selection=a.tile_selection, empty_selection_fallback="GRID" if a.tile_selection.startswith("PRESELECTION") else None)
+    pipe = pl.TiledPairPipeline(ex, mt, rank, world, selection=a.tile_selection, empty_selection_fallback="GRID" if a.tile_selection.startswith("PRESELECTION") else None,
+                                tile_pair_batch=a.tile_pair_batch)
     pairs = pl.exhaustive_pairs(a.images, a.job_pairs)
     P = int(pairs.shape[0])
 
@@ -361,8 +368,13 @@ def run_config5(a, rank, world, dev, dist, lib):
     tot_ms, launches = ctypes.c_double(), ctypes.c_int()
     capi.check(lib, lib.dim_profile_stop(ctypes.byref(tot_ms), ctypes.byref(launches)))
     tt = torch.tensor([dt] + [phases[k] for k in phases], dtype=torch.float64, device=dev)
+    fb = torch.tensor([pipe.n_fallback, pipe.timings.get("tile_pairs_this_rank", 0)], dtype=torch.int64, device=dev)
+    cost = torch.tensor([pipe.timings.get("cost_this_rank", 0.0)], dtype=torch.float64, device=dev)
+    cost_max = cost.clone()
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+        dist.all_reduce(cost_max, op=dist.ReduceOp.MAX)
     dt = float(tt[0].item())
     sat_total, sat_sites = capi.saturation(lib, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), reset=True)
     if rank == 0:
@@ -380,14 +392,20 @@ def run_config5(a, rank, world, dev, dist, lib):
                                    "aliked-n16rot geometry, 16 tiles of 1500x1000 per image, 4000 keypoints per tile; tile selection " + a.tile_selection + " on the device; LightGlue "
                                    "(128-d, adaptive depth / width 0.95 / 0.99, threshold 0.1) on the selected tile pairs; seeded synthetic weights",
                        "images": a.images, "job_pairs": P,
-                       "sharding": f"images i mod {world}, ONE all-gather of the merged tile tables ({pipe.timings['feature_gather_bytes'] / 1e6:.0f} MB), image pairs j mod {world}, "
+                       "sharding": f"images i mod {world}, ONE all-gather of the merged tile tables ({pipe.timings['feature_gather_bytes'] / 1e6:.0f} MB), tile selection of image pairs j mod {world}, "
+                                   f"ONE small all-gather of the selection masks ({pipe.timings.get('selection_gather_bytes', 0)} B), image pairs dealt by cost, "
                                    f"ONE all-gather of the match rows ({pipe.timings['match_gather_bytes'] / 1e6:.0f} MB)"},
             "phases_s_max_over_ranks": {k: float(v) / K for k, v in zip(phases, tt[1:].tolist())},
             "keypoints_per_image_mean": float(np.mean([int(f["keypoints"].shape[0]) for f in feats])),
             "matches_per_pair_mean": float(np.mean(nm)), "matches_per_pair_min": int(min(nm)), "pairs_with_matches": int(sum(1 for x in nm if x > 0)),
-            "tile_selection_note": "PRESELECTION (down-sampled SuperPoint + LightGlue on the device) runs and is timed for every image pair; with seeded synthetic "
-                                   "weights it cannot vote, so the GRID method (16 tile pairs per image pair) supplies the tile pairs that are matched "
-                                   f"(pairs that fell back on this rank: {pipe.n_fallback} of {len(pl.shard_indices(P, rank, world)) * K})",
+            "tile_pairs_total": int(pipe.timings.get("tile_pairs_total", 0)), "tile_pairs_per_s": float(pipe.timings.get("tile_pairs_total", 0)) * K / dt,
+            "tile_pairs_per_image_pair_mean": float(pipe.timings.get("tile_pairs_total", 0)) / max(1, P),
+            "image_pairs_fell_back_to_grid": int(fb[0].item()) // max(1, K),
+            "deal_balance": {"cost_max_over_ranks": float(cost_max.item()), "cost_mean_over_ranks": float(pipe.timings.get("cost_total", 0.0)) / world,
+                             "note": "image pairs dealt by sum(n0 x n1) over the SELECTED tile pairs (pipeline.balanced_shards)"},
+            "tile_selection_note": f"{a.tile_selection} on the device for every image pair (down-sampled SuperPoint + matching-capable LightGlue, tile_preselection_size {PRE} = "
+                                   "an exact 8 x 8 box down-sampling of 6000 x 4000, crops at multiples of 64 px): the votes select the tile pairs — a tile of image 0 "
+                                   "overlaps up to 4 tiles of image 1 —, nothing falls back",
             "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
             "roofline": {"kernel": "al_convx3_kernel<16, 9, 16> full-resolution launches (ALIKED block1.conv1 3 -> 16 and block1.conv2 16 -> 16, fp16x3, BatchNorm "
                                    "statistics in the epilogue)", "bound": "hbm", "achieved": bytes_per_launch / conv_ms / 1e6, "peak": 8000.0, "unit": "GB/s",
@@ -604,6 +622,7 @@ def measure_hook_path(dev, lib, n_img: int = 6, n_pair: int = 6):
 
 def main():
     a = parse()
+    torch.set_num_threads(min(16, os.cpu_count() or 16))     # the GPU box has 256 host CPUs: a 256-thread intra-op pool only adds spin-waiting
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -823,6 +842,13 @@ def main():
                          "avg_launch_ms": conv_ms, "launches": launches.value,
                          "algorithmic_gflop_per_launch": gflop_per_launch},
         }
+    # the per-call plugin hooks at the headline sizes: measured before the strong-scaling sub-run, whose host-side image
+    # synthesis spins up torch's CPU thread pool
+    if rank == 0 and not a.no_hook_path and not a.main_region_only:
+        try:
+            line["hook_path"] = measure_hook_path(dev, lib)
+        except Exception as e:
+            line["hook_path"] = {"error": repr(e)[:400]}
     # strong scaling where the driver's 1/2/4/8 command sees it: the FIXED config-4 job (150 images -> 10 000
     # exhaustive pairs, images and pairs sharded over the ranks, two all-gathers) after the headline region; `value` stays the headline.
     # The headline line is complete before it starts: a failure of the sub-run becomes `strong_scaling.error`, and if it never returns
@@ -830,16 +856,17 @@ def main():
     if not a.no_strong_scaling and not a.main_region_only:
         del pool, feats, flat, outs
         torch.cuda.empty_cache()
-        watchdog = None
-        if rank == 0:
-            def give_up():
+        # a watchdog on EVERY rank: a failure on one rank only (OOM, a HIP error) leaves the others inside an all-gather; rank 0
+        # prints the completed headline line, every rank leaves the process so that the launcher does not wait for them
+        def give_up():
+            if rank == 0:
                 line["strong_scaling"] = {"error": f"the config-4 sub-run did not return within {a.strong_timeout} s"}
                 line["cpu_baseline"] = None
                 print(json.dumps(line), flush=True)
-                os._exit(3)
-            watchdog = threading.Timer(a.strong_timeout, give_up)
-            watchdog.daemon = True
-            watchdog.start()
+            os._exit(3)
+        watchdog = threading.Timer(a.strong_timeout + (0.0 if rank == 0 else 5.0), give_up)
+        watchdog.daemon = True
+        watchdog.start()
         strong = None
         try:
             rec = measure_config4(a, rank, world, dev, dist, lib, steps=1, warmup=1)
@@ -848,17 +875,17 @@ def main():
                                               "matches_per_pair_mean", "pairs_with_at_least_100_matches", "fp16x3_range_guard")}
                 strong["workload"] = rec["config"]["workload"]
                 strong["sharding"] = rec["config"]["sharding"]
-        except Exception as e:   # (every rank runs the same deterministic job: an exception is raised on all of them or on none)
+        except Exception as e:   # an exception on every rank ends the sub-run cleanly; on one rank only, the others' watchdogs end theirs
             strong = {"error": repr(e)[:400]}
-        if watchdog is not None:
-            watchdog.cancel()
+            if world > 1:
+                if rank == 0:
+                    line["strong_scaling"] = strong
+                    line["cpu_baseline"] = None
+                    print(json.dumps(line), flush=True)
+                os._exit(3)      # the peers may be blocked in a collective this rank will never join: do not enter the final barrier
+        watchdog.cancel()
         if rank == 0:
             line["strong_scaling"] = strong
-    if rank == 0 and not a.no_hook_path and not a.main_region_only:
-        try:
-            line["hook_path"] = measure_hook_path(dev, lib)
-        except Exception as e:
-            line["hook_path"] = {"error": repr(e)[:400]}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_sample_pairs)

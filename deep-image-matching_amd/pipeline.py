@@ -226,65 +226,78 @@ class TiledPairPipeline:
       phase 1  images i = rank (mod world): the extractor plugin's batched ``_extract_by_tile`` (extractors/extractor_base.py:279-390:
                pad, unfold, one forward per tile, shift, border filter, np.unique merge — here one batch per image on the device),
       phase 2  ONE all-gather of a flat fp32 buffer per rank: [per][cap][keypoints 2 | score | tile_idx | descriptor D] + the counts'
-               bit patterns (cap = tiles x max keypoints per tile: the merged table of an image can hold no more),
-      phase 3  image pairs j = rank (mod world): ``tile_selection`` (matchers/matcher_base.py:989-1140; PRESELECTION runs its own
-               down-sampled SuperPoint + LightGlue on the device) and the batched tile-pair matching (MB:362-485),
-      phase 4  ONE all-gather of a flat int32 buffer per rank: [per][count | (idx0, idx1) rows].
+               bit patterns (cap = tiles x max keypoints per tile of the LARGEST image: the merged table of an image can hold no more),
+      phase 3a ``tile_selection`` (matchers/matcher_base.py:989-1140) of image pairs j = rank (mod world); PRESELECTION runs its own
+               down-sampled SuperPoint + LightGlue on the device for all of the rank's image pairs back to back (one read-back of the
+               vote tables at the end), then ONE small all-gather of the selection masks [pairs][tiles0 x tiles1] bytes,
+      phase 3b every rank deals the image pairs by cost — sum of n0 x n1 over the SELECTED tile pairs (balanced_shards) — and matches
+               its image pairs' tile pairs as ONE stream of dim_lg_match batches over a per-image tile table that is built once per image
+               (not once per image pair); tile-local match indices are mapped to merged-table indices, made unique per image pair and
+               sorted like np.unique(axis=0) (MB:462-474) on the device — no host read-back per image pair or per batch,
+      phase 4  ONE all-gather of a flat int32 buffer per rank: [per][count | (idx0, idx1) rows]; the slot size is the exact upper bound
+               sum(min(n0, n1)) over the selected tile pairs, which every rank derives from the gathered masks (no heuristic, no abort).
 
     ``extractor`` / ``matcher``: plugins.SuperPointExtractor / AlikedExtractor and plugins.LightGlueMatcher (any descriptor width and
-    channel count: both come from the extractor).  Every rank needs the image arrays of the pairs it matches only when the selection
-    method reads pixels (PRESELECTION*).  Results are identical on every rank and identical to a single-process run."""
+    channel count: both come from the extractor).  Every rank reads the SHAPES of all images; pixels only of its own extraction shard and —
+    when the selection method reads pixels (PRESELECTION*) — of the image pairs whose selection it runs.  Results are identical on every
+    rank and identical to a single-process run."""
 
     def __init__(self, extractor, matcher, rank: int = 0, world: int = 1, selection: str = "PRESELECTION", max_kpts_per_image: Optional[int] = None,
-                 max_matches_per_pair: Optional[int] = None, empty_selection_fallback: Optional[str] = None):
+                 max_matches_per_pair: Optional[int] = None, empty_selection_fallback: Optional[str] = None, tile_pair_batch: Optional[int] = None):
         self.ext, self.mat, self.rank, self.world = extractor, matcher, rank, world
         self.selection = selection
-        # benchmarks on seeded synthetic weights only: PRESELECTION needs a trained SuperPoint + LightGlue to vote for tile pairs; with
-        # random weights it runs (and is timed) but selects nothing, and the named method then supplies the tile pairs.  None (default,
-        # the reference's behaviour): an empty selection means an empty match list.
+        # benchmarks on seeded synthetic weights only: PRESELECTION needs a SuperPoint + LightGlue that can vote for tile pairs; when it
+        # selects nothing, the named method supplies the tile pairs.  None (default, the reference's behaviour): an empty selection means
+        # an empty match list.
         self.fallback = empty_selection_fallback
         self.n_fallback = 0
         self.max_kpts, self.max_matches = max_kpts_per_image, max_matches_per_pair
+        self.tile_pair_batch = int(tile_pair_batch if tile_pair_batch is not None else getattr(matcher, "tile_pair_batch", 8))
         self.timings: dict = {}
+        self._dev_feats = None      # device views of the last extract_all's exchange buffer ...
+        self._dev_token = None      # ... valid only for the list object that extract_all returned (ADVICE r4: no silent reuse)
 
     def _band(self, images, i):
-        """first band of image i as a contiguous float32 array, cached (extracting 1 of 3 interleaved channels of a 6000 x 4000 image
-        costs ~40 ms; every image takes part in n - 1 pairs)"""
+        """first band of image i as a contiguous float32 array (extracting 1 of 3 interleaved channels of a 6000 x 4000 image costs ~40 ms;
+        an image takes part in several pairs).  Keyed by the array object itself, dropped at the end of every match_all."""
         c = self.__dict__.setdefault("_band_cache", {})
-        key = (id(images), i)
-        if key not in c:
-            c[key] = _band1(images[i])
-        return c[key]
+        key = id(images[i])
+        if key not in c or c[key][0] is not images[i]:
+            c[key] = (images[i], _band1(images[i]))
+        return c[key][1]
 
     def _device(self):
         d = getattr(self.ext, "_device", "cuda")
         return torch.device(d if isinstance(d, (str, torch.device)) else "cuda")
 
-    def _cap(self, image) -> int:
-        if self.max_kpts is not None:
-            return int(self.max_kpts)
+    def _n_tiles(self, shape_hw) -> int:
         from .tile_matching import tile_grid
         general = self.ext.config["general"]
-        n_tiles = len(tile_grid(image.shape[:2], general["tile_size"], general.get("tile_overlap", 0)))
+        return len(tile_grid(tuple(shape_hw[:2]), general["tile_size"], general.get("tile_overlap", 0)))
+
+    def _cap(self, images) -> int:
+        """exchange slot = the largest merged tile table any image of the job can have"""
+        if self.max_kpts is not None:
+            return int(self.max_kpts)
         mk = int(self.ext.config["extractor"].get("max_num_keypoints", self.ext.config["extractor"].get("max_keypoints", -1)))
         if mk <= 0:
             raise ValueError("TiledPairPipeline: pass max_kpts_per_image when the extractor keeps all keypoints")
-        return n_tiles * mk
+        return max(self._n_tiles(np_shape(im)) for im in images) * mk
 
     # ---- phases 1 + 2 ----------------------------------------------------------------------
     @torch.no_grad()
     def extract_all(self, images: Sequence, as_numpy: bool = True) -> List[dict]:
-        """images: sequence of numpy arrays (H, W) or (H, W, C), 0..255, the same list on every rank (only this rank's shard is read).
-        Returns the feature dict of EVERY image (keypoints (N,2) f32, descriptors (D,N) f32, scores (N,), tile_idx (N,), image_size) as
-        numpy arrays; with ``as_numpy=False`` the device views of the exchange buffer that match_all uses anyway (keypoints [N,2],
-        descriptors_nd [N,D], tile_idx, scores: no device-to-host copy of 34 MB per image)."""
+        """images: sequence of numpy arrays (H, W) or (H, W, C), 0..255, the same list on every rank (pixels are read of this rank's shard
+        only, shapes of all).  Returns the feature dict of EVERY image (keypoints (N,2) f32, descriptors (D,N) f32, scores (N,), tile_idx (N,),
+        image_size) as numpy arrays; with ``as_numpy=False`` the device views of the exchange buffer (keypoints [N,2], descriptors_nd [N,D],
+        tile_idx, scores: no device-to-host copy of 34 MB per image).  match_all uses the device tables when it is handed THIS list."""
         import time
         import numpy as np
         n_img = len(images)
         mine = shard_indices(n_img, self.rank, self.world).tolist()
         per = (n_img + self.world - 1) // self.world
         D, dev = int(self.ext.descriptor_size), self._device()
-        cap = self._cap(images[0])
+        cap = self._cap(images)
         row = 2 + 1 + 1 + D
         flat = torch.zeros(per * cap * row + per, dtype=torch.float32, device=dev)
         body, cnt = flat[: per * cap * row].view(per, cap, row), flat[per * cap * row:].view(torch.int32)
@@ -294,7 +307,7 @@ class TiledPairPipeline:
             f = self.ext._extract_by_tile(np.asarray(images[i]), as_device=True)
             k = int(f["keypoints"].shape[0])
             if k > cap:
-                raise ValueError(f"TiledPairPipeline: image {i} has {k} keypoints, more than the exchange slot ({cap})")
+                raise ValueError(f"TiledPairPipeline: image {i} has {k} keypoints, more than the exchange slot ({cap}): max_kpts_per_image is too small")
             body[s, :k, 0:2] = f["keypoints"]
             body[s, :k, 2] = f["scores"]
             body[s, :k, 3] = f["tile_idx"]
@@ -307,21 +320,98 @@ class TiledPairPipeline:
         out: List[dict] = []
         gb = g[:, : per * cap * row].reshape(self.world, per, cap, row)
         gc = (g[:, per * cap * row:].reshape(self.world, per).view(torch.int32) if self.world > 1 else cnt.view(1, per)).cpu()
-        self._dev_feats = []
+        dev_feats = []
         for i in range(n_img):
             r, s = i % self.world, i // self.world
             k = int(gc[r, s])
-            size = np.array(np.asarray(images[i]).shape[:2], dtype=np.int32)
+            size = np.array(np_shape(images[i])[:2], dtype=np.int32)
             t = gb[r, s, :k]
-            self._dev_feats.append({"keypoints": t[:, 0:2], "descriptors_nd": t[:, 4:], "tile_idx": t[:, 3], "scores": t[:, 2], "image_size": size})
+            dev_feats.append({"keypoints": t[:, 0:2], "descriptors_nd": t[:, 4:], "tile_idx": t[:, 3], "scores": t[:, 2], "image_size": size})
             if as_numpy:
                 h = t.cpu().numpy()
                 out.append({"keypoints": np.ascontiguousarray(h[:, 0:2]), "scores": np.ascontiguousarray(h[:, 2]), "tile_idx": np.ascontiguousarray(h[:, 3]),
                             "descriptors": np.ascontiguousarray(h[:, 4:].T), "image_size": size})
             else:
-                out.append(self._dev_feats[-1])
+                out.append(dev_feats[-1])
+        self._dev_feats, self._dev_token = dev_feats, out      # valid for exactly this list object; replaced by the next extract_all
         self.timings.update(extract_s=t1 - t0, feature_gather_s=time.perf_counter() - t1, feature_gather_bytes=int(flat.numel() * 4 * self.world))
         return out
+
+    def release(self):
+        """Drop the device tables of the last extract_all (they pin the all-gathered exchange buffer in HBM)."""
+        self._dev_feats = self._dev_token = None
+
+    def _device_tables(self, feats: List[dict], dev) -> List[dict]:
+        """Device feature tables for match_all: the exchange-buffer views when ``feats`` IS the list the last extract_all returned, else the
+        caller's dicts uploaded (numpy keypoints (N,2), descriptors (D,N), tile_idx (N,)) — a filtered / modified / foreign list is never
+        silently replaced by cached tables."""
+        import numpy as np
+        if self._dev_feats is not None and feats is self._dev_token:
+            return self._dev_feats
+        out = []
+        for f in feats:
+            if torch.is_tensor(f["keypoints"]):
+                out.append(f)
+                continue
+            out.append({"keypoints": torch.from_numpy(np.ascontiguousarray(f["keypoints"], dtype=np.float32)).to(dev),
+                        "descriptors_nd": torch.from_numpy(np.ascontiguousarray(np.asarray(f["descriptors"], dtype=np.float32).T)).to(dev),
+                        "tile_idx": torch.from_numpy(np.ascontiguousarray(f["tile_idx"], dtype=np.float32)).to(dev),
+                        "image_size": np.asarray(f["image_size"]).reshape(2)})
+        return out
+
+    # ---- phase 3a ---------------------------------------------------------------------------
+    def _select(self, images, names, pairs, mine, n_tiles):
+        """tile_selection of the image pairs ``mine`` -> {p: sorted [(t0, t1)]}.  PRESELECTION: the device preselector's LightGlue calls and
+        vote kernels of all pairs are enqueued back to back under ONE range-guard read; the vote tables come back in one copy."""
+        import numpy as np
+        from . import capi
+        from .tile_matching import get_size_by_quality, select_tile_pairs, tile_grid
+        general = self.mat.config["general"]
+        quality = getattr(general.get("quality", "HIGH"), "name", general.get("quality", "HIGH"))
+        tile_size, overlap = general["tile_size"], general.get("tile_overlap", 0)
+        min_matches = int(getattr(self.mat, "min_matches_per_tile", general.get("min_matches_per_tile", 5)))
+        shape_only = lambda i: np.broadcast_to(np.float32(0), np_shape(images[i])[:2])
+        grid = lambda i: tile_grid(get_size_by_quality(quality, np_shape(images[i])[:2]), tile_size, overlap)
+        sel = {}
+        if self.selection == "PRESELECTION" and len(mine):
+            if general.get("preselection_pipeline", "superpoint+lightglue") != "superpoint+lightglue":
+                raise ValueError("Only the superpoint+lightglue preselection pipeline is built on the MI355X path")
+            pre = self.mat._preselector()
+            dev = self._device()
+            tmax = max(n_tiles)
+            votes = torch.zeros(len(mine), tmax, tmax, dtype=torch.int32, device=dev)
+            grids = {}
+
+            def run():
+                for s, p in enumerate(mine):
+                    a, b = int(pairs[p, 0]), int(pairs[p, 1])
+                    for i in (a, b):
+                        if i not in grids:
+                            grids[i] = grid(i)
+                    v = torch.empty(len(grids[a]), len(grids[b]), dtype=torch.int32, device=dev)
+                    pre.votes_device(names[a], (lambda i=a: self._band(images, i)), names[b], (lambda i=b: self._band(images, i)), grids[a], grids[b],
+                                     tile_size, quality, out=v, guarded=False)
+                    votes[s, : v.shape[0], : v.shape[1]] = v
+
+            stream = ctypes_stream_of(dev)
+            capi.run_guarded(pre.lib, stream, run, "tile preselection", "fallback")       # one guard read (and synchronisation) for the phase
+            vh = votes.cpu().numpy().astype(np.int64)
+            for s, p in enumerate(mine):
+                a, b = int(pairs[p, 0]), int(pairs[p, 1])
+                sel[p] = select_tile_pairs("PRESELECTION", list(grids[a]), list(grids[b]), vh[s, : len(grids[a]), : len(grids[b])], min_matches)
+        else:
+            needs_pixels = self.selection.startswith("PRESELECTION")
+            for p in mine:
+                a, b = int(pairs[p, 0]), int(pairs[p, 1])
+                band = (lambda i: self._band(images, i)) if needs_pixels else shape_only
+                sel[p] = self.mat.tile_selection(names[a], names[b], self.selection, image0=band(a), image1=band(b))
+        if self.fallback is not None:
+            for p in mine:
+                if len(sel[p]) == 0:
+                    self.n_fallback += 1
+                    a, b = int(pairs[p, 0]), int(pairs[p, 1])
+                    sel[p] = self.mat.tile_selection(names[a], names[b], self.fallback, image0=shape_only(a), image1=shape_only(b))
+        return sel
 
     # ---- phases 3 + 4 ----------------------------------------------------------------------
     @torch.no_grad()
@@ -330,52 +420,146 @@ class TiledPairPipeline:
         (the arrays MatcherBase._match_by_tile returns, MB:362-485)."""
         import time
         import numpy as np
-        from .tile_matching import match_tile_pairs_batched, match_tile_pairs_batched_device
         P = int(pairs.shape[0])
-        dev_feats = getattr(self, "_dev_feats", None)
-        use_dev = dev_feats is not None and len(dev_feats) == len(feats)      # tables of the last extract_all are still in HBM
-        mine = shard_indices(P, self.rank, self.world).tolist()
-        per = (P + self.world - 1) // self.world
         dev = self._device()
-        cap_m = int(self.max_matches if self.max_matches is not None else 2 * max(1, max(int(f["keypoints"].shape[0]) for f in feats)))
+        names = names if names is not None else [f"image{i:05d}" for i in range(len(feats))]
+        n_tiles = [self._n_tiles(np_shape(im)) for im in images]
+        tmax = max(n_tiles) if n_tiles else 1
+        tables = self._device_tables(feats, dev)
+        t0 = time.perf_counter()
+        # ---- 3a: selection of the image pairs p = rank (mod world), then ONE small all-gather of the masks ----
+        mine_sel = shard_indices(P, self.rank, self.world).tolist()
+        per_sel = (P + self.world - 1) // self.world
+        sel_mine = self._select(images, names, pairs, mine_sel, n_tiles)
+        mask = torch.zeros(per_sel, tmax * tmax, dtype=torch.uint8)
+        for s, p in enumerate(mine_sel):
+            for (ta, tb) in sel_mine[p]:
+                mask[s, ta * tmax + tb] = 1
+        fb = torch.tensor([self.n_fallback], dtype=torch.int32)
+        gm = _all_gather_cat(mask.to(dev)[None], self.world).cpu()                  # [world, per_sel, tmax^2]
+        sel = []
+        for p in range(P):
+            idx = torch.nonzero(gm[p % self.world, p // self.world]).reshape(-1).tolist()
+            sel.append([(k // tmax, k % tmax) for k in idx])                            # ascending = sorted (t0, t1): the reference's order
+        t_sel = time.perf_counter()
+        # ---- per-image tile counts (identical on every rank: every rank holds every table) and the cost-balanced deal ----
+        counts = {}
+        used = sorted({int(pairs[p, k]) for p in range(P) if sel[p] for k in (0, 1)})
+        if used:
+            cdev = torch.stack([torch.bincount(tables[i]["tile_idx"].to(torch.int64), minlength=tmax)[:tmax] if tables[i]["tile_idx"].numel()
+                                else torch.zeros(tmax, dtype=torch.int64, device=dev) for i in used])
+            for i, c in zip(used, cdev.cpu().tolist()):                                  # ONE host read-back for the whole job
+                counts[i] = c
+        cost = torch.zeros(P, dtype=torch.float64)
+        bound = torch.zeros(P, dtype=torch.int64)
+        for p in range(P):
+            a, b = int(pairs[p, 0]), int(pairs[p, 1])
+            sel[p] = [(ta, tb) for ta, tb in sel[p] if counts[a][ta] > 0 and counts[b][tb] > 0]   # an empty tile cannot match (tile_matching.py)
+            cost[p] = float(sum(counts[a][ta] * counts[b][tb] for ta, tb in sel[p]))
+            bound[p] = sum(min(counts[a][ta], counts[b][tb]) for ta, tb in sel[p])
+        rank_of, slot_of = balanced_shards(cost, self.world) if P else (torch.zeros(0, dtype=torch.long),) * 2
+        mine = torch.nonzero(rank_of == self.rank).reshape(-1).tolist()
+        per = (P + self.world - 1) // self.world
+        cap_m = int(self.max_matches) if self.max_matches is not None else max(1, int(bound.max()) if P else 1)
         flat = torch.zeros(per + per * cap_m * 2, dtype=torch.int32, device=dev)
         cnt, rows = flat[:per], flat[per:].view(per, cap_m, 2)
-        names = names if names is not None else [f"image{i:05d}" for i in range(len(feats))]
-        sel_s = mat_s = 0.0
-        t0 = time.perf_counter()
-        for s, p in enumerate(mine):
-            a, b = int(pairs[p, 0]), int(pairs[p, 1])
-            ts = time.perf_counter()
-            needs_pixels = self.selection.startswith("PRESELECTION")
-            shape_only = lambda i: np.broadcast_to(np.float32(0), np.asarray(images[i]).shape[:2])     # the grid methods read the shape only
-            band = lambda i: self._band(images, i) if needs_pixels else shape_only(i)
-            tile_pairs = self.mat.tile_selection(names[a], names[b], self.selection, image0=band(a), image1=band(b))
-            if len(tile_pairs) == 0 and self.fallback is not None:
-                self.n_fallback += 1
-                tile_pairs = self.mat.tile_selection(names[a], names[b], self.fallback, image0=shape_only(a), image1=shape_only(b))
-            tm_ = time.perf_counter()
-            if use_dev:
-                m = match_tile_pairs_batched_device(self.mat._ensure_pairs, dev_feats[a], dev_feats[b], tile_pairs, getattr(self.mat, "tile_pair_batch", 8))
-            else:
-                m = torch.from_numpy(match_tile_pairs_batched(self.mat._ensure_pairs, feats[a], feats[b], tile_pairs, dev, getattr(self.mat, "tile_pair_batch", 8))).to(dev)
-            sel_s += tm_ - ts
-            mat_s += time.perf_counter() - tm_
-            if m.shape[0] > cap_m:
-                raise ValueError(f"TiledPairPipeline: pair ({a}, {b}) has {m.shape[0]} matches, more than the exchange slot ({cap_m})")
-            rows[s, : m.shape[0]] = m.to(torch.int32)
-            cnt[s] = m.shape[0]
+        n_tp = sum(len(sel[p]) for p in mine)
+        if n_tp:
+            self._match_tile_pairs(tables, counts, pairs, sel, mine, cnt, rows, cap_m, tmax, dev)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         g = _all_gather_cat(flat[None], self.world)          # phase 4: ONE collective
-        gc, gr = g[:, :per].cpu(), g[:, per:].reshape(self.world, per, cap_m, 2)
+        gc, gr = g[:, :per].cpu().numpy(), g[:, per:].reshape(self.world, per, cap_m, 2).cpu().numpy()
         out = []
         for p in range(P):
-            r, s = p % self.world, p // self.world
-            out.append(gr[r, s, : int(gc[r, s])].cpu().numpy().astype(np.int64))
-        self.timings.update(match_s=t1 - t0, tile_selection_s=sel_s, tile_matching_s=mat_s, match_gather_s=time.perf_counter() - t1,
-                            match_gather_bytes=int(flat.numel() * 4 * self.world))
+            r, s = int(rank_of[p]), int(slot_of[p])
+            out.append(gr[r, s, : int(gc[r, s])].astype(np.int64))
+        self.__dict__.pop("_band_cache", None)
+        self.timings.update(match_s=t1 - t0, tile_selection_s=t_sel - t0, tile_matching_s=t1 - t_sel, match_gather_s=time.perf_counter() - t1,
+                            match_gather_bytes=int(flat.numel() * 4 * self.world), selection_gather_bytes=int(mask.numel() * self.world),
+                            tile_pairs_total=int(sum(len(x) for x in sel)), tile_pairs_this_rank=int(n_tp),
+                            cost_this_rank=float(sum(float(cost[p]) for p in mine)), cost_total=float(cost.sum()))
         return out
+
+    def _match_tile_pairs(self, tables, counts, pairs, sel, mine, cnt, rows, cap_m, tmax, dev):
+        """The rank's tile pairs as ONE stream of dim_lg_match batches.  Per-image tile tables [tiles][cap_t][...] are gathered once per
+        image; a tile pair is a row pair of the concatenated table; matches come back as tile-local indices and are mapped to merged-table
+        indices through ``it``.  Per image pair: unique + lexicographic order (np.unique(axis=0), MB:462-474) = a sort of the 64-bit keys
+        slot << 40 | idx0 << 20 | idx1."""
+        from . import capi
+        imgs = sorted({int(pairs[p, k]) for p in mine if sel[p] for k in (0, 1)})
+        base = {i: j * tmax for j, i in enumerate(imgs)}
+        cap_t = max(1, max(max(counts[i]) for i in imgs))
+        T = len(imgs) * tmax
+        D = int(tables[imgs[0]]["descriptors_nd"].shape[1])
+        assert cap_t < (1 << 20) and max(int(tables[i]["keypoints"].shape[0]) for i in imgs) < (1 << 20) and len(mine) < (1 << 22)
+        kt = torch.zeros(T, cap_t, 2, dtype=torch.float32, device=dev)
+        dt = torch.zeros(T, cap_t, D, dtype=torch.float32, device=dev)
+        it = torch.zeros(T, cap_t, dtype=torch.int64, device=dev)        # tile-local slot -> index in the image's merged table
+        nt = torch.zeros(T, dtype=torch.int32, device=dev)
+        st = torch.zeros(T, 2, dtype=torch.float32, device=dev)
+        for i in imgs:        # keypoints grouped by tile, original order inside a tile (= the boolean-mask order of get_features_by_tile)
+            f = tables[i]
+            ti = f["tile_idx"].to(torch.int64)
+            order = torch.argsort(ti, stable=True)
+            c = torch.tensor(counts[i], dtype=torch.int64, device=dev)
+            starts = torch.cumsum(c, 0) - c
+            ts = ti[order]
+            r, pos = base[i] + ts, torch.arange(order.numel(), device=dev) - starts[ts]
+            kt[r, pos] = f["keypoints"][order]
+            dt[r, pos] = f["descriptors_nd"][order]
+            it[r, pos] = order
+            nt[base[i]: base[i] + tmax] = c.to(torch.int32)
+            st[base[i]: base[i] + tmax] = torch.as_tensor(np_f32(f["image_size"]), device=dev)
+        tp = [(s, base[int(pairs[p, 0])] + ta, base[int(pairs[p, 1])] + tb) for s, p in enumerate(mine) for ta, tb in sel[p]]
+        B = max(1, min(self.tile_pair_batch, len(tp)))
+        net = self.mat._ensure_pairs(cap_t, B)
+        NK = net.nk
+        pidx_all = torch.tensor([[r0, r1] for _, r0, r1 in tp], dtype=torch.int32, device=dev).contiguous()
+        slot_all = torch.tensor([s for s, _, _ in tp], dtype=torch.int64, device=dev)
+        SENT = torch.iinfo(torch.int64).max
+        keys = torch.full((len(tp), NK), SENT, dtype=torch.int64, device=dev)
+        ar = torch.arange(NK, device=dev)[None, :]
+
+        def run():
+            out = None
+            for s0 in range(0, len(tp), B):
+                pidx = pidx_all[s0:s0 + B].contiguous()
+                b = int(pidx.shape[0])
+                out = net.match_batch(kt, dt, nt, st, pair_idx=pidx, n_pairs=b, out=out)
+                m, c = out["matches"][:b], out["n_matches"][:b].to(torch.int64)
+                g0 = torch.gather(it[pidx[:, 0].long()], 1, m[..., 0].clamp(0, cap_t - 1))
+                g1 = torch.gather(it[pidx[:, 1].long()], 1, m[..., 1].clamp(0, cap_t - 1))
+                k = (slot_all[s0:s0 + b, None] << 40) | (g0 << 20) | g1
+                keys[s0:s0 + b] = torch.where(ar < c[:, None], k, torch.full_like(k, SENT))
+
+        _guarded(net, run, "tiled pipeline matching")        # ONE range-guard read for the phase; a re-run overwrites every key row
+        u = torch.unique(keys.reshape(-1))                     # sorted: by image-pair slot, then (idx0, idx1) lexicographically
+        u = u[u != SENT]
+        slot = u >> 40
+        n_slot = torch.bincount(slot, minlength=len(mine))[: len(mine)]
+        start = torch.cumsum(n_slot, 0) - n_slot
+        pos = torch.arange(u.numel(), device=dev) - start[slot]
+        keep = pos < cap_m                                     # only with an explicit max_matches_per_pair below the bound
+        rows[slot[keep], pos[keep], 0] = ((u[keep] >> 20) & 0xFFFFF).to(torch.int32)
+        rows[slot[keep], pos[keep], 1] = (u[keep] & 0xFFFFF).to(torch.int32)
+        cnt[: len(mine)] = torch.clamp(n_slot, max=cap_m).to(torch.int32)
+
+
+def np_shape(image):
+    import numpy as np
+    return tuple(image.shape) if hasattr(image, "shape") else np.asarray(image).shape
+
+
+def np_f32(x):
+    import numpy as np
+    return np.asarray(x, dtype=np.float32).reshape(2)
+
+
+def ctypes_stream_of(dev):
+    import ctypes
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if torch.device(dev).type == "cuda" else None
 
 
 def _band1(image):

@@ -82,6 +82,55 @@ def _saturation_policy(conf: dict) -> str:
     return pol
 
 
+class _PinnedStaging:
+    """Page-locked host staging for the per-call hooks (one image in, one feature set out per call).  The reference's
+    ``torch.tensor(image / 255.0).to(device)`` / ``.cpu().numpy()`` go through pageable memory; on the MI355X box that cost 5 - 15 ms per
+    call around 0.8 ms of kernels (profiles/r05_hook_profile.txt).  Buffers grow on demand and are reused: a call must have finished with
+    them (the hooks synchronise before they return) before the next call touches them."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, tag: str, nbytes: int) -> torch.Tensor:
+        b = self._buf.get(tag)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+            self._buf[tag] = b
+        return b
+
+    def upload(self, a: np.ndarray, device) -> torch.Tensor:
+        """contiguous float32 numpy array -> device tensor of the same shape (async copy on the current stream)."""
+        pin = self.get("in", a.nbytes)[: a.nbytes].view(torch.float32).view(a.shape)
+        pin.copy_(torch.from_numpy(a))
+        return pin.to(device, non_blocking=True)
+
+    def download(self, tensors, device) -> list:
+        """device tensors -> owned numpy arrays through ONE pinned buffer and ONE synchronisation."""
+        sizes = [t.numel() * t.element_size() for t in tensors]
+        off = [0]
+        for z in sizes:
+            off.append(off[-1] + ((z + 255) & ~255))
+        pin = self.get("out", off[-1])
+        views = []
+        for t, o, z in zip(tensors, off, sizes):
+            v = pin[o:o + z].view(t.dtype).view(t.shape)
+            v.copy_(t, non_blocking=True)
+            views.append(v)
+        torch.cuda.current_stream(device).synchronize()
+        return [v.numpy().copy() for v in views]
+
+
+def _frame2array(image: np.ndarray) -> np.ndarray:
+    """The host half of the reference's _frame2tensor (SPX:134-146, ALX:66-78): (H, W) -> [1, 1, H, W], (H, W, C) -> [1, C, H, W], then
+    ``image / 255.0`` as float32 — the numpy division and the float32 rounding are the reference's own (torch.tensor(image / 255.0,
+    dtype=torch.float)), so the tensor is bit-identical to it."""
+    if len(image.shape) == 2:
+        image = image[None][None]
+    elif len(image.shape) == 3:
+        image = image.transpose(2, 0, 1)[None]
+    return np.ascontiguousarray(image / 255.0, dtype=np.float32)
+
+
 def _resolve_device(device, what: str):
     """The plugin's device: the reference's ``self._device`` ("cuda" unless general.force_cpu).  There is no CPU
     path; the CPU tests install the emulator build through capi.install(), which also names the device."""
@@ -174,20 +223,39 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
         image_ = self._frame2tensor(image, self._device)
         if image_.shape[1] != 1:
             raise ValueError("SuperPoint expects a single-channel image")
-        self._ensure(image_.shape[-2], image_.shape[-1])
-        feats = self._net(image_)
+        H, W = int(image_.shape[-2]), int(image_.shape[-1])
+        self._ensure(H, W)
+        img = image_.reshape(1, H, W)
+        out = self._net.extract_batch_guarded(img)
         if self._regrow(self._net, 1):
-            self._ensure(image_.shape[-2], image_.shape[-1])
-            feats = self._net(image_)
-        return {k: v.cpu().numpy() for k, v in feats.items()}
+            self._ensure(H, W)
+            out = self._net.extract_batch_guarded(img)
+        return _features_to_numpy(self, out)
 
     def _frame2tensor(self, image: np.ndarray, device: str = "cuda"):
-        """SPX:134-146."""
-        if len(image.shape) == 2:
-            image = image[None][None]
-        elif len(image.shape) == 3:
-            image = image.transpose(2, 0, 1)[None]
-        return torch.tensor(image / 255.0, dtype=torch.float).to(device)
+        """SPX:134-146 (through page-locked staging on a GPU)."""
+        return _to_device(self, _frame2array(image), device)
+
+
+def _to_device(plugin, a: np.ndarray, device):
+    if str(getattr(device, "type", device)).startswith("cuda"):
+        st = plugin.__dict__.setdefault("_staging", _PinnedStaging())
+        return st.upload(a, device)
+    return torch.from_numpy(a).to(device)
+
+
+def _features_to_numpy(plugin, out) -> dict:
+    """(kpts [1,cap,2], scores [1,cap], desc [1,cap,D], n [1]) of a batch-1 library call -> the reference's numpy dict: keypoints (N,2), scores
+    (N,), descriptors (D,N) (SPX:126-130, ALX:57-61).  On a GPU: one pinned buffer, one synchronisation; the descriptors come back as the
+    transposed VIEW of an owned (N,D) array — (D,N) to every consumer, and featuresDict2Lightglue's (N,D) costs nothing."""
+    kp, sc, de, n = out
+    if kp.device.type == "cuda":
+        st = plugin.__dict__.setdefault("_staging", _PinnedStaging())
+        kp_h, sc_h, de_h, n_h = st.download([kp[0], sc[0], de[0], n[:1]], kp.device)
+    else:
+        kp_h, sc_h, de_h, n_h = kp[0].numpy().copy(), sc[0].numpy().copy(), de[0].numpy().copy(), n[:1].numpy()
+    k = int(n_h[0])
+    return {"keypoints": kp_h[:k], "scores": sc_h[:k], "descriptors": de_h[:k].T}
 
 
 class AlikedExtractor(BatchedTilingMixin, _ExtractorBase):
@@ -246,18 +314,16 @@ class AlikedExtractor(BatchedTilingMixin, _ExtractorBase):
     def _extract(self, image: np.ndarray) -> dict:
         """image: float32 HxWx3 RGB (or HxW), 0..255.  Returns numpy keypoints (N,2), descriptors
         (128,N) (ALX:57-58 transposes), scores (N,) (ALX:60-61 renames keypoint_scores)."""
-        image_ = self._frame2tensor(image, self._device)
-        self._ensure(image_.shape[-2], image_.shape[-1])
-        feats = self._net(image_)
-        return {k: v.cpu().numpy() for k, v in feats.items()}
+        # the library reads HWC: the reference's CHW tensor (ALX:66-78, _frame2tensor below) would be transposed there and back
+        a = np.ascontiguousarray(image / 255.0, dtype=np.float32)
+        if a.ndim == 2:
+            a = a[..., None]
+        self._ensure(a.shape[0], a.shape[1])
+        return _features_to_numpy(self, self._net.extract_batch_guarded(_to_device(self, a, self._device)[None]))
 
     def _frame2tensor(self, image: np.ndarray, device: str = "cuda"):
-        """ALX:66-78."""
-        if len(image.shape) == 2:
-            image = image[None][None]
-        elif len(image.shape) == 3:
-            image = image.transpose(2, 0, 1)[None]
-        return torch.tensor(image / 255.0, dtype=torch.float).to(device)
+        """ALX:66-78 (through page-locked staging on a GPU)."""
+        return _to_device(self, _frame2array(image), device)
 
 
 def featuresDict2Lightglue(feats: dict) -> dict:

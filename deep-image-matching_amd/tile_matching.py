@@ -281,12 +281,13 @@ class TilePreselector:
         return dst, scale
 
     def features(self, key: str, image: np.ndarray, quality: str = "HIGH"):
-        """(kpts [1,cap,2], desc [1,cap,256], n [1] int32, scale) of the down-sampled image, cached by (key, quality)."""
+        """(kpts [1,cap,2], desc [1,cap,256], n [1] int32, scale) of the down-sampled image, cached by (key, quality).  ``image`` may be a
+        callable returning the array (the pipeline's lazily extracted first band: not touched on a cache hit)."""
         key = (key, quality)
         if key in self._cache:
             self._cache.move_to_end(key)
             return self._cache[key]
-        small, scale = self.downsample(image, quality)
+        small, scale = self.downsample(image() if callable(image) else image, quality)
         h, w = small.shape
         if self._sp is None or h > self._sp_hw[0] or w > self._sp_hw[1]:
             self._sp_hw = (max(h, self._sp_hw[0], self.size), max(w, self._sp_hw[1], self.size))
@@ -299,34 +300,43 @@ class TilePreselector:
             self._cache.popitem(last=False)
         return ent
 
-    def match(self, f0, f1):
+    def match(self, f0, f1, guarded: bool = True):
         """LightGlue on two cached feature sets; image_size is absent in the reference's call (MB:1077-1079),
-        so the keypoint extent is used (LGN:26-27)."""
+        so the keypoint extent is used (LGN:26-27) — computed on the device (no host read-back: the pipeline enqueues the
+        preselection of all its image pairs back to back; ``guarded=False`` leaves the range-guard read to the caller's phase)."""
         if self._lg is None:
             self._lg = LightGlueHIP(self._lg_sd, PRESELECTION_LG_CONF, max_pairs=1, max_kpts=4096, device=self.device, lib=self.lib)
         kt = torch.cat([f0[0], f1[0]]).contiguous()
         dt = torch.cat([f0[1], f1[1]]).contiguous()
         nt = torch.cat([f0[2], f1[2]]).contiguous()
-        sizes = []
-        for kp, n in ((f0[0][0], f0[2]), (f1[0][0], f1[2])):
-            k = kp[: int(n.item())]
-            sizes.append(1 + k.max(0).values - k.min(0).values if k.numel() else torch.ones(2, device=self.device))
-        st = torch.stack(sizes).to(torch.float32).contiguous()
-        return self._lg.match_batch_guarded(kt, dt, nt, st, n_pairs=1, logger=logger)
+        live = torch.arange(kt.shape[1], device=self.device)[None, :, None] < nt[:, None, None]
+        big = torch.finfo(torch.float32).max
+        ext = 1 + torch.where(live, kt, -big).amax(1) - torch.where(live, kt, big).amin(1)
+        st = torch.where(nt[:, None] > 0, ext, torch.ones_like(ext)).to(torch.float32).contiguous()
+        if guarded:
+            return self._lg.match_batch_guarded(kt, dt, nt, st, n_pairs=1, logger=logger)
+        return self._lg.match_batch(kt, dt, nt, st, n_pairs=1)
 
-    def votes(self, key0: str, image0: np.ndarray, key1: str, image1: np.ndarray, origins0: Dict[int, Tuple[int, int]],
-              origins1: Dict[int, Tuple[int, int]], tile_size, quality: str = "HIGH") -> np.ndarray:
+    def votes_device(self, key0: str, image0: np.ndarray, key1: str, image1: np.ndarray, origins0: Dict[int, Tuple[int, int]],
+                     origins1: Dict[int, Tuple[int, int]], tile_size, quality: str = "HIGH", out: Optional[torch.Tensor] = None,
+                     guarded: bool = True) -> torch.Tensor:
+        """votes[t0, t1] (int32, sorted tile keys) left on the device; ``out``: a [n0, n1] int32 view to write into."""
         f0, f1 = self.features(key0, image0, quality), self.features(key1, image1, quality)
-        o = self.match(f0, f1)
+        o = self.match(f0, f1, guarded=guarded)
         k0, k1 = sorted(origins0), sorted(origins1)
         og0 = torch.tensor([origins0[k] for k in k0], dtype=torch.int32, device=self.device).contiguous()
         og1 = torch.tensor([origins1[k] for k in k1], dtype=torch.int32, device=self.device).contiguous()
-        votes = torch.empty(len(k0), len(k1), dtype=torch.int32, device=self.device)
+        votes = out if out is not None else torch.empty(len(k0), len(k1), dtype=torch.int32, device=self.device)
+        assert votes.is_contiguous() and votes.shape == (len(k0), len(k1))
         capi.check(self.lib, self.lib.dim_op_tile_pair_votes(
             capi.ptr(f0[0]), capi.ptr(f1[0]), capi.ptr(o["matches"]), capi.ptr(o["n_matches"]), int(o["matches"].shape[1]),
             ctypes_float(f0[3]), ctypes_float(f1[3]), capi.ptr(og0), len(k0), capi.ptr(og1), len(k1), int(tile_size[0]), int(tile_size[1]),
             capi.ptr(votes), self._stream()))
-        return votes.cpu().numpy().astype(np.int64)
+        return votes
+
+    def votes(self, key0: str, image0: np.ndarray, key1: str, image1: np.ndarray, origins0: Dict[int, Tuple[int, int]],
+              origins1: Dict[int, Tuple[int, int]], tile_size, quality: str = "HIGH") -> np.ndarray:
+        return self.votes_device(key0, image0, key1, image1, origins0, origins1, tile_size, quality).cpu().numpy().astype(np.int64)
 
     def matched_points(self, key0: str, image0: np.ndarray, key1: str, image1: np.ndarray, quality: str = "HIGH"):
         """The matched preselection keypoints scaled back to the (quality-resized) image frames: kp / scale in fp32 like numpy

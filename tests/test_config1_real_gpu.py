@@ -214,7 +214,7 @@ def test_batched_image_matcher_on_the_jpeg_files_equals_the_hooks(hip_lib, sp_pl
         ia = {tuple(k): i for i, k in enumerate(f["keypoints"].tolist())}
         ib = {tuple(k): i for i, k in enumerate(hk.tolist())}
         assert len(ia) == len(ib) == 2000 and set(ia) == set(ib), (n, len(set(ia) ^ set(ib)))
-        perm = np.array([ib[k] for k in f["keypoints"].tolist()])
+        perm = np.array([ib[tuple(k)] for k in f["keypoints"].tolist()])
         assert np.array_equal(f["descriptors"], hd[:, perm]), n
         same_order = bool(np.array_equal(f["keypoints"], hk))
         if not same_order:
