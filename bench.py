@@ -212,21 +212,28 @@ def measure_config4(a, rank, world, dev, dist, lib, steps, warmup):
     workloads = importlib.import_module(PKG + ".workloads")
     capi = importlib.import_module(PKG + ".capi")
     B, K, W = a.pairs, steps, warmup
-    cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": 2048, "remove_borders": 4}
+    # the job's geometry: BASELINE's (1024 x 1024 images, 2048 keypoints) unless the caller scales it down — tests/test_bench_multirank_gloo.py runs
+    # this very function at world 8 over gloo on the CPU emulator build with 48 x 64 images and 32 keypoints
+    (IH, IW), NKP = getattr(a, "c4_hw", (1024, 1024)), int(getattr(a, "c4_kpts", 2048))
+    if os.environ.get("DIM_BENCH_TEST_FAIL_RANK") == str(rank):     # test hook: a failure on ONE rank only (the watchdog / error path of main())
+        raise RuntimeError(f"injected failure on rank {rank}")
+    on_gpu = torch.device(dev).type == "cuda"
+    cfg = {"nms_radius": 3, "keypoint_threshold": 0.0005, "max_keypoints": NKP, "remove_borders": 4}
     conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}
-    ext = sp.SuperPointHIP(weights.synthetic_superpoint_state_dict(1234), cfg, max_batch=B, max_hw=(1024, 1024), capacity=2048, device=dev)
-    imgs = workloads.shifted_crops(a.images, 1024, 1024, max_shift=256, seed=7)[0].to(dev)
+    ext = sp.SuperPointHIP(weights.synthetic_superpoint_state_dict(1234), cfg, max_batch=B, max_hw=(IH, IW), capacity=NKP, device=dev, lib=None if on_gpu else lib)
+    imgs = workloads.shifted_crops(a.images, IH, IW, max_shift=min(256, IH // 4 // 8 * 8), seed=7)[0].to(dev)
     center = workloads.descriptor_mean(ext, imgs)     # same on every rank (same images, deterministic kernels)
-    mat = lg.LightGlueHIP(weights.synthetic_lightglue_matching_state_dict(0, 256, center=center), conf, max_pairs=B, max_kpts=2048, device=dev)
+    mat = lg.LightGlueHIP(weights.synthetic_lightglue_matching_state_dict(0, 256, center=center), conf, max_pairs=B, max_kpts=NKP, device=dev,
+                          lib=None if on_gpu else lib)
     pipe = pl.PairMatchingPipeline(ext, mat, rank, world)
     pairs = pl.exhaustive_pairs(a.images, a.job_pairs)
     P = int(pairs.shape[0])
 
     def barrier():
-        torch.cuda.synchronize()
+        _sync(dev)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync(dev)
 
     for _ in range(W):   # reduced pass: both networks, both collectives, every buffer size class touched once
         nw = min(a.images, 2 * B * world)
@@ -251,9 +258,11 @@ def measure_config4(a, rank, world, dev, dist, lib, steps, warmup):
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt[0].item())
-    sat_total, sat_sites = capi.saturation(lib, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), reset=True)
+    sat_total, sat_sites = capi.saturation(lib, _stream_ptr(dev), reset=True)
+    gathered = {"feature_gather_bytes": pipe.timings.get("feature_gather_bytes"), "match_gather_bytes": pipe.timings.get("match_gather_bytes")}
     del ext, mat, pipe, imgs, table, mt, ms
-    torch.cuda.empty_cache()
+    if on_gpu:
+        torch.cuda.empty_cache()
     if rank != 0:
         return None
     per_rank_pairs = (P + world - 1) // world
@@ -265,12 +274,13 @@ def measure_config4(a, rank, world, dev, dist, lib, steps, warmup):
         "metric": "image-pairs/s (SuperPoint+LightGlue, 1024^2, 2048 kpts)", "value": K * P / dt, "unit": "image-pairs/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[3] (config 4): {a.images} synthetic 1024x1024 images (crops of one canvas: true correspondences) -> first {P} "
+        "config": {"workload": f"configs[3] (config 4): {a.images} synthetic {IH}x{IW} images (crops of one canvas: true correspondences) -> first {P} "
                                "exhaustive pairs, extraction amortised over the images + 1 LightGlue match per pair (fixed-work, 9 layers, matching-capable "
                                "synthetic weights, threshold 0.1), through PairMatchingPipeline phases 1-4",
                    "images": a.images, "job_pairs": P, "pair_batch": B, "gflop_per_pair": LG_GFLOP_PER_PAIR + SP_GFLOP_PER_IMAGE * a.images / P,
-                   "sharding": f"images i mod {world}, ONE all-gather of feature tables ({pipe_bytes(a.images, world)[0] / 1e6:.0f} MB), pairs "
-                               f"dealt by cost n0 x n1 (balanced_shards; equal costs = round-robin), ONE all-gather of match tables ({pipe_bytes(P, world)[1] / 1e6:.0f} MB)"},
+                   "sharding": f"images i mod {world}, ONE all-gather of feature tables ({pipe_bytes(a.images, world, NKP, 256, NKP)[0] / 1e6:.0f} MB), pairs "
+                               f"dealt by cost n0 x n1 (balanced_shards; equal costs = round-robin), ONE all-gather of match tables ({pipe_bytes(P, world, NKP, 256, NKP)[1] / 1e6:.0f} MB)"},
+        "gathered_bytes_measured": gathered,
         "phases_s_max_over_ranks": {k: float(v) / K for k, v in zip(phases, tt[1:].tolist())},
         "matches_total": total_matches, "matches_per_pair_mean": total_matches / max(1, P), "pairs_with_at_least_100_matches": pairs_with_100,
         "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
@@ -280,6 +290,15 @@ def measure_config4(a, rank, world, dev, dist, lib, steps, warmup):
                      "launches": launches.value, "algorithmic_gflop_per_launch": gflop_per_launch},
         "cpu_baseline": None,
     }
+
+
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def _stream_ptr(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if torch.device(dev).type == "cuda" else None
 
 
 def pipe_bytes(n_items, world, cap=2048, D=256, NK=2048):
@@ -326,6 +345,9 @@ def run_config5(a, rank, world, dev, dist, lib):
     mt._sd = weights.synthetic_lightglue_matching_state_dict(0, 128)          # ALIKED's synthetic descriptors are discriminative (mean cosine 0.12): no centring
     rng = np.random.default_rng(5)
     canvas = rng.integers(0, 256, (4000 + 512, 6000 + 512, 3), dtype=np.uint8)
+    # the FIRST band (the one tile_selection reads, MB:1021-1024) is noise at 8 x 8-block scale: its down-sampled image keeps the full contrast, which the
+    # seeded SuperPoint needs for distinguishable descriptors (pixel-scale noise box-averages to a flat grey: 3500 common keypoints, 4 matches)
+    canvas[..., 0] = np.kron(rng.integers(0, 256, ((4000 + 512) // 8, (6000 + 512) // 8), dtype=np.uint8), np.ones((8, 8), np.uint8))
     offs = [(0, 0)] + [(int(rng.integers(0, 9)) * 64, int(rng.integers(0, 9)) * 64) for _ in range(a.images - 1)]      # multiples of 64 (and so of ALIKED's stride 32)
     images = [np.ascontiguousarray(canvas[dy:dy + 4000, dx:dx + 6000]).astype(np.float32) for dy, dx in offs]
     del canvas
@@ -620,6 +642,75 @@ def measure_hook_path(dev, lib, n_img: int = 6, n_pair: int = 6):
     return rec
 
 
+def strong_scaling_subrun(a, rank, world, dev, dist, lib, line):
+    """Strong scaling where the driver's 1/2/4/8 command sees it: the FIXED config-4 job (150 images -> 10 000 exhaustive
+    pairs, images and pairs sharded over the ranks, two all-gathers) after the headline region; `value` stays the headline.  ``line`` (rank 0's
+    headline record, complete before this starts) receives the `strong_scaling` sub-record.  Failure handling, exercised at world 3 over gloo by
+    tests/test_bench_multirank_gloo.py: an exception on every rank becomes `strong_scaling.error`; a failure on ONE rank only (OOM, a HIP error)
+    leaves the others inside an all-gather.  Every rank therefore runs a watchdog thread that ends the process when the sub-run has
+    not returned after --strong-timeout seconds OR as soon as a peer reports a failure through the rendezvous store — rank 0 printing the
+    headline line first; the failing rank waits for rank 0's acknowledgement (a launcher kills the surviving ranks the moment one exits
+    non-zero) and then leaves without entering another collective."""
+    store = None
+    if dist is not None:
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
+    done = threading.Event()
+
+    def leave(reason):
+        if rank == 0:
+            line["strong_scaling"] = {"error": reason}
+            line["cpu_baseline"] = None
+            print(json.dumps(line), flush=True)
+            if store is not None:
+                try:
+                    store.set("dim_strong_ack", "1")
+                except Exception:
+                    pass
+        os._exit(3)
+
+    def watch():
+        t0 = time.perf_counter()
+        limit = a.strong_timeout + (0.0 if rank == 0 else 5.0)
+        while not done.wait(0.5):
+            if time.perf_counter() - t0 > limit:
+                leave(f"the config-4 sub-run did not return within {a.strong_timeout} s")
+            if store is not None:
+                try:
+                    if store.check(["dim_strong_fail"]):
+                        leave("a peer rank failed inside the config-4 sub-run: " + store.get("dim_strong_fail").decode(errors="replace")[:300])
+                except Exception:
+                    pass
+
+    watchdog = threading.Thread(target=watch, daemon=True)
+    watchdog.start()
+    strong = None
+    try:
+        rec = measure_config4(a, rank, world, dev, dist, lib, steps=1, warmup=1)
+        if rec is not None:
+            strong = {k: rec[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "phases_s_max_over_ranks", "matches_total",
+                                          "matches_per_pair_mean", "pairs_with_at_least_100_matches", "fp16x3_range_guard", "gathered_bytes_measured")}
+            strong["workload"] = rec["config"]["workload"]
+            strong["sharding"] = rec["config"]["sharding"]
+    except Exception as e:
+        strong = {"error": repr(e)[:400]}
+        if world > 1:    # the peers may be blocked in a collective this rank will never join: report, wait for rank 0's line, leave
+            if rank == 0:
+                leave(strong["error"])
+            if store is not None:
+                try:
+                    store.set("dim_strong_fail", f"rank {rank}: {strong['error']}")
+                    store.wait(["dim_strong_ack"], __import__("datetime").timedelta(seconds=15))
+                except Exception:
+                    pass
+            os._exit(3)
+    done.set()
+    if rank == 0:
+        line["strong_scaling"] = strong
+
+
 def main():
     a = parse()
     torch.set_num_threads(min(16, os.cpu_count() or 16))     # the GPU box has 256 host CPUs: a 256-thread intra-op pool only adds spin-waiting
@@ -849,43 +940,10 @@ def main():
             line["hook_path"] = measure_hook_path(dev, lib)
         except Exception as e:
             line["hook_path"] = {"error": repr(e)[:400]}
-    # strong scaling where the driver's 1/2/4/8 command sees it: the FIXED config-4 job (150 images -> 10 000
-    # exhaustive pairs, images and pairs sharded over the ranks, two all-gathers) after the headline region; `value` stays the headline.
-    # The headline line is complete before it starts: a failure of the sub-run becomes `strong_scaling.error`, and if it never returns
-    # (a rank lost inside a collective) rank 0 still prints the line after --strong-timeout seconds and exits non-zero.
     if not a.no_strong_scaling and not a.main_region_only:
         del pool, feats, flat, outs
         torch.cuda.empty_cache()
-        # a watchdog on EVERY rank: a failure on one rank only (OOM, a HIP error) leaves the others inside an all-gather; rank 0
-        # prints the completed headline line, every rank leaves the process so that the launcher does not wait for them
-        def give_up():
-            if rank == 0:
-                line["strong_scaling"] = {"error": f"the config-4 sub-run did not return within {a.strong_timeout} s"}
-                line["cpu_baseline"] = None
-                print(json.dumps(line), flush=True)
-            os._exit(3)
-        watchdog = threading.Timer(a.strong_timeout + (0.0 if rank == 0 else 5.0), give_up)
-        watchdog.daemon = True
-        watchdog.start()
-        strong = None
-        try:
-            rec = measure_config4(a, rank, world, dev, dist, lib, steps=1, warmup=1)
-            if rec is not None:
-                strong = {k: rec[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "phases_s_max_over_ranks", "matches_total",
-                                              "matches_per_pair_mean", "pairs_with_at_least_100_matches", "fp16x3_range_guard")}
-                strong["workload"] = rec["config"]["workload"]
-                strong["sharding"] = rec["config"]["sharding"]
-        except Exception as e:   # an exception on every rank ends the sub-run cleanly; on one rank only, the others' watchdogs end theirs
-            strong = {"error": repr(e)[:400]}
-            if world > 1:
-                if rank == 0:
-                    line["strong_scaling"] = strong
-                    line["cpu_baseline"] = None
-                    print(json.dumps(line), flush=True)
-                os._exit(3)      # the peers may be blocked in a collective this rank will never join: do not enter the final barrier
-        watchdog.cancel()
-        if rank == 0:
-            line["strong_scaling"] = strong
+        strong_scaling_subrun(a, rank, world, dev, dist, lib, line)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_sample_pairs)

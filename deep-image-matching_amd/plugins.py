@@ -98,10 +98,13 @@ class _PinnedStaging:
             self._buf[tag] = b
         return b
 
-    def upload(self, a: np.ndarray, device) -> torch.Tensor:
-        """contiguous float32 numpy array -> device tensor of the same shape (async copy on the current stream)."""
-        pin = self.get("in", a.nbytes)[: a.nbytes].view(torch.float32).view(a.shape)
-        pin.copy_(torch.from_numpy(a))
+    def upload_scaled(self, image: np.ndarray, device) -> torch.Tensor:
+        """``image / 255.0`` as float32, computed by numpy STRAIGHT INTO the page-locked buffer (one pass, no torch CPU op: a 256-thread intra-op
+        pool needs milliseconds to wake up for a 4 MB copy), then an asynchronous copy to the device on the current stream.  Same values as the
+        reference's torch.tensor(image / 255.0, dtype=torch.float): numpy divides in the input's precision and the result is rounded to float32."""
+        n = int(image.size) * 4
+        pin = self.get("in", n)[:n].view(torch.float32).view(tuple(image.shape))
+        np.divide(image, 255.0, out=pin.numpy(), casting="same_kind")
         return pin.to(device, non_blocking=True)
 
     def download(self, tensors, device) -> list:
@@ -121,14 +124,12 @@ class _PinnedStaging:
 
 
 def _frame2array(image: np.ndarray) -> np.ndarray:
-    """The host half of the reference's _frame2tensor (SPX:134-146, ALX:66-78): (H, W) -> [1, 1, H, W], (H, W, C) -> [1, C, H, W], then
-    ``image / 255.0`` as float32 — the numpy division and the float32 rounding are the reference's own (torch.tensor(image / 255.0,
-    dtype=torch.float)), so the tensor is bit-identical to it."""
+    """The layout half of the reference's _frame2tensor (SPX:134-146, ALX:66-78): (H, W) -> [1, 1, H, W], (H, W, C) -> [1, C, H, W] (a view)."""
     if len(image.shape) == 2:
-        image = image[None][None]
-    elif len(image.shape) == 3:
-        image = image.transpose(2, 0, 1)[None]
-    return np.ascontiguousarray(image / 255.0, dtype=np.float32)
+        return image[None][None]
+    if len(image.shape) == 3:
+        return image.transpose(2, 0, 1)[None]
+    return image
 
 
 def _resolve_device(device, what: str):
@@ -237,11 +238,12 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
         return _to_device(self, _frame2array(image), device)
 
 
-def _to_device(plugin, a: np.ndarray, device):
+def _to_device(plugin, image: np.ndarray, device):
+    """image / 255.0 (float32, the reference's values) on ``device``, same shape as ``image``."""
     if str(getattr(device, "type", device)).startswith("cuda"):
         st = plugin.__dict__.setdefault("_staging", _PinnedStaging())
-        return st.upload(a, device)
-    return torch.from_numpy(a).to(device)
+        return st.upload_scaled(image, device)
+    return torch.from_numpy(np.ascontiguousarray(image / 255.0, dtype=np.float32)).to(device)
 
 
 def _features_to_numpy(plugin, out) -> dict:
@@ -315,11 +317,9 @@ class AlikedExtractor(BatchedTilingMixin, _ExtractorBase):
         """image: float32 HxWx3 RGB (or HxW), 0..255.  Returns numpy keypoints (N,2), descriptors
         (128,N) (ALX:57-58 transposes), scores (N,) (ALX:60-61 renames keypoint_scores)."""
         # the library reads HWC: the reference's CHW tensor (ALX:66-78, _frame2tensor below) would be transposed there and back
-        a = np.ascontiguousarray(image / 255.0, dtype=np.float32)
-        if a.ndim == 2:
-            a = a[..., None]
+        a = image if image.ndim == 3 else image[..., None]
         self._ensure(a.shape[0], a.shape[1])
-        return _features_to_numpy(self, self._net.extract_batch_guarded(_to_device(self, a, self._device)[None]))
+        return _features_to_numpy(self, self._net.extract_batch_guarded(_to_device(self, a, self._device)[None].contiguous()))
 
     def _frame2tensor(self, image: np.ndarray, device: str = "cuda"):
         """ALX:66-78 (through page-locked staging on a GPU)."""

@@ -32,6 +32,8 @@ def test_tiled_pair_pipeline_at_6000x4000_vs_the_oracle_chain(hip_lib):
     mt._sd = lg_sd
     rng = np.random.default_rng(9)
     canvas = rng.integers(0, 256, (4000 + 256, 6000 + 256, 3), dtype=np.uint8)
+    # first band (the one tile_selection reads) = noise at 8 x 8-block scale: the down-sampled image keeps its contrast (see bench.py run_config5)
+    canvas[..., 0] = np.kron(rng.integers(0, 256, ((4000 + 256) // 8, (6000 + 256) // 8), dtype=np.uint8), np.ones((8, 8), np.uint8))
     offs = [(0, 0), (192, 128), (64, 256)]
     images = [np.ascontiguousarray(canvas[dy:dy + 4000, dx:dx + 6000]).astype(np.float32) for dy, dx in offs]
     sp_sd = weights.synthetic_superpoint_state_dict(1234)
