@@ -84,7 +84,10 @@ class BatchedImageMatcher:
         def flush(shape, chunk):
             H, W = shape[:2]
             net = self.ext._ensure_batch(H, W, self.image_batch)
-            stack = torch.from_numpy(np.stack([im for _, im in chunk])).to(net.device) / 255.0      # _frame2tensor's /255
+            # _frame2tensor's /255 as the reference computes it — numpy's true division on the host; a device-side `tensor / 255.0` is a
+            # multiplication by the rounded reciprocal and differs in the last bit of some pixels (found on the real photographs of config 1:
+            # the hooks' and the batched path's float16 descriptors differed in a few elements)
+            stack = torch.from_numpy(np.ascontiguousarray(np.stack([im for _, im in chunk]) / 255.0, dtype=np.float32)).to(net.device)
             run = getattr(net, "extract_batch_guarded", net.extract_batch)
             kp, sc, de, n = run(stack.contiguous())
             if hasattr(self.ext, "_regrow") and self.ext._regrow(net, len(chunk)):
