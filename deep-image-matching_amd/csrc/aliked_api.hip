@@ -114,8 +114,9 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
               cfg->c4, cfg->dim, cfg->K, cfg->M);
   const int c1 = cfg->c1, c2 = cfg->c2, c3 = cfg->c3, c4 = cfg->c4, dim = cfg->dim, G = cfg->dim / 4;
   const int M = cfg->M, M2 = 2 * cfg->M;   // SDDH sample positions; offset channels (ALN:503-519)
-  // detection_threshold <= 0 selects DKD's top-k mode (ALN:602: top_k = max_num_keypoints): the max_num_keypoints highest NMS maxima
-  DIM_REQUIRE(cfg->detection_threshold > 0 || cfg->max_num_keypoints > 0, "dim_aliked_create: detection_threshold <= 0 (top-k mode) needs max_num_keypoints > 0");
+  // detection_threshold <= 0 with max_num_keypoints > 0 selects DKD's top-k mode (ALN:624-627: top_k = max_num_keypoints): the
+  // max_num_keypoints highest NMS maxima; with max_num_keypoints <= 0 as well the reference's top_k is <= 0 and DKD thresholds at the image's
+  // MEAN score (ALN:161-163), at most `capacity` (<= 4096) of them — both handled in dim_aliked_extract
   DIM_REQUIRE(cfg->nms_radius >= 1 && cfg->nms_radius <= 6, "dim_aliked_create: nms_radius %d", cfg->nms_radius);
   DIM_REQUIRE(capacity > 0 && capacity <= 4096 && cfg->max_num_keypoints <= capacity, "dim_aliked_create: capacity %d (<= 4096) must cover max_num_keypoints %d", capacity, cfg->max_num_keypoints);
   DIM_REQUIRE(max_batch > 0 && max_batch <= 64 && max_h >= 16 && max_w >= 16, "dim_aliked_create: bad sizes");
@@ -358,13 +359,17 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     AL_RUN(launch_select_ex(h->nms, batch, H, W, (float)h->cfg.detection_threshold, nullptr, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 1, s));
     AL_RUN(launch_al_pick_threshold(h->ncand, h->mean, (float)h->cfg.detection_threshold, h->thr_eff, batch, s));
     AL_RUN(launch_select_ex(h->nms, batch, H, W, 0.f, h->thr_eff, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 0, s));
+  } else if (h->cfg.max_num_keypoints <= 0) {
+    // no threshold and no top-k (ALN:161-163): masks = nms_scores > mean score of the image
+    AL_RUN(launch_al_pick_threshold(h->ncand, h->mean, 0.f, h->thr_eff, batch, s));     // thr <= 0 -> the mean
+    AL_RUN(launch_select_ex(h->nms, batch, H, W, 0.f, h->thr_eff, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 0, s));
   } else {
     // top-k mode (ALN:150-151: topk over the border-cleared NMS map): every maximum is a candidate (the map is zero elsewhere, scores are
     // sigmoids > 0) and launch_topk keeps the max_num_keypoints highest.  With FEWER maxima than that the reference fills up with zero-score
     // pixels in torch.topk's unspecified tie order; this path returns the maxima only.
     AL_RUN(launch_select_ex(h->nms, batch, H, W, 0.f, nullptr, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 0, s));
   }
-  const int n_limit = h->cfg.max_num_keypoints > 0 ? h->cfg.max_num_keypoints : cap;
+  const int n_limit = h->cfg.max_num_keypoints > 0 ? h->cfg.max_num_keypoints : cap;   // the reference's n_limit_max is 20000 (ALN:571); a slot holds at most 4096 (launch_topk): INTEGRATION.md
   AL_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H, W, n_limit, cap, h->kpts_px, h->sc_tmp, n_kpts_dev, s));
   // Q8: DIM's "scores" are the dispersities (ALN:682 unpacks DKD's return in the wrong order)
   AL_RUN(launch_al_dkd_refine(h->score, h->kpts_px, n_kpts_dev, h->kpts_norm, scores_dev, h->kscore, kpts_xy_dev, batch, H, W, cap, r, s));

@@ -116,6 +116,22 @@ def test_aliked_top_k_mode_vs_oracle(emu_lib):
     assert {tuple(r) for r in out["keypoints"].round().int().tolist()} == {tuple(r) for r in out2["keypoints"].round().int().tolist()}
 
 
+def test_aliked_mean_threshold_mode_vs_oracle(emu_lib):
+    """detection_threshold <= 0 AND max_num_keypoints <= 0: the reference's top_k is then <= 0 and DKD keeps every NMS maximum above
+    the image's MEAN score (ALN:161-163) — at most 4096 of them here (the reference's n_limit_max is 20000: INTEGRATION.md)."""
+    case = gc.AL_CASES["rgb_pad"]
+    cfg = {**case["cfg"], "detection_threshold": -1.0, "max_num_keypoints": -1}
+    sd, img = gc.al_weights(case), gc.al_image(case)
+    net = al_mod.AlikedHIP(sd, cfg, max_batch=1, max_hw=(case["H"], case["W"]), device="cpu", lib=emu_lib)
+    assert net.capacity == 4096
+    out = {k: v.cpu() for k, v in net(img).items()}
+    ref = aliked_ref.aliked_forward(img, sd, cfg, taps=True)
+    mean = float(ref["score_map"].mean())
+    assert ref["keypoints"].shape[0] > 100
+    res = compare_aliked(out, ref, ref_score_map=ref["score_map"], threshold=mean, nms_radius=cfg["nms_radius"])
+    assert res["n_out"] == ref["keypoints"].shape[0]
+
+
 REAL_ALIKED = Path(__file__).parent / "assets" / "aliked-n16rot.pth"   # byte copy of the reference's thirdparty/ALIKED/models/aliked-n16rot.pth
 REAL_ALIKED_N32 = Path(__file__).parent / "assets" / "aliked-n32.pth"  # likewise (md5 fb7434eaaf6c52604541322d7e0fde58)
 
