@@ -102,12 +102,19 @@ class AlikedHIP:
         return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
 
     @torch.no_grad()
-    def extract_batch(self, images: torch.Tensor):
+    def extract_batch(self, images: torch.Tensor, out=None):
         """images [B,H,W,C] float32 in [0,1] (HWC, C = 3 or 1) on self.device -> device tensors
-        (kpts [B,cap,2], scores [B,cap], desc [B,cap,dim], n [B] int32); no host sync."""
+        (kpts [B,cap,2], scores [B,cap], desc [B,cap,dim], n [B] int32); no host sync.  ``out`` = a tuple of such tensors to write into
+        (contiguous views of a larger buffer: pipeline.PairMatchingPipeline's exchange buffer)."""
         assert images.dim() == 4 and images.dtype == torch.float32 and images.is_contiguous()
         B, H, W, C = images.shape
         dev = images.device
+        if out is not None:
+            kp, sc, de, n = out
+            with self._ctx():
+                capi.check(self.lib, self.lib.dim_aliked_extract(self._h, capi.ptr(images), B, H, W, C, capi.ptr(kp), capi.ptr(sc), capi.ptr(de),
+                                                                 capi.ptr(n), self._stream()))
+            return kp, sc, de, n
         kp = torch.empty(B, self.capacity, 2, dtype=torch.float32, device=dev)
         sc = torch.empty(B, self.capacity, dtype=torch.float32, device=dev)
         de = torch.empty(B, self.capacity, self.dim, dtype=torch.float32, device=dev)

@@ -88,7 +88,8 @@ def _guarded(net, fn, what: str):
 
 
 class PairMatchingPipeline:
-    """extractor: SuperPointHIP, matcher: LightGlueHIP (both resident on this rank's device)."""
+    """extractor: SuperPointHIP (images [n, H, W]) or AlikedHIP (images [n, H, W, C]; its descriptor width is read from the extractor: 128, 64
+    for aliked-t16), matcher: LightGlueHIP of the same input_dim (both resident on this rank's device)."""
 
     def __init__(self, extractor, matcher, rank: int = 0, world: int = 1):
         self.ext, self.mat, self.rank, self.world = extractor, matcher, rank, world
@@ -97,14 +98,14 @@ class PairMatchingPipeline:
     # ---- phases 1+2 ------------------------------------------------------------------------
     @torch.no_grad()
     def extract_all(self, images: torch.Tensor, image_sizes: Optional[torch.Tensor] = None):
-        """images [n_img, H, W] float32 in [0,1], identical on every rank (or at least the
+        """images [n_img, H, W] (SuperPoint) or [n_img, H, W, C] (ALIKED) float32 in [0,1], identical on every rank (or at least the
         rank's own shard valid).  Returns the GLOBAL feature table (kpts [n_img,cap,2],
         scores [n_img,cap], desc [n_img,cap,D], n [n_img], size [n_img,2]) on every rank."""
         import time
-        n_img, H, W = images.shape
+        n_img, H, W = images.shape[:3]
         mine = shard_indices(n_img, self.rank, self.world)
         per = (n_img + self.world - 1) // self.world
-        cap, dev, D = self.ext.capacity, images.device, 256
+        cap, dev, D = self.ext.capacity, images.device, int(getattr(self.ext, "dim", 256))      # 256: SuperPoint; AlikedHIP.dim: 128 / 64
         # one flat buffer per rank, sections [kp | sc | de | n]: the extractor writes into views of it, the collective ships it whole
         sizes = (per * cap * 2, per * cap, per * cap * D, per)
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)

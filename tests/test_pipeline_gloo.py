@@ -164,3 +164,34 @@ def test_cost_balanced_shards():
         for k in range(world):
             idx = torch.nonzero(r == k).reshape(-1)
             assert s[idx].tolist() == list(range(idx.numel()))                  # slots follow the index order inside a rank
+
+
+def test_pair_matching_pipeline_with_aliked_features():
+    """PairMatchingPipeline takes the descriptor width from the extractor (AlikedHIP.dim: 128) — ALIKED on un-tiled images
+    goes through the cost-balanced pipeline; every pair equals the one-pair call on the same features."""
+    import ctypes
+    build = importlib.import_module("deep-image-matching_amd.build")
+    al = importlib.import_module("deep-image-matching_amd.aliked_hip")
+    lg = importlib.import_module("deep-image-matching_amd.lightglue_hip")
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    pl = importlib.import_module("deep-image-matching_amd.pipeline")
+    lib = ctypes.CDLL(str(build.build_emu()))
+    lib.dim_last_error.restype = ctypes.c_char_p
+    cfg = {"model_name": "aliked-n16rot", "max_num_keypoints": 24, "detection_threshold": 0.2, "nms_radius": 2}
+    conf = {"n_layers": 2, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0}
+    ext = al.AlikedHIP(weights.synthetic_aliked_state_dict(7, "aliked-n16rot"), cfg, max_batch=2, max_hw=(64, 96), capacity=24, device="cpu", lib=lib)
+    lsd = weights.synthetic_lightglue_state_dict(3, 128, n_layers=2, gain=2.0)
+    mat = lg.LightGlueHIP(lsd, conf, max_pairs=2, max_kpts=24, device="cpu", lib=lib)
+    pipe = pl.PairMatchingPipeline(ext, mat)
+    imgs = torch.rand(3, 64, 96, 3, generator=torch.Generator().manual_seed(12))
+    table = pipe.extract_all(imgs)
+    kp, sc, de, n, size = table
+    assert de.shape == (3, 24, 128) and int(n.min()) > 0 and size.tolist() == [[64.0, 96.0]] * 3
+    pairs = pl.exhaustive_pairs(3)
+    cnt, mt, ms = pipe.match_all(table, pairs)
+    one = lg.LightGlueHIP(lsd, conf, max_pairs=1, max_kpts=24, device="cpu", lib=lib)
+    for p, (a, b) in enumerate(pairs.tolist()):
+        o = one.match_batch(kp[[a, b]].contiguous(), de[[a, b]].contiguous(), n[[a, b]].contiguous(), size[[a, b]].contiguous(), n_pairs=1)
+        S = int(o["n_matches"][0])
+        assert int(cnt[p]) == S and torch.equal(mt[p, :S], o["matches"][0, :S])
+    assert int(cnt.sum()) > 0
