@@ -75,6 +75,7 @@ __device__ __forceinline__ unsigned ft_now() {
 // step) in front of its use, in the same 32 registers; the activation prefetch goes out between the chunk's two steps (requests retire in order).
 template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32, bool DB = false, bool ROLL = false>
 __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, int by) {
+  if constexpr (DIM_AGPR_GEMM >= 2 || (DIM_AGPR_GEMM == 1 && KV != 4)) DIM_MFMA_ACC_IN_AGPR();
   using S = SplitMma<MODE>;
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
   constexpr int NPL = S::NPL, NLD = BM * KCH / 1024;  // float4 loads per thread and chunk

@@ -32,7 +32,8 @@ __device__ __forceinline__ void filler(float (&v)[16], f32x4 (&q)[8], f32x2 (&p)
   if constexpr (CLS == 7) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(d) : "v"(m1), "v"(m2));
 }
 
-// MF = 1: MFMAs + fillers; MF = 0: fillers only (same count as the NF stream would issue)
+// MF = 1: MFMAs + fillers with the accumulators in AGPRs; MF = 2: the same with the accumulators in VGPRs (what hipcc chooses by itself for a kernel
+// that fits 256 registers: every production kernel of csrc/ — 8424 of 8856 MFMAs of conv_x6.hip are the VGPR form); MF = 0: fillers only
 template <int CLS, int NF, int WPS, int MF>
 __global__ __launch_bounds__(256, WPS) void k(float* out, unsigned long long* cyc, int periods) {
   extern __shared__ float lds[];
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256, WPS) void k(float* out, unsigned long long* cy
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
       if constexpr (MF == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c[i & 7]) : "v"(a), "v"(b));
+      if constexpr (MF == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[i & 7]) : "v"(a), "v"(b));
 #pragma unroll
       for (int j = 0; j < NF; ++j) filler<CLS>(v, q, p, i * NF + j, m1, m2, lds_addr);
     }
@@ -116,5 +118,10 @@ int main(int argc, char** argv) {
   run<0, 0, 2, 1>(P);      // MFMA only, two waves per SIMD
   sweep<0, 1>(P); sweep<1, 1>(P); sweep<2, 1>(P); sweep<3, 1>(P); sweep<4, 1>(P); sweep<5, 1>(P); sweep<6, 1>(P); sweep<7, 1>(P);
   sweep<0, 2>(P); sweep<2, 2>(P); sweep<3, 2>(P); sweep<4, 2>(P);
+  // accumulators in VGPRs (the form the compiler picks for the production kernels) instead of AGPRs: MFMA only, then with fillers
+  run<0, 0, 1, 2>(P); run<0, 2, 1, 2>(P); run<0, 4, 1, 2>(P); run<0, 5, 1, 2>(P); run<0, 8, 1, 2>(P);
+  run<4, 2, 1, 2>(P); run<4, 4, 1, 2>(P); run<4, 8, 1, 2>(P);
+  run<0, 0, 2, 2>(P); run<0, 2, 2, 2>(P); run<0, 4, 2, 2>(P); run<0, 5, 2, 2>(P); run<0, 8, 2, 2>(P);
+  run<4, 4, 2, 2>(P); run<4, 8, 2, 2>(P); run<3, 2, 2, 2>(P);
   return 0;
 }
