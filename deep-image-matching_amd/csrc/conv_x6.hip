@@ -59,7 +59,6 @@ __global__ __launch_bounds__(256, ((PF == 2 || MR == 4) ? 2 : 3)) void conv3x3_x
                                                             int cout, int relu, int tiles_x, const float* __restrict__ w1a,
                                                             const float* __restrict__ b1a, const float* __restrict__ inv_ch, unsigned* sat,
                                                             unsigned* sat_image) {
-  if constexpr (DIM_AGPR_CONV >= 2 || (DIM_AGPR_CONV == 1 && !F1A)) DIM_MFMA_ACC_IN_AGPR();
   static_assert(!(PIN || POUT) || MODE == 2, "pre-split planes exist for the fp16x3 mode only");
   static_assert(!(PIN && F1A), "the fused conv1a computes its own input");
   using S = SplitMma<MODE>;

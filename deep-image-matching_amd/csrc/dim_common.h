@@ -302,28 +302,6 @@ void dim_sat_host_bump(int site);  // a range violation established on the host 
     }                                     \
   } while (0)
 
-// ---- MFMA accumulators in AGPRs (round 5) ----
-// hipcc selects the VGPR form of v_mfma (C / D in VGPRs) for every kernel that fits 256 registers and does not otherwise need AGPRs — all of
-// csrc/.  scripts/probe/mfma_filler_1wave_probe.hip: with the accumulators in AGPRs single-issue VALU work placed behind an MFMA hides in its
-// shadow (<= 5 v_fma_f32 per 32x32x16 MFMA, one AND two waves per SIMD); the measurement with VGPR accumulators is in profiles/r05_*.  An (empty)
-// inline-asm statement that names an AGPR makes the function "need AGPRs", and instruction selection then uses the AGPR form for all its MFMAs.
-// Opt-in per kernel family and build until measured on the whole step: -DDIM_AGPR_CONV=1 (pre-split convolutions) / 2 (+ the fused
-// conv1a + conv1b kernel), -DDIM_AGPR_ATTN=1, -DDIM_AGPR_GEMM=1 (q|k|v, wide blocks, small blocks) / 2 (+ the fused feed-forward).
-#ifndef DIM_AGPR_CONV
-#define DIM_AGPR_CONV 0
-#endif
-#ifndef DIM_AGPR_ATTN
-#define DIM_AGPR_ATTN 0
-#endif
-#ifndef DIM_AGPR_GEMM
-#define DIM_AGPR_GEMM 0
-#endif
-#if defined(__AMDGCN__)
-#define DIM_MFMA_ACC_IN_AGPR() asm volatile("" ::: "a0")
-#else
-#define DIM_MFMA_ACC_IN_AGPR() ((void)0)
-#endif
-
 // ---- per-handle overrides of the dim_tune_set choices (include/dim_hip.h: dim_handle_tune_set) ----
 // Every extractor / matcher handle starts with a DimHandleBase; the C-ABI entry points open a DimTuneScope on it, and the accessors
 // (dim_precision_mode(), dim_fuse_conv1a(), ...) return the handle's override while the scope is open on this thread, else the process default.

@@ -75,7 +75,6 @@ __device__ __forceinline__ unsigned ft_now() {
 // step) in front of its use, in the same 32 registers; the activation prefetch goes out between the chunk's two steps (requests retire in order).
 template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32, bool DB = false, bool ROLL = false>
 __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, int by) {
-  if constexpr (DIM_AGPR_GEMM >= 2 || (DIM_AGPR_GEMM == 1 && KV != 4)) DIM_MFMA_ACC_IN_AGPR();
   using S = SplitMma<MODE>;
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
   constexpr int NPL = S::NPL, NLD = BM * KCH / 1024;  // float4 loads per thread and chunk
@@ -85,7 +84,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   static_assert(!ROLL || (((KV == 3 || KV == 4) && !PIPE) || (PIPE && KCH == 32 && !DB)) && (PROBE & ~1) == 0, "rolling fragment requests exist for the 64 x 512 blocks and (prototype) the pipelined 32-wide K loop");
   constexpr int ABUF = NPL * BM * RS;   // dwords of one staged activation tile
   constexpr int BN = 32 * NT * WN;
-  static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && BM == 128), "the K|V image epilogue exists for the fp16x3 128 x 256 block");
+  static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && (BM == 128 || BM == 256)), "the K|V image epilogue exists for the fp16x3 128 / 256 x 256 blocks");
   static_assert(KV != 4 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4 && NT == 4), "the fused ffn exists for the fp16x3 64 x 512 block");
   static_assert(KV != 3 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4), "the LayerNorm + GELU epilogue exists for the fp16x3 64 x 512 block");
   const int z = blockIdx.z;
@@ -753,7 +752,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 }
 
 template <int MODE, int BM, int NT = 2, int WN = 2>
-__global__ __launch_bounds__(256, ((BM / (32 * (4 / WN))) * NT >= 8 ? 2 : 3)) void gemm_x6_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, ((BM / (32 * (4 / WN))) * NT >= 16 ? 1 : ((BM / (32 * (4 / WN))) * NT >= 8 ? 2 : 3))) void gemm_x6_kernel(GemmArgs a) {
   __shared__ unsigned Ap[SplitMma<MODE>::NPL * BM * RS];
   gemm_x6_body<MODE, BM, NT, 0, WN, 0, (WN == 4)>(a, Ap, (int)blockIdx.y);   // the wide block runs the pipelined K loop
 }
@@ -862,6 +861,16 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : 2)) void gemm_x6_nt_kernel(Ge
   }
 }
 #ifdef DIM_RESEARCH   // prototypes that lost their A/B: research build only
+// ---- round 5: 256-row blocks at the 512-register point (dim_tune_set key 14 = 256): every wave owns 256 rows x 64 columns = 16 accumulators
+// (AGPRs), one workgroup per CU, one wave per SIMD.  A weight fragment fetched from L2 then serves twice the rows: the wide blocks stream
+// 4.4 TB/s of weight fragments through an L2 that delivers ~8 — the kernels are as much L2- as matrix-bound ----
+__global__ __launch_bounds__(256, 1) void gemm_x6_qkv256_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 256 * RS];
+  const int by = (int)blockIdx.y;
+  if (by == a.kv_kblock) gemm_x6_body<2, 256, 2, 1, 4, 0, true>(a, Ap, by);
+  else if (by == a.kv_vblock) gemm_x6_body<2, 256, 2, 2, 4, 0, true>(a, Ap, by);
+  else gemm_x6_body<2, 256, 2, 0, 4, 0, true>(a, Ap, by);
+}
 // ---- prototypes with 64-wide K chunks (dim_tune_set key 14 = 64; measured in round 4): the plain 128 x 256 block and the q|k|v kernel ----
 constexpr int RS64 = 64 / 2 + 4;
 __global__ __launch_bounds__(256, 2) void gemm_x6_wide_kc64_kernel(GemmArgs a) {
@@ -1018,7 +1027,8 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
       DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
       DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == (int)grid.y - 1, "gemm_x6: the K and V blocks must be the last two");
 #ifdef DIM_RESEARCH
-      if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_qkv_roll_kernel, grid, dim3(256), 0, s, a);
+      if (dim_gemm_kc() == 256) hipLaunchKernelGGL(gemm_x6_qkv256_kernel, dim3(cdiv(a.M, 256), grid.y, grid.z), dim3(256), 0, s, a);
+      else if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_qkv_roll_kernel, grid, dim3(256), 0, s, a);
       else if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_qkv_db_kernel, grid, dim3(256), 0, s, a);
       else if (dim_gemm_kc() == 64 && a.K % 64 == 0) hipLaunchKernelGGL(gemm_x6_qkv_kc64_kernel, grid, dim3(256), 0, s, a);
       else
@@ -1040,7 +1050,8 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
 #endif
       default:
 #ifdef DIM_RESEARCH
-        if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_wide_roll_kernel, grid, dim3(256), 0, s, a);
+        if (dim_gemm_kc() == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 256, 2, 4>), dim3(cdiv(a.M, 256), grid.y, grid.z), dim3(256), 0, s, a);
+        else if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_wide_roll_kernel, grid, dim3(256), 0, s, a);
         else if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_wide_db_kernel, grid, dim3(256), 0, s, a);
         else if (dim_gemm_kc() == 64 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(gemm_x6_wide_kc64_kernel, grid, dim3(256), 0, s, a);
         else

@@ -108,7 +108,6 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
 // product kernel to materialise the zeroed score accumulator (16 v_mov per key tile; every VALU instruction is time)
 template <int MODE, int PROBE = 0>
 __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnArgs6 a) {
-  if constexpr (DIM_AGPR_ATTN >= 1) DIM_MFMA_ACC_IN_AGPR();
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, TILE_SLOTS = tile_slots(NPL), KSL = NPL * 256, NCP = TILE_SLOTS / 256;
   // K, Q, V and P are multiplied by the (power-of-two) activation scale before the split: exact factors

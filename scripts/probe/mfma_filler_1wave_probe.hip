@@ -35,12 +35,20 @@ __device__ __forceinline__ void filler(float (&v)[16], f32x4 (&q)[8], f32x2 (&p)
 // MF = 1: MFMAs + fillers with the accumulators in AGPRs; MF = 2: the same with the accumulators in VGPRs (what hipcc chooses by itself for a kernel
 // that fits 256 registers: every production kernel of csrc/ — 8424 of 8856 MFMAs of conv_x6.hip are the VGPR form); MF = 0: fillers only
 template <int CLS, int NF, int WPS, int MF>
-__global__ __launch_bounds__(256, WPS) void k(float* out, unsigned long long* cyc, int periods) {
+__global__ __launch_bounds__(256, WPS) void k(float* out, unsigned long long* cyc, int periods, int operands) {
   extern __shared__ float lds[];
   for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = 0.f;
   __syncthreads();
-  f16x8 a, b;
-  for (int e = 0; e < 8; ++e) { a[e] = (_Float16)0.f; b[e] = (_Float16)0.f; }
+  // operands == 0: zeros (the multipliers do not toggle: the package stays far below its power cap and the clock near 2.4 GHz — issue
+  // behaviour in isolation); operands == 1: pseudo-random fp16 values, two alternating operand sets (every MFMA sees new inputs): the regime
+  // of the production kernels, where the firmware holds the package at its power cap by lowering the clock
+  f16x8 a, b, a2, b2;
+  unsigned lcg = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  for (int e = 0; e < 8; ++e) {
+    float r[4];
+    for (int q = 0; q < 4; ++q) { lcg = lcg * 1664525u + 1013904223u; r[q] = operands ? ((int)(lcg >> 8) % 4096 - 2048) * (1.0f / 1024.0f) : 0.f; }
+    a[e] = (_Float16)r[0]; b[e] = (_Float16)r[1]; a2[e] = (_Float16)r[2]; b2[e] = (_Float16)r[3];
+  }
   f32x16 c[8];
   for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
   float v[16];
@@ -48,15 +56,15 @@ __global__ __launch_bounds__(256, WPS) void k(float* out, unsigned long long* cy
   f32x2 p[8];
   for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 1e-6f;
   for (int i = 0; i < 8; ++i) { q[i] = f32x4{0, 0, 0, 0}; p[i] = f32x2{1e-6f, 1e-6f}; }
-  float m1 = 1.0f, m2 = 1e-6f;
+  float m1 = operands ? -0.9990234f : 1.0f, m2 = operands ? 0.37f : 1e-6f;     // (random mode: a sign-alternating contraction: the filler registers keep toggling, bounded)
   asm volatile("" : "+v"(m1), "+v"(m2));
   const unsigned lds_addr = (threadIdx.x & 63) * 16;     // conflict-free b128 pattern, 1 KB per wave
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int pp = 0; pp < periods; ++pp) {
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
-      if constexpr (MF == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c[i & 7]) : "v"(a), "v"(b));
-      if constexpr (MF == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[i & 7]) : "v"(a), "v"(b));
+      if constexpr (MF == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c[i & 7]) : "v"((i & 1) ? a2 : a), "v"((i & 1) ? b2 : b));
+      if constexpr (MF == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[i & 7]) : "v"((i & 1) ? a2 : a), "v"((i & 1) ? b2 : b));
 #pragma unroll
       for (int j = 0; j < NF; ++j) filler<CLS>(v, q, p, i * NF + j, m1, m2, lds_addr);
     }
@@ -76,6 +84,7 @@ static unsigned long long* d_cyc;
 static unsigned long long h_cyc[4096];
 static const char* CLSN[8] = {"v_fma_f32", "v_cvt_pk_f16_f32", "v_exp_f32", "ds_read_b128", "v_fma_mix_f32", "v_pk_fma_f32", "v_perm_b32", "v_max3_f32"};
 
+static int g_operands = 0;
 template <int CLS, int NF, int WPS, int MF>
 void run(int periods) {
   // WPS 1: 100 KB of LDS per workgroup -> one workgroup per CU, grid = 256 (one round); WPS 2: 64 KB -> two per CU, grid = 512
@@ -84,10 +93,10 @@ void run(int periods) {
   hipFuncSetAttribute((const void*)k<CLS, NF, WPS, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<CLS, NF, WPS, MF>), dim3(grid), dim3(256), lds, 0, d_out, d_cyc, 50);
+  hipLaunchKernelGGL((k<CLS, NF, WPS, MF>), dim3(grid), dim3(256), lds, 0, d_out, d_cyc, 50, g_operands);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((k<CLS, NF, WPS, MF>), dim3(grid), dim3(256), lds, 0, d_out, d_cyc, periods);
+  hipLaunchKernelGGL((k<CLS, NF, WPS, MF>), dim3(grid), dim3(256), lds, 0, d_out, d_cyc, periods, g_operands);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -98,9 +107,9 @@ void run(int periods) {
   const double slots = (double)periods * NM;
   // both clocks are reported: s_memtime ticks per slot (average and slowest wave) and the event time per slot; the MFMA-only row gives the
   // ticks <-> ns relation of the run (32 shader cycles per slot)
-  printf("{\"class\": \"%s\", \"fillers_per_mfma\": %d, \"waves_per_simd\": %d, \"mfma\": %d, \"ns_per_slot\": %.3f, \"memtime_ticks_per_slot_avg\": %.4f, "
+  printf("{\"operands\": \"%s\", \"class\": \"%s\", \"fillers_per_mfma\": %d, \"waves_per_simd\": %d, \"mfma\": %d, \"ns_per_slot\": %.3f, \"memtime_ticks_per_slot_avg\": %.4f, "
          "\"memtime_ticks_per_slot_max\": %.4f, \"ms\": %.4f}\n",
-         CLSN[CLS], NF, WPS, MF, ms * 1e6 / slots, sum / (grid * 4) / slots, mx / slots, ms);
+         g_operands ? "random" : "zero", CLSN[CLS], NF, WPS, MF, ms * 1e6 / slots, sum / (grid * 4) / slots, mx / slots, ms);
   fflush(stdout);
 }
 
@@ -114,6 +123,16 @@ int main(int argc, char** argv) {
   hipMalloc(&d_out, 4);
   hipMalloc(&d_cyc, sizeof(unsigned long long) * 4096);
   const int P = argc > 1 ? atoi(argv[1]) : 4000;
+  if (argc > 2 && atoi(argv[2]) == 1) {
+    // the power-limited regime: long runs (P ~ 400 000: 0.2 - 0.5 s each, the firmware's time scale) on toggling operands, the production
+    // occupancy (two waves per SIMD).  Cycles per slot (s_memtime) say whether the fillers still hide; ns per slot what that is worth in time.
+    g_operands = 1;
+    run<0, 0, 2, 1>(P); run<0, 5, 2, 0>(P); run<0, 5, 2, 1>(P); run<0, 2, 2, 1>(P); run<4, 4, 2, 0>(P); run<4, 4, 2, 1>(P); run<0, 8, 2, 1>(P);
+    run<0, 0, 1, 1>(P); run<0, 5, 1, 1>(P);
+    g_operands = 0;
+    run<0, 0, 2, 1>(P); run<0, 5, 2, 1>(P);
+    return 0;
+  }
   run<0, 0, 1, 1>(P);      // MFMA only, one wave per SIMD: the floor (32 cycles per slot)
   run<0, 0, 2, 1>(P);      // MFMA only, two waves per SIMD
   sweep<0, 1>(P); sweep<1, 1>(P); sweep<2, 1>(P); sweep<3, 1>(P); sweep<4, 1>(P); sweep<5, 1>(P); sweep<6, 1>(P); sweep<7, 1>(P);

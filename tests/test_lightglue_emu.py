@@ -207,7 +207,7 @@ def test_wide_gemm_blocks_with_64_wide_k_chunks_are_bit_identical(emu_research_l
         emu_lib = emu_research_lib
         try:
             emu_lib.dim_tune_set(6, 2)
-            for kc in ((32, 64, 33, 36, 37) if name == "fixed" else (32, 36, 37)):   # the two prototypes on one case, the A/B loop of the product kernel on both
+            for kc in ((32, 64, 33, 36, 37, 256) if name == "fixed" else (32, 36, 37, 256)):   # 256 (round 5): 256-row blocks at the 512-register point   # the two prototypes on one case, the A/B loop of the product kernel on both
                 assert emu_lib.dim_tune_set(14, kc) == 0
                 out, ref = run_case(emu_lib, case)
                 compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
