@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r04_bench_n1.json = `python bench.py` on one MI355X) carries the contract's fields and is
+"""The committed bench line (profiles/r05_bench_n1.json = `python bench.py` on one MI355X) carries the contract's fields and is
 self-consistent: metric / unit are BASELINE.json's, value = pairs / timed region, roofline.frac = achieved / peak with the algorithmic work
 stated, the cpu_baseline object is complete, the strong_scaling sub-record ran the fixed config-4 job with non-empty match tables."""
 import json
@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def _line():
-    return json.loads((ROOT / "profiles" / "r04_bench_n1.json").read_text().strip().splitlines()[-1])
+    return json.loads((ROOT / "profiles" / "r05_bench_n1.json").read_text().strip().splitlines()[-1])
 
 
 def test_contract_fields_and_baseline_metric():
@@ -43,3 +43,18 @@ def test_strong_scaling_sub_record_is_the_fixed_job_with_real_matches():
     assert s["scaling"] == "strong" and s["n_gpus"] == 1 and s["value"] > 0
     assert s["matches_per_pair_mean"] >= 100 and s["pairs_with_at_least_100_matches"] > 0 and s["fp16x3_range_guard"]["violations"] == 0
     assert set(s["phases_s_max_over_ranks"]) == {"extract_s", "feature_gather_s", "match_s", "match_gather_s"}
+
+
+def test_hook_path_sub_record_and_config1_line():
+    """Round 5: the default line carries the per-call plugin hooks' wall time beside the device time of the same batch-1 calls,
+    and profiles/r05_config1.json is BASELINE configs[0] on its real inputs with the reference's CPU path beside it (next #1)."""
+    h = _line()["hook_path"]
+    assert set(h) >= {"ms_per_image", "ms_per_pair", "device_only_ms_per_image", "device_only_ms_per_pair"}
+    assert h["device_only_ms_per_image"] <= h["ms_per_image"] < 3.0 and h["device_only_ms_per_pair"] <= h["ms_per_pair"] < 4.0
+    c = json.loads((ROOT / "profiles" / "r05_config1.json").read_text().strip().splitlines()[-1])
+    assert "configs[0]" in c["config"]["workload"] and c["config"]["images"] == 5 and c["config"]["pairs"] == 10 and c["n_gpus"] == 1
+    assert abs(c["value"] - 10 / (c["hook_path"]["extract_s"] + c["hook_path"]["match_s"])) < 1e-6 * c["value"]
+    assert c["fp16x3_range_guard"]["violations"] == 0 and c["batched_image_matcher"]["value"] > 0
+    assert c["cpu_baseline"]["kind"] in ("port", "reference") and c["value"] / c["cpu_baseline"]["value"] > 50
+    ref = json.loads((ROOT / "profiles" / "r05_config1_cpu_reference.json").read_text().strip().splitlines()[-1])["cpu_baseline"]
+    assert ref["kind"] == "reference" and 0.5 < ref["value"] < 5.0 and "imported from /root/reference" in ref["sample"]
