@@ -85,7 +85,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   constexpr int ABUF = NPL * BM * RS;   // dwords of one staged activation tile
   constexpr int BN = 32 * NT * WN;
   static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && (BM == 128 || BM == 256)), "the K|V image epilogue exists for the fp16x3 128 / 256 x 256 blocks");
-  static_assert(KV != 4 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4 && NT == 4), "the fused ffn exists for the fp16x3 64 x 512 block");
+  static_assert(KV != 4 || (MODE == 2 && BN == 512 && (BM == 64 || BM == 128) && WN == 4 && NT == 4), "the fused ffn exists for the fp16x3 64 / 128 x 512 blocks");
   static_assert(KV != 3 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4), "the LayerNorm + GELU epilogue exists for the fp16x3 64 x 512 block");
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
@@ -342,9 +342,10 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     // packed with the same permutation on the host (split_weights, kperm).  Every wave holds 128 of the 512 hidden units, i.e. a
     // K-slice of ffn.3: the four partial 64 x 256 outputs are reduced through LDS, 64 columns at a time, each wave ending up
     // with one 32 x 32 tile that it finishes (scale, bias, residual, range guard) and stores. =================
+    constexpr int TOK = 32 * MT;                       // tokens (rows) of the block: 64, or 128 in the 512-register variant
     float* const prm = (float*)(Ap + NPL * BM * RS);   // [inv0 | bias0 | gamma | beta] x 512 — filled before the K loop
-    float* const red = prm + 2048;                     // [2 passes][4 waves][64 tokens]
-    float* const xbuf = red + 512;                     // [4 owner tiles][3 sources][4 register quads][64 lanes][4]
+    float* const red = prm + 2048;                     // [2 passes][4 waves][TOK tokens]
+    float* const xbuf = red + 8 * TOK;                 // [4 owner tiles][3 sources][4 register quads][64 lanes][4]
     // ---- v = acc * inv + bias in place; LayerNorm statistics per token: registers + lane halves + the four waves ----
     float part[MT];
 #pragma unroll
@@ -369,11 +370,11 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const float v = p[m] + __shfl_xor(p[m], 32);
-        if (half == 0) region[wn * 64 + m * 32 + lx] = v;
+        if (half == 0) region[wn * TOK + m * 32 + lx] = v;
       }
       __syncthreads();
 #pragma unroll
-      for (int m = 0; m < MT; ++m) out[m] = (region[m * 32 + lx] + region[64 + m * 32 + lx]) + (region[128 + m * 32 + lx] + region[192 + m * 32 + lx]);
+      for (int m = 0; m < MT; ++m) out[m] = (region[m * 32 + lx] + region[TOK + m * 32 + lx]) + (region[2 * TOK + m * 32 + lx] + region[3 * TOK + m * 32 + lx]);
     };
     token_total(part, red, mean);
 #pragma unroll
@@ -384,7 +385,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float d = acc[m][n][r] - mean[m]; part[m] = fmaf(d, d, part[m]); }
-    token_total(part, red + 256, rstd);
+    token_total(part, red + 4 * TOK, rstd);
 #pragma unroll
     for (int m = 0; m < MT; ++m) rstd[m] = 1.0f / sqrtf(rstd[m] * (1.0f / 512.0f) + 1e-5f);
     FT_TICK(4);
@@ -444,14 +445,13 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) f[ct][p] = Bf2[((((size_t)p * NB2 + 2 * grp + ct) * KS2 + wn * 8 + ks) * 2 + half) * 32 + lx];
       };
-      auto step2 = [&](const u32x4 (&hm0)[NPL], const u32x4 (&hm1)[NPL], const u32x4 (&f)[2][NPL]) {
+      auto step2 = [&](int n, int q, const u32x4 (&f)[2][NPL]) {      // k-step (tile n, register half q) of ffn.3 on every 32-row tile m
 #pragma unroll
         for (int tm = 0; tm < S::NT; ++tm)
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            acc2[0][ct] = S::mma(hm0[S::ta(tm)], f[ct][S::tb(tm)], acc2[0][ct]);
-            acc2[1][ct] = S::mma(hm1[S::ta(tm)], f[ct][S::tb(tm)], acc2[1][ct]);
-          }
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc2[m][ct] = S::mma(hq[m][n][S::ta(tm)][q], f[ct][S::tb(tm)], acc2[m][ct]);
       };
       u32x4 fa2[2][NPL], fb2[2][NPL];
       load_w3(0, fa2);
@@ -459,24 +459,29 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       for (int n = 0; n < NT; ++n) {
         load_w3(2 * n + 1, fb2);
         __builtin_amdgcn_sched_barrier(0);
-        { const u32x4 h0[NPL] = {hq[0][n][0][0], hq[0][n][1][0]}, h1[NPL] = {hq[1][n][0][0], hq[1][n][1][0]}; step2(h0, h1, fa2); }
+        step2(n, 0, fa2);
         __builtin_amdgcn_sched_barrier(0);
         if (n + 1 < NT) load_w3(2 * n + 2, fa2);
         __builtin_amdgcn_sched_barrier(0);
-        { const u32x4 h0[NPL] = {hq[0][n][0][1], hq[0][n][1][1]}, h1[NPL] = {hq[1][n][0][1], hq[1][n][1][1]}; step2(h0, h1, fb2); }
+        step2(n, 1, fb2);
       }
       FT_TICK(6);
-      // the residual of the tile this wave will own (tile wn: rows 32 (wn >> 1) .., columns 64 grp + 32 (wn & 1) ..), requested
+      // the 2 MT partial tiles of the round are finished in MT / 2 passes of four (one per wave): pass mp = rows 64 mp .. 64 mp + 63
+#pragma unroll
+      for (int mp = 0; mp < MT / 2; ++mp) {
+      // the residual of the tile this wave will own (tile wn: rows 64 mp + 32 (wn >> 1) .., columns 64 grp + 32 (wn & 1) ..), requested
       // before the exchange so that its latency hides behind it
       const int ocol = 64 * grp + 32 * (wn & 1) + lx;
+      const int orow_p = orow + 64 * mp;
+      const unsigned obase_p = obase + (unsigned)(64 * mp) * (unsigned)a.ldc * 4u;
       const unsigned goff = (unsigned)__builtin_amdgcn_readfirstlane(grp * 256);
       float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = (r & 3) + 8 * (r >> 2);
-        rv[r] = orow + k < rows ? buf_load_f32_s(Rr, obase, goff + (unsigned)k * (unsigned)a.ldc * 4u) : 0.0f;
+        rv[r] = orow_p + k < rows ? buf_load_f32_s(Rr, obase_p, goff + (unsigned)k * (unsigned)a.ldc * 4u) : 0.0f;
       }
-      // ---- exchange: tile t = (m = t >> 1, ct = t & 1) belongs to wave t; the other three waves hand over their partial sums ----
+      // ---- exchange: tile t = (m = 2 mp + (t >> 1), ct = t & 1) belongs to wave t; the other three waves hand over their partial sums ----
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4)
         if (t4 != wn) {
@@ -484,7 +489,8 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq)
             *(float4*)(xbuf + ((((t4 * 3 + src) * 4 + rq) * 64 + lane) << 2)) =
-                make_float4(acc2[t4 >> 1][t4 & 1][4 * rq], acc2[t4 >> 1][t4 & 1][4 * rq + 1], acc2[t4 >> 1][t4 & 1][4 * rq + 2], acc2[t4 >> 1][t4 & 1][4 * rq + 3]);
+                make_float4(acc2[2 * mp + (t4 >> 1)][t4 & 1][4 * rq], acc2[2 * mp + (t4 >> 1)][t4 & 1][4 * rq + 1], acc2[2 * mp + (t4 >> 1)][t4 & 1][4 * rq + 2],
+                            acc2[2 * mp + (t4 >> 1)][t4 & 1][4 * rq + 3]);
         }
       FT_TICK(7);
       __syncthreads();
@@ -492,7 +498,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       float own[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float a0 = (wn & 1) ? acc2[0][1][r] : acc2[0][0][r], a1 = (wn & 1) ? acc2[1][1][r] : acc2[1][0][r];
+        const float a0 = (wn & 1) ? acc2[2 * mp][1][r] : acc2[2 * mp][0][r], a1 = (wn & 1) ? acc2[2 * mp + 1][1][r] : acc2[2 * mp + 1][0][r];
         own[r] = (wn >> 1) ? a1 : a0;
       }
 #pragma unroll
@@ -510,10 +516,11 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
         const float v = (own[r] * iv3 + bv3) + rv[r];
         vmax2 = fmaxf(vmax2, fabsf(v));
         const int k = (r & 3) + 8 * (r >> 2);
-        if (orow + k < rows) buf_store_f32_s(Cr, obase, goff + (unsigned)k * (unsigned)a.ldc * 4u, v);
+        if (orow_p + k < rows) buf_store_f32_s(Cr, obase_p, goff + (unsigned)k * (unsigned)a.ldc * 4u, v);
       }
       FT_TICK(9);
-      __syncthreads();   // the exchange buffer is rewritten by the next round
+      __syncthreads();   // the exchange buffer is rewritten by the next pass / round
+      }
       FT_TICK(10);
     }
     sat_report(a.sat2, vmax2);
@@ -910,7 +917,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_qkv_roll_kernel(GemmArgs a) {
 }
 #endif   // DIM_RESEARCH
 // LightGlue's ffn.0 -> LayerNorm -> GELU -> ffn.3 (+ residual) in one kernel: 64 rows per workgroup, the hidden tensor stays on the CU
-constexpr int FFN_LDS_DWORDS = 2 * 64 * RS + 2048 + 512 + 4 * 3 * 4 * 64 * 4;
+constexpr int ffn_lds_dwords(int bm) { return 2 * bm * RS + 2048 + 8 * bm + 4 * 3 * 4 * 64 * 4; }
+constexpr int FFN_LDS_DWORDS = ffn_lds_dwords(64);
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_kernel(GemmArgs a) {
   __shared__ unsigned Ap[FFN_LDS_DWORDS];
   float* const prm = (float*)(Ap + 2 * 64 * RS);
@@ -920,6 +928,17 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_kernel(GemmArgs a) {
   gemm_x6_body<2, 64, 4, 4, 4, 0, false, 32, false, true>(a, Ap, 0);   // rolling fragment requests (round 4: 593 -> 576 us; the k-step-pipelined
 }                                                                       // loop needs 32 more registers here: measured slower, 613 vs 592 us)
 #ifdef DIM_RESEARCH
+// round 5 (dim_tune_set key 14 = 128): the fused feed-forward on 128-row blocks at the 512-register point — 16 ffn.0 accumulators per wave in
+// AGPRs, one workgroup per CU.  A 64-row block streams 1.5 MB of weight fragments from L2: 3200 workgroups x 1.5 MB in 558 us = 8.6 TB/s, the
+// L2's limit; a 128-row block halves that.
+__global__ __launch_bounds__(256, 1) void gemm_x6_ffn_fused128_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[ffn_lds_dwords(128)];
+  float* const prm = (float*)(Ap + 2 * 128 * RS);
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    prm[i] = a.inv_ch[i]; prm[512 + i] = a.bias[i]; prm[1024 + i] = a.ln_gamma[i]; prm[1536 + i] = a.ln_beta[i];
+  }
+  gemm_x6_body<2, 128, 4, 4, 4, 0, false, 32, false, true>(a, Ap, 0);
+}
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_fused_step_kernel(GemmArgs a) {   // round 3's loop (one k-step's fragments at a time), kept for A/B: dim_tune_set(14, 36)
   __shared__ unsigned Ap[FFN_LDS_DWORDS];
   float* const prm = (float*)(Ap + 2 * 64 * RS);
@@ -987,7 +1006,8 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
                 a.kv_img == nullptr && a.ldr == a.ldc && a.strideR == a.strideC,
                 "gemm_x6: the fused feed-forward needs the fp16x3 512 -> 256 shapes, a residual laid out like the output and both bias vectors");
 #ifdef DIM_RESEARCH
-    if (dim_gemm_kc() == 35) hipLaunchKernelGGL(gemm_x6_ffn_fused_roll_probe_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    if (dim_gemm_kc() == 128) hipLaunchKernelGGL(gemm_x6_ffn_fused128_kernel, dim3(cdiv(a.M, 128), 1, batch), dim3(256), 0, s, a);
+    else if (dim_gemm_kc() == 35) hipLaunchKernelGGL(gemm_x6_ffn_fused_roll_probe_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
     else if (dim_gemm_kc() == 36) hipLaunchKernelGGL(gemm_x6_ffn_fused_step_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
     else
 #endif

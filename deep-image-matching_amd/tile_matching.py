@@ -257,6 +257,11 @@ class TilePreselector:
     def _stream(self):
         return ctypes_stream(self.device)
 
+    @staticmethod
+    def _capacity() -> int:
+        """keypoint slots of the preselection networks: the next power of two >= PRESELECTION_SP_CONF's max_keypoints (4000 -> 4096)"""
+        return max(64, 1 << (int(PRESELECTION_SP_CONF["max_keypoints"]) - 1).bit_length())
+
     def _resize(self, src: torch.Tensor, h: int, w: int, linear: bool = False) -> torch.Tensor:
         H, W = src.shape
         dst = torch.empty(h, w, dtype=torch.float32, device=self.device)
@@ -291,7 +296,7 @@ class TilePreselector:
         h, w = small.shape
         if self._sp is None or h > self._sp_hw[0] or w > self._sp_hw[1]:
             self._sp_hw = (max(h, self._sp_hw[0], self.size), max(w, self._sp_hw[1], self.size))
-            self._sp = SuperPointHIP(self._sp_sd, PRESELECTION_SP_CONF, max_batch=1, max_hw=self._sp_hw, capacity=4096,
+            self._sp = SuperPointHIP(self._sp_sd, PRESELECTION_SP_CONF, max_batch=1, max_hw=self._sp_hw, capacity=self._capacity(),
                                      device=self.device, lib=self.lib)
         kp, _, de, n = self._sp.extract_batch_guarded(small[None].contiguous(), logger=logger)
         ent = (kp, de, n, scale)
@@ -305,7 +310,7 @@ class TilePreselector:
         so the keypoint extent is used (LGN:26-27) — computed on the device (no host read-back: the pipeline enqueues the
         preselection of all its image pairs back to back; ``guarded=False`` leaves the range-guard read to the caller's phase)."""
         if self._lg is None:
-            self._lg = LightGlueHIP(self._lg_sd, PRESELECTION_LG_CONF, max_pairs=1, max_kpts=4096, device=self.device, lib=self.lib)
+            self._lg = LightGlueHIP(self._lg_sd, PRESELECTION_LG_CONF, max_pairs=1, max_kpts=self._capacity(), device=self.device, lib=self.lib)
         kt = torch.cat([f0[0], f1[0]]).contiguous()
         dt = torch.cat([f0[1], f1[1]]).contiguous()
         nt = torch.cat([f0[2], f1[2]]).contiguous()

@@ -3,7 +3,13 @@ put two workgroups on every CU, twice (determinism), and its time at the bench s
 import ctypes, importlib, json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.test_ops_emu import _ffn_fused_case
-capi = importlib.import_module('deep-image-matching_amd.capi'); lib = capi.load()
+capi = importlib.import_module('deep-image-matching_amd.capi')
+# DIM_LIB=<path of a variant library> DIM_TUNE14=<value>: check / time a research variant of the kernel (e.g. the 128-row block: 14 = 128)
+lib = capi.load(os.environ["DIM_LIB"]) if os.environ.get("DIM_LIB") else capi.load()
+if os.environ.get("DIM_LIB"):
+    capi.install(lib, None)
+if os.environ.get("DIM_TUNE14"):
+    assert lib.dim_tune_set(14, int(os.environ["DIM_TUNE14"])) == 0
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 res = {}
 for M in (2048 + 37, 65536, 204800):
@@ -38,4 +44,5 @@ def two():
 def one():
     capi.check(lib, lib.dim_op_ffn_fused_f32(p(A), K, h0, p(b512), p(gm), p(bt), h3p, p(b256), p(R), 256, p(C256), 256, M, K, stream))
 res["two_kernels_us"] = t(two); res["fused_us"] = t(one); res["two_kernels_us_again"] = t(two); res["fused_us_again"] = t(one)
+res["tune_14"] = os.environ.get("DIM_TUNE14", "32")
 print(json.dumps(res))

@@ -17,7 +17,7 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _args(images=11, job_pairs=24, pairs=2, timeout=900.0):      # (the watchdog ends the PROCESS: generous, the suite may run these on a loaded host)
+def _args(images=11, job_pairs=16, pairs=2, timeout=900.0):      # (the watchdog ends the PROCESS: generous, the suite may run these on a loaded host)
     return types.SimpleNamespace(images=images, job_pairs=job_pairs, pairs=pairs, c4_hw=(48, 64), c4_kpts=32, strong_timeout=timeout)
 
 
@@ -79,17 +79,17 @@ def test_world_8_strong_scaling_subrecord_with_uneven_shards_equals_world_1(tmp_
     got = [torch.load(tmp_path / f"bench{r}.pt", weights_only=False) for r in range(8)]
     s8 = got[0]["line"]["strong_scaling"]
     assert "error" not in s8 and s8["n_gpus"] == 8 and s8["scaling"] == "strong", s8
-    # the same job, the same matches, whatever the sharding: 11 images over 8 ranks (2, 2, 2, 1, 1, 1, 1, 1), 24 pairs (3 per rank, dealt by cost)
+    # the same job, the same matches, whatever the sharding: 11 images over 8 ranks (2, 2, 2, 1, 1, 1, 1, 1), 16 pairs (2 per rank, dealt by cost)
     assert s8["matches_total"] == s1["matches_total"] and s8["pairs_with_at_least_100_matches"] == s1["pairs_with_at_least_100_matches"]
     assert set(s8["phases_s_max_over_ranks"]) == {"extract_s", "feature_gather_s", "match_s", "match_gather_s"}
     assert all(g["line"]["strong_scaling"] is None for g in got[1:])          # only rank 0 assembles the record
     # exactly two data collectives per pass (warm-up pass + timed pass), of the sizes the formulas give: per = ceil(n / world) slots
-    per_i, per_p, cap, D, NK = 2, 3, 32, 256, 32
+    per_i, per_p, cap, D, NK = 2, 2, 32, 256, 32
     feat, match = per_i * cap * (2 + 1 + D) + per_i, per_p * 2 + per_p * NK * 3
     big = [c for c in got[3]["collectives"] if c[1] in (feat, match)]
     assert ("torch.float32", feat) in big and ("torch.int32", match) in big, got[3]["collectives"]
     assert s8["gathered_bytes_measured"] == {"feature_gather_bytes": feat * 4 * 8, "match_gather_bytes": match * 4 * 8}
-    assert bench.pipe_bytes(11, 8, cap, D, NK)[0] == feat * 4 * 8 and bench.pipe_bytes(24, 8, cap, D, NK)[1] == match * 4 * 8
+    assert bench.pipe_bytes(11, 8, cap, D, NK)[0] == feat * 4 * 8 and bench.pipe_bytes(16, 8, cap, D, NK)[1] == match * 4 * 8
 
 
 def test_full_size_job_buffers_at_world_8_fit_the_gpu_many_times_over():

@@ -207,7 +207,7 @@ def test_wide_gemm_blocks_with_64_wide_k_chunks_are_bit_identical(emu_research_l
         emu_lib = emu_research_lib
         try:
             emu_lib.dim_tune_set(6, 2)
-            for kc in ((32, 64, 33, 36, 37, 256) if name == "fixed" else (32, 36, 37, 256)):   # 256 (round 5): 256-row blocks at the 512-register point   # the two prototypes on one case, the A/B loop of the product kernel on both
+            for kc in ((32, 64, 33, 36, 37, 256) if name == "fixed" else (32, 256)):   # 256 (round 5): 256-row blocks at the 512-register point   # the two prototypes on one case, the A/B loop of the product kernel on both
                 assert emu_lib.dim_tune_set(14, kc) == 0
                 out, ref = run_case(emu_lib, case)
                 compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
@@ -226,3 +226,24 @@ def test_lightglue_64_wide_descriptors_vs_oracle(emu_lib):
     out, ref = run_case(emu_lib, case)
     compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
     assert out["matches0"].shape[-1] == case["m"]
+
+
+def test_fused_feed_forward_variants_are_bit_identical(emu_research_lib):
+    """RESEARCH build, the one-kernel feed-forward forced on (11 = 4): the product loop (14 = 32), round 3's loop (36) and round 5's 128-row block at the
+    512-register point (128: 16 ffn.0 accumulators per wave, the reduce-scatter of ffn.3 in two passes of four tiles) — the same terms in the same
+    order for every output element: every bit equal, on a ragged adaptive case and the fixed-work case."""
+    lib = emu_research_lib
+    for name in ("default",):       # ragged counts, adaptive depth (the fixed-work case adds nothing to these kernels)
+        case = gc.LG_CASES[name]
+        outs = []
+        try:
+            lib.dim_tune_set(6, 2); lib.dim_tune_set(11, 4)
+            for kc in (32, 36, 128):
+                assert lib.dim_tune_set(14, kc) == 0
+                out, ref = run_case(lib, case)
+                compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+                outs.append(out)
+        finally:
+            lib.dim_tune_set(6, 1); lib.dim_tune_set(11, 3); lib.dim_tune_set(14, 32)
+        for b in outs[1:]:
+            assert torch.equal(outs[0]["dense"], b["dense"]) and torch.equal(outs[0]["matches0"], b["matches0"]), name

@@ -157,6 +157,8 @@ def test_preselection_votes_on_the_device_select_the_tile_pairs_and_nothing_fall
     weights = importlib.import_module("deep-image-matching_amd.weights")
     lib = ctypes.CDLL(str(build.build_emu()))
     capi.install(lib, "cpu")
+    old_kp = tm.PRESELECTION_SP_CONF["max_keypoints"]
+    tm.PRESELECTION_SP_CONF["max_keypoints"] = 256      # (the reference's 4000 sizes the emulated LightGlue state for 4096 keypoints per image: minutes)
     try:
         # preselection size 192 = the image width: the down-sampling is the identity, so crops at multiples of 8 px are SuperPoint-equivariant
         general = {"tile_size": (96, 64), "tile_overlap": 0, "min_matches_per_tile": 1, "quality": "HIGH", "tile_preselection_size": 192,
@@ -186,4 +188,5 @@ def test_preselection_votes_on_the_device_select_the_tile_pairs_and_nothing_fall
             want = tm.match_tile_pairs_batched(mt._ensure_pairs, feats[a], feats[b], sel, "cpu", 3)
             assert np.array_equal(m, want), (a, b, sel)
     finally:
+        tm.PRESELECTION_SP_CONF["max_keypoints"] = old_kp
         capi.install(None)
