@@ -163,3 +163,31 @@ def test_keep_all_mode_never_drops_keypoints(emu_install):
     assert ref["keypoints"].shape[0] > 64
     assert f["keypoints"].shape[0] == ref["keypoints"].shape[0]
     assert np.array_equal(f["keypoints"], ref["keypoints"].numpy())  # row-major order, like torch.nonzero
+
+
+def test_arithmetic_is_a_per_handle_choice(emu_install):
+    """Round 5: `dim_handle_tune_set` overrides a process default for ONE handle.  Two matchers side by side — one created with
+    arithmetic "fp32", one without — keep their own arithmetic across interleaved calls, the process default stays fp16x3, and the override is visible
+    in the results (fp32-MFMA and fp16x3 scores differ in the last bits while every integer output agrees)."""
+    lib = emu_install
+    lg = __import__("importlib").import_module("deep-image-matching_amd.lightglue_hip")
+    sd = weights.synthetic_lightglue_state_dict(3, 256, n_layers=2, gain=2.0)
+    conf = {"n_layers": 2, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0}
+    a = lg.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=64, device="cpu", lib=lib, arithmetic="fp32")
+    b = lg.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=64, device="cpu", lib=lib)
+    g = torch.Generator().manual_seed(5)
+    kt = torch.rand(2, 64, 2, generator=g) * 100
+    dt = torch.nn.functional.normalize(torch.randn(2, 64, 256, generator=g), dim=-1)
+    nt = torch.tensor([60, 64], dtype=torch.int32)
+    st = torch.full((2, 2), 100.0)
+    outs = [(h.match_batch(kt, dt, nt, st, n_pairs=1)) for h in (a, b, a, b)]
+    assert capi.get_arithmetic(lib) == 2
+    assert torch.equal(outs[0]["mscores01"], outs[2]["mscores01"]) and torch.equal(outs[1]["mscores01"], outs[3]["mscores01"])    # each handle reproduces itself
+    assert torch.equal(outs[0]["matches01"], outs[1]["matches01"])                                                                  # same decisions
+    assert not torch.equal(outs[0]["mscores01"], outs[1]["mscores01"])                                                              # different arithmetic really ran
+    assert (outs[0]["mscores01"] - outs[1]["mscores01"]).abs().max().item() < 1e-5
+    # back to the process default: handle a now equals handle b bit for bit
+    capi.set_handle_arithmetic(lib, a._h, None)
+    assert torch.equal(a.match_batch(kt, dt, nt, st, n_pairs=1)["mscores01"], outs[1]["mscores01"])
+    # a key without a per-handle form is refused
+    assert lib.dim_handle_tune_set(a._h, 6, 2) != 0 and b"per-handle" in lib.dim_last_error()
