@@ -73,7 +73,21 @@ __device__ __forceinline__ unsigned ft_now() {
 // ROLL (the fused feed-forward's K loop since round 4; dim_tune_set key 14 = 36 selects the previous one-k-step-at-a-time loop): the weight fragments of column tile n are
 // re-requested for the NEXT k-step right after this step's MFMAs on tile n have been issued — every request has the other tiles' MFMAs (3/4 of a
 // step) in front of its use, in the same 32 registers; the activation prefetch goes out between the chunk's two steps (requests retire in order).
-template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32, bool DB = false, bool ROLL = false>
+// STREAM (round 5 prototype, research build only: dim_tune_set key 14 = 63 on the 64 x 128 block of SMALL problems — one pair per call through the plugin
+// hooks, fp16x3): no LDS, no barriers.  The idea: a launch with fewer workgroups than the chip has slots runs for as long as ONE workgroup's serial chain,
+// and the staged loop's chain is K / 32 x {wait for the activation prefetch, split, ds_write, barrier, wait for the weight fragments, ds_read, 12 MFMAs,
+// barrier}.  Here every wave reads the fp32 rows of ITS 32 x 16 A fragment straight from global memory (a lane's 8 consecutive k values = two 16-byte
+// loads), splits them in registers into the operand the LDS image would have held, and keeps DIM_STREAM_D k-steps of activations AND weight fragments in
+// flight in a register ring (vmcnt(18..22) in the ISA).  Same pieces, same per-accumulator term order, same epilogue: bit-identical results.  MEASURED
+// (profiles/r05_ab_small_gemm_stream.jsonl, 4096 rows): 16.6 vs 13.3 us (256 -> 768), 9.8 vs 9.1 (256 -> 256 + residual), 16.9 vs 15.4 (512 -> 512),
+// 15.8 vs 15.2 (512 -> 256 + residual); a ring of 8 k-steps is slower still.  The chain was not the bound: both loops cost ~0.38 us per 16-wide k-step
+// per workgroup, i.e. the ~24 KB per k-step that the workgroup's four waves pull through the CU's 64 B / clk vector-memory path (every weight fragment
+// twice, and here every activation row twice and in half-used cache lines), and a launch is ~4.7 us before it does anything (the duration rocprofv3
+// reports for the one-workgroup lg_decide_kernel).  Kept for the record.
+#ifndef DIM_STREAM_D
+#define DIM_STREAM_D 4
+#endif
+template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32, bool DB = false, bool ROLL = false, bool STREAM = false, int STREAM_KS = 0>
 __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, int by) {
   using S = SplitMma<MODE>;
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
@@ -87,6 +101,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && (BM == 128 || BM == 256)), "the K|V image epilogue exists for the fp16x3 128 / 256 x 256 blocks");
   static_assert(KV != 4 || (MODE == 2 && BN == 512 && (BM == 64 || BM == 128) && WN == 4 && NT == 4), "the fused ffn exists for the fp16x3 64 / 128 x 512 blocks");
   static_assert(KV != 3 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4), "the LayerNorm + GELU epilogue exists for the fp16x3 64 x 512 block");
+  static_assert(!STREAM || (MT == 1 && KV == 0 && PROBE == 0 && !PIPE && !DB && !ROLL && KCH == 32), "the streaming K loop exists for one 32-row tile per wave and the plain epilogue");
   const int z = blockIdx.z;
   if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
@@ -199,6 +214,51 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     }
   };
 
+  if constexpr (STREAM) {
+    constexpr int STREAM_D = DIM_STREAM_D;   // k-steps in flight, each 8 + 16 registers
+    const int arow = min(m0 + wm * 32 + lx, rows - 1);   // rows past the ragged end re-read the last valid row (never stored)
+    const float* const ap0 = A0 + (size_t)arow * a.lda0 + half * 8;
+    const float* const ap1 = A1 ? A1 + (size_t)arow * a.lda1 + half * 8 : nullptr;
+    float4 ar[STREAM_D][2];
+    u32x4 br[STREAM_D][NT][NPL];
+    auto fetch = [&](int ks, float4 (&x)[2], u32x4 (&f)[NT][NPL]) {
+      const int k0 = ks * 16;
+      const float* src = (ap1 == nullptr || k0 < a.ksplit) ? ap0 + k0 : ap1 + (k0 - a.ksplit);
+      x[0] = *(const float4*)src;
+      x[1] = *(const float4*)(src + 4);
+      load_b(ks, f);
+    };
+#pragma unroll
+    for (int d = 0; d < STREAM_D; ++d) fetch(min(d, KS - 1), ar[d], br[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    // STREAM_KS (16, 32 = K 256, 512: every linear of LightGlue): the loop is unrolled completely — in straight-line code the compiler sizes every
+    // wait for exactly the request it needs (vmcnt = what was issued after it); at a loop header it waits for everything in flight, i.e. the ring
+    // would drain once per round.  0: run-time K, that loop.
+    const int ksn = STREAM_KS ? STREAM_KS : KS;
+#pragma unroll
+    for (int ks0 = 0; ks0 < ksn; ks0 += STREAM_D) {
+#pragma unroll
+      for (int d = 0; d < STREAM_D; ++d) {
+        if (ks0 + d < ksn) {   // (wave-uniform)
+          unsigned pc[4][NPL];
+          S::split(ar[d][0].x, ar[d][0].y, S::act_scale(), pc[0]);
+          S::split(ar[d][0].z, ar[d][0].w, S::act_scale(), pc[1]);
+          S::split(ar[d][1].x, ar[d][1].y, S::act_scale(), pc[2]);
+          S::split(ar[d][1].z, ar[d][1].w, S::act_scale(), pc[3]);
+          u32x4 fa[NPL];
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) fa[pl] = u32x4{pc[0][pl], pc[1][pl], pc[2][pl], pc[3][pl]};
+#pragma unroll
+          for (int tm = 0; tm < S::NT; ++tm)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[0][n] = S::mma(fa[S::ta(tm)], br[d][n][S::tb(tm)], acc[0][n]);
+          __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every request to just in front of its use: 76 registers, vmcnt(0) everywhere)
+          if (!STREAM_KS || ks0 + d + STREAM_D < STREAM_KS) fetch(min(ks0 + d + STREAM_D, KS - 1), ar[d], br[d]);   // (run-time K: the tail harmlessly re-reads the last k-step)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  } else {
   load_chunk(0);
   const int k_end = (PROBE & 32) ? KC : a.K;   // probe bit 5: one K chunk only
   if (PIPE && ROLL) {
@@ -331,6 +391,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     __syncthreads();
     FT_TICK(3);
   }
+  }   // (!STREAM)
 
   if constexpr (ffn) {
     // ================= LightGlue's whole feed-forward in one workgroup (LGN:141-142,159,209): the 64 x 512 hidden tile never
@@ -763,6 +824,13 @@ __global__ __launch_bounds__(256, ((BM / (32 * (4 / WN))) * NT >= 16 ? 1 : ((BM 
   __shared__ unsigned Ap[SplitMma<MODE>::NPL * BM * RS];
   gemm_x6_body<MODE, BM, NT, 0, WN, 0, (WN == 4)>(a, Ap, (int)blockIdx.y);   // the wide block runs the pipelined K loop
 }
+#ifdef DIM_RESEARCH
+// small problems, fp16x3: the streaming K loop (see STREAM above; prototype, dim_tune_set key 14 = 63); no LDS
+template <int KS_T>
+__global__ __launch_bounds__(256, 2) void gemm_x6_stream_kernel(GemmArgs a) {
+  gemm_x6_body<2, 64, 2, 0, 2, 0, false, 32, false, false, true, KS_T>(a, nullptr, (int)blockIdx.y);
+}
+#endif
 // LightGlue's ffn.0 with LayerNorm + GELU in the epilogue: one workgroup owns 64 rows x all 512 columns
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 64 * RS];
@@ -1039,6 +1107,12 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.kv_img == nullptr || (!small && wide_block(a.M, a.n_pad, batch, a.split_mode)), "gemm_x6: K|V images need the 128 x 256 block (gemm_x6_fuses_kv)");
   if (small) {
     dim3 grid(cdiv(a.M, 64), cdiv(a.N, BN), batch);
+#ifdef DIM_RESEARCH   // the streaming K loop (14 = 63): bit-identical, measured SLOWER than the staged loop at every LightGlue shape (see STREAM above)
+    if (a.split_mode == 2 && dim_gemm_kc() == 63 && a.K == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<16>), grid, dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && dim_gemm_kc() == 63 && a.K == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<32>), grid, dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && dim_gemm_kc() == 63) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<0>), grid, dim3(256), 0, s, a);
+    else
+#endif
     if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<1, 64>), grid, dim3(256), 0, s, a);
   } else if (wide_block(a.M, a.n_pad, batch, a.split_mode)) {

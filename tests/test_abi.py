@@ -72,5 +72,5 @@ def test_product_library_rejects_the_research_keys_and_the_research_build_has_th
     assert hasattr(rlib, "dim_conv_wg_phase_read")
     # the prototype / probe kernels are not in the product binary at all (their names appear in the embedded code object's symbol table)
     prod, res = (build.LIBDIR / "libdim_hip.so").read_bytes(), (build.LIBDIR / "libdim_hip_research.so").read_bytes()
-    for name in (b"conv3x3_wg_f1a_kernel", b"gemm_x6_probe_kernel", b"gemm_x6_qkv_kc64_kernel", b"gemm_x6_ffn_fused_step_kernel"):
+    for name in (b"conv3x3_wg_f1a_kernel", b"gemm_x6_probe_kernel", b"gemm_x6_qkv_kc64_kernel", b"gemm_x6_ffn_fused_step_kernel", b"gemm_x6_stream_kernel"):
         assert name in res and name not in prod, name

@@ -118,6 +118,29 @@ def test_gemm_wide_blocks_are_bit_identical(emu_lib, M, N, K):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K", [(130, 256, 512), (200, 500, 64), (70, 128, 256)])
+def test_gemm_streaming_k_loop_prototype_is_bit_identical(emu_research_lib, M, N, K):
+    """Research build only (dim_tune_set key 14 = 63): the small-problem block with the barrier-free streaming K loop (activation fragments straight from
+    global memory, register ring) — same pieces, same term order as the staged loop; measured slower on hardware (profiles/r05_ab_small_gemm_stream.jsonl)."""
+    lib = emu_research_lib
+    g = torch.Generator().manual_seed(K + M)
+    A, W = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g).contiguous()
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    dev, npad = ctypes.c_void_p(), ctypes.c_int()
+    assert lib.dim_x3_create(p(W), K, N, ctypes.byref(dev), ctypes.byref(npad)) == 0
+    outs = []
+    try:
+        for kc in (0, 63):
+            assert lib.dim_tune_set(14, kc) == 0
+            C = torch.full((M, N), -3.0)
+            assert lib.dim_op_gemm_x6_f32(p(A), K, dev, npad.value, p(bias), p(R), N, p(C), N, M, N, K, 1, None) == 0, lib.dim_last_error()
+            outs.append(C)
+    finally:
+        lib.dim_tune_set(14, 0)
+        lib.dim_x3_destroy(dev)
+    assert torch.equal(outs[0], outs[1]) and (outs[0] != -3.0).all()
+
+
 @pytest.mark.parametrize("cin,cout,H,W,pool", [(64, 64, 20, 37, 1), (64, 128, 9, 33, 0), (128, 128, 16, 34, 1)])
 def test_conv3x3_split_precision_is_fp32_accurate(emu_lib, split_mode, cin, cout, H, W, pool):
     g = torch.Generator().manual_seed(cin + H)
