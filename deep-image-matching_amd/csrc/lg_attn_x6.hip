@@ -349,6 +349,7 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
   a.splits = (st.attn_part && st.n_items <= st.attn_part_items) ? (wgs <= 128 ? 4 : (wgs <= 256 ? 2 : 1)) : 1;
   a.probe = cross ? dim_attn_probe() : 0;
   if (a.probe == 2) a.splits = 16;  // probe 2: every query block's key range in 16 parts -> the partial-record volume of a shared score tile, written AND merged
+  if (dim_attn_probe() == 8 || dim_attn_probe() == 16) { a.probe = 0; if (a.splits > 1) a.splits = dim_attn_probe(); }   // research: a finer key split for small batches (results stay correct)
   a.qblocks = cdiv(st.nmax, 128) * a.splits;
   a.groups = 4 * st.n_items;
   dim3 grid((unsigned)(cdiv(a.groups, 8) * 8 * a.qblocks));  // whole rounds of 8 groups, one per XCD (surplus workgroups exit)

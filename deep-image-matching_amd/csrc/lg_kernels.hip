@@ -514,21 +514,25 @@ __global__ __launch_bounds__(256) void lg_row_stats4_kernel(LgState st, int tag,
   s = wave_sum(s);
   if (lane == 0) { st.rmax[r] = m; st.rlse[r] = logf(s); }
 }
-// thread = 4 adjacent columns x every 16th row; workgroup = 256 columns
+// thread = 4 adjacent columns x every COL_RG-th row; workgroup = 4 COL_CW columns.  COL_CW 16 (round 5; 64 before): 32 instead of 8 workgroups per pair
+// at 2048 columns, 32 instead of 128 dependent loop steps per thread — ONE pair per call (the plugin hooks) ran these two passes on 8 of the chip's 256
+// CUs (65 + 39 us per pair; the row passes, one wave per row, take 7 + 7).  A row segment of a workgroup is still 256 contiguous bytes.  The SAME shape
+// at every batch size: a pair's result does not depend on how many pairs share the launch.
+constexpr int COL_CW = 16, COL_RG = 1024 / COL_CW;
 __global__ __launch_bounds__(1024) void lg_col_stats4_kernel(LgState st, int tag) {
-  __shared__ float4 redm[16][64], reds[16][64];
+  __shared__ float4 redm[COL_RG][COL_CW], reds[COL_RG][COL_CW];
   const int p = blockIdx.y;
   if (st.done[p] != tag) return;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 256 + tx * 4;
+  const int tx = threadIdx.x % COL_CW, ty = threadIdx.x / COL_CW;
+  const int col = blockIdx.x * (4 * COL_CW) + tx * 4;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
-  if (blockIdx.x * 256 >= ncol) return;
+  if (blockIdx.x * (4 * COL_CW) >= ncol) return;
   const bool ok = col < ncol;
   const float* sp = st.sim + (size_t)p * st.nmax * st.nmax + col;
   float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
   if (ok) {
 #pragma unroll 4
-    for (int i = ty; i < nrow; i += 16) {
+    for (int i = ty; i < nrow; i += COL_RG) {
       const float4 v = *(const float4*)(sp + (size_t)i * st.nmax);
       const float xv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -541,15 +545,15 @@ __global__ __launch_bounds__(1024) void lg_col_stats4_kernel(LgState st, int tag
   }
   redm[ty][tx] = make_float4(m[0], m[1], m[2], m[3]); reds[ty][tx] = make_float4(sm[0], sm[1], sm[2], sm[3]);
   __syncthreads();
-  if (ty < 4 && ok) {   // thread (tx, e = ty): merges the 16 row groups of column col + e
+  if (ty < 4 && ok) {   // thread (tx, e = ty): merges the COL_RG row groups of column col + e
     const int e = ty;
     if (col + e < ncol) {
       float M = -INFINITY;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) M = fmaxf(M, ((const float*)&redm[g][tx])[e]);
+#pragma unroll 16
+      for (int g = 0; g < COL_RG; ++g) M = fmaxf(M, ((const float*)&redm[g][tx])[e]);
       float S = 0.f;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
+#pragma unroll 16
+      for (int g = 0; g < COL_RG; ++g) {
         const float mg = ((const float*)&redm[g][tx])[e];
         if (mg > -INFINITY) S += ((const float*)&reds[g][tx])[e] * exp_le0(mg - M);
       }
@@ -594,14 +598,14 @@ __global__ __launch_bounds__(256) void lg_row_argmax4_kernel(LgState st, int tag
   if (lane == 0) { st.best[r0] = best; st.arg[r0] = bi; }
 }
 __global__ __launch_bounds__(1024) void lg_col_argmax4_kernel(LgState st, int tag) {
-  __shared__ float4 redv[16][64];
-  __shared__ int redi[16][64][4];
+  __shared__ float4 redv[COL_RG][COL_CW];
+  __shared__ int redi[COL_RG][COL_CW][4];
   const int p = blockIdx.y;
   if (st.done[p] != tag) return;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 256 + tx * 4;
+  const int tx = threadIdx.x % COL_CW, ty = threadIdx.x / COL_CW;
+  const int col = blockIdx.x * (4 * COL_CW) + tx * 4;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
-  if (blockIdx.x * 256 >= ncol) return;
+  if (blockIdx.x * (4 * COL_CW) >= ncol) return;
   const bool ok = col < ncol;
   const size_t r0 = (size_t)(2 * p) * st.nmax, c = (size_t)(2 * p + 1) * st.nmax + (ok ? col : 0);
   const float4 cm = *(const float4*)(st.rmax + c), cl = *(const float4*)(st.rlse + c), z1 = *(const float4*)(st.zls + c);
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(1024) void lg_col_argmax4_kernel(LgState st, int ta
   int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
   if (ok) {
 #pragma unroll 4
-    for (int i = ty; i < nrow; i += 16) {
+    for (int i = ty; i < nrow; i += COL_RG) {
       const float4 x = *(const float4*)(sp + (size_t)i * st.nmax);
       const float rm = st.rmax[r0 + i], rl = st.rlse[r0 + i], z0 = st.zls[r0 + i];
       const float xv[4] = {x.x, x.y, x.z, x.w};
@@ -630,8 +634,8 @@ __global__ __launch_bounds__(1024) void lg_col_argmax4_kernel(LgState st, int ta
     const int e = ty;
     float b = -INFINITY;
     int ix = 0x7fffffff;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {  // first maximal row index wins ties (Tensor.max on CPU)
+#pragma unroll 16
+    for (int g = 0; g < COL_RG; ++g) {  // first maximal row index wins ties (Tensor.max on CPU)
       const float ov = ((const float*)&redv[g][tx])[e];
       const int oi = redi[g][tx][e];
       if (ov > b || (ov == b && oi < ix)) { b = ov; ix = oi; }
@@ -644,7 +648,7 @@ static bool assign_fast_shape(const LgState& st) { return (st.nmax & 3) == 0 && 
 int launch_lg_assign_stats(const LgState& st, int tag, const float* w_match, const float* b_match, hipStream_t s) {
   if (assign_fast_shape(st)) {
     hipLaunchKernelGGL(lg_row_stats4_kernel, dim3(cdiv(st.nmax, 4), st.n_items), dim3(256), 0, s, st, tag, w_match, b_match);
-    hipLaunchKernelGGL(lg_col_stats4_kernel, dim3(cdiv(st.nmax, 256), st.n_pairs), dim3(1024), 0, s, st, tag);
+    hipLaunchKernelGGL(lg_col_stats4_kernel, dim3(cdiv(st.nmax, 4 * COL_CW), st.n_pairs), dim3(1024), 0, s, st, tag);
     DIM_LAUNCH_CHECK();
     return 0;
   }
@@ -656,7 +660,7 @@ int launch_lg_assign_stats(const LgState& st, int tag, const float* w_match, con
 int launch_lg_assign_argmax(const LgState& st, int tag, float* dense_scores, hipStream_t s) {
   if (assign_fast_shape(st)) {
     hipLaunchKernelGGL(lg_row_argmax4_kernel, dim3(cdiv(st.nmax, 4), st.n_pairs), dim3(256), 0, s, st, tag, dense_scores);
-    hipLaunchKernelGGL(lg_col_argmax4_kernel, dim3(cdiv(st.nmax, 256), st.n_pairs), dim3(1024), 0, s, st, tag);
+    hipLaunchKernelGGL(lg_col_argmax4_kernel, dim3(cdiv(st.nmax, 4 * COL_CW), st.n_pairs), dim3(1024), 0, s, st, tag);
     DIM_LAUNCH_CHECK();
     return 0;
   }

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
   __shared__ unsigned long long keys[TOPK_MAX];
   __shared__ int hist[256];
   __shared__ unsigned long long sh_prefix;
-  __shared__ int sh_krem, sh_cnt;
+  __shared__ int sh_krem, sh_cnt, sh_done;
   const int t = threadIdx.x, b = blockIdx.x;
   const int n = ncand[b];
   const float* cs = cand_score + (size_t)b * H8 * W8;
@@ -350,7 +350,11 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
   }
 
   // ---- radix select of the k-th largest key, one byte per pass from the top ----
-  if (t == 0) { sh_prefix = 0ull; sh_krem = k; }
+  // Round 5 (one image per call through the plugin hooks = ONE workgroup on the chip: 125 us of the call's 830): (a) four candidates per thread
+  // in flight per step instead of one dependent load per step; (b) the passes stop as soon as the selected bin is needed WHOLE (every key of it
+  // belongs to the top k: the remaining low bytes of the threshold are then 0) — with distinct scores that happens inside the score bytes, and
+  // the four index bytes (which only order ties of the k-th score) are never walked.  Same selection, same order.
+  if (t == 0) { sh_prefix = 0ull; sh_krem = k; sh_done = 0; }
   __syncthreads();
   for (int byte = 7; byte >= 0; --byte) {
     if (t < 256) hist[t] = 0;
@@ -360,15 +364,26 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
     // a thread's consecutive hits of one bin are merged into a single atomic: the leading bytes of positive float
     // scores are (nearly) constant, which would otherwise serialise every key of the image on one LDS counter
     int run_bin = -1, run_cnt = 0;
-    for (int i = t; i < n; i += 1024) {
-      const unsigned long long key = ((unsigned long long)__float_as_uint(cs[i]) << 32) | (unsigned)(~ci[i]);
-      if ((key & himask) == prefix) {
-        const int bin = (int)((key >> (8 * byte)) & 0xffull);
-        if (bin == run_bin) {
-          ++run_cnt;
-        } else {
-          if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
-          run_bin = bin; run_cnt = 1;
+    for (int i0 = t; i0 < n; i0 += 4096) {
+      float sv[4]; int iv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 1024 * u;
+        sv[u] = i < n ? cs[i] : 0.0f;
+        iv[u] = i < n ? ci[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + 1024 * u >= n) break;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(sv[u]) << 32) | (unsigned)(~iv[u]);
+        if ((key & himask) == prefix) {
+          const int bin = (int)((key >> (8 * byte)) & 0xffull);
+          if (bin == run_bin) {
+            ++run_cnt;
+          } else {
+            if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
+            run_bin = bin; run_cnt = 1;
+          }
         }
       }
     }
@@ -385,17 +400,19 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
         if (t + o < 64) suf += v;
       }
       const int a3 = suf - tot, a2 = a3 + h3, a1 = a2 + h2, a0 = a1 + h1;  // keys above bins 4t+3 .. 4t
-      int d = -1, above = 0;
-      if (a3 < krem && krem <= a3 + h3) { d = 4 * t + 3; above = a3; }
-      else if (a2 < krem && krem <= a2 + h2) { d = 4 * t + 2; above = a2; }
-      else if (a1 < krem && krem <= a1 + h1) { d = 4 * t + 1; above = a1; }
-      else if (a0 < krem && krem <= a0 + h0) { d = 4 * t; above = a0; }
+      int d = -1, above = 0, hd = 0;
+      if (a3 < krem && krem <= a3 + h3) { d = 4 * t + 3; above = a3; hd = h3; }
+      else if (a2 < krem && krem <= a2 + h2) { d = 4 * t + 2; above = a2; hd = h2; }
+      else if (a1 < krem && krem <= a1 + h1) { d = 4 * t + 1; above = a1; hd = h1; }
+      else if (a0 < krem && krem <= a0 + h0) { d = 4 * t; above = a0; hd = h0; }
       if (d >= 0) {  // exactly one lane (the prefix always holds >= krem keys)
         sh_krem = krem - above;
         sh_prefix = prefix | ((unsigned long long)d << (8 * byte));
+        sh_done = (krem - above == hd) ? 1 : 0;   // the whole bin is taken: the threshold's remaining bytes are 0
       }
     }
     __syncthreads();
+    if (sh_done) break;   // (uniform)
   }
   const unsigned long long kth = sh_prefix;
 
@@ -405,11 +422,21 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
   for (int i = t; i < P; i += 1024) keys[i] = 0ull;
   if (t == 0) sh_cnt = 0;
   __syncthreads();
-  for (int i = t; i < n; i += 1024) {
-    const unsigned long long key = ((unsigned long long)__float_as_uint(cs[i]) << 32) | (unsigned)(~ci[i]);
-    if (key >= kth) {
-      const int pos = atomicAdd(&sh_cnt, 1);
-      if (pos < P) keys[pos] = key;
+  for (int i0 = t; i0 < n; i0 += 4096) {
+    float sv[4]; int iv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 1024 * u;
+      sv[u] = i < n ? cs[i] : 0.0f;
+      iv[u] = i < n ? ci[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long key = ((unsigned long long)__float_as_uint(sv[u]) << 32) | (unsigned)(~iv[u]);
+      if (i0 + 1024 * u < n && key >= kth) {
+        const int pos = atomicAdd(&sh_cnt, 1);
+        if (pos < P) keys[pos] = key;
+      }
     }
   }
   __syncthreads();
