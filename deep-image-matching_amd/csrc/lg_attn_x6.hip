@@ -106,8 +106,16 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(AttnArgs6 a) {
 // (16 query blocks x 4 heads x 16 items) run as ONE round on 256 CUs instead of 1.33 rounds at 3 per CU
 // PROBE: the round-3 timing probes (dim_tune_set key 12) as a TEMPLATE parameter: as a run-time test around the score MFMAs they forced the
 // product kernel to materialise the zeroed score accumulator (16 v_mov per key tile; every VALU instruction is time)
-template <int MODE, int PROBE = 0>
+// NBUF: key-tile images in LDS.  2 (the product): the next tile arrives while this one is consumed.  3 (round 5 prototype, research build, dim_tune_set key
+// 12 = 22, the key-split launches of SMALL batches — one pair per call through the plugin hooks): two tiles ahead; the wait in front of the barrier then
+// retires the OLDEST transfer only (vector-memory operations complete in order: vmcnt(4) leaves the newer tile's four 16-byte copies in flight).  The
+// idea: with 2 workgroups per CU instead of 3.6 nothing else covers the L2 / HBM round trip of a 16-KB tile image.  MEASURED (profiles/r05_batch1_calls.json):
+// one 2048 x 2048 pair 1.953 / 1.958 ms against 1.920 / 1.918 with one tile ahead — the 2.2 us a workgroup spends per key tile are its own dependent
+// chain (12 MFMAs into one score accumulator, the softmax, 12 more), not the transfer.  Bit-identical; kept for the record and for the emulator's
+// partial-wait model (tests/test_lightglue_emu.py).
+template <int MODE, int PROBE = 0, int NBUF = 2>
 __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnArgs6 a) {
+  static_assert(NBUF == 2 || (NBUF == 3 && MODE == 2 && PROBE == 0), "three tile images exist for the fp16x3 product kernel");
   using S = SplitMma<MODE>;
   constexpr int NPL = S::NPL, TILE_SLOTS = tile_slots(NPL), KSL = NPL * 256, NCP = TILE_SLOTS / 256;
   // K, Q, V and P are multiplied by the (power-of-two) activation scale before the split: exact factors
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
 
   // two tile images: the next key tile arrives by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass)
   // in the other half while this one is consumed — one barrier per tile
-  __shared__ u32x4 img[2 * TILE_SLOTS];
+  __shared__ u32x4 img[NBUF * TILE_SLOTS];
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, lx = lane & 31, half = lane >> 5;
   const int qrow = q0 + wv * 32 + lx;
@@ -187,13 +195,32 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
   const int per = ((nk + 31) / 32 + a.splits - 1) / a.splits * 32;
   const int kt0 = sp * per, kt1 = min(nk, kt0 + per);
   if (kt0 < kt1) load_tile(kt0, 0);
+  if (NBUF == 3 && kt0 + 32 < kt1) load_tile(kt0 + 32, 1);
+#if defined(__AMDGCN__)
+  if (NBUF == 3) {
+    // the Q fragments of a cross launch are plain loads that nothing consumes before the loop: retire them HERE (the empty asm makes them inputs),
+    // or the compiler, which cannot see that the partial wait below covers them, puts a vmcnt(0) in front of every tile's first MFMA
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) asm volatile("" : "+v"(qf[s][pl]));
+  }
+#endif
   int buf = 0;
-  for (int kt = kt0; kt < kt1; kt += 32, buf ^= 1) {
+  for (int kt = kt0; kt < kt1; kt += 32, buf = (NBUF == 2 ? buf ^ 1 : (buf == 2 ? 0 : buf + 1))) {
     // the compiler does not order the barrier after the DMA by itself; after it every wave has also left the tile that
-    // lived in the other half, which the next transfer may overwrite
-    lds_dma_wait_all();
-    __syncthreads();
-    if (kt + 32 < kt1) load_tile(kt + 32, buf ^ 1);
+    // lived in the buffer the next transfer overwrites
+    if (NBUF == 2) {
+      lds_dma_wait_all();
+      __syncthreads();
+      if (kt + 32 < kt1) load_tile(kt + 32, buf ^ 1);
+    } else {
+      // this tile's transfer is the oldest in flight; the next tile's (if there is one) stays in flight.  lgkmcnt(0): this wave's LDS reads of the
+      // previous tile are done (their MFMAs were issued).  A plain s_barrier: __syncthreads() would bring its own vmcnt(0).
+      if (kt + 32 < kt1) __builtin_amdgcn_s_waitcnt(0x0074); else __builtin_amdgcn_s_waitcnt(0x0070);
+      __builtin_amdgcn_s_barrier();
+      if (kt + 64 < kt1) load_tile(kt + 64, buf == 0 ? 2 : buf - 1);
+    }
     const u32x4* Kp = img + buf * TILE_SLOTS;
     const u32x4* Vp = Kp + KSL;
 
@@ -350,6 +377,9 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
   a.probe = cross ? dim_attn_probe() : 0;
   if (a.probe == 2) a.splits = 16;  // probe 2: every query block's key range in 16 parts -> the partial-record volume of a shared score tile, written AND merged
   if (dim_attn_probe() == 8 || dim_attn_probe() == 16) { a.probe = 0; if (a.splits > 1) a.splits = dim_attn_probe(); }   // research: a finer key split for small batches (results stay correct)
+  const bool two_ahead = dim_attn_probe() == 22;   // research, 22: the key-split launches with TWO tiles of prefetch distance (prototype; results identical, measured slower)
+  if (two_ahead) a.probe = 0;
+  (void)two_ahead;
   a.qblocks = cdiv(st.nmax, 128) * a.splits;
   a.groups = 4 * st.n_items;
   dim3 grid((unsigned)(cdiv(a.groups, 8) * 8 * a.qblocks));  // whole rounds of 8 groups, one per XCD (surplus workgroups exit)
@@ -358,6 +388,8 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
 #ifdef DIM_RESEARCH   // cross-attention timing probes (wrong results by design): research build only
     if (a.probe == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2, 1>), grid, dim3(256), 0, s, a);
     else if (a.probe == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2, 3>), grid, dim3(256), 0, s, a);
+    else
+    if (a.splits > 1 && two_ahead) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2, 0, 3>), grid, dim3(256), 0, s, a);
     else
 #endif
     hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_x6_kernel<2>), grid, dim3(256), 0, s, a);

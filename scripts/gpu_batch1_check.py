@@ -1,6 +1,6 @@
 """GPU: the batch-1 calls of the plugin hooks on resident tensors (HIP events): SuperPoint on one 1024 x 1024 image, LightGlue on one 2048 x 2048 pair
 (9 layers, fixed work), the latter with the key range of its attention launches cut into 4 (product), 8 or 16 parts (research library,
-dim_tune_set(12, 8 / 16), set before the matcher allocates its partial-result scratch)."""
+dim_tune_set(12, 8 / 16), set before the matcher allocates its partial-result scratch) and with two instead of one key tiles of prefetch distance (12 = 22)."""
 import ctypes, importlib, json, os, sys
 import numpy as np, torch
 torch.set_num_threads(min(16, os.cpu_count() or 16))
@@ -38,7 +38,7 @@ kp, sc, de, n = out_sp
 kt = torch.stack([kp[0], kp[0]]).contiguous(); dt_ = torch.stack([de[0], de[0]]).contiguous()
 nt = torch.stack([n[0], n[0]]).contiguous(); st = torch.full((2, 2), 1024.0, device=dev)
 ref = None
-for splits in (0, 8, 16, 0):
+for splits in (0, 22, 0, 22, 8):
     assert lib.dim_tune_set(12, splits) == 0, lib.dim_last_error()
     mt = plugins.LightGlueMatcher({"general": {}, "matcher": {"name": "lightglue", "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1,
                                                                "allow_synthetic_weights": True}}, local_features="superpoint")
@@ -49,7 +49,7 @@ for splits in (0, 8, 16, 0):
     nm = int(out["n_matches"][0]); m = out["matches"][0, :nm].cpu()
     if ref is None:
         ref = m
-    res.setdefault("lightglue_batch1", []).append({"key_splits": splits or 4, "ms_per_pair": t_ms(lambda: lgn.match_batch(kt, dt_, nt, st, n_pairs=1, out=out)),
+    res.setdefault("lightglue_batch1", []).append({"knob_12": splits, "what": {0: "product: 4 key parts, one key tile ahead", 22: "4 key parts, two key tiles ahead (prototype)", 8: "8 key parts", 16: "16 key parts"}[splits], "ms_per_pair": t_ms(lambda: lgn.match_batch(kt, dt_, nt, st, n_pairs=1, out=out)),
                                                    "matches": nm, "same_matches_as_4_splits": bool(m.shape == ref.shape and torch.equal(m, ref))})
     del mt, lgn
     torch.cuda.empty_cache()

@@ -76,15 +76,18 @@ void dma_issue(void* lds_dst, const void* src, unsigned size) {
   pending_dma[cur->flat].push_back(d);
 }
 void set_dma_mode(int early) { dma_early = early; }
-void dma_retire() {
+void dma_retire(unsigned keep_newest) {   // s_waitcnt vmcnt(keep_newest): in-order completion, the newest `keep_newest` transfers stay in flight
   if (pending_dma.size() <= cur->flat) return;
-  for (const PendingDma& d : pending_dma[cur->flat]) memcpy(d.dst, d.data, d.size);
-  pending_dma[cur->flat].clear();
+  std::vector<PendingDma>& q = pending_dma[cur->flat];
+  if (q.size() <= keep_newest) return;
+  const size_t n = q.size() - keep_newest;
+  for (size_t i = 0; i < n; ++i) memcpy(q[i].dst, q[i].data, q[i].size);
+  q.erase(q.begin(), q.begin() + n);
 }
 
 static void fiber_main() {
   (*body_fn)();
-  dma_retire();  // a thread's outstanding transfers complete at the latest when it ends
+  dma_retire(0);  // a thread's outstanding transfers complete at the latest when it ends
   Fiber* f = cur;
   f->state = 2;
   waves[f->wave].alive--;

@@ -85,7 +85,7 @@ void wave_collective(const void* in, unsigned bytes, void (*compute)(const unsig
 // the emulated transfer snapshots its source bytes at issue and lands only when the issuing thread executes
 // s_waitcnt vmcnt(0) (or exits) — a kernel that forgets the wait reads stale LDS here too and fails its parity test.
 void dma_issue(void* lds_dst, const void* src, unsigned size);
-void dma_retire();
+void dma_retire(unsigned keep_newest = 0);
 void set_dma_mode(int early);  // 1: land at issue instead (exposes restaging a buffer other threads still read)
 }  // namespace hipemu
 
@@ -289,9 +289,11 @@ static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(hipemu_rsrc r, int o
 static inline void __builtin_amdgcn_global_load_lds(const void* gptr, __attribute__((address_space(3))) void* lds, unsigned size, int offset, int) {
   hipemu::dma_issue((char*)(unsigned long long)lds + (size_t)hipemu::cur->lane * size + offset, gptr, size);
 }
-// s_waitcnt simm16 (gfx9 encoding): vmcnt = bits 3:0 | bits 15:14 << 4.  vmcnt(0) retires this thread's LDS-DMA transfers.
+// s_waitcnt simm16 (gfx9 encoding): vmcnt = bits 3:0 | bits 15:14 << 4.  vmcnt(N) retires this thread's LDS-DMA transfers except the N newest
+// (vector-memory operations complete in order); 63 = "any" retires nothing.
 static inline void __builtin_amdgcn_s_waitcnt(int imm) {
-  if ((((unsigned)imm & 0xFu) | ((((unsigned)imm >> 14) & 3u) << 4)) == 0) hipemu::dma_retire();
+  const unsigned n = ((unsigned)imm & 0xFu) | ((((unsigned)imm >> 14) & 3u) << 4);
+  if (n < 63u) hipemu::dma_retire(n);
 }
 
 // DPP quad permutes used by the kernels: 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2)

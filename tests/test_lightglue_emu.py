@@ -87,6 +87,41 @@ def test_attention_tile_dma_is_ordered_both_ways(emu_lib):
     assert torch.equal(out["dense"], out2["dense"]) and torch.equal(out["matches"][0], out2["matches"][0])
 
 
+def test_key_split_attention_with_two_tiles_of_prefetch_distance(emu_research_lib):
+    """One pair per call (the plugin hooks): the attention launches cut the key range into 4 parts.  Round-5 prototype (research build, knob 12 = 22;
+    measured slower on hardware): TWO key-tile images in flight (three LDS buffers, `s_waitcnt vmcnt(4)` = retire the oldest
+    transfer only, a plain s_barrier).  The golden cases have one tile per part — this one has 4 / 3 (ragged last part), so the ring wraps: equal bit
+    for bit to the product's one-tile-ahead kernel, with the emulated transfers landing at the wait (a wait that retires too little reads a stale tile
+    — the emulator's s_waitcnt retires all but the N newest transfers of a thread) AND at issue with the waves maximally out of step (a transfer into a
+    buffer that is still being read corrupts it); the product kernel equals the oracle."""
+    lib = emu_research_lib
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_lightglue_state_dict(7, 256, n_layers=1, gain=2.0)
+    conf = {"n_layers": 1, "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0}
+    g = torch.Generator().manual_seed(11)
+    n0, n1 = 500, 361
+    f = [{"kpts": torch.rand(n, 2, generator=g) * 640, "desc": torch.nn.functional.normalize(torch.randn(n, 256, generator=g), dim=-1)} for n in (n0, n1)]
+    size = torch.tensor([480.0, 640.0])
+    data = {"image0": {"keypoints": f[0]["kpts"][None], "descriptors": f[0]["desc"][None], "image_size": size[None]},
+            "image1": {"keypoints": f[1]["kpts"][None], "descriptors": f[1]["desc"][None], "image_size": size[None]}}
+    outs = []
+    try:
+        for knob, dma_early in ((0, 0), (22, 0), (22, 1)):
+            assert lib.dim_tune_set(12, knob) == 0
+            lib.hipemu_set_dma_mode(dma_early)
+            lib.hipemu_set_schedule(1 if dma_early else 0)
+            net = lg_mod.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=n0, device="cpu", lib=lib)
+            outs.append(net(data, dense=True))
+    finally:
+        lib.dim_tune_set(12, 0)
+        lib.hipemu_set_dma_mode(0)
+        lib.hipemu_set_schedule(1 if os.environ.get("HIPEMU_ORDER") == "wave_serial" else 0)
+    for o in outs[1:]:
+        assert torch.equal(outs[0]["dense"], o["dense"]) and torch.equal(outs[0]["matches"][0], o["matches"][0])
+    ref = lightglue_ref.lightglue_forward(f[0]["kpts"], f[0]["desc"], size, f[1]["kpts"], f[1]["desc"], size, sd, conf, taps=True)
+    compare_lightglue(outs[0], ref, dense_ref=ref.get("log_assignment"), dense_out=outs[0]["dense"])
+
+
 def test_batch_with_ragged_and_empty_images_on_the_projection_written_images(emu_lib):
     """A batch of ragged pairs (one image without keypoints) through pair_idx on the large-batch path (K | V tile images written
     by the projection GEMM, forced with dim_tune_set(6, 2)), adaptive depth and width on: every pair equals the same pair
