@@ -97,6 +97,8 @@ def parse():
     ap.add_argument("--cpu-only", action="store_true", help="config1: run only the CPU leg (the reference modules when /root/reference exists): this is how the "
                     "build container produces profiles/*_config1_cpu_reference.json")
     ap.add_argument("--no-hook-path", action="store_true", help="skip the hook_path sub-record (batch-1 calls through the plugin classes)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="keep roofline.traffic at the value cited from profiles/conv1b_hbm_bytes.json instead of measuring it with two "
+                    "rocprofv3 --pmc passes of a one-step child run (N = 1 only; skipped when rocprofv3 is not on PATH)")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the strong_scaling sub-record (the config-4 job run after the timed region)")
     a = ap.parse_args()
     if a.images is None:
@@ -642,6 +644,55 @@ def measure_hook_path(dev, lib, n_img: int = 6, n_pair: int = 6):
     return rec
 
 
+def measure_traffic_live(a, timeout_s: float = 240.0):
+    """roofline.traffic of THIS run: HBM bytes per launch of the dominant kernel from the L2's memory-side counters, collected as
+    MI355X_MICROARCH.md section HBM prescribes — two SEPARATE rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; no trace domain
+    next to the counters), each over a one-step child run of this very command (same pairs per step = same images per launch), FETCH_SIZE doubled (gfx950
+    tallies the 128-byte requests of wide coalesced reads at 64 bytes), WRITE_SIZE as reported (it checks out exactly against known byte counts), counter
+    unit KiB per dispatch.  Returns {"hbm_bytes_per_launch", "fetch_bytes_corrected_x2", "write_bytes", "launches_counted", "seconds"}."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        raise RuntimeError("rocprofv3 not on PATH")
+    t0 = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="dim_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    child = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", str(a.pairs), "--no-cpu-baseline", "--main-region-only",
+             "--no-hook-path", "--no-strong-scaling", "--no-live-traffic"]
+    if a.lib:
+        child += ["--lib", a.lib]
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", *child]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=timeout_s / 2)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)          # exactly the process group this call started
+                raise RuntimeError(f"the {counter} pass did not finish in {timeout_s / 2:.0f} s")
+            files = [os.path.join(r, f) for r, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if p.returncode != 0 or not files:
+                raise RuntimeError(f"the {counter} pass failed (rc {p.returncode}, {len(files)} counter files)")
+            rows = [r for r in csv.DictReader(open(files[0])) if "conv3x3_x6_kernel<64, 1, 1, true, 2" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not rows:
+                raise RuntimeError(f"no dispatch of the dominant kernel in the {counter} pass")
+            grid = max(int(r["Grid_Size"]) for r in rows)       # the full 2P-image launches (the warm-up step has the same shape)
+            vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == grid]
+            per[counter] = (sum(vals) / len(vals) * 1024.0, len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = 2.0 * per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
+    return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
+            "launches_counted": {"FETCH_SIZE": per["FETCH_SIZE"][1], "WRITE_SIZE": per["WRITE_SIZE"][1]}, "seconds": time.perf_counter() - t0}
+
+
 def strong_scaling_subrun(a, rank, world, dev, dist, lib, line):
     """Strong scaling where the driver's 1/2/4/8 command sees it: the FIXED config-4 job (150 images -> 10 000 exhaustive
     pairs, images and pairs sharded over the ranks, two all-gathers) after the headline region; `value` stays the headline.  ``line`` (rank 0's
@@ -931,7 +982,9 @@ def main():
                                       "achieved": gflop_per_launch / (iso_ms.value / max(1, iso_n.value)),
                                       "frac": gflop_per_launch / (iso_ms.value / max(1, iso_n.value)) / PEAK_BF16_MFMA_TFLOPS},
                          "avg_launch_ms": conv_ms, "launches": launches.value,
-                         "algorithmic_gflop_per_launch": gflop_per_launch},
+                         "algorithmic_gflop_per_launch": gflop_per_launch,
+                         # what the launch must move: the fp32 image in, the pooled 64-channel map out as two fp16 planes (= 4 bytes per value)
+                         "algorithmic_hbm_bytes_per_launch": (1024 * 1024 * 4 + 512 * 512 * 64 * 4) * 2 * P},
         }
     # the per-call plugin hooks at the headline sizes: measured before the strong-scaling sub-run, whose host-side image
     # synthesis spins up torch's CPU thread pool
@@ -944,6 +997,16 @@ def main():
         del pool, feats, flat, outs
         torch.cuda.empty_cache()
         strong_scaling_subrun(a, rank, world, dev, dist, lib, line)
+    if rank == 0 and world == 1 and not a.no_live_traffic and not a.main_region_only:
+        # after everything that is timed: two counter passes over a one-step child run (the GPU is idle, this process's batch tables are released)
+        try:
+            tr = measure_traffic_live(a)
+            line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            line["roofline"]["traffic_note"] = ("MEASURED by this run: HBM bytes per launch of this kernel from two separate rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE / "
+                                                "--pmc WRITE_SIZE) over a one-step child run of the same command, FETCH_SIZE doubled (MI355X_MICROARCH.md section HBM)")
+            line["roofline"]["traffic_measurement"] = tr
+        except Exception as e:
+            line["roofline"]["traffic_measurement"] = {"error": repr(e)[:300], "fallback": "the cited value (traffic_note)"}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_sample_pairs)

@@ -31,6 +31,10 @@ def test_roofline_and_cpu_baseline_objects():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.1 < r["frac"] <= 1.0 / 3.0          # three fp16 passes per fp32-accurate product
     assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_ms"]) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] > 0
+    tm = r.get("traffic_measurement")
+    if tm is not None and "error" not in tm:   # measured by the run itself (two rocprofv3 --pmc passes over a one-step child run): within a few % of the algorithmic bytes
+        assert r["traffic"] == tm["hbm_bytes_per_launch"] and "MEASURED" in r["traffic_note"]
+        assert 0.95 < r["traffic"] / r["algorithmic_hbm_bytes_per_launch"] < 1.15 and min(tm["launches_counted"].values()) >= 2
     p = r["power_limited"]
     assert abs(p["frac_of_sustained"] - 3 * r["achieved"] / p["sustained_peak"]) < 1e-9 and p["frac_of_sustained"] < 1.0
     c = d["cpu_baseline"]
