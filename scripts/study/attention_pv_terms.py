@@ -21,6 +21,13 @@ MODE = {"v": "fp32"}
 def pv(attn, v):
     if MODE["v"] == "fp32" or attn.dtype == torch.float64:
         return attn @ v
+    if MODE["v"] == "two_consistent":
+        # round 5: the probabilities ROUNDED to fp16 and used as they are in the numerator AND in the normaliser (the kernel's l_run would sum the
+        # rounded values): P' V / sum P' — two MFMA terms (P' V_hi, P' V_lo), no P_lo plane, no residual split
+        pr = attn / attn.amax(dim=-1, keepdim=True) * 16.0          # the kernel's p = 2^(s - m_run + 4): <= 16 right after a rescale
+        ph = pr.half().float()
+        vh, vl = split16(v, 16.0)
+        return (ph @ vh + ph @ vl) / ph.sum(dim=-1, keepdim=True) / 16.0
     ph, pl = split16(attn, 4096.0)        # probabilities are produced scaled by 2^12 (<= 4096) in the kernel's log2-domain softmax
     vh, vl = split16(v, 16.0)
     acc = ph @ vh + ph @ vl
@@ -60,8 +67,8 @@ for gain in (2.0,):           # the gain of the parity tests' synthetic weights
     la64 = L.lightglue_forward(f0["kpts"].double(), f0["desc"].double(), f0["size"].double(), f1["kpts"].double(), f1["desc"].double(),
                                f1["size"].double(), sd64, {**conf, "dtype": torch.float64}, taps=True)["log_assignment"][:N, :N]
     out = {}
-    for mode in ("fp32", "three", "two"):
+    for mode in ("fp32", "three", "two", "two_consistent"):
         MODE["v"] = mode
         la = L.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, conf, taps=True)["log_assignment"][:N, :N]
         out[mode] = float((la.double() - la64).abs().max())
-    print(f"gain {gain}: max |delta log-assignment| vs fp64 — fp32 P V {out['fp32']:.2e}, three-term split {out['three']:.2e}, without P_lo*V_hi {out['two']:.2e}")
+    print(f"gain {gain}: max |delta log-assignment| vs fp64 — fp32 P V {out['fp32']:.2e}, three-term split {out['three']:.2e}, without P_lo*V_hi {out['two']:.2e}, P rounded to fp16 in numerator AND normaliser {out['two_consistent']:.2e}")
