@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, (WREG ? 2 : 3)) void al_convx3_kernel(const fl
   }
   if (partial != nullptr) {
     double d1 = (double)s1, d2 = (double)s2;
-    d1 += __shfl_xor(d1, 32); d2 += __shfl_xor(d2, 32);
+    d1 = half_pair_sum(d1); d2 = half_pair_sum(d2);
     if (half == 0) { red[wv][lx][0] = d1; red[wv][lx][1] = d2; }
     __syncthreads();
     if (t < 32) {

@@ -204,6 +204,27 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
   return (r0 + r1) + (r2 + r3);
 }
+// max / sum over a lane and its partner in the other lane half (lane ^ 32; the two halves of a 32x32 MFMA tile's column).  __shfl_xor(v, 32) is a
+// ds_bpermute_b32: an LDS-pipe round trip in the middle of a dependent chain (the attention's row maximum sits between the score MFMAs and the
+// exponentials of EVERY key tile).  gfx950's v_permlane32_swap exchanges the upper half of one register with the lower half of another in one VALU
+// instruction: with (v, v) the two results hold {lower value in all lanes} and {upper value in all lanes}.  Same operands, commutative operation:
+// the same bits as the shuffle form (which the test emulator runs).
+__device__ __forceinline__ float half_pair_max(float v) {
+#if defined(__AMDGCN__) && !defined(DIM_NO_PERMLANE)   // (DIM_NO_PERMLANE: the shuffle form, for A/B builds)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+  return fmaxf(v, __shfl_xor(v, 32));
+#endif
+}
+__device__ __forceinline__ float half_pair_sum(float v) {
+#if defined(__AMDGCN__) && !defined(DIM_NO_PERMLANE)   // (DIM_NO_PERMLANE: the shuffle form, for A/B builds)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#else
+  return v + __shfl_xor(v, 32);
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -430,7 +430,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     auto token_total = [&](float (&p)[MT], float* region, float (&out)[MT]) {   // sum over the 512 units of the lane's tokens
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const float v = p[m] + __shfl_xor(p[m], 32);
+        const float v = half_pair_sum(p[m]);
         if (half == 0) region[wn * TOK + m * 32 + lx] = v;
       }
       __syncthreads();

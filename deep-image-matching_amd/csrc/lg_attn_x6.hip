@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
 #pragma unroll
     for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[r]), sacc[r + 1]);
     tmax = fmaxf(tmax, sacc[15]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * inv_qk;
+    tmax = half_pair_max(tmax) * inv_qk;
     constexpr float RESCALE_LOG2 = 8.0f;
     if (__any(tmax > m_run + RESCALE_LOG2)) {
       const float m_new = fmaxf(m_run, tmax);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 4 : 2)) void attn_x6_kernel(AttnA
   }
 
   // fp16x3: the V·P accumulator holds scale^2 x the sum and l_run scale x the normaliser: divide by scale * l_run
-  const float l_both = l_run + __shfl_xor(l_run, 32);
+  const float l_both = half_pair_sum(l_run);
   if (a.splits > 1) {  // partial result for attn_combine_kernel
     if (qok) {
       float* pp = a.part + ((((size_t)item * 4 + head) * a.nmax + qrow) * a.splits + sp) * PART;
