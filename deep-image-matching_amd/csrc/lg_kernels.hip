@@ -113,27 +113,51 @@ __global__ __launch_bounds__(256) void lg_ln_gelu_kernel(LgState st, const float
 // ---------------------------------------------------------------------------
 // token confidence (LGN:73-83) and matchability (LGN:277-278) per live point, plus
 // the per-pair count of points with confidence < thr (LGN:600-603).
+// One wave per point, CONF_ROWS points per wave one after the other (their descriptor loads go out together), one count per WORKGROUP: until round 5
+// every low-confidence point did its own atomicAdd on the pair's counter — with weights that are not confident (every synthetic set, and the first
+// layers of trained ones) that is 2 x n atomics on ONE address per pair and launch, which the memory system serialises: 0.99 ms per launch at
+// 16 tile pairs x 4096 points (22 % of the GPU time of the config-5 benchmark, profiles/r05_config5_kernel_stats_before.csv), ~0.5 ms at 50 pairs x
+// 2048.  Now 1 / (4 CONF_ROWS) of them.  Integer counts: the same decisions.
+constexpr int CONF_ROWS = 8;
 __global__ __launch_bounds__(256) void lg_confidence_kernel(LgState st, const float* __restrict__ w_tok,
                                                             const float* __restrict__ b_tok,
                                                             const float* __restrict__ w_match,
                                                             const float* __restrict__ b_match, float thr, int use_token) {
+  __shared__ int blk_cnt[4];
   const int item = blockIdx.y;
   if (st.done[item >> 1] != 0) return;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= st.n_cur[item]) return;
-  const size_t r = (size_t)item * st.nmax + row;
-  const float4 d = *(const float4*)(st.desc + r * 256 + lane * 4);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + wv) * CONF_ROWS, n = st.n_cur[item];
+  if (blockIdx.x * 4 * CONF_ROWS >= n) return;   // (block-uniform)
   const float4 wm = *(const float4*)(w_match + lane * 4);
-  const float zm = wave_sum(d.x * wm.x + d.y * wm.y + d.z * wm.z + d.w * wm.w) + b_match[0];
-  float cf = 0.0f;
-  if (use_token) {
-    const float4 wt = *(const float4*)(w_tok + lane * 4);
-    cf = sigmoidf_(wave_sum(d.x * wt.x + d.y * wt.y + d.z * wt.z + d.w * wt.w) + b_tok[0]);
+  float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (use_token) wt = *(const float4*)(w_tok + lane * 4);
+  float4 d[CONF_ROWS];
+#pragma unroll
+  for (int i = 0; i < CONF_ROWS; ++i) {
+    const size_t r = (size_t)item * st.nmax + min(row0 + i, n - 1);
+    d[i] = *(const float4*)(st.desc + r * 256 + lane * 4);
   }
-  if (lane == 0) {
-    st.mtch[r] = sigmoidf_(zm);
-    st.conf[r] = cf;
-    if (use_token && cf < thr) atomicAdd(&st.cnt_lt[item >> 1], 1);
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < CONF_ROWS; ++i) {
+    const int row = row0 + i;
+    if (row >= n) break;   // (wave-uniform)
+    const size_t r = (size_t)item * st.nmax + row;
+    const float zm = wave_sum(d[i].x * wm.x + d[i].y * wm.y + d[i].z * wm.z + d[i].w * wm.w) + b_match[0];
+    float cf = 0.0f;
+    if (use_token) cf = sigmoidf_(wave_sum(d[i].x * wt.x + d[i].y * wt.y + d[i].z * wt.z + d[i].w * wt.w) + b_tok[0]);
+    if (lane == 0) {
+      st.mtch[r] = sigmoidf_(zm);
+      st.conf[r] = cf;
+    }
+    cnt += (use_token && cf < thr) ? 1 : 0;   // (cf is wave-uniform: wave_sum leaves the total in every lane)
+  }
+  if (lane == 0) blk_cnt[wv] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int c = (blk_cnt[0] + blk_cnt[1]) + (blk_cnt[2] + blk_cnt[3]);
+    if (c) atomicAdd(&st.cnt_lt[item >> 1], c);
   }
 }
 
@@ -451,7 +475,7 @@ int launch_lg_ln_gelu(const LgState& st, const float* gamma, const float* beta, 
 }
 int launch_lg_confidence(const LgState& st, const float* w_tok, const float* b_tok, const float* w_match,
                          const float* b_match, float thr, int use_token, hipStream_t s) {
-  hipLaunchKernelGGL(lg_confidence_kernel, dim3(cdiv(st.nmax, 4), st.n_items), dim3(256), 0, s, st, w_tok, b_tok, w_match,
+  hipLaunchKernelGGL(lg_confidence_kernel, dim3(cdiv(st.nmax, 4 * CONF_ROWS), st.n_items), dim3(256), 0, s, st, w_tok, b_tok, w_match,
                      b_match, thr, use_token);
   DIM_LAUNCH_CHECK();
   return 0;
