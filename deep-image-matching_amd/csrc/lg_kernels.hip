@@ -223,13 +223,18 @@ __global__ __launch_bounds__(256) void lg_prune_gather_kernel(LgState st, int pr
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (st.n_cur[item] <= pruning_min || row >= st.n_cur[item]) return;
   const size_t base = (size_t)item * st.nmax;
+  // nothing pruned on this side in this layer (every set of weights that is not confident yet; n_cur is committed after the copy-back): the compaction
+  // is the identity — only the counters move, the two 1-KB-per-point copies (through scratch and back: 2.5 % of the config-5 benchmark's GPU time) do not
+  const bool identity = st.n_new[item] == st.n_cur[item];
   const int d = st.dest[base + row];
   if (d < 0) return;
-  *(float4*)(st.tdesc + (base + d) * 256 + lane * 4) = *(const float4*)(st.desc + (base + row) * 256 + lane * 4);
-  st.tenc[(base + d) * 64 + lane] = st.enc[(base + row) * 64 + lane];
+  if (!identity) {
+    *(float4*)(st.tdesc + (base + d) * 256 + lane * 4) = *(const float4*)(st.desc + (base + row) * 256 + lane * 4);
+    st.tenc[(base + d) * 64 + lane] = st.enc[(base + row) * 64 + lane];
+  }
   if (lane == 0) {
     const int orig = st.ind[base + row];
-    st.tind[base + d] = orig;
+    if (!identity) st.tind[base + d] = orig;
     st.prune[base + orig] += 1;
   }
 }
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void lg_prune_copyback_kernel(LgState st, int 
   const int item = blockIdx.y;
   if (st.done[item >> 1] != 0) return;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (st.n_cur[item] <= pruning_min || row >= st.n_new[item]) return;
+  if (st.n_cur[item] <= pruning_min || row >= st.n_new[item] || st.n_new[item] == st.n_cur[item]) return;   // (identity: see the gather)
   const size_t r = (size_t)item * st.nmax + row;
   *(float4*)(st.desc + r * 256 + lane * 4) = *(const float4*)(st.tdesc + r * 256 + lane * 4);
   st.enc[r * 64 + lane] = st.tenc[r * 64 + lane];

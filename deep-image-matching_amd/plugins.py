@@ -431,5 +431,66 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
                 d["image_size"] = (1 + k.max(0).values - k.min(0).values).reshape(1, 2) if k.numel() else torch.ones(1, 2)
             return d
 
+        dev = torch.device(self._net.device)
+        if dev.type == "cuda":
+            return self._match_pairs_staged(f0, f1, dev)
         res = self._net({"image0": img(f0), "image1": img(f1)})
         return res["matches"][0].cpu().numpy()
+
+    def _match_pairs_staged(self, f0: dict, f1: dict, dev) -> np.ndarray:
+        """The same call with ONE host-to-device and ONE device-to-host transfer (round 5).  LightGlueHIP.__call__ — the reference-shaped
+        entry the parity tests use — spends ~25 small operations around the match (two table fills, four pageable uploads and four slice copies, the
+        count / size tensors, two .item() read-backs, the .long() conversions, the result download): 0.5 ms of host time around 2.0 ms of kernels
+        at 2048 x 2048 keypoints, 12 % of the GPU time of the config-1 line in copy kernels (profiles/r05_config1_kernel_stats.csv).  Here both
+        images' keypoints, descriptors, sizes and counts are written into one page-locked buffer laid out as the library's feature table
+        ([2][cap][2] | [2][cap][D] | [2][2] | int32 [2]) and uploaded in one copy; the match count and the (S, 2) index table share one device
+        buffer and come back in one copy, enqueued behind the match so that the range guard's synchronisation covers it."""
+        net = self._net
+        k0, k1 = np.asarray(f0["keypoints"], dtype=np.float32), np.asarray(f1["keypoints"], dtype=np.float32)
+        m, n, D = k0.shape[0], k1.shape[0], net.input_dim
+        cap = max(m, n, 1)
+
+        def size_of(f, k):   # LGN:26-27: size inferred from the keypoint extent when the features carry none
+            if "image_size" in f:
+                return np.asarray(f["image_size"], dtype=np.float32).reshape(2)
+            return (1 + k.max(0) - k.min(0)).astype(np.float32) if k.size else np.ones(2, np.float32)
+
+        o_kt, o_dt, o_st = 0, 4 * cap, 4 * cap + 2 * cap * D
+        nfl = o_st + 4 + 2
+        st = self.__dict__.setdefault("_staging", _PinnedStaging())
+        pin = st.get("lg_in", nfl * 4)[: nfl * 4].view(torch.float32)
+        h = pin.numpy()
+        kt, dt = h[o_kt:o_dt].reshape(2, cap, 2), h[o_dt:o_st].reshape(2, cap, D)
+        for i, (k, f, cnt) in enumerate(((k0, f0, m), (k1, f1, n))):
+            kt[i, :cnt] = k
+            dt[i, :cnt] = f["descriptors"]            # ((D, N) inputs arrive as a transposed view: the copy un-transposes)
+            kt[i, cnt:] = 0.0
+            dt[i, cnt:] = 0.0
+        h[o_st:o_st + 2] = size_of(f0, k0)
+        h[o_st + 2:o_st + 4] = size_of(f1, k1)
+        h[o_st + 4:o_st + 6].view(np.int32)[:] = (m, n)
+        lean = self.__dict__.get("_lean")
+        NK = net.nk
+        if lean is None or lean["net"] is not net or lean["dev"].numel() < nfl:
+            flat = torch.zeros(2 + NK * 2, dtype=torch.int64, device=dev)       # [n_matches (int32) | pad | matches NK x 2]
+            out = {"matches": flat[2:].view(1, NK, 2), "scores": torch.zeros(1, NK, dtype=torch.float32, device=dev),
+                   "n_matches": flat[:1].view(torch.int32)[:1], "matches01": torch.zeros(1, 2, NK, dtype=torch.int32, device=dev),
+                   "mscores01": torch.zeros(1, 2, NK, dtype=torch.float32, device=dev), "stop": torch.zeros(1, dtype=torch.int32, device=dev),
+                   "prune01": torch.zeros(1, 2, NK, dtype=torch.int32, device=dev)}
+            lean = {"net": net, "dev": torch.empty(max(nfl, 2 * NK * (2 + D) + 6), dtype=torch.float32, device=dev), "flat": flat, "out": out}
+            self.__dict__["_lean"] = lean
+        d = lean["dev"]
+        pout = st.get("lg_out", (2 + NK * 2) * 8)[: (2 + NK * 2) * 8].view(torch.int64)
+
+        def run():
+            d[:nfl].copy_(pin, non_blocking=True)
+            net.match_batch(d[o_kt:o_dt].view(2, cap, 2), d[o_dt:o_st].view(2, cap, D), d[o_st + 4:o_st + 6].view(torch.int32), d[o_st:o_st + 4].view(2, 2),
+                            n_pairs=1, out=lean["out"])
+            pout.copy_(lean["flat"], non_blocking=True)
+
+        with net._ctx():
+            capi.run_guarded(net.lib, net._stream(), run, "LightGlue", net.on_saturation, logger, handle=net._h, arithmetic=net.arithmetic)
+        torch.cuda.current_stream(dev).synchronize()
+        res = pout.numpy()
+        S = int(res[:1].view(np.int32)[0])
+        return res[2:2 + 2 * S].reshape(S, 2).copy()
