@@ -254,6 +254,7 @@ class TiledPairPipeline:
         self.n_fallback = 0
         self.max_kpts, self.max_matches = max_kpts_per_image, max_matches_per_pair
         self.tile_pair_batch = int(tile_pair_batch if tile_pair_batch is not None else getattr(matcher, "tile_pair_batch", 8))
+        self.preselection_pair_batch = 16   # image pairs per LightGlue call of the PRESELECTION phase (down-sampled features, <= 4096 keypoints: ~0.1 GB of state per pair)
         self.timings: dict = {}
         self._dev_feats = None      # device views of the last extract_all's exchange buffer ...
         self._dev_token = None      # ... valid only for the list object that extract_all returned (no silent reuse)
@@ -384,14 +385,17 @@ class TiledPairPipeline:
             grids = {}
 
             def run():
+                jobs, views = [], []
                 for s, p in enumerate(mine):
                     a, b = int(pairs[p, 0]), int(pairs[p, 1])
                     for i in (a, b):
                         if i not in grids:
                             grids[i] = grid(i)
                     v = torch.empty(len(grids[a]), len(grids[b]), dtype=torch.int32, device=dev)
-                    pre.votes_device(names[a], (lambda i=a: self._band(images, i)), names[b], (lambda i=b: self._band(images, i)), grids[a], grids[b],
-                                     tile_size, quality, out=v, guarded=False)
+                    jobs.append((names[a], (lambda i=a: self._band(images, i)), names[b], (lambda i=b: self._band(images, i)), grids[a], grids[b], v))
+                    views.append(v)
+                pre.votes_device_many(jobs, tile_size, quality, pair_batch=self.preselection_pair_batch)   # one LightGlue stream over all the pairs
+                for s, v in enumerate(views):
                     votes[s, : v.shape[0], : v.shape[1]] = v
 
             stream = ctypes_stream_of(dev)
