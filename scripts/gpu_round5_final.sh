@@ -14,6 +14,8 @@ timeout 300 python bench.py --workload config5 > $O/config5_$TAG.json 2> $O/conf
 timeout 300 python scripts/gpu_end_to_end.py > $O/end_to_end_$TAG.json 2> $O/end_to_end_$TAG.err; tail -c 600 $O/end_to_end_$TAG.json
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $O/pmc_${TAG}_coexec -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --main-region-only > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_c5 -o c5 -- python $R/bench.py --workload config5 > /dev/null 2>&1
+f=$(find $O/prof_${TAG}_c5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_config5_kernel_stats.csv; rm -rf $O/prof_${TAG}_c5
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_b1 -o b1 -- python $R/scripts/gpu_b1_bench.py > $O/b1_$TAG.json 2>/dev/null
 f=$(find $O/prof_${TAG}_b1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_b1_kernel_stats.csv; rm -rf $O/prof_${TAG}_b1
 cd $R
