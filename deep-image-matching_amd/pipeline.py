@@ -288,7 +288,7 @@ class TiledPairPipeline:
 
     # ---- phases 1 + 2 ----------------------------------------------------------------------
     @torch.no_grad()
-    def extract_all(self, images: Sequence, as_numpy: bool = True) -> List[dict]:
+    def extract_all(self, images: Sequence, as_numpy: bool = True, names: Optional[Sequence[str]] = None) -> List[dict]:
         """images: sequence of numpy arrays (H, W) or (H, W, C), 0..255, the same list on every rank (pixels are read of this rank's shard
         only, shapes of all).  Returns the feature dict of EVERY image (keypoints (N,2) f32, descriptors (D,N) f32, scores (N,), tile_idx (N,),
         image_size) as numpy arrays; with ``as_numpy=False`` the device views of the exchange buffer (keypoints [N,2], descriptors_nd [N,D],
@@ -304,9 +304,21 @@ class TiledPairPipeline:
         flat = torch.zeros(per * cap * row + per, dtype=torch.float32, device=dev)
         body, cnt = flat[: per * cap * row].view(per, cap, row), flat[per * cap * row:].view(torch.int32)
         t0 = time.perf_counter()
+        # PRESELECTION: the down-sampled SuperPoint features of this rank's own images are derived from the device copy the extraction makes anyway
+        # and land in the preselector's cache under the image's name (``names`` as in match_all; the same default) — the selection phase then never
+        # touches the pixels of these images again (extracting the first band of a 6000 x 4000 x 3 float array costs ~20 ms on the host, 80 % of the
+        # selection phase of the config-5 benchmark).  Images extracted by OTHER ranks miss the cache and take the host path as before: same values.
+        pre_hook = None
+        if self.selection.startswith("PRESELECTION") and hasattr(self.mat, "_preselector"):
+            general = self.mat.config["general"]
+            if general.get("preselection_pipeline", "superpoint+lightglue") == "superpoint+lightglue":
+                quality = getattr(general.get("quality", "HIGH"), "name", general.get("quality", "HIGH"))
+                pre = self.mat._preselector()
+                keys = names if names is not None else [f"image{i:05d}" for i in range(n_img)]
+                pre_hook = lambda i: (lambda src: pre.features(keys[i], src if src.dim() == 2 else src[..., 0], quality))
         for s, i in enumerate(mine):
             # the merged tile table never leaves HBM: merge_tile_features_device -> views of the exchange buffer
-            f = self.ext._extract_by_tile(np.asarray(images[i]), as_device=True)
+            f = self.ext._extract_by_tile(np.asarray(images[i]), as_device=True, **({"on_device_image": pre_hook(i)} if pre_hook else {}))
             k = int(f["keypoints"].shape[0])
             if k > cap:
                 raise ValueError(f"TiledPairPipeline: image {i} has {k} keypoints, more than the exchange slot ({cap}): max_kpts_per_image is too small")

@@ -273,7 +273,10 @@ class TilePreselector:
         """The image-side half of tile_selection on the device: ``resize_image`` to the extraction quality (MB:1026-1034;
         utils/image.py:52-57: INTER_AREA, INTER_LINEAR when an axis is enlarged), then cv2.resize(i, size_new, INTER_AREA) to
         the preselection size (MB:1062-1069); frame2tensor's /255 happens in the extractor call."""
-        src = torch.as_tensor(np.ascontiguousarray(image, dtype=np.float32)).to(self.device)
+        if torch.is_tensor(image):      # already on the device (the tiled pipeline's extraction phase): [H, W] float32, 0..255
+            src = image.to(self.device, torch.float32).contiguous()
+        else:
+            src = torch.as_tensor(np.ascontiguousarray(image, dtype=np.float32)).to(self.device)
         if quality != "HIGH":
             H, W = src.shape
             h, w = get_size_by_quality(quality, (H, W))

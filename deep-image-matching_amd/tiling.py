@@ -153,10 +153,11 @@ class BatchedTilingMixin:
     tile_batch = 16
 
     @torch.no_grad()
-    def _extract_by_tile(self, image: np.ndarray, select_unique: bool = True, as_device: bool = False) -> dict:
+    def _extract_by_tile(self, image: np.ndarray, select_unique: bool = True, as_device: bool = False, on_device_image=None) -> dict:
         """The image goes to the device ONCE (one H2D copy of the caller's array); zero padding, tile slicing and
         _frame2tensor's /255 happen there (IEEE fp32 division: bit-identical to the host's), so no host pass touches
-        the 288 MB of a 6000x4000 RGB float image."""
+        the 288 MB of a 6000x4000 RGB float image.  ``on_device_image(src)``: called with the device copy ([H, W] or [H, W, C] float32, 0..255) while
+        it exists — the tiled pipeline derives the tile-preselection features of the image from it instead of touching the host array again."""
         general = self.config["general"]
         win, ov = general["tile_size"], general.get("tile_overlap", 0)
         win_hw = (win, win) if isinstance(win, int) else (win[1], win[0])
@@ -174,6 +175,8 @@ class BatchedTilingMixin:
         dev = net.device
         src = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).to(dev)
         C = 1 if src.dim() == 2 else int(src.shape[2])
+        if on_device_image is not None:
+            on_device_image(src)
         idxs = sorted(origins)
         tables = []
         from . import capi
