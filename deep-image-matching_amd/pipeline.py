@@ -301,24 +301,44 @@ class TiledPairPipeline:
         D, dev = int(self.ext.descriptor_size), self._device()
         cap = self._cap(images)
         row = 2 + 1 + 1 + D
-        flat = torch.zeros(per * cap * row + per, dtype=torch.float32, device=dev)
-        body, cnt = flat[: per * cap * row].view(per, cap, row), flat[per * cap * row:].view(torch.int32)
-        t0 = time.perf_counter()
-        # PRESELECTION: the down-sampled SuperPoint features of this rank's own images are derived from the device copy the extraction makes anyway
-        # and land in the preselector's cache under the image's name (``names`` as in match_all; the same default) — the selection phase then never
-        # touches the pixels of these images again (extracting the first band of a 6000 x 4000 x 3 float array costs ~20 ms on the host, 80 % of the
-        # selection phase of the config-5 benchmark).  Images extracted by OTHER ranks miss the cache and take the host path as before: same values.
-        pre_hook = None
+        n_main = per * cap * row + per
+        # PRESELECTION: the down-sampled SuperPoint features of an image (<= pcap keypoints: 4 MB at the reference's 4000) are derived from the device
+        # copy the tiled extraction makes anyway, and TRAVEL WITH THE TILE TABLES: a third section of the exchange buffer, [per][kpts pcap x 2 | desc
+        # pcap x 256] + counts + scales, +12 % of its size at config-5 shapes.  After the all-gather every rank files them in the preselector's cache under
+        # the image's name (``names`` as in match_all; the same default), so the selection phase reads no pixels at all — extracting the first band of
+        # a 6000 x 4000 x 3 float array costs ~20 ms on the host, which was 80 % of the selection phase of the config-5 benchmark and would be a third
+        # of a rank's whole matching time at 8 ranks.
+        pre = quality = keys = None
+        pcap = psz = 0
         if self.selection.startswith("PRESELECTION") and hasattr(self.mat, "_preselector"):
             general = self.mat.config["general"]
             if general.get("preselection_pipeline", "superpoint+lightglue") == "superpoint+lightglue":
                 quality = getattr(general.get("quality", "HIGH"), "name", general.get("quality", "HIGH"))
                 pre = self.mat._preselector()
-                keys = names if names is not None else [f"image{i:05d}" for i in range(n_img)]
-                pre_hook = lambda i: (lambda src: pre.features(keys[i], src if src.dim() == 2 else src[..., 0], quality))
+                keys = list(names) if names is not None else [f"image{i:05d}" for i in range(n_img)]
+                pcap = pre._capacity()
+                psz = pcap * (2 + 256)
+                pre._cache_size = max(pre._cache_size, 2 * n_img)      # (entries of other ranks' images are views of the gathered buffer)
+        flat = torch.zeros(n_main + (per * psz + 2 * per if pre is not None else 0), dtype=torch.float32, device=dev)
+        body, cnt = flat[: per * cap * row].view(per, cap, row), flat[per * cap * row:n_main].view(torch.int32)
+        if pre is not None:
+            pbody = flat[n_main:n_main + per * psz].view(per, psz)
+            pn, pscale = flat[n_main + per * psz:n_main + per * psz + per].view(torch.int32), flat[n_main + per * psz + per:]
+
+        def pre_hook(i, s):
+            def hook(src):
+                pre._cache.pop((keys[i], quality), None)               # this call has the pixels: whatever an earlier job cached under the name is stale
+                kp, de, n, scale = pre.features(keys[i], src if src.dim() == 2 else src[..., 0], quality)
+                pbody[s, : pcap * 2] = kp.reshape(-1)
+                pbody[s, pcap * 2:] = de.reshape(-1)
+                pn[s] = n[0]
+                pscale[s] = float(scale)
+            return hook
+
+        t0 = time.perf_counter()
         for s, i in enumerate(mine):
             # the merged tile table never leaves HBM: merge_tile_features_device -> views of the exchange buffer
-            f = self.ext._extract_by_tile(np.asarray(images[i]), as_device=True, **({"on_device_image": pre_hook(i)} if pre_hook else {}))
+            f = self.ext._extract_by_tile(np.asarray(images[i]), as_device=True, **({"on_device_image": pre_hook(i, s)} if pre is not None else {}))
             k = int(f["keypoints"].shape[0])
             if k > cap:
                 raise ValueError(f"TiledPairPipeline: image {i} has {k} keypoints, more than the exchange slot ({cap}): max_kpts_per_image is too small")
@@ -333,7 +353,18 @@ class TiledPairPipeline:
         g = _all_gather_cat(flat[None], self.world)          # phase 2: ONE collective
         out: List[dict] = []
         gb = g[:, : per * cap * row].reshape(self.world, per, cap, row)
-        gc = (g[:, per * cap * row:].reshape(self.world, per).view(torch.int32) if self.world > 1 else cnt.view(1, per)).cpu()
+        gc = (g[:, per * cap * row:n_main].reshape(self.world, per).view(torch.int32) if self.world > 1 else cnt.view(1, per)).cpu()
+        if pre is not None and self.world > 1:
+            gsc = g[:, n_main + per * psz + per:].reshape(self.world, per).cpu()
+            for i in range(n_img):
+                r, s = i % self.world, i // self.world
+                if r == self.rank:
+                    continue                                           # (filed by the hook)
+                blk = g[r, n_main + s * psz:n_main + (s + 1) * psz]
+                ent = (blk[: pcap * 2].view(1, pcap, 2), blk[pcap * 2:].view(1, pcap, 256), g[r, n_main + per * psz + s:n_main + per * psz + s + 1].view(torch.int32),
+                       float(gsc[r, s]))
+                pre._cache.pop((keys[i], quality), None)
+                pre._cache[(keys[i], quality)] = ent
         dev_feats = []
         for i in range(n_img):
             r, s = i % self.world, i // self.world

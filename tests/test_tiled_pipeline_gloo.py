@@ -190,3 +190,102 @@ def test_preselection_votes_on_the_device_select_the_tile_pairs_and_nothing_fall
     finally:
         tm.PRESELECTION_SP_CONF["max_keypoints"] = old_kp
         capi.install(None)
+
+
+def _run_presel(lib_path, rank, world):
+    """three crops of one scene (shifts at multiples of 8 px), PRESELECTION with matching-capable preselector weights; returns (matches, n_fallback,
+    tile_pairs_total).  pipeline._band1 (the host-side first-band extraction) is replaced by a function that fails: the selection phase must live on the
+    preselection features that travelled with the tile tables."""
+    import ctypes
+
+    sys.path.insert(0, str(ROOT))
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    plugins = importlib.import_module("deep-image-matching_amd.plugins")
+    pl = importlib.import_module("deep-image-matching_amd.pipeline")
+    tm = importlib.import_module("deep-image-matching_amd.tile_matching")
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    lib = ctypes.CDLL(lib_path)
+    capi.install(lib, "cpu")
+    old_kp, old_band = tm.PRESELECTION_SP_CONF["max_keypoints"], pl._band1
+    tm.PRESELECTION_SP_CONF["max_keypoints"] = 256
+    try:
+        general = {"tile_size": (96, 64), "tile_overlap": 0, "min_matches_per_tile": 1, "quality": "HIGH", "tile_preselection_size": 192,
+                   "allow_synthetic_weights": True}
+        ex = plugins.AlikedExtractor({"general": general, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 24,
+                                                                         "detection_threshold": 0.2, "nms_radius": 2, "allow_synthetic_weights": True}})
+        mt = plugins.LightGlueMatcher({"general": general, "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1,
+                                                                       "filter_threshold": 0.0, "allow_synthetic_weights": True}}, local_features="aliked")
+        rng = np.random.default_rng(23)
+        base = (rng.random((128 + 64, 192 + 64, 3)) * 255).astype(np.float32)
+        images = [np.ascontiguousarray(base[dy:dy + 128, dx:dx + 192]) for dy, dx in ((0, 0), (32, 48), (16, 24))]
+        sp_sd = weights.synthetic_superpoint_state_dict(1234)
+        pre = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_state_dict(0, 256), tile_preselection_size=192, device="cpu", lib=lib)
+        f0 = pre.features("warm", np.ascontiguousarray(images[0][..., 0]), "HIGH")
+        center = f0[1][0, : int(f0[2][0])].mean(0)
+        mt._tile_preselector = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_matching_state_dict(0, 256, center=center), tile_preselection_size=192,
+                                                  device="cpu", lib=lib)
+        pipe = pl.TiledPairPipeline(ex, mt, rank, world, selection="PRESELECTION")
+        names = ["a", "b", "c"]
+        feats = pipe.extract_all(images, names=names)
+
+        def no_pixels(image):
+            raise AssertionError("the selection phase read an image's pixels")
+
+        pl._band1 = no_pixels
+        matches = pipe.match_all(images, feats, pl.exhaustive_pairs(3), names=names)
+        return matches, pipe.n_fallback, pipe.timings["tile_pairs_total"], (cap_of(feats), mt._preselector()._capacity())
+    finally:
+        tm.PRESELECTION_SP_CONF["max_keypoints"] = old_kp
+        pl._band1 = old_band
+
+
+def cap_of(feats):
+    return 4 * 24
+
+
+def _presel_worker(rank, world, port, lib_path, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    calls = []
+    orig = dist.all_gather_into_tensor
+
+    def counting(out, inp, *a, **k):
+        calls.append((inp.dtype, inp.numel()))
+        return orig(out, inp, *a, **k)
+
+    dist.all_gather_into_tensor = counting
+    matches, n_fb, n_tp, caps = _run_presel(lib_path, rank, world)
+    dist.all_gather_into_tensor = orig
+    torch.save({"matches": matches, "n_fallback": n_fb, "tile_pairs": n_tp, "collectives": calls, "caps": caps}, os.path.join(out_dir, f"presel{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_preselection_travels_with_the_tile_tables(tmp_path):
+    """PRESELECTION on two ranks (round 5): the down-sampled SuperPoint features of every image ride in the feature all-gather (a third section of the
+    exchange buffer), so the selection phase of EITHER rank never reads pixels — also not for image pairs whose images the other rank extracted —,
+    votes for real tile pairs (no fallback configured, none needed) and gives the single-process result; still exactly three collectives."""
+    build = importlib.import_module("deep-image-matching_amd.build")
+    lib_path = str(build.build_emu())
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    try:
+        matches1, n_fb1, n_tp1, _ = _run_presel(lib_path, 0, 1)
+    finally:
+        capi.install(None)
+    assert n_fb1 == 0 and n_tp1 > 0 and sum(m.shape[0] for m in matches1) > 0
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_presel_worker, args=(2, port, lib_path, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(tmp_path / f"presel{r}.pt", weights_only=False)
+        assert len(got["matches"]) == 3 and all(np.array_equal(a, b) for a, b in zip(got["matches"], matches1)), r
+        cap, pcap = got["caps"]
+        per = 2                                    # 3 images over 2 ranks
+        feat = per * cap * 132 + per + per * pcap * 258 + 2 * per
+        assert len(got["collectives"]) == 3 and got["collectives"][0] == (torch.float32, feat) and got["collectives"][1] == (torch.uint8, 2 * 16), got["collectives"]
