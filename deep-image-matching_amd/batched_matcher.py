@@ -96,20 +96,63 @@ class BatchedImageMatcher:
             kp, sc, de, n = kp.cpu().numpy(), sc.cpu().numpy(), de.cpu().numpy(), n.cpu().numpy()
             for j, (p, _) in enumerate(chunk):
                 k = int(n[j])
-                store.add(p.name, {"keypoints": kp[j, :k], "descriptors": np.ascontiguousarray(de[j, :k].T), "scores": sc[j, :k],
-                                   "tile_idx": np.zeros(k, np.float32), "image_size": np.array((H, W))})
+                write(p.name, {"keypoints": kp[j, :k].copy(), "descriptors": np.ascontiguousarray(de[j, :k].T), "scores": sc[j, :k].copy(),
+                               "tile_idx": np.zeros(k, np.float32), "image_size": np.array((H, W))})
 
-        for p in images:
-            img = self.loader(Path(p))
-            bucket = by_shape.setdefault(img.shape, [])
-            bucket.append((Path(p), img))
-            if len(bucket) >= self.image_batch:
-                flush(img.shape, bucket)
-                by_shape[img.shape] = []
-        for shape, bucket in by_shape.items():
-            if bucket:
-                flush(shape, bucket)
-        store.close()
+        # The host side of a job is as long as its device side (one image: ~10 - 50 ms of JPEG decode + grey conversion, ~40 ms of float16 conversion +
+        # deflate of its features; ~1 ms of kernels): images are decoded by a small thread pool a window ahead of the extraction (PIL and numpy release
+        # the GIL; order preserved, at most 2 image_batch decoded images wait), and the feature store is written by background threads
+        # (zlib releases the GIL too) — the stored datasets are the same bytes as with the serial loop.
+        import collections
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        images = [Path(p) for p in images]
+        pending_writes = collections.deque()
+        # (h5py serialises on its global lock: one writer; the .npz mirror has shard files for exactly this — FeatureStore.read sees their union)
+        n_writers = 1 if store.use_h5 else max(1, min(4, (os.cpu_count() or 2) // 2))
+        if not store.use_h5:
+            for stale in feature_path.parent.glob(feature_path.stem + ".shard*.npz"):      # shards of an earlier run in this directory would be read as part of this one
+                stale.unlink()
+        stores = [store] + [export.FeatureStore(feature_path, shard=k) for k in range(1, n_writers)]
+        writers = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"dim-features{k}") for k in range(n_writers)]
+        turn = [0]
+
+        def write(name, feats):      # flush() hands every image's features here: round-robin over the writer threads, each with its own shard
+            k = turn[0] % n_writers
+            turn[0] += 1
+            pending_writes.append(writers[k].submit(stores[k].add, name, feats))
+
+        try:
+            with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1)), thread_name_prefix="dim-decode") as decoders:
+                window, ahead = 2 * self.image_batch, collections.deque()
+                it = iter(images)
+                for p in it:
+                    ahead.append((p, decoders.submit(self.loader, p)))
+                    if len(ahead) >= window:
+                        break
+                while ahead:
+                    p, fut = ahead.popleft()
+                    img = fut.result()
+                    nxt = next(it, None)
+                    if nxt is not None:
+                        ahead.append((nxt, decoders.submit(self.loader, nxt)))
+                    bucket = by_shape.setdefault(img.shape, [])
+                    bucket.append((p, img))
+                    if len(bucket) >= self.image_batch:
+                        flush(img.shape, bucket)
+                        by_shape[img.shape] = []
+                    while len(pending_writes) > 4 * self.image_batch:      # bounded: the writer is at most a few batches behind
+                        pending_writes.popleft().result()
+                for shape, bucket in by_shape.items():
+                    if bucket:
+                        flush(shape, bucket)
+                while pending_writes:
+                    pending_writes.popleft().result()                      # (re-raises a writer error here)
+        finally:
+            for w in writers:
+                w.shutdown(wait=True)
+            for st_ in stores:
+                st_.close()
         return feature_path
 
     # ---- phase 2: image_matching.py:438-494 ------------------------------------------------------------------------
