@@ -486,7 +486,9 @@ int launch_conv3x3_x6_planes(const float* in, const SplitWeights& wt, const floa
   DIM_REQUIRE(!planes_out || relu, "conv3x3_x6 planes: a pre-split output implies ReLU (its clamp starts at 0)");
   if (batch <= 0 || H <= 0 || W <= 0) return 0;
   const int var = dim_conv_x6_variant();
-  const bool big = planes_in && (var & 16);
+  // 16-row tiles unless they leave most of the chip idle: ONE image per call (the plugin hooks) gives the 128 x 128 maps of conv4a .. convDa 8 x 4 tiles
+  // x 2 channel blocks = 64 workgroups on 256 CUs; 8-row tiles double that (same K order per output: bit-identical; the batched path never gets here)
+  const bool big = planes_in && (var & 16) && (long)cdiv(W, TW) * cdiv(H, tile_rows(4)) * (cout / 64) * batch >= 256;
   const int mr = big ? 4 : 2;
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, tile_rows(mr));
   dim3 grid(tiles_x * tiles_y, cout / 64, batch);
