@@ -144,54 +144,6 @@ def test_device_resident_tile_matching_equals_the_numpy_path():
         capi.install(None)
 
 
-def test_preselection_votes_on_the_device_select_the_tile_pairs_and_nothing_falls_back():
-    """PRESELECTION through the pipeline (all image pairs' preselector LightGlue calls + vote kernels enqueued back to back, one read-back) must
-    select exactly what the per-pair host path (BatchedTileMatchingMixin.tile_selection) selects, and — with matching-capable weights on crops
-    whose down-sampled overlaps are shifted copies — must actually VOTE: no image pair falls back (VERDICT r4 next #4)."""
-    import ctypes
-    build = importlib.import_module("deep-image-matching_amd.build")
-    capi = importlib.import_module("deep-image-matching_amd.capi")
-    tm = importlib.import_module("deep-image-matching_amd.tile_matching")
-    pl = importlib.import_module("deep-image-matching_amd.pipeline")
-    plugins = importlib.import_module("deep-image-matching_amd.plugins")
-    weights = importlib.import_module("deep-image-matching_amd.weights")
-    lib = ctypes.CDLL(str(build.build_emu()))
-    capi.install(lib, "cpu")
-    old_kp = tm.PRESELECTION_SP_CONF["max_keypoints"]
-    tm.PRESELECTION_SP_CONF["max_keypoints"] = 256      # (the reference's 4000 sizes the emulated LightGlue state for 4096 keypoints per image: minutes)
-    try:
-        # preselection size 192 = the image width: the down-sampling is the identity, so crops at multiples of 8 px are SuperPoint-equivariant
-        general = {"tile_size": (96, 64), "tile_overlap": 0, "min_matches_per_tile": 1, "quality": "HIGH", "tile_preselection_size": 192,
-                   "allow_synthetic_weights": True}
-        ex = plugins.AlikedExtractor({"general": general, "extractor": {"name": "aliked", "model_name": "aliked-n16rot", "max_num_keypoints": 24,
-                                                                         "detection_threshold": 0.2, "nms_radius": 2, "allow_synthetic_weights": True}})
-        mt = plugins.LightGlueMatcher({"general": general, "matcher": {"name": "lightglue", "n_layers": 2, "depth_confidence": -1, "width_confidence": -1,
-                                                                       "filter_threshold": 0.0, "allow_synthetic_weights": True}}, local_features="aliked")
-        rng = np.random.default_rng(23)
-        base = (rng.random((128 + 64, 192 + 64, 3)) * 255).astype(np.float32)
-        images = [np.ascontiguousarray(base[dy:dy + 128, dx:dx + 192]) for dy, dx in ((0, 0), (32, 48))]
-        sp_sd = weights.synthetic_superpoint_state_dict(1234)
-        pre = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_state_dict(0, 256), tile_preselection_size=192, device="cpu", lib=lib)
-        f0 = pre.features("warm", np.ascontiguousarray(images[0][..., 0]), "HIGH")
-        center = f0[1][0, : int(f0[2][0])].mean(0)
-        mt._tile_preselector = tm.TilePreselector(sp_sd, weights.synthetic_lightglue_matching_state_dict(0, 256, center=center), tile_preselection_size=192,
-                                                  device="cpu", lib=lib)
-        pipe = pl.TiledPairPipeline(ex, mt, 0, 1, selection="PRESELECTION", empty_selection_fallback="GRID")
-        feats = pipe.extract_all(images)
-        pairs = pl.exhaustive_pairs(2)
-        names = ["a", "b"]
-        matches = pipe.match_all(images, feats, pairs, names=names)
-        assert pipe.n_fallback == 0 and pipe.timings["tile_pairs_total"] > 0
-        for (a, b), m in zip(pairs.tolist(), matches):
-            sel = mt.tile_selection(names[a], names[b], "PRESELECTION", image0=np.ascontiguousarray(images[a][..., 0]), image1=np.ascontiguousarray(images[b][..., 0]))
-            assert len(sel) > 0
-            want = tm.match_tile_pairs_batched(mt._ensure_pairs, feats[a], feats[b], sel, "cpu", 3)
-            assert np.array_equal(m, want), (a, b, sel)
-    finally:
-        tm.PRESELECTION_SP_CONF["max_keypoints"] = old_kp
-        capi.install(None)
-
-
 def _run_presel(lib_path, rank, world):
     """three crops of one scene (shifts at multiples of 8 px), PRESELECTION with matching-capable preselector weights; returns (matches, n_fallback,
     tile_pairs_total).  pipeline._band1 (the host-side first-band extraction) is replaced by a function that fails: the selection phase must live on the
@@ -232,15 +184,21 @@ def _run_presel(lib_path, rank, world):
             raise AssertionError("the selection phase read an image's pixels")
 
         pl._band1 = no_pixels
-        matches = pipe.match_all(images, feats, pl.exhaustive_pairs(3), names=names)
-        return matches, pipe.n_fallback, pipe.timings["tile_pairs_total"], (cap_of(feats), mt._preselector()._capacity())
+        pairs = pl.exhaustive_pairs(3)
+        matches = pipe.match_all(images, feats, pairs, names=names)
+        if world == 1:
+            # the pipeline's batched selection (all image pairs' preselector LightGlue calls in one stream, vote kernels, one read-back) must select
+            # exactly what the per-pair host path (BatchedTileMatchingMixin.tile_selection) selects — and must actually VOTE
+            for (a, b), m in list(zip(pairs.tolist(), matches))[:1]:      # (one image pair: every further one costs the emulator ~20 s)
+                sel = mt.tile_selection(names[a], names[b], "PRESELECTION", image0=np.ascontiguousarray(images[a][..., 0]), image1=np.ascontiguousarray(images[b][..., 0]))
+                assert len(sel) > 0
+                want = tm.match_tile_pairs_batched(mt._ensure_pairs, feats[a], feats[b], sel, "cpu", 3)
+                assert np.array_equal(m, want), (a, b, sel)
+        return matches, pipe.n_fallback, pipe.timings["tile_pairs_total"], (4 * 24, mt._preselector()._capacity())      # (exchange slot: 4 tiles x 24 keypoints)
     finally:
         tm.PRESELECTION_SP_CONF["max_keypoints"] = old_kp
         pl._band1 = old_band
 
-
-def cap_of(feats):
-    return 4 * 24
 
 
 def _presel_worker(rank, world, port, lib_path, out_dir):
@@ -266,9 +224,11 @@ def _presel_worker(rank, world, port, lib_path, out_dir):
 
 
 def test_two_rank_preselection_travels_with_the_tile_tables(tmp_path):
-    """PRESELECTION on two ranks (round 5): the down-sampled SuperPoint features of every image ride in the feature all-gather (a third section of the
-    exchange buffer), so the selection phase of EITHER rank never reads pixels — also not for image pairs whose images the other rank extracted —,
-    votes for real tile pairs (no fallback configured, none needed) and gives the single-process result; still exactly three collectives."""
+    """PRESELECTION through the pipeline, one and two ranks.  One process: the batched selection equals the per-pair host path and votes for real tile
+    pairs (matching-capable preselector weights on crops whose down-sampled overlaps are shifted copies; no fallback configured, none needed).  Two ranks
+    (round 5): the down-sampled SuperPoint features of every image ride in the feature all-gather (a third section of the exchange buffer), so the
+    selection phase of EITHER rank never reads pixels — also not for image pairs whose images the other rank extracted — and gives the single-process
+    result; still exactly three collectives."""
     build = importlib.import_module("deep-image-matching_amd.build")
     lib_path = str(build.build_emu())
     capi = importlib.import_module("deep-image-matching_amd.capi")
