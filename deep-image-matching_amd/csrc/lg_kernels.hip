@@ -144,9 +144,10 @@ __global__ __launch_bounds__(256) void lg_confidence_kernel(LgState st, const fl
     const int row = row0 + i;
     if (row >= n) break;   // (wave-uniform)
     const size_t r = (size_t)item * st.nmax + row;
-    const float zm = wave_sum(d[i].x * wm.x + d[i].y * wm.y + d[i].z * wm.z + d[i].w * wm.w) + b_match[0];
+    // (wave_sum_dpp: DPP row reductions + four v_readlane instead of six ds_bpermute round trips per sum — 16 sums per wave here)
+    const float zm = wave_sum_dpp(d[i].x * wm.x + d[i].y * wm.y + d[i].z * wm.z + d[i].w * wm.w) + b_match[0];
     float cf = 0.0f;
-    if (use_token) cf = sigmoidf_(wave_sum(d[i].x * wt.x + d[i].y * wt.y + d[i].z * wt.z + d[i].w * wt.w) + b_tok[0]);
+    if (use_token) cf = sigmoidf_(wave_sum_dpp(d[i].x * wt.x + d[i].y * wt.y + d[i].z * wt.z + d[i].w * wt.w) + b_tok[0]);
     if (lane == 0) {
       st.mtch[r] = sigmoidf_(zm);
       st.conf[r] = cf;
