@@ -355,6 +355,7 @@ class TiledPairPipeline:
         gb = g[:, : per * cap * row].reshape(self.world, per, cap, row)
         gc = (g[:, per * cap * row:n_main].reshape(self.world, per).view(torch.int32) if self.world > 1 else cnt.view(1, per)).cpu()
         if pre is not None and self.world > 1:
+            self.__dict__["_pre_foreign"] = []
             gsc = g[:, n_main + per * psz + per:].reshape(self.world, per).cpu()
             for i in range(n_img):
                 r, s = i % self.world, i // self.world
@@ -365,6 +366,7 @@ class TiledPairPipeline:
                        float(gsc[r, s]))
                 pre._cache.pop((keys[i], quality), None)
                 pre._cache[(keys[i], quality)] = ent
+                self.__dict__.setdefault("_pre_foreign", []).append((pre, (keys[i], quality)))      # (views of the gathered buffer: dropped by release())
         dev_feats = []
         for i in range(n_img):
             r, s = i % self.world, i // self.world
@@ -385,6 +387,8 @@ class TiledPairPipeline:
     def release(self):
         """Drop the device tables of the last extract_all (they pin the all-gathered exchange buffer in HBM)."""
         self._dev_feats = self._dev_token = None
+        for pre, key in self.__dict__.pop("_pre_foreign", []):
+            pre._cache.pop(key, None)              # other ranks' preselection features are views of that buffer too (a miss re-derives them from the pixels)
 
     def _device_tables(self, feats: List[dict], dev) -> List[dict]:
         """Device feature tables for match_all: the exchange-buffer views when ``feats`` IS the list the last extract_all returned, else the
