@@ -39,6 +39,9 @@ class _AlWeights(ctypes.Structure):
     _fields_ = [(n, _F) for n, _ in _W_FIELDS] + [("bn_weight", _F * 8), ("bn_bias", _F * 8)] + [(n, _F) for n, _ in _TAIL]
 
 
+N_LIMIT_MAX = 20000   # ALN:571: DKD's n_limit when max_num_keypoints <= 0 (the keep-all modes)
+
+
 class _AlConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("c1", "c2", "c3", "c4", "dim", "K", "M", "max_num_keypoints")] + \
                [("detection_threshold", ctypes.c_double), ("nms_radius", ctypes.c_int)]
@@ -74,7 +77,7 @@ class AlikedHIP:
         geo = ALIKED_CFGS[self.cfg["model_name"]]
         self.dim = int(geo[4])     # descriptor length: 128, or 64 for aliked-t16
         mk = int(self.cfg["max_num_keypoints"])
-        self.capacity = int(capacity if capacity is not None else (mk if mk > 0 else 4096))
+        self.capacity = int(capacity if capacity is not None else (mk if mk > 0 else N_LIMIT_MAX))
         c = _AlConfig(*geo, mk, float(self.cfg["detection_threshold"]), int(self.cfg["nms_radius"]))
         self.max_batch, self.max_hw = int(max_batch), (int(max_hw[0]), int(max_hw[1]))
         self._h = ctypes.c_void_p()

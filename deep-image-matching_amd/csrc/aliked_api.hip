@@ -31,6 +31,7 @@ struct dim_aliked {
   float *cand_score, *kpts_px, *sc_tmp, *kpts_norm, *kscore, *patches, *hidden, *feats, *feats2, *bn_alpha, *bn_beta, *mean, *thr_eff, *cols;
   double* partial;
   int *cand_idx, *rowcount, *rowoff, *ncand;
+  unsigned long long* topk_keys;   // launch_topk's global key table (n_limit > 4096 only)
   int last_hp, last_wp, last_h, last_w, last_batch;
   float* dbg_x1234;  // debug tap only: materialised on request by dim_aliked_debug_buffers
   std::vector<void*> allocs;
@@ -115,10 +116,11 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
   const int c1 = cfg->c1, c2 = cfg->c2, c3 = cfg->c3, c4 = cfg->c4, dim = cfg->dim, G = cfg->dim / 4;
   const int M = cfg->M, M2 = 2 * cfg->M;   // SDDH sample positions; offset channels (ALN:503-519)
   // detection_threshold <= 0 with max_num_keypoints > 0 selects DKD's top-k mode (ALN:624-627: top_k = max_num_keypoints): the
-  // max_num_keypoints highest NMS maxima; with max_num_keypoints <= 0 as well the reference's top_k is <= 0 and DKD thresholds at the image's
-  // MEAN score (ALN:161-163), at most `capacity` (<= 4096) of them — both handled in dim_aliked_extract
+  // max_num_keypoints highest NMS maxima (filled up with zero-score pixels when there are fewer, as torch.topk does); with max_num_keypoints <= 0
+  // as well the reference's top_k is <= 0 and DKD thresholds at the image's MEAN score (ALN:161-163), at most n_limit_max = 20000 (ALN:571)
+  // of them (or `capacity`, if that is smaller) — both handled in dim_aliked_extract
   DIM_REQUIRE(cfg->nms_radius >= 1 && cfg->nms_radius <= 6, "dim_aliked_create: nms_radius %d", cfg->nms_radius);
-  DIM_REQUIRE(capacity > 0 && capacity <= 4096 && cfg->max_num_keypoints <= capacity, "dim_aliked_create: capacity %d (<= 4096) must cover max_num_keypoints %d", capacity, cfg->max_num_keypoints);
+  DIM_REQUIRE(capacity > 0 && capacity <= 32768 && cfg->max_num_keypoints <= capacity, "dim_aliked_create: capacity %d (<= 32768) must cover max_num_keypoints %d", capacity, cfg->max_num_keypoints);
   DIM_REQUIRE(max_batch > 0 && max_batch <= 64 && max_h >= 16 && max_w >= 16, "dim_aliked_create: bad sizes");
   dim_aliked* h = new dim_aliked();
   h->cfg = *cfg;
@@ -214,6 +216,8 @@ int dim_aliked_create(const dim_aliked_weights* w, const dim_aliked_config* cfg,
   AL_TRY(dev_alloc(h, &h->feats2, B * cap * M * dim)); AL_TRY(dev_alloc(h, &h->bn_alpha, 2 * B * 128)); AL_TRY(dev_alloc(h, &h->bn_beta, 2 * B * 128));   // two slots: a conv's input and output BatchNorm
   AL_TRY(dev_alloc(h, &h->mean, B)); AL_TRY(dev_alloc(h, &h->thr_eff, B)); AL_TRY(dev_alloc(h, &h->partial, B * 256 * 128 * 2));
   AL_TRY(dev_alloc(h, &h->tile_partial, al_convx3_partial_doubles((int)B, (int)Hp, (int)Wp)));
+  h->topk_keys = nullptr;
+  if (topk_scratch_keys(max_batch, capacity)) AL_TRY(dev_alloc(h, &h->topk_keys, topk_scratch_keys(max_batch, capacity)));
 #undef AL_TRY
   *out = h;
   return 0;
@@ -365,12 +369,15 @@ int dim_aliked_extract(dim_aliked* h, const float* images_dev, int batch, int H,
     AL_RUN(launch_select_ex(h->nms, batch, H, W, 0.f, h->thr_eff, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 0, s));
   } else {
     // top-k mode (ALN:150-151: topk over the border-cleared NMS map): every maximum is a candidate (the map is zero elsewhere, scores are
-    // sigmoids > 0) and launch_topk keeps the max_num_keypoints highest.  With FEWER maxima than that the reference fills up with zero-score
-    // pixels in torch.topk's unspecified tie order; this path returns the maxima only.
+    // sigmoids > 0) and launch_topk keeps the max_num_keypoints highest, sorted; with FEWER maxima than that, zero-score pixels fill up
+    // (launch_topk_zero_fill: which pixels torch.topk takes among the equal zeros is an artefact of its sort, not a rule)
     AL_RUN(launch_select_ex(h->nms, batch, H, W, 0.f, nullptr, r, h->rowcount, h->rowoff, h->ncand, h->cand_score, h->cand_idx, 0, s));
   }
-  const int n_limit = h->cfg.max_num_keypoints > 0 ? h->cfg.max_num_keypoints : cap;   // the reference's n_limit_max is 20000 (ALN:571); a slot holds at most 4096 (launch_topk): INTEGRATION.md
-  AL_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H, W, n_limit, cap, h->kpts_px, h->sc_tmp, n_kpts_dev, s));
+  const bool topk_mode = !(h->cfg.detection_threshold > 0) && h->cfg.max_num_keypoints > 0;
+  // n_limit (ALN:624-626): max_num_keypoints, or n_limit_max = 20000 (ALN:571) in the keep-all modes (bounded by the slot)
+  const int n_limit = h->cfg.max_num_keypoints > 0 ? h->cfg.max_num_keypoints : (cap < 20000 ? cap : 20000);
+  AL_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H, W, n_limit, cap, h->kpts_px, h->sc_tmp, n_kpts_dev, h->topk_keys, topk_mode ? 1 : 0, s));
+  if (topk_mode) AL_RUN(launch_topk_zero_fill(h->nms, batch, H, W, 0.f, r, n_limit, cap, h->kpts_px, h->sc_tmp, n_kpts_dev, s));
   // Q8: DIM's "scores" are the dispersities (ALN:682 unpacks DKD's return in the wrong order)
   AL_RUN(launch_al_dkd_refine(h->score, h->kpts_px, n_kpts_dev, h->kpts_norm, scores_dev, h->kscore, kpts_xy_dev, batch, H, W, cap, r, s));
   // SDDH (ALN:503-558)

@@ -27,6 +27,7 @@ struct dim_sp {
   // activations
   float *a1, *b1, *a2, *b2, *a3, *b3, *a4, *x, *pa, *logits, *da, *dd, *smap, *nms, *cand_score;
   int *cand_idx, *rowcount, *rowoff, *ncand;
+  unsigned long long* topk_keys;   // launch_topk's global key table (max_keypoints > 4096 only)
   int last_h, last_w, last_batch;
   float conv1a_bound; // max over channels of sum|w1a| + |b1a|: bound on conv1a's outputs for |image| <= 1 (fp16x3 range guard)
   bool x_is_planes;   // the last extract stored the encoder output as pre-split planes
@@ -157,6 +158,8 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
   SP_TRY(dev_alloc(h, &h->rowcount, B * hh * 8));
   SP_TRY(dev_alloc(h, &h->rowoff, B * hh * 8));
   SP_TRY(dev_alloc(h, &h->ncand, B));
+  h->topk_keys = nullptr;
+  if (topk_scratch_keys(max_batch, cfg->max_keypoints)) SP_TRY(dev_alloc(h, &h->topk_keys, topk_scratch_keys(max_batch, cfg->max_keypoints)));
 #undef SP_TRY
   *out = h;
   return 0;
@@ -238,7 +241,7 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
   SP_RUN(launch_select(h->nms, batch, H8, W8, h->cfg.keypoint_threshold, h->cfg.remove_borders, h->rowcount, h->rowoff,
                        h->ncand, h->cand_score, h->cand_idx, s));
   SP_RUN(launch_topk(h->cand_score, h->cand_idx, h->ncand, batch, H8, W8, h->cfg.max_keypoints, h->capacity, kpts_xy_dev,
-                     scores_dev, n_kpts_dev, s));
+                     scores_dev, n_kpts_dev, h->topk_keys, 0, s));
   // descriptor head (SPN:213-221)
   if (planes) SP_SITE(DIM_PROF_SP_CONVDA, convp(10, h->x, h->da, hh, ww, 128, 256, 0, 1, 0));
   else SP_SITE(DIM_PROF_SP_CONVDA, conv(10, h->x, h->da, hh, ww, 128, 256, 0));

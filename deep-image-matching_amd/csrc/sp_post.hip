@@ -319,47 +319,59 @@ __global__ __launch_bounds__(256) void emit_rows_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// one block per image.  key = score bits (positive floats order like uints) << 32 |
-// (~idx): descending key order = descending score, ascending index among ties.
+// top-k (SPN:74-78; DKD's n_limit cut ALN:169-173).  key = score bits (positive floats order like uints) << 32 |
+// (~idx): descending key order = descending score, ascending index among ties; keys are unique (the index half), and a real
+// key is never 0 (~idx != 0), so 0 pads.
+//   k <= 4096 : ONE workgroup per image does everything in LDS (topk_kernel).
+//   k  > 4096 : (round 6: config/aliked.yaml and config/superpoint+superglue.yaml ask for 8000, ALN:571 allows 20 000)
+//               topk_select_big_kernel (the same radix select; the k keys >= the k-th go, unordered, to a global table padded to a
+//               multiple of 4096), topk_chunk_sort_kernel (one workgroup per 4096-key chunk: bitonic sort in LDS) and topk_merge_kernel
+//               (one thread per key: rank = own position + the number of larger keys in every other chunk, by binary search — unique
+//               keys make the rank a permutation, so the output is the same whatever order the gather's atomics produced).
 constexpr int TOPK_MAX = 4096;
-__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ cand_score, const int* __restrict__ cand_idx,
-                                                    const int* __restrict__ ncand, int H8, int W8, int k, int capacity,
-                                                    float* __restrict__ kpts, float* __restrict__ scores,
-                                                    int* __restrict__ n_out) {
-  __shared__ unsigned long long keys[TOPK_MAX];
-  __shared__ int hist[256];
-  __shared__ unsigned long long sh_prefix;
-  __shared__ int sh_krem, sh_cnt, sh_done;
-  const int t = threadIdx.x, b = blockIdx.x;
-  const int n = ncand[b];
-  const float* cs = cand_score + (size_t)b * H8 * W8;
-  const int* ci = cand_idx + (size_t)b * H8 * W8;
-  float* kp = kpts + (size_t)b * capacity * 2;
-  float* sc = scores + (size_t)b * capacity;
+constexpr int TOPK_BIG_MAX = 32768;
 
-  if (k < 0 || n <= k) {  // keep all, row-major order (SPN:75-76)
-    const int m = min(n, capacity);
-    for (int i = t; i < m; i += 1024) {
-      const int idx = ci[i];
-      kp[2 * i] = (float)(idx % W8);
-      kp[2 * i + 1] = (float)(idx / W8);
-      sc[i] = cs[i];
-    }
-    if (t == 0) n_out[b] = m;
-    return;
+__device__ __forceinline__ unsigned long long topk_key(float score, int idx) {
+  return ((unsigned long long)__float_as_uint(score) << 32) | (unsigned)(~idx);
+}
+__device__ __forceinline__ void topk_emit(unsigned long long key, int W8, float* kp, float* sc, int i) {
+  const int idx = (int)(~(unsigned)(key & 0xffffffffull));
+  kp[2 * i] = (float)(idx % W8);
+  kp[2 * i + 1] = (float)(idx / W8);
+  sc[i] = __uint_as_float((unsigned)(key >> 32));
+}
+// keep all, row-major order (SPN:75-76)
+__device__ __forceinline__ void topk_keep_all(const float* cs, const int* ci, int n, int capacity, int W8, float* kp, float* sc, int* n_out) {
+  const int t = threadIdx.x;
+  const int m = min(n, capacity);
+  for (int i = t; i < m; i += 1024) {
+    const int idx = ci[i];
+    kp[2 * i] = (float)(idx % W8);
+    kp[2 * i + 1] = (float)(idx / W8);
+    sc[i] = cs[i];
   }
+  if (t == 0) *n_out = m;
+}
 
-  // ---- radix select of the k-th largest key, one byte per pass from the top ----
-  // Round 5 (one image per call through the plugin hooks = ONE workgroup on the chip: 125 us of the call's 830): (a) four candidates per thread
-  // in flight per step instead of one dependent load per step; (b) the passes stop as soon as the selected bin is needed WHOLE (every key of it
-  // belongs to the top k: the remaining low bytes of the threshold are then 0) — with distinct scores that happens inside the score bytes, and
-  // the four index bytes (which only order ties of the k-th score) are never walked.  Same selection, same order.
-  if (t == 0) { sh_prefix = 0ull; sh_krem = k; sh_done = 0; }
+// ---- radix select of the k-th largest key, one byte per pass from the top (1024 threads; returns the key, uniform) ----
+// Round 5 (one image per call through the plugin hooks = ONE workgroup on the chip: 125 us of the call's 830): (a) four candidates per thread
+// in flight per step instead of one dependent load per step; (b) the passes stop as soon as the selected bin is needed WHOLE (every key of it
+// belongs to the top k: the remaining low bytes of the threshold are then 0) — with distinct scores that happens inside the score bytes, and
+// the four index bytes (which only order ties of the k-th score) are never walked.  Same selection, same order.
+struct TopkSelectShared {
+  int hist[256];
+  unsigned long long prefix;
+  int krem, done;
+};
+__device__ __forceinline__ unsigned long long topk_radix_select(const float* __restrict__ cs, const int* __restrict__ ci, int n, int k,
+                                                                TopkSelectShared& sh) {
+  const int t = threadIdx.x;
+  if (t == 0) { sh.prefix = 0ull; sh.krem = k; sh.done = 0; }
   __syncthreads();
   for (int byte = 7; byte >= 0; --byte) {
-    if (t < 256) hist[t] = 0;
+    if (t < 256) sh.hist[t] = 0;
     __syncthreads();
-    const unsigned long long prefix = sh_prefix;
+    const unsigned long long prefix = sh.prefix;
     const unsigned long long himask = (byte == 7) ? 0ull : (~0ull << (8 * (byte + 1)));
     // a thread's consecutive hits of one bin are merged into a single atomic: the leading bytes of positive float
     // scores are (nearly) constant, which would otherwise serialise every key of the image on one LDS counter
@@ -375,23 +387,23 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (i0 + 1024 * u >= n) break;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(sv[u]) << 32) | (unsigned)(~iv[u]);
+        const unsigned long long key = topk_key(sv[u], iv[u]);
         if ((key & himask) == prefix) {
           const int bin = (int)((key >> (8 * byte)) & 0xffull);
           if (bin == run_bin) {
             ++run_cnt;
           } else {
-            if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
+            if (run_cnt) atomicAdd(&sh.hist[run_bin], run_cnt);
             run_bin = bin; run_cnt = 1;
           }
         }
       }
     }
-    if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
+    if (run_cnt) atomicAdd(&sh.hist[run_bin], run_cnt);
     __syncthreads();
     if (t < 64) {  // wave 0: digit d with  above(d) < krem <= above(d) + hist[d],  above(d) = keys in higher bins
-      const int krem = sh_krem;
-      const int h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+      const int krem = sh.krem;
+      const int h0 = sh.hist[4 * t], h1 = sh.hist[4 * t + 1], h2 = sh.hist[4 * t + 2], h3 = sh.hist[4 * t + 3];
       const int tot = h0 + h1 + h2 + h3;
       int suf = tot;  // inclusive suffix sum over lanes t..63
 #pragma unroll
@@ -406,22 +418,20 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
       else if (a1 < krem && krem <= a1 + h1) { d = 4 * t + 1; above = a1; hd = h1; }
       else if (a0 < krem && krem <= a0 + h0) { d = 4 * t; above = a0; hd = h0; }
       if (d >= 0) {  // exactly one lane (the prefix always holds >= krem keys)
-        sh_krem = krem - above;
-        sh_prefix = prefix | ((unsigned long long)d << (8 * byte));
-        sh_done = (krem - above == hd) ? 1 : 0;   // the whole bin is taken: the threshold's remaining bytes are 0
+        sh.krem = krem - above;
+        sh.prefix = prefix | ((unsigned long long)d << (8 * byte));
+        sh.done = (krem - above == hd) ? 1 : 0;   // the whole bin is taken: the threshold's remaining bytes are 0
       }
     }
     __syncthreads();
-    if (sh_done) break;   // (uniform)
+    if (sh.done) break;   // (uniform)
   }
-  const unsigned long long kth = sh_prefix;
-
-  // ---- gather the k keys >= kth, pad to a power of two, bitonic sort descending ----
-  int P = 1;
-  while (P < k) P <<= 1;
-  for (int i = t; i < P; i += 1024) keys[i] = 0ull;
-  if (t == 0) sh_cnt = 0;
-  __syncthreads();
+  return sh.prefix;
+}
+// the keys >= kth (exactly k of them) to dst[0 .. P) in the order the atomics fall; the caller zeroed dst and *cnt
+__device__ __forceinline__ void topk_gather(const float* __restrict__ cs, const int* __restrict__ ci, int n, unsigned long long kth,
+                                            unsigned long long* dst, int P, int* cnt) {
+  const int t = threadIdx.x;
   for (int i0 = t; i0 < n; i0 += 4096) {
     float sv[4]; int iv[4];
 #pragma unroll
@@ -432,14 +442,17 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const unsigned long long key = ((unsigned long long)__float_as_uint(sv[u]) << 32) | (unsigned)(~iv[u]);
+      const unsigned long long key = topk_key(sv[u], iv[u]);
       if (i0 + 1024 * u < n && key >= kth) {
-        const int pos = atomicAdd(&sh_cnt, 1);
-        if (pos < P) keys[pos] = key;
+        const int pos = atomicAdd(cnt, 1);
+        if (pos < P) dst[pos] = key;
       }
     }
   }
-  __syncthreads();
+}
+// bitonic sort, descending, of P (power of two) keys in LDS by 1024 threads
+__device__ __forceinline__ void topk_bitonic_desc(unsigned long long* keys, int P) {
+  const int t = threadIdx.x;
   for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int i = t; i < (P >> 1); i += 1024) {
@@ -452,14 +465,146 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ ca
       __syncthreads();
     }
   }
-  for (int i = t; i < k; i += 1024) {
-    const unsigned long long key = keys[i];
-    const int idx = (int)(~(unsigned)(key & 0xffffffffull));
-    kp[2 * i] = (float)(idx % W8);
-    kp[2 * i + 1] = (float)(idx / W8);
-    sc[i] = __uint_as_float((unsigned)(key >> 32));
+}
+
+// one block per image
+__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ cand_score, const int* __restrict__ cand_idx,
+                                                    const int* __restrict__ ncand, int H8, int W8, int k, int capacity,
+                                                    int sort_always, float* __restrict__ kpts, float* __restrict__ scores,
+                                                    int* __restrict__ n_out) {
+  __shared__ unsigned long long keys[TOPK_MAX];
+  __shared__ TopkSelectShared sel;
+  __shared__ int sh_cnt;
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int n = ncand[b];
+  const float* cs = cand_score + (size_t)b * H8 * W8;
+  const int* ci = cand_idx + (size_t)b * H8 * W8;
+  float* kp = kpts + (size_t)b * capacity * 2;
+  float* sc = scores + (size_t)b * capacity;
+
+  const bool all = k < 0 || n <= k;
+  if (all && !(sort_always && k > 0)) {
+    topk_keep_all(cs, ci, n, capacity, W8, kp, sc, n_out + b);
+    return;
   }
-  if (t == 0) n_out[b] = k;
+  // sort_always (DKD's top-k mode, ALN:150-151: torch.topk returns its values sorted): fewer candidates than k are ALL taken, score-descending
+  const unsigned long long kth = all ? 0ull : topk_radix_select(cs, ci, n, k, sel);
+  const int m = all ? n : k;
+
+  // ---- gather the m keys >= kth, pad to a power of two, bitonic sort descending ----
+  int P = 1;
+  while (P < m) P <<= 1;
+  for (int i = t; i < P; i += 1024) keys[i] = 0ull;
+  if (t == 0) sh_cnt = 0;
+  __syncthreads();
+  topk_gather(cs, ci, n, kth, keys, P, &sh_cnt);
+  __syncthreads();
+  topk_bitonic_desc(keys, P);
+  for (int i = t; i < m; i += 1024) topk_emit(keys[i], W8, kp, sc, i);
+  if (t == 0) n_out[b] = m;
+}
+
+// ---- k > 4096: select + unordered gather into the global key table [batch][P], P = k rounded up to whole chunks ----
+__global__ __launch_bounds__(1024) void topk_select_big_kernel(const float* __restrict__ cand_score, const int* __restrict__ cand_idx,
+                                                               const int* __restrict__ ncand, int H8, int W8, int k, int capacity, int P,
+                                                               int sort_always, unsigned long long* __restrict__ gkeys, float* __restrict__ kpts,
+                                                               float* __restrict__ scores, int* __restrict__ n_out) {
+  __shared__ TopkSelectShared sel;
+  __shared__ int sh_cnt;
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int n = ncand[b];
+  const float* cs = cand_score + (size_t)b * H8 * W8;
+  const int* ci = cand_idx + (size_t)b * H8 * W8;
+  if (n <= k && !sort_always) {   // keep all; the sort / merge workgroups of this image see n <= k and leave
+    topk_keep_all(cs, ci, n, capacity, W8, kpts + (size_t)b * capacity * 2, scores + (size_t)b * capacity, n_out + b);
+    return;
+  }
+  const unsigned long long kth = n <= k ? 0ull : topk_radix_select(cs, ci, n, k, sel);
+  unsigned long long* dst = gkeys + (size_t)b * P;
+  for (int i = t; i < P; i += 1024) dst[i] = 0ull;
+  if (t == 0) sh_cnt = 0;
+  __syncthreads();
+  topk_gather(cs, ci, n, kth, dst, P, &sh_cnt);
+  if (t == 0) n_out[b] = min(n, k);
+}
+__global__ __launch_bounds__(1024) void topk_chunk_sort_kernel(const int* __restrict__ ncand, int k, int P, int sort_always, unsigned long long* __restrict__ gkeys) {
+  __shared__ unsigned long long keys[TOPK_MAX];
+  const int t = threadIdx.x, b = blockIdx.y;
+  if (ncand[b] <= k && !sort_always) return;   // (uniform)
+  unsigned long long* src = gkeys + (size_t)b * P + (size_t)blockIdx.x * TOPK_MAX;
+  for (int i = t; i < TOPK_MAX; i += 1024) keys[i] = src[i];
+  __syncthreads();
+  topk_bitonic_desc(keys, TOPK_MAX);
+  for (int i = t; i < TOPK_MAX; i += 1024) src[i] = keys[i];
+}
+__global__ __launch_bounds__(256) void topk_merge_kernel(const int* __restrict__ ncand, int W8, int k, int capacity, int P, int sort_always,
+                                                         const unsigned long long* __restrict__ gkeys, float* __restrict__ kpts,
+                                                         float* __restrict__ scores) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if ((ncand[b] <= k && !sort_always) || i >= P) return;
+  const unsigned long long* g = gkeys + (size_t)b * P;
+  const unsigned long long key = g[i];
+  if (key == 0ull) return;   // padding
+  const int own = i / TOPK_MAX;
+  int rank = i - own * TOPK_MAX;   // keys of the own chunk in front of this one
+  for (int c = 0; c < P / TOPK_MAX; ++c) {
+    if (c == own) continue;
+    const unsigned long long* ch = g + (size_t)c * TOPK_MAX;   // descending; the number of keys > key = first position with ch[pos] < key
+    int lo = 0, hi = TOPK_MAX;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (ch[mid] > key) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  if (rank < k) topk_emit(key, W8, kpts + (size_t)b * capacity * 2, scores + (size_t)b * capacity, rank);
+}
+
+// DKD's top-k mode with FEWER maxima than k (ALN:150-151): torch.topk over the border-cleared NMS map then fills up with zero-score pixels.
+// Which ones is an artefact of the sort it runs (libstdc++'s heap / introselect on the reference's CPU path, a radix select on its CUDA path:
+// different pixels) — here the first k - n non-candidate pixels in row-major order, appended behind the n sorted maxima with score 0.
+// One workgroup per image; 1024 pixels per step, wave ballots + a 16-entry LDS scan give every pixel its slot.
+__global__ __launch_bounds__(1024) void topk_zero_fill_kernel(const float* __restrict__ nms, int H8, int W8, float thr, int border, int k,
+                                                              int capacity, float* __restrict__ kpts, float* __restrict__ scores,
+                                                              int* __restrict__ n_out) {
+  __shared__ int wave_cnt[16];
+  __shared__ int sh_base;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, b = blockIdx.x;
+  const int n = n_out[b];
+  if (n >= k) return;   // (uniform)
+  const float* src = nms + (size_t)b * H8 * W8;
+  float* kp = kpts + (size_t)b * capacity * 2;
+  float* sc = scores + (size_t)b * capacity;
+  const int total = H8 * W8;
+  if (t == 0) sh_base = n;
+  __syncthreads();
+  for (int i0 = 0; i0 < total; i0 += 1024) {
+    const int base = sh_base;
+    if (base >= k) break;   // (uniform)
+    const int i = i0 + t;
+    const int y = i / W8, x = i - y * W8;
+    const bool fill = i < total && !sp_is_candidate(src[min(i, total - 1)], y, x, H8, W8, thr, border);
+    const unsigned long long m = __ballot(fill);
+    if (lane == 0) wave_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int c = wave_cnt[w];
+      before += w < wv ? c : 0;
+      all += c;
+    }
+    const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
+    if (fill && pos < k) {
+      kp[2 * pos] = (float)x;
+      kp[2 * pos + 1] = (float)y;
+      sc[pos] = 0.0f;
+    }
+    __syncthreads();
+    if (t == 0) sh_base = base + all;
+    __syncthreads();
+  }
+  if (t == 0) n_out[b] = min(sh_base, k);
 }
 
 // ---------------------------------------------------------------------------
@@ -564,11 +709,33 @@ int launch_select(const float* nms, int batch, int H8, int W8, float thr, int bo
   return launch_select_ex(nms, batch, H8, W8, thr, nullptr, border, rowcount, rowoff, ncand, cand_score, cand_idx, 0, s);
 }
 
+size_t topk_scratch_keys(int batch, int k) {   // 8-byte keys of launch_topk's global table (0: the one-workgroup form needs none)
+  if (k <= TOPK_MAX) return 0;
+  return (size_t)batch * (size_t)(cdiv(k, TOPK_MAX) * TOPK_MAX);
+}
 int launch_topk(const float* cand_score, const int* cand_idx, const int* ncand, int batch, int H8, int W8, int k,
-                int capacity, float* kpts, float* scores, int* n_out, hipStream_t s) {
-  DIM_REQUIRE(k <= TOPK_MAX, "topk: max_keypoints %d > %d unsupported", k, TOPK_MAX);
+                int capacity, float* kpts, float* scores, int* n_out, unsigned long long* scratch, int sort_always, hipStream_t s) {
+  DIM_REQUIRE(k <= TOPK_BIG_MAX, "topk: max_keypoints %d > %d unsupported", k, TOPK_BIG_MAX);
   if (batch <= 0) return 0;
-  hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(1024), 0, s, cand_score, cand_idx, ncand, H8, W8, k, capacity, kpts, scores, n_out);
+  if (k <= TOPK_MAX) {
+    hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(1024), 0, s, cand_score, cand_idx, ncand, H8, W8, k, capacity, sort_always, kpts, scores, n_out);
+  } else {
+    DIM_REQUIRE(scratch != nullptr, "topk: max_keypoints %d needs the key table (topk_scratch_keys)", k);
+    DIM_REQUIRE(k <= capacity, "topk: max_keypoints %d > capacity %d", k, capacity);
+    const int P = cdiv(k, TOPK_MAX) * TOPK_MAX;
+    hipLaunchKernelGGL(topk_select_big_kernel, dim3(batch), dim3(1024), 0, s, cand_score, cand_idx, ncand, H8, W8, k, capacity, P, sort_always, scratch, kpts, scores, n_out);
+    hipLaunchKernelGGL(topk_chunk_sort_kernel, dim3(P / TOPK_MAX, batch), dim3(1024), 0, s, ncand, k, P, sort_always, scratch);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(P / 256, batch), dim3(256), 0, s, ncand, W8, k, capacity, P, sort_always, (const unsigned long long*)scratch, kpts, scores);
+  }
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
+int launch_topk_zero_fill(const float* nms, int batch, int H8, int W8, float thr, int border, int k, int capacity, float* kpts, float* scores,
+                          int* n_out, hipStream_t s) {
+  DIM_REQUIRE(k <= capacity, "topk fill: k %d > capacity %d", k, capacity);
+  DIM_REQUIRE((long long)k <= (long long)H8 * W8, "selected index k out of range: top_k %d > %d x %d pixels", k, H8, W8);   // torch.topk's error (ALN:150)
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(topk_zero_fill_kernel, dim3(batch), dim3(1024), 0, s, nms, H8, W8, thr, border, k, capacity, kpts, scores, n_out);
   DIM_LAUNCH_CHECK();
   return 0;
 }

@@ -299,7 +299,7 @@ class AlikedExtractor(BatchedTilingMixin, _ExtractorBase):
         if self._net is None or H > self._net_hw[0] or W > self._net_hw[1]:
             hw = (max(H, self._net_hw[0]), max(W, self._net_hw[1]))
             mk = self._net_cfg["max_num_keypoints"]
-            self._net = AlikedHIP(self._sd, self._net_cfg, max_batch=1, max_hw=hw, capacity=mk if mk > 0 else 4096,
+            self._net = AlikedHIP(self._sd, self._net_cfg, max_batch=1, max_hw=hw, capacity=mk if mk > 0 else None,
                                   device=self._device, lib=self._lib)
             self._net_hw = hw
 
@@ -307,7 +307,7 @@ class AlikedExtractor(BatchedTilingMixin, _ExtractorBase):
         key = getattr(self, "_tile_key", None)
         if key is None or H > key[0] or W > key[1] or batch > key[2]:
             mk = self._net_cfg["max_num_keypoints"]
-            self._tile_net = AlikedHIP(self._sd, self._net_cfg, max_batch=batch, max_hw=(H, W), capacity=mk if mk > 0 else 4096,
+            self._tile_net = AlikedHIP(self._sd, self._net_cfg, max_batch=batch, max_hw=(H, W), capacity=mk if mk > 0 else None,
                                        device=self._device, lib=self._lib)
             self._tile_key = (H, W, batch)
         return self._tile_net

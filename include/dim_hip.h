@@ -115,7 +115,7 @@ typedef struct dim_sp_weights {
 typedef struct dim_sp_config {
   int nms_radius;           /* >= 0 */
   float keypoint_threshold; /* s > thr */
-  int max_keypoints;        /* -1 = keep all (bounded by capacity) */
+  int max_keypoints;        /* -1 = keep all (bounded by capacity); top-k up to 32768 (config/superpoint+superglue.yaml: 8000) */
   int remove_borders;
   int fix_sampling;         /* 0: SPN:81-98 sampler, 1: extractors/superpoint.py:16-27 */
 } dim_sp_config;
@@ -180,8 +180,9 @@ typedef struct dim_aliked_weights {
 /* ALIKED._default_conf (ALN:562-567) + the geometry row of ALIKED.cfgs (ALN:573-579). */
 typedef struct dim_aliked_config {
   int c1, c2, c3, c4, dim, K, M;   /* ALN:573-579: aliked-n16 / n16rot 16,32,64,128,128,3,16; aliked-n32 the same with M = 32; aliked-t16 8,16,32,64,64,3,16 (desc_dev rows are dim floats) */
-  int max_num_keypoints;           /* n_limit of DKD; -1 = capacity */
-  double detection_threshold;      /* > 0 */
+  int max_num_keypoints;           /* n_limit of DKD (ALN:624-626), up to 32768 (config/aliked.yaml: 8000); <= 0 = n_limit_max 20000 (ALN:571), bounded by capacity */
+  double detection_threshold;      /* > 0: threshold mode; <= 0: DKD's top-k mode (exactly max_num_keypoints per image, zero-score pixels filling up,
+                                      ALN:150-151) or, with max_num_keypoints <= 0 as well, the mean-score threshold (ALN:161-163) */
   int nms_radius;
 } dim_aliked_config;
 

@@ -136,29 +136,39 @@ def _simple_nms(scores, r):
     return torch.where(keep, scores, torch.zeros_like(scores))
 
 
-def dkd(score_map: torch.Tensor, radius: int, scores_th: float, n_limit: int, top_k: int = -1):
-    """DKD.forward for one image (ALN:123-244, sub_pixel=True).  Returns keypoints in [-1,1]
-    (x,y), score dispersity, bilinear keypoint score."""
+def dkd_nms_map(score_map: torch.Tensor, radius: int) -> torch.Tensor:
+    """simple_nms + the border clearing of DKD.forward (ALN:136-147, image_size=None)."""
     _, _, h, w = score_map.shape
     nms = _simple_nms(score_map, radius)
     nms[:, :, :radius, :] = 0
     nms[:, :, :, :radius] = 0
     nms[:, :, h - radius:, :] = 0
     nms[:, :, :, w - radius:] = 0
+    return nms
+
+
+def dkd_select(score_map: torch.Tensor, radius: int, scores_th: float, n_limit: int, top_k: int = -1) -> torch.Tensor:
+    """The flat pixel indices DKD.forward detects (ALN:149-174)."""
+    nms = dkd_nms_map(score_map, radius)
     flat = score_map.reshape(-1)
     if top_k > 0:
-        idx = torch.topk(nms.reshape(-1), top_k).indices
-    else:
-        if scores_th > 0:
-            mask = nms > scores_th
-            if mask.sum() == 0:
-                mask = nms > flat.mean()
-        else:
+        return torch.topk(nms.reshape(-1), top_k).indices
+    if scores_th > 0:
+        mask = nms > scores_th
+        if mask.sum() == 0:
             mask = nms > flat.mean()
-        idx = mask.reshape(-1).nonzero()[:, 0]
-        if len(idx) > n_limit:
-            order = flat[idx].sort(descending=True)[1]
-            idx = idx[order[:n_limit]]
+    else:
+        mask = nms > flat.mean()
+    idx = mask.reshape(-1).nonzero()[:, 0]
+    if len(idx) > n_limit:
+        order = flat[idx].sort(descending=True)[1]
+        idx = idx[order[:n_limit]]
+    return idx
+
+
+def dkd_refine(score_map: torch.Tensor, idx: torch.Tensor, radius: int):
+    """The sub-pixel half of DKD.forward at the given flat pixel indices (ALN:176-216)."""
+    _, _, h, w = score_map.shape
     ks = 2 * radius + 1
     patches = F.unfold(score_map, kernel_size=ks, padding=radius)[0].t()[idx]  # [M, ks*ks], zero padded
     g = torch.linspace(-radius, radius, ks, dtype=score_map.dtype)   # fp32 in the reference; the fp64 yardstick runs pass doubles
@@ -174,6 +184,15 @@ def dkd(score_map: torch.Tensor, radius: int, scores_th: float, n_limit: int, to
     kp = (xy + res) / wh * 2 - 1
     ksc = F.grid_sample(score_map, kp.view(1, 1, -1, 2), mode="bilinear", align_corners=True)[0, 0, 0]
     return kp, disp, ksc
+
+
+def dkd(score_map: torch.Tensor, radius: int, scores_th: float, n_limit: int, top_k: int = -1, idx: Optional[torch.Tensor] = None):
+    """DKD.forward for one image (ALN:123-244, sub_pixel=True).  Returns keypoints in [-1,1]
+    (x,y), score dispersity, bilinear keypoint score.  ``idx``: evaluate at these flat pixel indices instead of DKD's own detections
+    (tests of the top-k mode's zero-score fill, whose pixels torch.topk picks by the accidents of its sort)."""
+    if idx is None:
+        idx = dkd_select(score_map, radius, scores_th, n_limit, top_k)
+    return dkd_refine(score_map, idx, radius)
 
 
 def _get_patches(feat: torch.Tensor, corners_xy: torch.Tensor, ps: int) -> torch.Tensor:
@@ -208,7 +227,8 @@ def sddh(feat: torch.Tensor, kpts: torch.Tensor, sd, K: int, M: int) -> torch.Te
 
 
 @torch.no_grad()
-def aliked_forward(image: torch.Tensor, sd: Dict[str, torch.Tensor], cfg: Optional[dict] = None, taps: bool = False):
+def aliked_forward(image: torch.Tensor, sd: Dict[str, torch.Tensor], cfg: Optional[dict] = None, taps: bool = False,
+                   idx: Optional[torch.Tensor] = None):
     """image [1,3,H,W] (or [1,1,H,W]) float32 in [0,1].  Returns DIM's feature dict for one image:
     keypoints (N,2) pixel (x,y), descriptors (D,N), scores (N,) (= dispersities, Q8)."""
     cfg = {**DEFAULT_CFG, **(cfg or {})}
@@ -218,7 +238,7 @@ def aliked_forward(image: torch.Tensor, sd: Dict[str, torch.Tensor], cfg: Option
     feat, score = dense_maps(image, sd)
     th = cfg["detection_threshold"]
     mk = cfg["max_num_keypoints"]
-    kp, disp, ksc = dkd(score, cfg["nms_radius"], th, mk if mk > 0 else N_LIMIT_MAX, top_k=-1 if th > 0 else mk)
+    kp, disp, ksc = dkd(score, cfg["nms_radius"], th, mk if mk > 0 else N_LIMIT_MAX, top_k=-1 if th > 0 else mk, idx=idx)
     desc = sddh(feat, kp, sd, K, M)
     h, w = image.shape[-2:]
     wh = torch.tensor([w - 1, h - 1], dtype=image.dtype)

@@ -189,3 +189,23 @@ def fp16_round_trip(feats: dict) -> dict:
     """save_features_h5 (extractor_base.py:56-86, quirk Q6): every float32 array is stored as float16; the matcher reads that back."""
     import numpy as np
     return {k: (np.asarray(v).astype(np.float16).astype(np.float32) if np.asarray(v).dtype == np.float32 else np.asarray(v)) for k, v in feats.items()}
+
+
+def real_mosaic(height: int, width: int):
+    """(height, width, 3) uint8 canvas tiled with the eight real photographs (shelf packing in list order, cropped at the canvas edges, repeated
+    until full): a large-format, texture-rich input for the tile-sized tests (config/aliked.yaml: 2000 x 2000 tiles, 8000 keypoints)."""
+    import numpy as np
+    canvas = np.zeros((height, width, 3), np.uint8)
+    photos = [real_rgb(n) for n in SACRE_COEUR + PYTEST_IMAGES]
+    y, i = 0, 0
+    while y < height:
+        x, shelf = 0, 0
+        while x < width:
+            p = photos[i % len(photos)]
+            i += 1
+            h, w = min(p.shape[0], height - y), min(p.shape[1], width - x)
+            canvas[y:y + h, x:x + w] = p[:h, :w]
+            x += p.shape[1]
+            shelf = max(shelf, p.shape[0])
+        y += shelf
+    return canvas

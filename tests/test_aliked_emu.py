@@ -118,18 +118,100 @@ def test_aliked_top_k_mode_vs_oracle(emu_lib):
 
 def test_aliked_mean_threshold_mode_vs_oracle(emu_lib):
     """detection_threshold <= 0 AND max_num_keypoints <= 0: the reference's top_k is then <= 0 and DKD keeps every NMS maximum above
-    the image's MEAN score (ALN:161-163) — at most 4096 of them here (the reference's n_limit_max is 20000: INTEGRATION.md)."""
+    the image's MEAN score (ALN:161-163) — at most n_limit_max = 20000 of them (ALN:571), which is the slot size of the keep-all modes."""
     case = gc.AL_CASES["rgb_pad"]
     cfg = {**case["cfg"], "detection_threshold": -1.0, "max_num_keypoints": -1}
     sd, img = gc.al_weights(case), gc.al_image(case)
     net = al_mod.AlikedHIP(sd, cfg, max_batch=1, max_hw=(case["H"], case["W"]), device="cpu", lib=emu_lib)
-    assert net.capacity == 4096
+    assert net.capacity == aliked_ref.N_LIMIT_MAX == 20000
     out = {k: v.cpu() for k, v in net(img).items()}
     ref = aliked_ref.aliked_forward(img, sd, cfg, taps=True)
     mean = float(ref["score_map"].mean())
     assert ref["keypoints"].shape[0] > 100
     res = compare_aliked(out, ref, ref_score_map=ref["score_map"], threshold=mean, nms_radius=cfg["nms_radius"])
     assert res["n_out"] == ref["keypoints"].shape[0]
+
+
+def _fill_reference(img, sd, cfg, ref_full, k):
+    """What DKD's top-k mode returns when the image has FEWER NMS maxima than top_k (ALN:150-151), with the zero-score fill pixels fixed to
+    the first non-maximum pixels in row-major order (which pixels torch.topk takes among the equal zeros is an accident of its sort: libstdc++'s
+    heap / introselect on the CPU, a radix select on CUDA): the reference's arithmetic (oracle dkd_refine + SDDH) at those indices."""
+    r = cfg["nms_radius"]
+    nms = aliked_ref.dkd_nms_map(ref_full["score_map"], r).reshape(-1)
+    maxima = (nms > 0).nonzero()[:, 0]
+    order = torch.sort(nms[maxima], descending=True, stable=True)[1]
+    fill = (nms <= 0).nonzero()[:k - len(maxima), 0]
+    idx = torch.cat([maxima[order], fill])
+    return aliked_ref.aliked_forward(img, sd, cfg, taps=True, idx=idx), len(maxima)
+
+
+def test_aliked_top_k_mode_fills_up_with_zero_score_pixels(emu_lib):
+    """DKD's top-k mode on an image with fewer NMS maxima than max_num_keypoints: the reference's torch.topk still returns top_k indices — the
+    maxima, score-descending, then zero-score pixels (ALN:150-151).  Count, order of the maxima and the values at every returned pixel must be
+    the reference's; the fill pixels' identity is pinned to row-major order (see _fill_reference)."""
+    case = gc.AL_CASES["rgb_pad"]
+    sd, img = gc.al_weights(case), gc.al_image(case)
+    base = {**case["cfg"], "detection_threshold": -1.0}
+    ref_all = aliked_ref.aliked_forward(img, sd, {**base, "max_num_keypoints": -1}, taps=True)
+    n_max = int((aliked_ref.dkd_nms_map(ref_all["score_map"], base["nms_radius"]) > 0).sum())
+    k = n_max + 37
+    cfg = {**base, "max_num_keypoints": k}
+    ref_torch = aliked_ref.aliked_forward(img, sd, cfg)
+    assert ref_torch["keypoints"].shape[0] == k          # the reference's count: top_k, not the number of maxima
+    net = al_mod.AlikedHIP(sd, cfg, max_batch=1, max_hw=(case["H"], case["W"]), device="cpu", lib=emu_lib)
+    out = {kk: v.cpu() for kk, v in net(img).items()}
+    assert out["keypoints"].shape[0] == k
+    ref, m = _fill_reference(img, sd, cfg, ref_all, k)
+    assert m == n_max
+    # the maxima: the reference's own torch.topk output (paired by position: near-equal scores may swap neighbours in the order)
+    part = lambda d, a, b: {kk: d[kk][..., a:b] if kk == "descriptors" else d[kk][a:b] for kk in ("keypoints", "scores", "descriptors")}  # noqa: E731
+    res = compare_aliked(part(out, 0, m), part(ref_torch, 0, m))
+    assert res["common"] == m
+    # the fill, in order
+    assert (out["keypoints"][m:] - ref["keypoints"][m:]).abs().max().item() <= 1e-3
+    assert (out["scores"][m:] - ref["scores"][m:]).abs().max().item() <= 1e-3
+    assert (out["descriptors"][:, m:] - ref["descriptors"][:, m:]).abs().max().item() <= 1e-3
+    # score-descending order of the maxima (torch.topk sorts).  The true keypoint scores are not exported (Q8): pair every output keypoint with
+    # its twin in `ref` (whose maxima are in stable score-descending order) and read the NMS score there
+    from scipy.spatial import cKDTree
+    nms = aliked_ref.dkd_nms_map(ref_all["score_map"], base["nms_radius"]).reshape(-1)
+    v_sorted = torch.sort(nms[nms > 0], descending=True, stable=True)[0]
+    dist, twin = cKDTree(ref["keypoints"][:m].numpy().astype(np.float64)).query(out["keypoints"][:m].numpy().astype(np.float64))
+    assert dist.max() <= 0.05 and len(set(twin.tolist())) == m
+    v = v_sorted[torch.from_numpy(twin)]
+    assert (v[1:] <= v[:-1] + 2e-5).all()
+
+
+def test_aliked_more_than_4096_keypoints(emu_lib):
+    """config/aliked.yaml asks for max_num_keypoints 8000 and ALN:571 allows 20000: above 4096 the selection runs as radix select -> 4096-key
+    chunk sorts -> rank merge (sp_post.hip).  128 x 192 noise at nms_radius 1 has ~4400 maxima: k = 4200 takes the select path (n > k), k = 5000
+    the sort-everything + zero-fill path (n < k), both across two chunks."""
+    case = gc.AL_CASES["rgb_pad"]
+    sd = gc.al_weights(case)
+    H, W = 128, 192
+    img = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(5))
+    base = {**case["cfg"], "nms_radius": 1, "detection_threshold": -1.0}
+    ref_all = aliked_ref.aliked_forward(img, sd, {**base, "max_num_keypoints": -1}, taps=True)
+    n_max = int((aliked_ref.dkd_nms_map(ref_all["score_map"], 1) > 0).sum())
+    assert 4200 < n_max < 5000, n_max
+    for k in (4200, 5000):
+        cfg = {**base, "max_num_keypoints": k}
+        net = al_mod.AlikedHIP(sd, cfg, max_batch=1, max_hw=(H, W), device="cpu", lib=emu_lib)
+        out = {kk: v.cpu() for kk, v in net(img).items()}
+        assert out["keypoints"].shape[0] == k
+        if k < n_max:
+            ref = aliked_ref.aliked_forward(img, sd, cfg, taps=True)
+            res = compare_aliked(out, ref, ref_score_map=ref["score_map"], threshold=0.0, nms_radius=1, n_limit=k)
+            assert res["n_out"] == k and res["common"] >= k - 4, res
+        else:
+            ref, m = _fill_reference(img, sd, cfg, ref_all, k)
+            res = compare_aliked({kk: v[..., :m] if kk == "descriptors" else v[:m] for kk, v in out.items()},
+                                 {kk: ref[kk][..., :m] if kk == "descriptors" else ref[kk][:m] for kk in ("keypoints", "scores", "descriptors")},
+                                 ref_score_map=ref_all["score_map"], threshold=0.0, nms_radius=1)
+            assert res["common"] >= m - 4, res
+            if res["common"] == m:   # identical maxima sets: the fill pixels are then the same row-major prefix on both sides
+                assert (out["keypoints"][m:] - ref["keypoints"][m:]).abs().max().item() <= 1e-3
+                assert (out["descriptors"][:, m:] - ref["descriptors"][:, m:]).abs().max().item() <= 1e-3
 
 
 REAL_ALIKED = Path(__file__).parent / "assets" / "aliked-n16rot.pth"   # byte copy of the reference's thirdparty/ALIKED/models/aliked-n16rot.pth

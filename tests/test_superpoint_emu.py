@@ -174,3 +174,21 @@ def test_wide_score_rows_keep_the_reference_candidate_order(emu_lib, H, W, k):
     ref = superpoint_ref.superpoint_forward(img, sd, cfg)
     assert torch.equal(out["keypoints"].cpu(), ref["keypoints"]) and ref["keypoints"].shape[0] > 50
     assert (out["scores"].cpu() - ref["scores"]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("k", [4097, 9000])
+def test_top_k_above_4096_keypoints(emu_lib, k):
+    """config/superpoint+superglue.yaml:9 asks for max_keypoints 8000: above the one-workgroup kernel's 4096 the selection is a radix select
+    into a global key table, 4096-key chunk sorts and a rank merge (sp_post.hip).  Same keypoints in the same order as torch.topk on the same
+    NMS map (scores of a noise image are distinct): 2 chunks (4097: one real key in the second) and 3 chunks."""
+    case = gc.SP_CASES["noise_topk"]
+    sd = gc.sp_weights(case)
+    H, W = 160, 224
+    img = torch.rand(1, 1, H, W, generator=torch.Generator().manual_seed(5))
+    cfg = {**case["cfg"], "nms_radius": 0, "keypoint_threshold": 0.0, "max_keypoints": k}     # radius 0: every pixel inside the border is a candidate (~32 000)
+    net = sp_mod.SuperPointHIP(sd, cfg, max_batch=1, max_hw=(H, W), capacity=k, device="cpu", lib=emu_lib)
+    out = net(img)
+    taps = net.debug_taps()
+    yx, sc = superpoint_ref.select_keypoints(taps["nms_map"][0], cfg["keypoint_threshold"], cfg["remove_borders"], k)
+    assert out["keypoints"].shape[0] == k
+    assert torch.equal(torch.flip(yx, [1]), out["keypoints"].long()) and torch.equal(sc, out["scores"])
