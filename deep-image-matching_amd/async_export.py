@@ -424,7 +424,8 @@ class EndToEndRunner:
         for s in range(0, n_img, B):
             e = min(n_img, s + B)
             chunk = images[s:e].contiguous()
-            k_, s_, d_, n_ = capi.run_guarded(lib, stream(), lambda: self.ext.extract_batch(chunk), "EndToEndRunner.extract", self.policy, _Count())
+            k_, s_, d_, n_ = capi.run_guarded(lib, stream(), lambda: self.ext.extract_batch(chunk), "EndToEndRunner.extract", self.policy, _Count(),
+                                                  handle=self.ext._h, arithmetic=getattr(self.ext, "arithmetic", None))
             kp[s:e], sc[s:e], de[s:e], n[s:e] = k_, s_, d_, n_
             if self.exp is not None:
                 self.exp.put_features(names[s:e], kp[s:e], sc[s:e], de[s:e], n[s:e], [(H, W)] * (e - s))
@@ -439,7 +440,8 @@ class EndToEndRunner:
         vstream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.ver is not None and self.overlap_verification) else None
         for s in range(0, pairs.shape[0], PB):
             pp = pairs_dev[s:s + PB].contiguous()
-            o = capi.run_guarded(lib, stream(), lambda: self.mat.match_batch(kp, de, n, size, pair_idx=pp), "EndToEndRunner.match", self.policy, _Count())
+            o = capi.run_guarded(lib, stream(), lambda: self.mat.match_batch(kp, de, n, size, pair_idx=pp), "EndToEndRunner.match", self.policy, _Count(),
+                                 handle=self.mat._h, arithmetic=getattr(self.mat, "arithmetic", None))
             if vstream is not None:
                 vstream.wait_stream(torch.cuda.current_stream(dev))
                 for t_ in (o["matches"], o["n_matches"], pp):

@@ -149,7 +149,7 @@ class LowresPairSelector:
                 counts[torch.tensor(chunk, device=self.device)] = out["n_matches"][: len(chunk)]
 
         with self._lg._ctx():
-            capi.run_guarded(self.lib, self._stream(), run, "matching_lowres", self._lg.on_saturation)
+            capi.run_guarded(self.lib, self._stream(), run, "matching_lowres", self._lg.on_saturation, handle=self._lg._h, arithmetic=self._lg.arithmetic)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)  # shards are disjoint: the sum is the gather

@@ -84,7 +84,10 @@ def _guarded(net, fn, what: str):
     from . import capi
 
     with net._ctx():
-        return capi.run_guarded(net.lib, net._stream(), fn, what, getattr(net, "on_saturation", "fallback"))
+        # the handle and its own arithmetic override (plugin option `arithmetic`): the guard must decide from THAT handle's mode and re-run
+        # THAT handle in bf16x6 — a handle override beats the process default inside the library
+        return capi.run_guarded(net.lib, net._stream(), fn, what, getattr(net, "on_saturation", "fallback"), handle=getattr(net, "_h", None),
+                                arithmetic=getattr(net, "arithmetic", None))
 
 
 class PairMatchingPipeline:

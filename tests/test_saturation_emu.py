@@ -40,13 +40,11 @@ def test_superpoint_adversarial_ranges(emu_lib, name):
         strict(img)
 
 
-@pytest.mark.parametrize("big", [False, True], ids=["small-batch-kernels", "large-batch-kernels"])
-@pytest.mark.parametrize("name", adv.LG_CASES)
+# (the input-side cases desc_1e5 / tiny_desc go through the same init kernel on both paths: small-batch kernels only)
+@pytest.mark.parametrize("name,big", [(n, b) for n in adv.LG_CASES for b in (False, True) if not (b and n in ("desc_1e5", "tiny_desc"))])
 def test_lightglue_adversarial_ranges(emu_lib, name, big):
     """big: the kernels that only large batches select — 128 x 256 GEMM blocks writing the K | V tile images (dim_tune_set 6 = 2) and
     the one-kernel feed-forward (11 = 4), whose range guards sit in different code — forced at this size."""
-    if big and name in ("desc_1e5", "tiny_desc"):
-        pytest.skip("input-side cases: the same init kernel on both paths")
     sd, f0, f1, conf, expect_guard = adv.lg_case(name, m=40, n=36, n_layers=2)
     if big:
         emu_lib.dim_tune_set(6, 2); emu_lib.dim_tune_set(11, 4)
@@ -141,3 +139,29 @@ def test_aliked_range_guard_and_the_three_arithmetics(emu_lib):
     assert capi.get_arithmetic(emu_lib) == 2
     # train-mode BatchNorm makes the network (nearly) invariant to the input scale: same oracle call on the scaled image
     compare_aliked(out, aliked_ref.aliked_forward(big, sd, case["cfg"]))
+
+
+def test_phase_guards_follow_the_handle_arithmetic(emu_lib):
+    """the plugin option ``arithmetic`` is a per-handle override; the phase guards of the batched drivers (pipeline._guarded, pairs.py,
+    async_export.py) must decide from THAT handle's mode and re-run THAT handle in bf16x6.  Process default bf16x6 + a handle set to fp16x3 on an
+    image that leaves the fp16 range: before the fix the guard read the process default, ran the phase unguarded and returned the saturated
+    result."""
+    pipeline = importlib.import_module("deep-image-matching_amd.pipeline")
+    sd, img, expect_guard = adv.sp_case("bright", 40, 56)
+    assert expect_guard
+    ref = superpoint_ref.superpoint_forward(img, sd, CFG)
+    prev = capi.set_arithmetic(emu_lib, "bf16x6")
+    try:
+        net = sp_mod.SuperPointHIP(sd, CFG, max_batch=1, max_hw=(40, 56), capacity=256, device="cpu", lib=emu_lib, arithmetic="fp16x3")
+        capi.saturation(emu_lib, None, reset=True)
+        net.extract_batch(img[0].contiguous())
+        assert capi.saturation(emu_lib, None, reset=True)[0] > 0            # the handle really runs fp16x3 under a bf16x6 process default
+        kp, sc, de, n = pipeline._guarded(net, lambda: net.extract_batch(img[0].contiguous()), "phase")
+        k = int(n[0])
+        compare_superpoint({"keypoints": kp[0, :k], "scores": sc[0, :k], "descriptors": de[0, :k].t()}, ref)
+        assert capi.get_arithmetic(emu_lib) == 1                             # the process default was not touched
+        capi.saturation(emu_lib, None, reset=True)
+        net.extract_batch(img[0].contiguous())
+        assert capi.saturation(emu_lib, None, reset=True)[0] > 0            # and the handle is back on its own fp16x3 after the re-run
+    finally:
+        capi.set_arithmetic(emu_lib, prev)

@@ -39,13 +39,11 @@ def test_superpoint_gpu_adversarial_ranges(hip_lib, name):
     compare_superpoint(out, ref)
 
 
-@pytest.mark.parametrize("big", [False, True], ids=["small-batch-kernels", "large-batch-kernels"])
-@pytest.mark.parametrize("name", adv.LG_CASES)
+# (the input-side cases desc_1e5 / tiny_desc go through the same init kernel on both paths: small-batch kernels only)
+@pytest.mark.parametrize("name,big", [(n, b) for n in adv.LG_CASES for b in (False, True) if not (b and n in ("desc_1e5", "tiny_desc"))])
 def test_lightglue_gpu_adversarial_ranges(hip_lib, name, big):
     """big: the large-batch-only kernels (K | V images from the 128 x 256 projection blocks, dim_tune_set 6 = 2; the one-kernel
     feed-forward, 11 = 4) forced at this size: their range guards are different code."""
-    if big and name in ("desc_1e5", "tiny_desc"):
-        pytest.skip("input-side cases: the same init kernel on both paths")
     if big:
         hip_lib.dim_tune_set(6, 2); hip_lib.dim_tune_set(11, 4)
     try:
