@@ -87,10 +87,13 @@ def parse():
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="developer knob: dim_tune_set(KEY, VALUE) before the "
                     "networks are created (A/B runs of kernel variants; the default line uses none)")
     ap.add_argument("--overlap", action="store_true", help="time the two-stream schedule (extraction of batch i+1 overlapping matching "
-                    "of batch i) as the main region; by default it is measured after it and reported as two_stream_overlap")
+                    "of batch i) as the main region")
+    ap.add_argument("--other-schedule", action="store_true", help="also time the K steps under the other schedule right after the main region "
+                    "(reported as two_stream_overlap / single_stream); off by default: BENCH_r05 measured 605.22 vs 605.13 pairs/s")
     ap.add_argument("--no-overlap", action="store_true", help="(default since round 1) kept for compatibility")
     ap.add_argument("--main-region-only", action="store_true", help="skip the second (other-schedule) region: used for the rocprofv3 passes")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=4)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=5)
+    ap.add_argument("--no-adaptive", action="store_true", help="skip the adaptive-depth / width sub-record (LightGlue's reference defaults on a batch that really adapts)")
     ap.add_argument("--tile-pair-batch", type=int, default=16, help="config5: tile pairs per dim_lg_match call")
     ap.add_argument("--tile-selection", default="PRESELECTION", help="config5: tile_selection method (PRESELECTION | GRID | EXHAUSTIVE | PRESELECTION_AFFINE_TRANSFORM)")
     ap.add_argument("--strong-timeout", type=float, default=300.0, help="seconds after which rank 0 prints the headline line without the strong_scaling sub-record and exits 3")
@@ -188,13 +191,16 @@ def cpu_baseline(n_pairs: int):
                                         f[1]["keypoints"], f[1]["descriptors"].t().contiguous(), size, lg_sd, conf)
 
     one_pair(1000)  # warm-up
-    t0 = time.perf_counter()
+    times = []
     for i in range(n_pairs):
+        t0 = time.perf_counter()
         one_pair(i)
-    dt = time.perf_counter() - t0
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2] if len(times) % 2 else 0.5 * (sorted(times)[len(times) // 2 - 1] + sorted(times)[len(times) // 2])
     kind = "reference" if ref_mods is not None else "port"
     what = "the reference's SuperPoint / LightGlue modules (imported from /root/reference)" if ref_mods is not None else "oracle/*.py"
-    return {"value": n_pairs / dt, "unit": "image-pairs/s", "cores": cores, "kind": kind,
+    return {"value": 1.0 / med, "unit": "image-pairs/s", "cores": cores, "kind": kind, "statistic": f"1 / median of {n_pairs} per-pair times (SURVEY 8(d): warm-up 1, median of >= 5)",
+            "mean_value": n_pairs / sum(times), "per_pair_s": [round(t, 3) for t in times],
             "sample": f"{n_pairs} pairs (= {2 * n_pairs} SuperPoint 1024x1024 forwards + {n_pairs} LightGlue 2048x2048 "
                       f"9-layer forwards) after 1 warm-up pair, {what} on torch CPU, {cores} threads"}
 
@@ -644,6 +650,68 @@ def measure_hook_path(dev, lib, n_img: int = 6, n_pair: int = 6):
     return rec
 
 
+def measure_adaptive(dev, lib, P: int = 50, reps: int = 5):
+    """The reference's DEFAULT LightGlue (adaptive depth 0.95 / width 0.99, LGN:494-516, 586-604) where it adapts: a
+    50-pair x 2048-keypoint batch whose pairs stop after 3 .. 9 layers and lose a quarter of their keypoints to pruning after the first layer
+    (workloads.adaptive_lightglue_workload: one set of matching-capable weights; the stop layers are designed into the inputs), timed next
+    to the fixed-work call on the SAME inputs.  `ideal` = the matrix work the adaptive call really needs / the fixed-work call's (per layer and
+    pair: the MACs of SURVEY 8(d)'s formula at the keypoint counts that are still alive), so achieved_of_ideal = (t_fixed x ideal) / t_adaptive."""
+    lg = importlib.import_module(PKG + ".lightglue_hip")
+    wl = importlib.import_module(PKG + ".workloads")
+    N = 2048
+    sd, kp, de, nt, st, expect = wl.adaptive_lightglue_workload(P, N)
+    kp, de, nt, st = kp.to(dev), de.to(dev), nt.to(dev), st.to(dev)
+    rec = {}
+    outs = {}
+    for name, conf in (("fixed_work", {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}),
+                       ("reference_default", {"depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.1, "pruning_min_kpts": 1536})):
+        net = lg.LightGlueHIP(sd, conf, max_pairs=P, max_kpts=N, device=dev)
+        out = net.match_batch(kp, de, nt, st)
+        for _ in range(2):
+            net.match_batch(kp, de, nt, st, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            net.match_batch(kp, de, nt, st, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        rec[name] = {"ms_per_batch": ms, "pairs_per_s": P / ms * 1e3, "matches_mean": float(out["n_matches"].float().mean())}
+        outs[name] = {k: out[k].cpu() for k in ("stop", "prune01", "n_matches")}
+        del net, out
+        torch.cuda.empty_cache()
+    stop = outs["reference_default"]["stop"].long()
+    prune = outs["reference_default"]["prune01"].long()          # [P, 2, N]: layers a keypoint took part in
+
+    def macs(n0, n1):   # one layer of one pair with n0 / n1 live keypoints (self blocks, cross block)
+        lin = lambda n: n * 256 * 768 + n * 256 * 256 + n * 512 * 512 + n * 512 * 256            # noqa: E731  q|k|v, out, ffn.0, ffn.3
+        lin_c = lambda n: 3 * n * 256 * 256 + n * 512 * 512 + n * 512 * 256                        # noqa: E731  to_qk, to_v, out, ffn
+        return lin(n0) + lin(n1) + 2 * 256 * (n0 * n0 + n1 * n1) + lin_c(n0) + lin_c(n1) + 3 * 256 * n0 * n1
+
+    # alive at layer l: the counter (LGN:509,516: +1 per pruning step the keypoint survived) exceeds l — or equals the side's maximum: below
+    # pruning_min_kpts the reference stops pruning AND counting, so the survivors' counters stand still
+    need = 0.0
+    for p_ in range(P):
+        mx = prune[p_].max(-1).values
+        for l in range(int(stop[p_])):
+            need += macs(int(((prune[p_, 0] > l) | (prune[p_, 0] == mx[0])).sum()), int(((prune[p_, 1] > l) | (prune[p_, 1] == mx[1])).sum()))
+    full = P * 9 * macs(N, N)
+    hist = {str(k): int((stop == k).sum()) for k in sorted(set(stop.tolist()))}
+    t_fix, t_ad = rec["fixed_work"]["ms_per_batch"], rec["reference_default"]["ms_per_batch"]
+    rec.update({"stop_layer_histogram": hist, "stop_layers_as_designed": bool(torch.equal(stop, expect.long())),
+                "keypoints_alive_after_layer_1_mean": float((prune > 1).sum(-1).float().mean()),
+                "kernel_level": "profiles/r06_adaptive_kernel_stats_{adaptive,fixed}.csv (scripts/gpu_adaptive_trace.sh): attention 0.47 of its fixed-work time (ideal 0.42), "
+                                "fused feed-forward 0.62 and q|k|v 0.64 (ideal 0.52: a stopped pair's and a pruned row's workgroups still launch and leave at once); "
+                                "token confidence + prune scan / gather / copy-back / commit + decide = 0.83 ms per batch on top",
+                "ideal_depth_only": float(stop.float().mean() / 9.0), "ideal": need / full,
+                "adaptive_over_fixed_time": t_ad / t_fix, "achieved_of_ideal": (t_fix * need / full) / t_ad,
+                "workload": f"{P} pairs x {N} x {N} keypoints, workloads.adaptive_lightglue_workload (stop layers 3..9 in equal shares, 25 % of the keypoints prunable "
+                            "after layer 1), matching-capable weights, filter_threshold 0.1; both calls on the same resident inputs, HIP events over "
+                            f"{reps} calls"})
+    return rec
+
+
 def measure_traffic_live(a, timeout_s: float = 240.0):
     """roofline.traffic of THIS run: HBM bytes per launch of the dominant kernel from the L2's memory-side counters, collected as
     MI355X_MICROARCH.md section HBM prescribes — two SEPARATE rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; no trace domain
@@ -663,7 +731,7 @@ def measure_traffic_live(a, timeout_s: float = 240.0):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     child = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", str(a.pairs), "--no-cpu-baseline", "--main-region-only",
-             "--no-hook-path", "--no-strong-scaling", "--no-live-traffic"]
+             "--no-hook-path", "--no-strong-scaling", "--no-live-traffic", "--no-adaptive"]
     if a.lib:
         child += ["--lib", a.lib]
     per = {}
@@ -834,8 +902,8 @@ def main():
     # duration is its own (the roofline figure) and agrees with the rocprofv3 trace.  The two-stream schedule —
     # while LightGlue matches batch i on stream B, SuperPoint already extracts batch i+1 on stream A
     # (double-buffered feature tables; power-limited MFMA convolutions and latency-bound attention / GEMMs
-    # share the CUs) — is timed right after it over the same K steps and reported as `two_stream_overlap`
-    # (about +9 % pairs/s, with every kernel stretched by the sharing); --overlap makes it the main region.
+    # share the CUs) — gives the same rate within 0.02 % since round 4's kernels fill the chip on their own (BENCH_r05: 605.22 vs 605.13
+    # pairs/s); --other-schedule times it right after the main region over the same K steps, --overlap makes it the main region.
     overlap = bool(a.overlap)
     s0 = torch.cuda.current_stream(dev)
     sA2, sB2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
@@ -905,7 +973,7 @@ def main():
 
     # the other schedule over the same K steps, timed the same way (not part of `value`)
     dt2 = float("nan")
-    if not a.main_region_only:
+    if a.other_schedule and not a.main_region_only:
         run(1, 0, not overlap)
         barrier()
         t1 = time.perf_counter()
@@ -950,7 +1018,7 @@ def main():
                        "sharding": f"pairs sharded over {world} rank(s); ONE RCCL all-gather of the match tables at the end "
                                    f"(flat int32: counts + (idx0, idx1, score) rows, {flat_numel * 4 / 1e6:.1f} MB per rank)",
                        "streams": "extraction of batch i+1 overlaps matching of batch i (2 HIP streams)" if overlap else "single stream"},
-            ("single_stream" if overlap else "two_stream_overlap"): None if a.main_region_only else {
+            ("single_stream" if overlap else "two_stream_overlap"): None if (a.main_region_only or not a.other_schedule) else {
                 "value": pairs_total / dt2, "unit": "image-pairs/s", "ms_per_step": dt2 / K * 1e3,
                 "note": "the same K steps under the other schedule, timed right after the main region (barrier + synchronize on both sides)"},
             "end_to_end_tflops_per_gpu": (2 * SP_GFLOP_PER_IMAGE + LG_GFLOP_PER_PAIR) * value / world / 1e3,
@@ -958,6 +1026,7 @@ def main():
             "fp16x3_range_guard": {"violations": sat_total, "sites": sat_sites},
             "strong_scaling": None,
             "hook_path": None,
+            "adaptive": None,
             "roofline": {"kernel": "conv3x3_x6_kernel<64,1,1,true,2> (SuperPoint conv1a 1->64 evaluated in the halo staging + conv1b 64->64 3x3 "
                                    "+ bias + ReLU + 2x2 max-pool, fp32-accurate on the fp16 MFMA (fp16x3); 1024^2 images)", "bound": "mfma",
                          "achieved": conv_tflops, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -993,6 +1062,11 @@ def main():
             line["hook_path"] = measure_hook_path(dev, lib)
         except Exception as e:
             line["hook_path"] = {"error": repr(e)[:400]}
+    if rank == 0 and not a.no_adaptive and not a.main_region_only:
+        try:
+            line["adaptive"] = measure_adaptive(dev, lib)
+        except Exception as e:
+            line["adaptive"] = {"error": repr(e)[:400]}
     if not a.no_strong_scaling and not a.main_region_only:
         del pool, feats, flat, outs
         torch.cuda.empty_cache()

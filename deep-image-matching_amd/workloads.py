@@ -52,3 +52,60 @@ def descriptor_mean(extractor, images: torch.Tensor, max_images: int = 8) -> tor
     kp, sc, de, n = extractor.extract_batch(images[:b].contiguous())
     rows = torch.cat([de[i, : int(n[i])] for i in range(b)])
     return rows.mean(0).cpu()
+
+
+def adaptive_lightglue_workload(n_pairs: int, n_kpts: int = 2048, dim: int = 256, seed: int = 11, lone_fraction: float = 0.25,
+                                stops=(3, 4, 5, 6, 7, 8, 9), n_layers: int = 9):
+    """A LightGlue batch on which the reference's adaptive depth AND width (LGN:494-516, 586-604) really adapt, under ONE set of weights:
+
+    * matching-capable weights (weights.synthetic_lightglue_matching_state_dict, sharpness 40) — image 1 is a shuffled, jittered copy of image 0
+      with graded descriptor noise (the flip-rate study's recipe) and ``lone_fraction`` of its keypoints replaced by unrelated ones;
+    * two descriptor coordinates are reserved as "difficulty" channels (the similarity heads ignore them): coordinate dim-2 carries a per-PAIR
+      value c_p that the token-confidence heads read (layer i: logit = 8 x + logit(thr_i) + i + 0.5), so that every keypoint of pair p turns
+      confident exactly at layer ``stops[p % len(stops)]`` and the depth criterion (ratio > 0.95) stops the pair there (9 = never); the
+      unrelated keypoints carry 0 there (confident from the first layer) and -1 on coordinate dim-1, which the matchability heads read
+      (sigmoid(-6) < 0.01): they are pruned after the first layer (width criterion), everything else (+1) stays.
+
+    Returns (state_dict, kpts [2P, N, 2], desc [2P, N, dim], counts [2P] int32, sizes [2P, 2], expected_stop [P]) — items 2p / 2p+1 are pair p."""
+    import math
+    from . import weights
+    g = torch.Generator().manual_seed(seed)
+    sd = weights.synthetic_lightglue_matching_state_dict(1, dim, n_layers=n_layers, sharpness=40.0)
+    thr = weights.lightglue_confidence_thresholds(n_layers)
+    cu, cv = dim - 2, dim - 1
+    for i in range(n_layers):
+        fp = f"log_assignment.{i}.final_proj.weight"
+        sd[fp] = sd[fp].clone()
+        sd[fp][:, cu:] = 0.0
+        sd[fp][cu:, :] = 0.0
+        mw = torch.zeros(1, dim); mw[0, cv] = 6.0
+        sd[f"log_assignment.{i}.matchability.weight"], sd[f"log_assignment.{i}.matchability.bias"] = mw, torch.zeros(1)
+        if i < n_layers - 1:
+            tw = torch.zeros(1, dim); tw[0, cu] = 8.0
+            t = float(thr[i])
+            sd[f"token_confidence.{i}.token.0.weight"] = tw
+            sd[f"token_confidence.{i}.token.0.bias"] = torch.tensor([math.log(t / (1.0 - t)) + i + 0.5])
+    kp, de, expect = [], [], []
+    for p in range(n_pairs):
+        s = int(stops[p % len(stops)])
+        expect.append(s)
+        k0 = torch.rand(n_kpts, 2, generator=g) * 1024.0
+        d0 = torch.nn.functional.normalize(torch.randn(n_kpts, dim, generator=g), dim=-1)
+        perm = torch.randperm(n_kpts, generator=g)
+        k1 = k0[perm] + torch.randn(n_kpts, 2, generator=g) * 2.0
+        sigma = torch.exp(torch.rand(n_kpts, 1, generator=g) * (math.log(6.0) - math.log(0.3)) + math.log(0.3))
+        d1 = d0[perm] + sigma * torch.randn(n_kpts, dim, generator=g) / math.sqrt(dim)
+        lone1 = torch.rand(n_kpts, generator=g) < lone_fraction
+        d1[lone1] = torch.randn(int(lone1.sum()), dim, generator=g)
+        d1 = torch.nn.functional.normalize(d1, dim=-1)
+        lone0 = torch.zeros(n_kpts, dtype=torch.bool)
+        lone0[perm[lone1]] = True                     # their partners in image 0 have nothing to match either
+        c = -(s - 1) / 8.0
+        for d, lone in ((d0, lone0), (d1, lone1)):
+            d[:, cu] = torch.where(lone, torch.zeros(n_kpts), torch.full((n_kpts,), c))
+            d[:, cv] = torch.where(lone, -torch.ones(n_kpts), torch.ones(n_kpts))
+        kp += [k0, k1]
+        de += [d0, d1]
+    counts = torch.full((2 * n_pairs,), n_kpts, dtype=torch.int32)
+    sizes = torch.full((2 * n_pairs, 2), 1024.0)
+    return sd, torch.stack(kp).contiguous(), torch.stack(de).contiguous(), counts, sizes, torch.tensor(expect)
