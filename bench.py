@@ -443,6 +443,19 @@ def run_config5(a, rank, world, dev, dist, lib):
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "cpu_baseline": None,
         }
+        if world == 1 and not a.no_live_traffic:
+            # after everything that is timed: two counter passes over a child that runs the same extraction launches (16 tiles of 1000 x 1500 per call)
+            try:
+                tr = measure_kernel_traffic([sys.executable, str(ROOT / "scripts" / "gpu_aliked_one.py"), "16", "1000", "1500", "2"], "al_convx3_kernel<16, 9, 16")
+                r = line["roofline"]
+                r["traffic"] = tr["hbm_bytes_per_launch"]
+                r["traffic_measurement"] = tr
+                r["traffic_note"] = ("MEASURED by this run: HBM bytes per full-resolution launch of this kernel (mean of block1.conv1 and block1.conv2) from two separate "
+                                     "rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE) over scripts/gpu_aliked_one.py 16 1000 1500, FETCH_SIZE doubled")
+                r["traffic_over_algorithmic"] = tr["hbm_bytes_per_launch"] / bytes_per_launch
+                r["frac_of_hbm_on_measured_traffic"] = tr["hbm_bytes_per_launch"] / conv_ms / 1e6 / 8000.0
+            except Exception as e:
+                line["roofline"]["traffic_measurement"] = {"error": repr(e)[:300]}
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
@@ -712,12 +725,13 @@ def measure_adaptive(dev, lib, P: int = 50, reps: int = 5):
     return rec
 
 
-def measure_traffic_live(a, timeout_s: float = 240.0):
-    """roofline.traffic of THIS run: HBM bytes per launch of the dominant kernel from the L2's memory-side counters, collected as
-    MI355X_MICROARCH.md section HBM prescribes — two SEPARATE rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; no trace domain
-    next to the counters), each over a one-step child run of this very command (same pairs per step = same images per launch), FETCH_SIZE doubled (gfx950
-    tallies the 128-byte requests of wide coalesced reads at 64 bytes), WRITE_SIZE as reported (it checks out exactly against known byte counts), counter
-    unit KiB per dispatch.  Returns {"hbm_bytes_per_launch", "fetch_bytes_corrected_x2", "write_bytes", "launches_counted", "seconds"}."""
+def measure_kernel_traffic(child, kernel_substr: str, timeout_s: float = 240.0):
+    """HBM bytes per launch of one kernel from the L2's memory-side counters, collected as MI355X_MICROARCH.md section HBM prescribes — two
+    SEPARATE rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`, `--pmc WRITE_SIZE`; no trace domain next to the counters), each over the
+    child command `child`, FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes), WRITE_SIZE as
+    reported (it checks out exactly against known byte counts), counter unit KiB per dispatch; averaged over the launches with the LARGEST grid
+    whose kernel name contains `kernel_substr`.  Returns {"hbm_bytes_per_launch", "fetch_bytes_corrected_x2", "write_bytes", "launches_counted",
+    "seconds"}."""
     import csv
     import shutil
     import subprocess
@@ -730,10 +744,6 @@ def measure_traffic_live(a, timeout_s: float = 240.0):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    child = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", str(a.pairs), "--no-cpu-baseline", "--main-region-only",
-             "--no-hook-path", "--no-strong-scaling", "--no-live-traffic", "--no-adaptive"]
-    if a.lib:
-        child += ["--lib", a.lib]
     per = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -748,10 +758,10 @@ def measure_traffic_live(a, timeout_s: float = 240.0):
             files = [os.path.join(r, f) for r, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
             if p.returncode != 0 or not files:
                 raise RuntimeError(f"the {counter} pass failed (rc {p.returncode}, {len(files)} counter files)")
-            rows = [r for r in csv.DictReader(open(files[0])) if "conv3x3_x6_kernel<64, 1, 1, true, 2" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            rows = [r for r in csv.DictReader(open(files[0])) if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
             if not rows:
-                raise RuntimeError(f"no dispatch of the dominant kernel in the {counter} pass")
-            grid = max(int(r["Grid_Size"]) for r in rows)       # the full 2P-image launches (the warm-up step has the same shape)
+                raise RuntimeError(f"no dispatch of the kernel in the {counter} pass")
+            grid = max(int(r["Grid_Size"]) for r in rows)       # the full-size launches (a warm-up step has the same shape)
             vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == grid]
             per[counter] = (sum(vals) / len(vals) * 1024.0, len(vals))
     finally:
@@ -759,6 +769,16 @@ def measure_traffic_live(a, timeout_s: float = 240.0):
     fetch, write = 2.0 * per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
     return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
             "launches_counted": {"FETCH_SIZE": per["FETCH_SIZE"][1], "WRITE_SIZE": per["WRITE_SIZE"][1]}, "seconds": time.perf_counter() - t0}
+
+
+def measure_traffic_live(a, timeout_s: float = 240.0):
+    """roofline.traffic of THIS run: measure_kernel_traffic over a one-step child run of this very command (same pairs per
+    step = same images per launch) for the dominant kernel."""
+    child = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--pairs", str(a.pairs), "--no-cpu-baseline", "--main-region-only",
+             "--no-hook-path", "--no-strong-scaling", "--no-live-traffic", "--no-adaptive"]
+    if a.lib:
+        child += ["--lib", a.lib]
+    return measure_kernel_traffic(child, "conv3x3_x6_kernel<64, 1, 1, true, 2", timeout_s)
 
 
 def strong_scaling_subrun(a, rank, world, dev, dist, lib, line):
