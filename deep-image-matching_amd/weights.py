@@ -113,7 +113,7 @@ def synthetic_lightglue_state_dict(seed: int = 0, input_dim: int = 256, n_layers
 
 def synthetic_lightglue_matching_state_dict(seed: int = 0, input_dim: int = 256, n_layers: int = 9, dim: int = 256,
                                             residual: float = 0.003, sharpness: float = 220.0, matchability_bias: float = 5.0,
-                                            center: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                                            center: Optional[torch.Tensor] = None, whiten: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """Seeded synthetic LightGlue weights (official key layout) that MATCH: the transformer blocks are near-identity (`ffn.3`
     scaled by ``residual``, so a keypoint's state stays close to its input descriptor), every `final_proj` is
     ``sharpness`` x (identity - ``center``) (an orthogonal map: the similarity is sharpness^2 / 16 x the inner product of the CENTRED
@@ -123,20 +123,35 @@ def synthetic_lightglue_matching_state_dict(seed: int = 0, input_dim: int = 256,
     1e-3 of noise) and the matchability heads say "matchable".  On two views that share keypoints with equal
     descriptors (workloads.shifted_crops) the mutual-NN assignment then returns the true correspondences — several hundred
     matches per pair with scores above the reference's default threshold 0.1 — so that verification, the match writers and the
-    multi-GPU match gather of the benchmarks carry real work (VERDICT r3 weak #3).  Same arithmetic, same FLOPs as any other weights."""
+    multi-GPU match gather of the benchmarks carry real work.  Same arithmetic, same FLOPs as any other weights.
+    ``whiten`` ([dim, dim], symmetric; ``descriptor_whitening``): `final_proj` = sharpness x whiten x (x - center) instead of the scaled identity.
+    DIFFERENT photographs share no equal descriptors, and in the plain centred dot product a few long descriptors are everyone's nearest
+    neighbour (20 - 41 mutual nearest neighbours among 2000 x 2000 keypoints of the DSC photographs under the seeded SuperPoint); after whitening
+    the similarity is a Mahalanobis one and 216 - 406 are mutual (sharpness 2: 132 - 180 matches above 0.1, logits <= 220)."""
     sd = synthetic_lightglue_state_dict(seed, input_dim, n_layers, dim, gain=1.0)
     for k in list(sd):
         if ".ffn.3." in k:
             sd[k] = sd[k] * residual
         elif k.endswith("final_proj.weight"):
-            sd[k] = torch.eye(dim) * sharpness
+            sd[k] = torch.eye(dim) * sharpness if whiten is None else (sharpness * whiten.detach().float().cpu()).contiguous()
         elif k.endswith("final_proj.bias"):
-            sd[k] = torch.zeros_like(sd[k]) if center is None else (-sharpness * center.detach().float().cpu().reshape(-1)).contiguous()
+            c = None if center is None else center.detach().float().cpu().reshape(-1)
+            sd[k] = torch.zeros_like(sd[k]) if c is None else (-sharpness * (c if whiten is None else whiten.detach().float().cpu() @ c)).contiguous()
         elif k.endswith("matchability.weight"):
             sd[k] = sd[k] * 0.1
         elif k.endswith("matchability.bias"):
             sd[k] = torch.full_like(sd[k], matchability_bias)
     return sd
+
+
+def descriptor_whitening(desc_nd: torch.Tensor, eps: float = 1e-5):
+    """(center [D], whiten [D, D] float32) of a descriptor sample [N, D]: the mean and the symmetric inverse square root of the covariance
+    (+ eps), computed in float64 — the arguments of synthetic_lightglue_matching_state_dict(center=, whiten=)."""
+    x = desc_nd.detach().double().cpu()
+    c = x.mean(0)
+    xc = x - c
+    ev, u = torch.linalg.eigh(xc.t() @ xc / x.shape[0])
+    return c.float(), (u @ torch.diag(1.0 / torch.sqrt(ev.clamp_min(0.0) + eps)) @ u.t()).float().contiguous()
 
 
 def load_lightglue_state_dict(path: str | None = None, seed: int = 0, input_dim: int = 256, n_layers: int = 9,

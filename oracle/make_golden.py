@@ -364,7 +364,8 @@ def main_config1():
                                 full and 4 fixed projections of all of them, all fp32;
       config1_features_f16.npz  the float16 arrays save_features_h5 would put into features.h5 (quirk Q6) — the matcher's actual inputs;
       config1_lg.npz            LightGlue (LGN) on those float16 features for the 10 brute-force pairs with DIM's (H, W) image_size (Q4), YAML
-                                confidences, three weight / threshold variants;
+                                confidences, three weight / threshold variants; + variant "dsc" (round 6): the three overlapping DSC photographs'
+                                SuperPoint features through matching-capable weights WHITENED on those descriptors: >= 100 matches per pair;
       config1_aliked.npz        ALIKED (ALN) with the TRAINED aliked-n16rot checkpoint the reference ships, zoo parameters (config.py:197-204),
                                 on the RGB photographs — real weights on real pixels;
       config1_aliked_lg.npz     LightGlue (128-d, matching-capable synthetic weights, threshold 0.1) on the trained ALIKED features: 13 pairs
@@ -398,7 +399,7 @@ def main_config1():
         sp_out[stem + "/desc_proj"] = de.t().double().numpy() @ P256
         f = gc.fp16_round_trip({"keypoints": kp.numpy(), "scores": sc.numpy(), "descriptors": de.numpy()})
         feats[n] = f
-        if n in gc.SACRE_COEUR:
+        if True:   # (round 6: the DSC photographs too — the SuperPoint -> LightGlue leg with real match lists, variant "dsc")
             for k in ("keypoints", "scores", "descriptors"):
                 f16_out[f"superpoint/{stem}/{k}"] = f[k].astype(np.float16)
             f16_out[f"superpoint/{stem}/image_size"] = np.array(gray.shape[:2], dtype=np.float16)   # (H, W) of the image, stored like every array
@@ -442,6 +443,18 @@ def main_config1():
                                  score_tol=1e-3 if vname == "matching" else 1e-5)
             tot, worst = tot + S, max(worst, d)
         print(f"config1 lg {vname}: 10 pairs, {tot} matches, max|dscore| {worst:.1e} ok (oracle == reference)")
+    # the SuperPoint -> LightGlue leg with REAL match lists: the three overlapping DSC photographs; the seeded SuperPoint's
+    # descriptors of different photographs share no equal vectors, so the similarity head is whitened on them (weights.descriptor_whitening)
+    c_dsc, w_dsc = weights.descriptor_whitening(torch.cat([torch.tensor(feats[n]["descriptors"]).t() for n in gc.PYTEST_IMAGES]))
+    lg_out["dsc/center"], lg_out["dsc/whiten"] = c_dsc.numpy(), w_dsc.numpy()
+    sd = weights.synthetic_lightglue_matching_state_dict(0, 256, sharpness=2.0, center=c_dsc, whiten=w_dsc)
+    conf = dict(gc.CONFIG1_LG)
+    net_ = reference_lightglue(sd, conf, 256)
+    for na, nb in combinations(gc.PYTEST_IMAGES, 2):
+        tag = "dsc/" + na.rsplit(".", 1)[0] + "__" + nb.rsplit(".", 1)[0]
+        stop, S, d = lg_pair(net_, sd, conf, feats[na], feats[nb], sizes[na], sizes[nb], tag, lg_out, 256, score_tol=1e-3)
+        assert S >= 100, (tag, S)
+        print(f"config1 lg {tag}: stop {stop}, {S} matches, max|dscore| {d:.1e} ok (oracle == reference)")
     np.savez_compressed(out_dir / "config1_lg.npz", **lg_out)
 
     al_sd = {k: v for k, v in torch.load(str(ROOT / "tests" / "assets" / "aliked-n16rot.pth"), map_location="cpu").items()}

@@ -75,6 +75,27 @@ def test_lightglue_oracle_on_the_reference_features_of_the_real_photographs(vari
         assert (out["matching_scores0"] - ref["matching_scores0"]).abs().max().item() < (1e-3 if variant == "matching" else 1e-5)
 
 
+def test_superpoint_to_lightglue_leg_has_real_match_lists_on_the_dsc_photographs():
+    """SuperPoint -> LightGlue on real pixels with real match lists.  The three overlapping DSC photographs, the seeded
+    SuperPoint's float16 features, matching-capable LightGlue weights whitened on those descriptors (weights.descriptor_whitening; the matrix
+    travels in the golden file): 132 / 180 / 140 reference matches at the default threshold 0.1."""
+    g = gold("lg")
+    sd = weights.synthetic_lightglue_matching_state_dict(0, 256, sharpness=2.0, center=torch.as_tensor(g["dsc/center"]), whiten=torch.as_tensor(g["dsc/whiten"]))
+    tags = [f"dsc/{stem(a)}__{stem(b)}" for a, b in combinations(gc.PYTEST_IMAGES, 2)]
+    assert [int(g[t_ + "/matches"].shape[0]) for t_ in tags] == [132, 180, 140]
+    # the whitening matrix is reproducible from the golden features (so the fixture is data, not a free parameter)
+    c, w = weights.descriptor_whitening(torch.cat([torch.as_tensor(golden_features("superpoint", n)["descriptors"].astype(np.float32)).t() for n in gc.PYTEST_IMAGES]))
+    assert (c - torch.as_tensor(g["dsc/center"])).abs().max().item() < 1e-6 and (w - torch.as_tensor(g["dsc/whiten"])).abs().max().item() < 1e-2 * float(w.abs().max())
+    na, nb = gc.PYTEST_IMAGES[0], gc.PYTEST_IMAGES[2]
+    fa, fb = golden_features("superpoint", na), golden_features("superpoint", nb)
+    t = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32))  # noqa: E731
+    out = lightglue_ref.lightglue_forward(t(fa["keypoints"]), t(fa["descriptors"]).t().contiguous(), t(fa["image_size"]),
+                                          t(fb["keypoints"]), t(fb["descriptors"]).t().contiguous(), t(fb["image_size"]), sd, dict(gc.CONFIG1_LG))
+    ref = lg_golden(g, f"dsc/{stem(na)}__{stem(nb)}")
+    assert out["stop"] == ref["stop"] and torch.equal(out["matches"].long(), ref["matches"]) and ref["matches"].shape[0] == 180
+    assert (out["scores"] - ref["scores"]).abs().max().item() < 1e-3
+
+
 @pytest.mark.skipif(not ALIKED_CKPT.exists(), reason="aliked-n16rot.pth asset not present")
 @pytest.mark.parametrize("name", [gc.SACRE_COEUR[0], gc.PYTEST_IMAGES[2]])
 def test_aliked_oracle_trained_checkpoint_on_the_real_photographs(name):

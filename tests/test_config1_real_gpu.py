@@ -114,6 +114,45 @@ def test_lightglue_hook_on_the_reference_float16_features_all_10_pairs(hip_lib, 
              "explained_near_ties": len(ties_seen)})
 
 
+def test_superpoint_hook_features_through_the_lightglue_hook_real_match_lists_on_the_dsc_photographs(hip_lib, sp_plugin):
+    """the SuperPoint -> LightGlue leg of config 1 with REAL match lists.  The three overlapping DSC photographs; (a) the
+    reference's float16 features through `_match_pairs` with matching-capable weights whitened on those descriptors: 132 / 180 / 140 reference
+    matches at the default threshold, index pairs equal (or a numerical tie of the reference's own assignment); (b) the DEVICE's own `_extract`
+    features of the same photographs (float16 round trip, as features.h5 stores them) through the same hook: the same keypoints match (compared
+    by pixel coordinates, since the top-k order among equal scores is free)."""
+    weights = _m("weights")
+    g = gold("lg")
+    sd = weights.synthetic_lightglue_matching_state_dict(0, 256, sharpness=2.0, center=torch.as_tensor(g["dsc/center"]), whiten=torch.as_tensor(g["dsc/whiten"]))
+    mt = _m("plugins").LightGlueMatcher({"general": {}, "matcher": {"name": "lightglue", **gc.CONFIG1_LG, "pruning_min_kpts": -1, "allow_synthetic_weights": True,
+                                                                     "on_saturation": "raise"}}, local_features="superpoint")
+    mt._sd = sd
+    own = {n: {**gc.fp16_round_trip(sp_plugin._extract(gc.real_gray(n))), "image_size": np.array(gc.real_gray(n).shape[:2], np.int32)} for n in gc.PYTEST_IMAGES}
+    n_ref, flips, same_px = 0, [], []
+    for na, nb in combinations(gc.PYTEST_IMAGES, 2):
+        fa, fb = golden_features("superpoint", na), golden_features("superpoint", nb)
+        ref = lg_golden(g, f"dsc/{stem(na)}__{stem(nb)}")
+        m = torch.from_numpy(mt._match_pairs(fa, fb))
+        n_ref += int(ref["matches"].shape[0])
+        assert ref["matches"].shape[0] >= 100
+        if not torch.equal(m, ref["matches"]):
+            t = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float32))  # noqa: E731
+            o = lightglue_ref.lightglue_forward(t(fa["keypoints"]), t(fa["descriptors"]).t().contiguous(), t(fa["image_size"]),
+                                                t(fb["keypoints"]), t(fb["descriptors"]).t().contiguous(), t(fb["image_size"]), sd, dict(gc.CONFIG1_LG), taps=True)
+            flips += match_list_difference_is_a_tie(m, ref["matches"], o["log_assignment"], 0.1, tie_tol=3.6e-4, ind0=o.get("ind0"), ind1=o.get("ind1"))
+        # (b) end to end on the device: extract -> float16 -> match; as pixel-coordinate pairs
+        mo = mt._match_pairs(own[na], own[nb])
+        px = lambda f, idx: [tuple(int(v) for v in f["keypoints"][i]) for i in idx]  # noqa: E731
+        got = set(zip(px(own[na], mo[:, 0]), px(own[nb], mo[:, 1])))
+        want = set(zip(px(fa, ref["matches"][:, 0].tolist()), px(fb, ref["matches"][:, 1].tolist())))
+        same_px.append((len(got & want), len(want)))
+        assert len(got & want) >= 0.95 * len(want) and len(got) <= 1.05 * len(want), (na, nb, len(got), len(want), len(got & want))
+    assert len(flips) <= 1, flips
+    total, sites = _m("capi").saturation(hip_lib, None, reset=True)
+    assert total == 0, sites
+    _record({"test": "config1_real_superpoint_lightglue_dsc", "pairs": 3, "reference_matches": n_ref, "explained_near_ties": len(flips),
+             "device_end_to_end_common_of_reference": same_px})
+
+
 @pytest.fixture(scope="module")
 def aliked_plugin(hip_lib):
     if not ALIKED_CKPT.exists():
