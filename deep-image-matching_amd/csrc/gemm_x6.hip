@@ -147,8 +147,13 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     for (int i = 0; i < NLD; ++i) {
       const int idx = t + 256 * i, row = idx >> Q4_SHIFT, q = idx & ((1 << Q4_SHIFT) - 1);
       unsigned p0[NPL], p1[NPL];
-      S::split(ra[i].x, ra[i].y, S::act_scale(), p0);
-      S::split(ra[i].z, ra[i].w, S::act_scale(), p1);
+      if (PROBE & 64) {   // probe bit 6: no split arithmetic — the raw bits go to LDS (what activations pre-split by their producer would at most save)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) { p0[pl] = __float_as_uint(pl ? ra[i].y : ra[i].x); p1[pl] = __float_as_uint(pl ? ra[i].w : ra[i].z); }
+      } else {
+        S::split(ra[i].x, ra[i].y, S::act_scale(), p0);
+        S::split(ra[i].z, ra[i].w, S::act_scale(), p1);
+      }
       unsigned* d = &Ab[row * RS + q * 2];
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) { d[pl * BM * RS] = p0[pl]; d[pl * BM * RS + 1] = p1[pl]; }
@@ -1138,6 +1143,10 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
       case 100: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<0, true>), grid, dim3(256), 0, s, a); break;
       case 104: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<4, true>), grid, dim3(256), 0, s, a); break;
       case 116: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<16, true>), grid, dim3(256), 0, s, a); break;
+      case 164: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<64, true>), grid, dim3(256), 0, s, a); break;   // round 6: no split VALU
+      case 172: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<72, true>), grid, dim3(256), 0, s, a); break;   // + weight fragments loaded once
+      case 108: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<8, true>), grid, dim3(256), 0, s, a); break;    // pipelined loop, weight fragments once (the bound of any weight-sharing scheme)
+      case 180: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<80, true>), grid, dim3(256), 0, s, a); break;   // no split + no epilogue traffic
       case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<48>), grid, dim3(256), 0, s, a); break;
       case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<32>), grid, dim3(256), 0, s, a); break;
       case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<16>), grid, dim3(256), 0, s, a); break;
