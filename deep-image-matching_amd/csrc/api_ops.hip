@@ -63,6 +63,8 @@ static int g_precision_mode = 2;
 int dim_precision_mode() { return tuned(1, g_precision_mode); }
 static int g_fuse_conv1a = 1;
 int dim_fuse_conv1a() { return tuned(3, g_fuse_conv1a); }
+static int g_fuse_sp_head = 1;
+int dim_fuse_sp_head() { return tuned(16, g_fuse_sp_head); }
 static int g_fold_out_proj = 1;
 int dim_fold_out_proj() { return tuned(4, g_fold_out_proj); }
 static int g_fuse_kv = 1;
@@ -281,6 +283,7 @@ int dim_tune_set(int key, int value) {
   if (key == 9) g_al_fuse_bn = value;
   if (key == 10) g_al_tile_rows = value;
   if (key == 11) g_fuse_ffn_ln = value;
+  if (key == 16) g_fuse_sp_head = value;
 #ifdef DIM_RESEARCH
   if (key == 12) g_attn_probe = value;
   if (key == 13) g_gemm_probe = value;
@@ -290,15 +293,15 @@ int dim_tune_set(int key, int value) {
   DIM_REQUIRE(key < 12 || key > 15, "dim_tune_set: key %d selects a research prototype / timing probe that the product library does not contain "
               "(build.build_variant(\"research\", [\"-DDIM_RESEARCH\"]) -> libdim_hip_research.so)", key);
 #endif
-  DIM_REQUIRE(key >= 0 && key <= 15, "dim_tune_set: unknown key %d", key);
+  DIM_REQUIRE(key >= 0 && key <= 16, "dim_tune_set: unknown key %d", key);
   return 0;
 }
 
 int dim_handle_tune_set(void* handle, int key, int value) {
   DimHandleBase* b = (DimHandleBase*)handle;
   DIM_REQUIRE(b != nullptr && b->magic == DIM_HANDLE_MAGIC, "dim_handle_tune_set: not an extractor / matcher handle of this library");
-  DIM_REQUIRE(key == 1 || key == 3 || key == 4 || key == 5 || key == 8 || key == 9 || key == 10 || key == 11,
-              "dim_handle_tune_set: key %d has no per-handle form (arithmetic 1; fusion 3, 4, 5, 8, 9, 11; ALIKED tile rows 10)", key);
+  DIM_REQUIRE(key == 1 || key == 3 || key == 4 || key == 5 || key == 8 || key == 9 || key == 10 || key == 11 || key == 16,
+              "dim_handle_tune_set: key %d has no per-handle form (arithmetic 1; fusion 3, 4, 5, 8, 9, 11, 16; ALIKED tile rows 10)", key);
   b->tune.v[key] = value < 0 ? -1 : value;
   return 0;
 }

@@ -58,6 +58,10 @@ struct GemmArgs {
   // never stored (gemm_x6_ffn_fused_kernel).  sat guards the hidden values, sat2 the outputs.
   const unsigned short* B2x3 = nullptr; const float* inv_ch2 = nullptr; const float* bias2 = nullptr; unsigned* sat2 = nullptr;
   void set_split2(const SplitWeights& w) { B2x3 = w.dev; inv_ch2 = w.inv_ch(); }
+  // SuperPoint's detector tail (fp16x3, N = 65 over M = maps x d2s_h x d2s_w cells, batch 1): when d2s_out != nullptr the block spans all 65
+  // channels of 128 cells and the epilogue applies the 65-way softmax, drops the dustbin and stores the 8 x 8 blocks of the score map
+  // [maps][8 d2s_h][8 d2s_w] (SPN:176-179) — C (the logits) is not written (gemm_x6_head_kernel).
+  float* d2s_out = nullptr; int d2s_h = 0, d2s_w = 0;
 };
 constexpr int KV_TILE_STRIDE = 3 * 8 * 32 + 3 * 2 * 2 * 64;  // 16-byte slots reserved per (item, head, 32-key tile) image (bf16x6 fills all 1536)
 bool gemm_x6_fuses_kv(int M, int n_pad, int batch, int split_mode);  // true when launch_gemm_x6 will honour kv_img for this shape
@@ -115,6 +119,7 @@ int dim_precision_mode();  // 2 (default): fp16x3, 1: bf16x6 on the 16-bit matri
 int dim_aliked_tile_rows();  // dim_tune_set key 10: tile rows (16 | 8) of ALIKED's 16-channel 3x3 matrix-core convolution
 int dim_aliked_fuse_bn();   // dim_tune_set key 9: ALIKED folds BatchNorm + SELU into the consuming convolution's staging (default 1)
 int dim_fuse_conv1a();     // 1 (default): SuperPoint conv1a is computed inside conv1b (dim_tune_set key 3)
+int dim_fuse_sp_head();    // 1 (default): SuperPoint's convPb + softmax + depth-to-space are one kernel in fp16x3 (dim_tune_set key 16)
 int dim_fold_out_proj();   // 1 (default): LightGlue out_proj folded into ffn.0's weights in the split modes (dim_tune_set key 4)
 #ifdef DIM_RESEARCH
 int dim_gemm_kc();           // dim_tune_set key 14: 32 (product); 64 / 33 = prototypes of the wide GEMM blocks, 36 = the fused feed-forward's previous K loop, 35 = timing probe

@@ -98,7 +98,8 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   static_assert(!ROLL || (((KV == 3 || KV == 4) && !PIPE) || (PIPE && KCH == 32 && !DB)) && (PROBE & ~1) == 0, "rolling fragment requests exist for the 64 x 512 blocks and (prototype) the pipelined 32-wide K loop");
   constexpr int ABUF = NPL * BM * RS;   // dwords of one staged activation tile
   constexpr int BN = 32 * NT * WN;
-  static_assert(KV == 0 || KV == 3 || KV == 4 || (MODE == 2 && BN == 256 && (BM == 128 || BM == 256)), "the K|V image epilogue exists for the fp16x3 128 / 256 x 256 blocks");
+  static_assert(KV == 0 || KV == 3 || KV == 4 || KV == 5 || (MODE == 2 && BN == 256 && (BM == 128 || BM == 256)), "the K|V image epilogue exists for the fp16x3 128 / 256 x 256 blocks");
+  static_assert(KV != 5 || (MODE == 2 && BM == 128 && NT == 3 && WN == 1), "the detector-head epilogue exists for the fp16x3 128 x 96 block (4 waves x 32 cells, all 65 channels per wave)");
   static_assert(KV != 4 || (MODE == 2 && BN == 512 && (BM == 64 || BM == 128) && WN == 4 && NT == 4), "the fused ffn exists for the fp16x3 64 / 128 x 512 blocks");
   static_assert(KV != 3 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4), "the LayerNorm + GELU epilogue exists for the fp16x3 64 x 512 block");
   static_assert(!STREAM || (MT == 1 && KV == 0 && PROBE == 0 && !PIPE && !DB && !ROLL && KCH == 32), "the streaming K loop exists for one 32-row tile per wave and the plain epilogue");
@@ -594,6 +595,52 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     return;
   }
 
+  if constexpr (KV == 5) {
+    // ================= SuperPoint's detector tail in the epilogue of convPb (SPN:176-179; round 6): the block's 128 cells x 65 logits never
+    // leave the CU.  Every wave holds ALL channels of its 32 cells (lane = channel lx of column tile n: channels lx, 32 + lx; tile 2's lane 0 =
+    // the dustbin), so the 65-way softmax is a max / sum over the 32 lanes of a lane half plus one broadcast value.  The arithmetic is
+    // softmax_d2s_kernel's, operation for operation — logit = acc * inv + bias as the plain epilogue stores it; wave_sum's association
+    // (channel c + channel c ^ 32 first, then the lane butterflies 16 .. 1); the dustbin's exponential added last — so the score map is
+    // bit-identical to the two-kernel path (tests/test_superpoint_emu.py).  The probabilities go through LDS (the staging buffer is free) and
+    // leave as 16-byte stores along the image rows: 128 consecutive cells = 1024 consecutive pixels of 8 rows.  No [cells][65] logits in HBM
+    // (426 MB written and read per 100 maps), no N = 65 -> 128 padding (96 columns issued instead of 128). =================
+    constexpr int HS = 72;                          // floats per cell row in LDS (64 + 8: the halves' rows land 32 banks apart)
+    float* const tile = (float*)Ap;                 // [128 cells][HS]
+    const float bv0 = a.bias[lx], bv1 = a.bias[32 + lx], bv2 = a.bias[64];
+    const float iv0 = a.inv_ch[lx], iv1 = a.inv_ch[32 + lx], iv2 = a.inv_ch[64];
+    float vmax = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v0 = acc[0][0][r] * iv0 + bv0, v1 = acc[0][1][r] * iv1 + bv1;
+      const float dust = __shfl(acc[0][2][r] * iv2 + bv2, lane & 32);   // column 64 sits in lane 0 of each half
+      vmax = sat_track(vmax, v0, v1);
+      float m = fmaxf(v0, v1);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      m = fmaxf(m, dust);
+      const float e0 = expf(v0 - m), e1 = expf(v1 - m);
+      float sum = e0 + e1;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      sum += expf(dust - m);
+      const int cell = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      tile[cell * HS + lx] = e0 / sum;
+      tile[cell * HS + 32 + lx] = e1 / sum;
+    }
+    (void)vmax;   // (logits feed no split product: nothing to guard)
+    __syncthreads();
+    // depth-to-space: thread -> (cell, half of its 8-pixel rows); channel c = 8 dy + dx (SPN:178-179)
+    const int cl = t >> 1, dxq = t & 1, cell = m0 + cl;
+    if (cell < rows) {
+      const int hw = a.d2s_h * a.d2s_w, b = cell / hw, rem = cell - b * hw, cy = rem / a.d2s_w, cx = rem - cy * a.d2s_w;
+      const int W8 = a.d2s_w * 8;
+      float* dst = a.d2s_out + ((size_t)b * a.d2s_h * 8 + (size_t)cy * 8) * W8 + cx * 8 + dxq * 4;
+#pragma unroll
+      for (int dy = 0; dy < 8; ++dy) *(float4*)(dst + (size_t)dy * W8) = *(const float4*)&tile[cl * HS + dy * 8 + dxq * 4];
+    }
+    return;
+  }
+
   if (kblk || vblk) {
     // ---- K | V tile images (layout: lg_attn_x6.hip).  Rows past the ragged end are copies of the last valid row (finite;
     // the attention kernel masks their scores), tiles past the image capacity are skipped. ----
@@ -665,7 +712,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
     return;
   }
 
-  if (lng) {
+  if constexpr (lng) {
     // ---- LayerNorm(512) + GELU over the block's full rows (LGN:141-142), then the store.
     // Row statistics: in-lane over the wave's 4 column tiles, DPP over the 16-lane rows, then through LDS (the activation
     // staging buffer is free after the K loop) over the 4 x 4 sixteen-lane groups that share a block row; mean first, then
@@ -840,6 +887,17 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_stream_kernel(GemmArgs a) {
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 64 * RS];
   gemm_x6_body<2, 64, 4, 3, 4, 0, true>(a, Ap, 0);
+}
+// SuperPoint's convPb (256 -> 65) + 65-way softmax + depth-to-space: one workgroup owns 128 cells x all 65 channels (KV = 5 above)
+#ifndef DIM_HEAD_WGS
+#define DIM_HEAD_WGS 3
+#endif
+#ifndef DIM_HEAD_PIPE
+#define DIM_HEAD_PIPE true
+#endif
+__global__ __launch_bounds__(256, DIM_HEAD_WGS) void gemm_x6_head_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[128 * 72];
+  gemm_x6_body<2, 128, 3, 5, 1, 0, DIM_HEAD_PIPE>(a, Ap, 0);
 }
 #ifdef DIM_RESEARCH   // timing probes (wrong results by design): research build only
 template <int PROBE, bool PIPE = false>
@@ -1074,6 +1132,14 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
   DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
   if (batch <= 0 || a.M <= 0 || a.N <= 0) return 0;
+  if (a.d2s_out != nullptr) {
+    DIM_REQUIRE(a.split_mode == 2 && a.N == 65 && a.n_pad >= 96 && a.bias && a.R == nullptr && a.relu == 0 && a.kv_img == nullptr && a.ln_gamma == nullptr && a.A1 == nullptr &&
+                batch == 1 && a.d2s_h > 0 && a.d2s_w > 0 && a.M % (a.d2s_h * a.d2s_w) == 0 && (a.d2s_w * 8) % 4 == 0,
+                "gemm_x6: the detector-head epilogue needs the fp16x3 256 -> 65 shape over [maps][h][w] cells");
+    hipLaunchKernelGGL(gemm_x6_head_kernel, dim3(cdiv(a.M, 128), 1, 1), dim3(256), 0, s, a);
+    DIM_LAUNCH_CHECK();
+    return 0;
+  }
   if (a.ln_gamma != nullptr && a.B2x3 != nullptr) {
     DIM_REQUIRE(a.split_mode == 2 && a.N == 512 && a.n_pad == 512 && a.K % KC == 0 && a.ln_beta && a.bias && a.bias2 && a.inv_ch2 && a.R && a.C && a.relu == 0 &&
                 a.kv_img == nullptr && a.ldr == a.ldc && a.strideR == a.strideC,

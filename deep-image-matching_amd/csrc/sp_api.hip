@@ -31,6 +31,7 @@ struct dim_sp {
   int last_h, last_w, last_batch;
   float conv1a_bound; // max over channels of sum|w1a| + |b1a|: bound on conv1a's outputs for |image| <= 1 (fp16x3 range guard)
   bool x_is_planes;   // the last extract stored the encoder output as pre-split planes
+  bool head_fused;    // the last extract ran convPb + softmax + depth-to-space as one kernel: h->logits is stale
   float* b1_dbg;      // fp32 copy of conv1b's pooled output (dim_sp_debug_conv1b)
   float* x_dbg;       // fp32 copy of it, built on request by dim_sp_debug_buffers
   std::vector<void*> allocs;
@@ -75,7 +76,7 @@ int dim_sp_create(const dim_sp_weights* w, const dim_sp_config* cfg, int max_bat
   h->cfg = *cfg;
   h->max_batch = max_batch; h->max_h = max_h; h->max_w = max_w; h->capacity = capacity;
   h->last_h = h->last_w = h->last_batch = 0;
-  h->b1_dbg = nullptr; h->x_dbg = nullptr;
+  h->b1_dbg = nullptr; h->x_dbg = nullptr; h->head_fused = false;
 #define SP_TRY(x) do { if ((x) != 0) { dim_sp_destroy(h); return -1; } } while (0)
   // ---- weights: OIHW (SPN:128-143) -> [tap][cin][cout] / [cin][cout_padded4] ----
   for (int l = 0; l < 12; ++l) {
@@ -232,10 +233,17 @@ int dim_sp_extract(dim_sp* h, const float* images_dev, int batch, int H, int W, 
     GemmArgs g;
     g.A0 = h->pa; g.lda0 = 256; g.B = h->wk[9]; g.ldb = 68; g.bias = h->bias[9];
     g.C = h->logits; g.ldc = 65; g.M = batch * hh * ww; g.N = 65; g.K = 256;
-    if (x6) { g.set_split(h->wsp[pmode][9]); SP_RUN(launch_gemm_x6(g, 1, s)); }
-    else SP_RUN(launch_gemm(g, 1, s));
+    // fp16x3: convPb + softmax + depth-to-space in one kernel (gemm_x6_head_kernel): the logits are not stored (dim_sp_debug_buffers rebuilds them)
+    h->head_fused = pmode == 2 && dim_fuse_sp_head();
+    if (h->head_fused) {
+      g.set_split(h->wsp[pmode][9]); g.d2s_out = h->smap; g.d2s_h = hh; g.d2s_w = ww;
+      SP_RUN(launch_gemm_x6(g, 1, s));
+    } else {
+      if (x6) { g.set_split(h->wsp[pmode][9]); SP_RUN(launch_gemm_x6(g, 1, s)); }
+      else SP_RUN(launch_gemm(g, 1, s));
+      SP_RUN(launch_softmax_d2s(h->logits, h->smap, batch, hh, ww, s));
+    }
   }
-  SP_RUN(launch_softmax_d2s(h->logits, h->smap, batch, hh, ww, s));
   SP_RUN(launch_nms(h->smap, h->nms, batch, H8, W8, h->cfg.nms_radius, s));
   // selection (SPN:183-210)
   SP_RUN(launch_select(h->nms, batch, H8, W8, h->cfg.keypoint_threshold, h->cfg.remove_borders, h->rowcount, h->rowoff,
@@ -272,7 +280,17 @@ int dim_sp_debug_buffers(dim_sp* h, const float** encoder, const float** logits,
       *encoder = h->x_dbg;
     }
   }
-  if (logits) *logits = h->logits;
+  if (logits) {
+    if (h->head_fused && h->last_batch > 0) {   // the fused detector tail never stores the logits: rebuild them with the plain GEMM on the last batch's convPa output
+      GemmArgs g;
+      g.A0 = h->pa; g.lda0 = 256; g.B = h->wk[9]; g.ldb = 68; g.bias = h->bias[9];
+      g.C = h->logits; g.ldc = 65; g.M = h->last_batch * h->last_h * h->last_w; g.N = 65; g.K = 256;
+      g.set_split(h->wsp[2][9]);
+      if (launch_gemm_x6(g, 1, nullptr) != 0) return -1;
+      DIM_HIP(hipDeviceSynchronize());
+    }
+    *logits = h->logits;
+  }
   if (score_map) *score_map = h->smap;
   if (nms_map) *nms_map = h->nms;
   if (dense_desc) *dense_desc = h->dd;

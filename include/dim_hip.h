@@ -47,6 +47,8 @@ int dim_device_synchronize(void);
  *   key 5  1 (default) SuperPoint conv-to-conv activations stored pre-split (fp16x3), 0 = fp32;
  *   key 8  1 (default) LightGlue's K | V attention tile images written by the projection GEMM, 0 = separate pre-split pass;
  *   key 9  1 (default) ALIKED BatchNorm + SELU applied while the consumer stages its input, 0 = separate pass;
+ *   key 16 1 (default) SuperPoint's detector tail (convPb 256 -> 65, softmax, depth-to-space) as one kernel in fp16x3, 0 = GEMM + softmax kernels
+ *          (bit-identical score maps);
  *   key 11 LightGlue's feed-forward: 3 (default) ffn.0 + LayerNorm + GELU + ffn.3 + residual as one kernel when the launch fills the GPU,
  *          4 = always, 1 / 2 = LayerNorm + GELU in ffn.0's epilogue only (when large / always), 0 = separate kernels;
  *   kernel-shape selection (same results; the defaults pick by problem size, the other values force a shape — used by the tests to reach

@@ -192,3 +192,27 @@ def test_top_k_above_4096_keypoints(emu_lib, k):
     yx, sc = superpoint_ref.select_keypoints(taps["nms_map"][0], cfg["keypoint_threshold"], cfg["remove_borders"], k)
     assert out["keypoints"].shape[0] == k
     assert torch.equal(torch.flip(yx, [1]), out["keypoints"].long()) and torch.equal(sc, out["scores"])
+
+
+def test_fused_detector_tail_equals_the_two_kernel_path(emu_lib):
+    """convPb + 65-way softmax + depth-to-space as one kernel (gemm_x6_head_kernel, dim_tune_set key 16) must give the score map of the
+    GEMM + softmax_d2s_kernel path BIT FOR BIT (it is the tap every NMS test pins): same logits, same reduction association, same
+    exponentials.  Ragged sizes: the last 128-cell block is partial and cell rows wrap inside a block."""
+    case = gc.SP_CASES[next(iter(gc.SP_CASES))]
+    sd = gc.sp_weights(case)
+    for H, W, B in ((44, 70, 1), (96, 128, 2), (160, 264, 1)):
+        img = torch.rand(B, H, W, generator=torch.Generator().manual_seed(H))
+        net = sp_mod.SuperPointHIP(sd, case["cfg"], max_batch=B, max_hw=(H, W), capacity=512, device="cpu", lib=emu_lib)
+        try:
+            emu_lib.dim_tune_set(16, 1)
+            a = [t.clone() for t in net.extract_batch(img)]; ta = net.debug_taps(B)
+            emu_lib.dim_tune_set(16, 0)
+            b = [t.clone() for t in net.extract_batch(img)]; tb = net.debug_taps(B)
+        finally:
+            emu_lib.dim_tune_set(16, 1)
+        assert torch.equal(ta["score_map"], tb["score_map"]), (H, W)
+        assert torch.equal(ta["logits"], tb["logits"])            # (the fused path rebuilds the tap with the plain GEMM)
+        assert torch.equal(a[3], b[3])
+        for i in range(B):   # (slots past the live count are uninitialised)
+            k = int(a[3][i])
+            assert all(torch.equal(x[i, :k], y[i, :k]) for x, y in zip(a[:3], b[:3]))
