@@ -24,7 +24,11 @@ from __future__ import annotations
 import itertools
 from typing import List, Optional, Sequence, Tuple
 
+import logging
+
 import torch
+
+logger = logging.getLogger("dim")
 
 
 def exhaustive_pairs(n_images: int, limit: Optional[int] = None) -> torch.Tensor:
@@ -250,6 +254,14 @@ class TiledPairPipeline:
                  max_matches_per_pair: Optional[int] = None, empty_selection_fallback: Optional[str] = None, tile_pair_batch: Optional[int] = None):
         self.ext, self.mat, self.rank, self.world = extractor, matcher, rank, world
         self.selection = selection
+        # the tile ids of the extracted features come from the FULL-resolution grid (extract_all does not resize), the selection grids from
+        # get_size_by_quality(quality, shape): they are the same grid only at quality HIGH — anything else would select tiles that are
+        # not the features' tiles
+        for cfg in (extractor.config, matcher.config):
+            q = cfg["general"].get("quality", "HIGH")
+            if getattr(q, "name", q) != "HIGH":
+                raise ValueError(f"TiledPairPipeline works on the full-resolution tiling (general.quality HIGH); got {getattr(q, 'name', q)!r} — "
+                                 "use the plugins under the reference's own loops for the resized qualities")
         # benchmarks on seeded synthetic weights only: PRESELECTION needs a SuperPoint + LightGlue that can vote for tile pairs; when it
         # selects nothing, the named method supplies the tile pairs.  None (default, the reference's behaviour): an empty selection means
         # an empty match list.
@@ -501,8 +513,8 @@ class TiledPairPipeline:
         counts = {}
         used = sorted({int(pairs[p, k]) for p in range(P) if sel[p] for k in (0, 1)})
         if used:
-            cdev = torch.stack([torch.bincount(tables[i]["tile_idx"].to(torch.int64), minlength=tmax)[:tmax] if tables[i]["tile_idx"].numel()
-                                else torch.zeros(tmax, dtype=torch.int64, device=dev) for i in used])
+            from .tile_matching import device_tile_counts
+            cdev = torch.stack([device_tile_counts(self.mat._lib, tables[i], tmax) for i in used])          # dim_op_tile_counts (csrc/sort_ops.hip)
             for i, c in zip(used, cdev.cpu().tolist()):                                  # ONE host read-back for the whole job
                 counts[i] = c
         cost = torch.zeros(P, dtype=torch.float64)
@@ -554,28 +566,21 @@ class TiledPairPipeline:
         it = torch.zeros(T, cap_t, dtype=torch.int64, device=dev)        # tile-local slot -> index in the image's merged table
         nt = torch.zeros(T, dtype=torch.int32, device=dev)
         st = torch.zeros(T, 2, dtype=torch.float32, device=dev)
-        for i in imgs:        # keypoints grouped by tile, original order inside a tile (= the boolean-mask order of get_features_by_tile)
+        from .tile_matching import device_group_by_tile, device_unique_match_rows
+        lib = self.mat._lib
+        for i in imgs:        # keypoints grouped by tile, original order inside a tile (= the boolean-mask order of get_features_by_tile): dim_op_group_by_tile
             f = tables[i]
-            ti = f["tile_idx"].to(torch.int64)
-            order = torch.argsort(ti, stable=True)
-            c = torch.tensor(counts[i], dtype=torch.int64, device=dev)
-            starts = torch.cumsum(c, 0) - c
-            ts = ti[order]
-            r, pos = base[i] + ts, torch.arange(order.numel(), device=dev) - starts[ts]
-            kt[r, pos] = f["keypoints"][order]
-            dt[r, pos] = f["descriptors_nd"][order]
-            it[r, pos] = order
-            nt[base[i]: base[i] + tmax] = c.to(torch.int32)
+            rot = torch.arange(base[i], base[i] + tmax, dtype=torch.int32, device=dev)
+            device_group_by_tile(lib, f, rot, cap_t, kt, dt, it, nt)
             st[base[i]: base[i] + tmax] = torch.as_tensor(np_f32(f["image_size"]), device=dev)
         tp = [(s, base[int(pairs[p, 0])] + ta, base[int(pairs[p, 1])] + tb) for s, p in enumerate(mine) for ta, tb in sel[p]]
         B = max(1, min(self.tile_pair_batch, len(tp)))
         net = self.mat._ensure_pairs(cap_t, B)
         NK = net.nk
         pidx_all = torch.tensor([[r0, r1] for _, r0, r1 in tp], dtype=torch.int32, device=dev).contiguous()
-        slot_all = torch.tensor([s for s, _, _ in tp], dtype=torch.int64, device=dev)
-        SENT = torch.iinfo(torch.int64).max
-        keys = torch.full((len(tp), NK), SENT, dtype=torch.int64, device=dev)
-        ar = torch.arange(NK, device=dev)[None, :]
+        slot_all = torch.tensor([s for s, _, _ in tp], dtype=torch.int32, device=dev)
+        keys = torch.empty(len(tp), NK, dtype=torch.int64, device=dev)
+        stream = ctypes_stream_of(dev)
 
         def run():
             out = None
@@ -583,23 +588,18 @@ class TiledPairPipeline:
                 pidx = pidx_all[s0:s0 + B].contiguous()
                 b = int(pidx.shape[0])
                 out = net.match_batch(kt, dt, nt, st, pair_idx=pidx, n_pairs=b, out=out)
-                m, c = out["matches"][:b], out["n_matches"][:b].to(torch.int64)
-                g0 = torch.gather(it[pidx[:, 0].long()], 1, m[..., 0].clamp(0, cap_t - 1))
-                g1 = torch.gather(it[pidx[:, 1].long()], 1, m[..., 1].clamp(0, cap_t - 1))
-                k = (slot_all[s0:s0 + b, None] << 40) | (g0 << 20) | g1
-                keys[s0:s0 + b] = torch.where(ar < c[:, None], k, torch.full_like(k, SENT))
+                # tile-local match indices -> 64-bit keys  slot << 40 | idx0 << 20 | idx1  in the images' merged index space (~0: dead rows)
+                capi.check(lib, lib.dim_op_tile_match_keys(capi.ptr(out["matches"]), capi.ptr(out["n_matches"]), capi.ptr(it), capi.ptr(pidx), capi.ptr(slot_all[s0:s0 + b]),
+                                                           b, NK, cap_t, capi.ptr(keys[s0:s0 + b]), stream))
 
         _guarded(net, run, "tiled pipeline matching")        # ONE range-guard read for the phase; a re-run overwrites every key row
-        u = torch.unique(keys.reshape(-1))                     # sorted: by image-pair slot, then (idx0, idx1) lexicographically
-        u = u[u != SENT]
-        slot = u >> 40
-        n_slot = torch.bincount(slot, minlength=len(mine))[: len(mine)]
-        start = torch.cumsum(n_slot, 0) - n_slot
-        pos = torch.arange(u.numel(), device=dev) - start[slot]
-        keep = pos < cap_m                                     # only with an explicit max_matches_per_pair below the bound
-        rows[slot[keep], pos[keep], 0] = ((u[keep] >> 20) & 0xFFFFF).to(torch.int32)
-        rows[slot[keep], pos[keep], 1] = (u[keep] & 0xFFFFF).to(torch.int32)
-        cnt[: len(mine)] = torch.clamp(n_slot, max=cap_m).to(torch.int32)
+        # per image pair: unique rows in lexicographic order (np.unique(axis=0), MB:452-459) straight into the exchange buffer's row table
+        n_full = torch.zeros(len(mine), dtype=torch.int32, device=dev)
+        device_unique_match_rows(lib, keys, len(mine), cap_m, rows, cnt, n_full)
+        over = int((n_full > cap_m).sum().item()) if self.max_matches is not None else 0     # only an explicit max_matches_per_pair can bind
+        self.timings["truncated_pairs"] = over
+        if over:
+            logger.warning("TiledPairPipeline: %d image pair(s) have more unique matches than max_matches_per_pair=%d; the lists are cut to their first rows", over, cap_m)
 
 
 def np_shape(image):

@@ -221,7 +221,7 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
     def _extract(self, image: np.ndarray) -> dict:
         """image: float32 HxW, values 0..255 (extractor_base.py:197-202).  Returns numpy
         keypoints (N,2) float32 (x,y), scores (N,), descriptors (256,N) (SPX:126-130)."""
-        image_ = self._frame2tensor(image, self._device)
+        image_ = _to_device(self, _frame2array(image), self._device)      # (= _frame2tensor without its synchronisation: this call synchronises below)
         if image_.shape[1] != 1:
             raise ValueError("SuperPoint expects a single-channel image")
         H, W = int(image_.shape[-2]), int(image_.shape[-1])
@@ -235,14 +235,19 @@ class SuperPointExtractor(BatchedTilingMixin, _ExtractorBase):
 
     def _frame2tensor(self, image: np.ndarray, device: str = "cuda"):
         """SPX:134-146 (through page-locked staging on a GPU)."""
-        return _to_device(self, _frame2array(image), device)
+        return _to_device(self, _frame2array(image), device, sync=True)
 
 
-def _to_device(plugin, image: np.ndarray, device):
-    """image / 255.0 (float32, the reference's values) on ``device``, same shape as ``image``."""
+def _to_device(plugin, image: np.ndarray, device, sync: bool = False):
+    """image / 255.0 (float32, the reference's values) on ``device``, same shape as ``image``.  The copy leaves a REUSED page-locked buffer
+    asynchronously: ``sync=True`` (the public _frame2tensor hooks) waits for it, so that a second call cannot overwrite the source of a copy
+    still in flight; _extract keeps the asynchronous form and synchronises before it returns."""
     if str(getattr(device, "type", device)).startswith("cuda"):
         st = plugin.__dict__.setdefault("_staging", _PinnedStaging())
-        return st.upload_scaled(image, device)
+        t = st.upload_scaled(image, device)
+        if sync:
+            torch.cuda.current_stream(t.device).synchronize()
+        return t
     return torch.from_numpy(np.ascontiguousarray(image / 255.0, dtype=np.float32)).to(device)
 
 
@@ -323,7 +328,7 @@ class AlikedExtractor(BatchedTilingMixin, _ExtractorBase):
 
     def _frame2tensor(self, image: np.ndarray, device: str = "cuda"):
         """ALX:66-78 (through page-locked staging on a GPU)."""
-        return _to_device(self, _frame2array(image), device)
+        return _to_device(self, _frame2array(image), device, sync=True)
 
 
 def featuresDict2Lightglue(feats: dict) -> dict:

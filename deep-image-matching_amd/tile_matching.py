@@ -461,78 +461,114 @@ def match_tile_pairs_batched(net_for, features0: dict, features1: dict, tile_pai
     return full
 
 
+def _stream_of(dev):
+    import ctypes
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if torch.device(dev).type == "cuda" else None
+
+
+def _row_stride(t: torch.Tensor) -> int:
+    return int(t.stride(0)) if t.shape[0] > 1 else max(1, int(t.shape[1]) if t.dim() > 1 else 1)
+
+
+def device_tile_counts(lib, f: dict, n_tiles: int) -> torch.Tensor:
+    """keypoints per tile of one image's merged device table (dim_op_tile_counts) -> int32 [n_tiles] on the device."""
+    from . import capi
+    ti = f["tile_idx"]
+    counts = torch.empty(n_tiles, dtype=torch.int32, device=ti.device)
+    capi.check(lib, lib.dim_op_tile_counts(capi.ptr(ti), _row_stride(ti), int(ti.numel()), n_tiles, capi.ptr(counts), _stream_of(ti.device)))
+    return counts
+
+
+def device_group_by_tile(lib, f: dict, row_of_tile: torch.Tensor, cap: int, kt, dt, it, nt):
+    """get_features_by_tile (MB:1380-1391) for every needed tile of one image at once (dim_op_group_by_tile): tile t of the merged table ``f``
+    (keypoints [N, 2], descriptors_nd [N, D], tile_idx [N]; device) fills row row_of_tile[t] (int32 device tensor, -1 = not needed) of the shared
+    tables kt / dt / it / nt, keypoints in their original order."""
+    import ctypes
+    from . import capi
+    ti = f["tile_idx"]
+    n, D, T = int(ti.numel()), int(f["descriptors_nd"].shape[1]), int(row_of_tile.numel())
+    if n == 0:
+        return
+    lib.dim_op_group_by_tile_workspace_bytes.restype = ctypes.c_size_t
+    ws = torch.empty(int(lib.dim_op_group_by_tile_workspace_bytes(n, T)), dtype=torch.uint8, device=ti.device)
+    kp, de = f["keypoints"], f["descriptors_nd"]      # (views of one packed [N][4 + D] table in the tiled pipeline: passed with their row strides, not copied)
+    assert kp.stride(-1) == 1 and de.stride(-1) == 1 and ti.dtype == kp.dtype == de.dtype == torch.float32
+    capi.check(lib, lib.dim_op_group_by_tile(capi.ptr(ti), _row_stride(ti), capi.ptr(kp), _row_stride(kp), capi.ptr(de), _row_stride(de), n, D, capi.ptr(row_of_tile), T,
+                                             int(cap), capi.ptr(kt), capi.ptr(dt), capi.ptr(it), capi.ptr(nt), capi.ptr(ws), _stream_of(ti.device)))
+
+
+def device_unique_match_rows(lib, keys: torch.Tensor, n_slots: int, cap_m: int, rows: torch.Tensor, cnt: torch.Tensor, n_full: Optional[torch.Tensor] = None):
+    """np.unique(matches, axis=0) per image pair (MB:452-459) on the device (dim_op_unique_match_rows): 64-bit keys slot << 40 | idx0 << 20 | idx1
+    (~0 = dead) -> rows [n_slots, cap_m, 2] (int32 or int64), cnt [n_slots]; n_full (optional) = the row counts before the cap_m cut."""
+    import ctypes
+    from . import capi
+    n = int(keys.numel())
+    lib.dim_op_unique_match_rows_workspace_bytes.restype = ctypes.c_size_t
+    ws = torch.empty(int(lib.dim_op_unique_match_rows_workspace_bytes(ctypes.c_longlong(n))), dtype=torch.uint8, device=keys.device)
+    capi.check(lib, lib.dim_op_unique_match_rows(capi.ptr(keys), ctypes.c_longlong(n), int(n_slots), int(cap_m), int(rows.dtype == torch.int64), capi.ptr(rows),
+                                                 capi.ptr(cnt), capi.ptr(n_full) if n_full is not None else None, capi.ptr(ws), _stream_of(keys.device)))
+
+
 def match_tile_pairs_batched_device(net_for, f0: dict, f1: dict, tile_pairs: Sequence[Tuple[int, int]], pair_batch: int = 8,
                                     select_unique: bool = True) -> torch.Tensor:
     """match_tile_pairs_batched with the feature tables ALREADY in HBM and the result left there (round 4: pipeline.TiledPairPipeline holds every
     image's merged tile table in its exchange buffer; the numpy version re-uploads 33 MB per image and image pair and unpacks on the host —
     two thirds of config 5's 108 ms per image pair).  f0 / f1: {"keypoints" [N, 2] f32, "descriptors_nd" [N, D] f32, "tile_idx" [N] f32
     (device tensors), "image_size" (2,)}.  Returns (M, 2) int64 on the device, identical to the numpy version's array (same tile
-    tables, same LightGlue calls, torch.unique(dim=0) orders rows like np.unique(axis=0))."""
+    tables, same LightGlue calls; rows unique and in np.unique(axis=0)'s lexicographic order).  Round 6: the grouping by tile, the index
+    mapping and the unique are the library's own kernels (csrc/sort_ops.hip) — no torch.argsort / torch.unique on the path."""
+    from . import capi
     dev = f0["keypoints"].device
     empty = torch.empty(0, 2, dtype=torch.int64, device=dev)
     if len(tile_pairs) == 0:
         return empty
     t0s, t1s = sorted({p[0] for p in tile_pairs}), sorted({p[1] for p in tile_pairs})
-
-    def grouped(f):   # keypoints grouped by tile, original order inside a tile (= the boolean-mask order of get_features_by_tile)
-        ti = f["tile_idx"].to(torch.int64)
-        order = torch.argsort(ti, stable=True)
-        counts = torch.bincount(ti, minlength=1)
-        return ti, order, counts
-
-    ti0, ord0, cnt0 = grouped(f0)
-    ti1, ord1, cnt1 = grouped(f1)
-    c0, c1 = cnt0.cpu().tolist(), cnt1.cpu().tolist()      # ONE host read-back per image pair (the table capacity depends on it)
+    lib = capi.load()
+    nt0, nt1 = max(t0s) + 1, max(t1s) + 1
+    cc = torch.cat([device_tile_counts(lib, f0, nt0), device_tile_counts(lib, f1, nt1)]).cpu().tolist()   # ONE host read-back per image pair (the table capacity depends on it)
+    c0, c1 = cc[:nt0], cc[nt0:]
     n_of = lambda c, t: c[t] if t < len(c) else 0
     tile_pairs = [(a, b) for a, b in tile_pairs if n_of(c0, a) > 0 and n_of(c1, b) > 0]
     if len(tile_pairs) == 0:
         return empty
     cap = max(1, max([n_of(c0, t) for t in t0s] + [n_of(c1, t) for t in t1s]))
+    assert cap < (1 << 20) and int(f0["keypoints"].shape[0]) < (1 << 20) and int(f1["keypoints"].shape[0]) < (1 << 20)
     D = int(f0["descriptors_nd"].shape[1])
     T = len(t0s) + len(t1s)
     kt = torch.zeros(T, cap, 2, dtype=torch.float32, device=dev)
     dt = torch.zeros(T, cap, D, dtype=torch.float32, device=dev)
     it = torch.zeros(T, cap, dtype=torch.int64, device=dev)           # tile-local slot -> index in the image's merged table
     nt = torch.zeros(T, dtype=torch.int32, device=dev)
-
-    def fill(f, ti, order, counts, tiles, row_base):
-        starts = torch.cumsum(counts, 0) - counts
-        row_of = torch.full((int(counts.numel()),), -1, dtype=torch.int64, device=dev)
-        row_of[torch.tensor(tiles, dtype=torch.int64, device=dev)] = torch.arange(row_base, row_base + len(tiles), device=dev)
-        ts = ti[order]
-        rows, pos = row_of[ts], torch.arange(order.numel(), device=dev) - starts[ts]
-        keep = rows >= 0
-        rows, pos, src = rows[keep], pos[keep], order[keep]
-        kt[rows, pos] = f["keypoints"][src]
-        dt[rows, pos] = f["descriptors_nd"][src]
-        it[rows, pos] = src
-        nt[row_base:row_base + len(tiles)] = counts[torch.tensor(tiles, dtype=torch.int64, device=dev)].to(torch.int32)
-
     t0v = [t for t in t0s if n_of(c0, t) > 0]
     t1v = [t for t in t1s if n_of(c1, t) > 0]
-    fill(f0, ti0, ord0, cnt0, t0v, 0)
-    fill(f1, ti1, ord1, cnt1, t1v, len(t0s))
     row0 = {t: i for i, t in enumerate(t0v)}
     row1 = {t: len(t0s) + i for i, t in enumerate(t1v)}
+    for f, rows_, ntile in ((f0, row0, nt0), (f1, row1, nt1)):
+        rot = torch.tensor([rows_.get(t, -1) for t in range(ntile)], dtype=torch.int32, device=dev)
+        device_group_by_tile(lib, f, rot, cap, kt, dt, it, nt)
     st = torch.zeros(T, 2, dtype=torch.float32, device=dev)
     st[: len(t0s)] = torch.as_tensor(np.asarray(f0["image_size"], dtype=np.float32).reshape(2), device=dev)
     st[len(t0s):] = torch.as_tensor(np.asarray(f1["image_size"], dtype=np.float32).reshape(2), device=dev)
     net = net_for(cap, min(pair_batch, len(tile_pairs)))
-    chunks = []
+    NK = net.nk
+    keys = torch.empty(len(tile_pairs), NK, dtype=torch.int64, device=dev)
+    zero_slot = torch.zeros(min(pair_batch, len(tile_pairs)), dtype=torch.int32, device=dev)
     for s in range(0, len(tile_pairs), pair_batch):
         chunk = tile_pairs[s:s + pair_batch]
         pidx = torch.tensor([[row0[a], row1[b]] for a, b in chunk], dtype=torch.int32, device=dev).contiguous()
         o = net.match_batch_guarded(kt, dt, nt, st, pair_idx=pidx, n_pairs=len(chunk), logger=logger)
-        m, cnt = o["matches"][: len(chunk)], o["n_matches"][: len(chunk)].to(torch.int64)
-        NK = m.shape[1]
-        live = torch.arange(NK, device=dev)[None, :] < cnt[:, None]
-        g0 = torch.gather(it[pidx[:, 0].long()], 1, m[..., 0].clamp(0, cap - 1))
-        g1 = torch.gather(it[pidx[:, 1].long()], 1, m[..., 1].clamp(0, cap - 1))
-        chunks.append(torch.stack([g0[live], g1[live]], 1))
-    full = torch.cat(chunks) if chunks else empty
-    if select_unique and full.shape[0]:
-        full = torch.unique(full, dim=0)
-    return full
+        capi.check(lib, lib.dim_op_tile_match_keys(capi.ptr(o["matches"]), capi.ptr(o["n_matches"]), capi.ptr(it), capi.ptr(pidx), capi.ptr(zero_slot), len(chunk), NK, cap,
+                                                   capi.ptr(keys[s:s + len(chunk)]), _stream_of(dev)))
+    cap_m = len(tile_pairs) * NK
+    rows = torch.empty(1, cap_m, 2, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    if select_unique:
+        device_unique_match_rows(lib, keys, 1, cap_m, rows, cnt)
+        return rows[0, : int(cnt.item())]
+    # concatenation order, duplicates kept (select_unique False): the live keys in tile-pair order
+    live = keys.reshape(-1) != -1
+    k = keys.reshape(-1)[live]
+    return torch.stack([(k >> 20) & 0xFFFFF, k & 0xFFFFF], 1)
 
 
 def _read_band1(path: Path) -> np.ndarray:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIM_HIP_ABI_VERSION 1
+#define DIM_HIP_ABI_VERSION 2   /* 2 (round 6): handle structs carry a tune header, dim_tune_set key 16, keypoint slots up to 32768 */
 
 const char* dim_last_error(void);
 int dim_abi_version(void);
@@ -351,6 +351,26 @@ size_t dim_op_merge_tiles_workspace_bytes(int n_tiles, int cap);
 int dim_op_merge_tiles(const float* kpts_tab, const float* scores_tab, const float* desc_tab, const int32_t* n_tab, const int32_t* origins_xy,
                        const float* tile_ids, int n_tiles, int cap, int D, int image_h, int image_w, int select_unique, void* workspace,
                        float* out_kpts, float* out_scores, float* out_tile_idx, float* out_desc, int32_t* n_out, void* stream);
+/* Integer bookkeeping of tile-wise matching on the device (csrc/sort_ops.hip) — get_features_by_tile's boolean masks (matchers/matcher_base.py:1380-1391)
+ * and _match_by_tile's np.unique(matches, axis=0) (:452-459) without host-language sort / unique calls:
+ *  (ld_*: row strides in floats — the three columns may be views of one packed [n][4 + D] table)
+ *  dim_op_tile_counts      counts[t] = keypoints of the merged table with tile_idx == t (tile_idx: the float values of "tile_idx");
+ *  dim_op_group_by_tile    the merged table (tile_idx [n], kpts [n][2], desc [n][D]) -> per-tile tables: tile t goes to table row row_of_tile[t]
+ *                          (-1: not needed), its keypoints in their ORIGINAL order (= the boolean-mask order) into kt [rows][cap][2], dt [rows][cap][D],
+ *                          it [rows][cap] int64 (index in the merged table), nt [rows] live counts.  The tables must arrive zeroed.
+ *  dim_op_tile_match_keys  dim_lg_match's lists of a batch of tile pairs (matches [n_pairs][nk][2] int64, n_matches) -> keys [n_pairs][nk] =
+ *                          slot << 40 | it[row0][m0] << 20 | it[row1][m1] (pair_rows [n_pairs][2] = the two table rows, slot = the image pair), ~0 for dead rows;
+ *  dim_op_unique_match_rows  n keys -> per slot the UNIQUE (idx0, idx1) rows in lexicographic order (np.unique(axis=0)): rows [n_slots][cap_m][2]
+ *                          (int32, or int64 with rows_are_i64), cnt[slot] = min(rows of the slot, cap_m), n_full[slot] (optional) = before that cut. */
+int dim_op_tile_counts(const float* tile_idx_dev, int ld_tile, int n, int n_tiles, int32_t* counts_dev, void* stream);
+size_t dim_op_group_by_tile_workspace_bytes(int n, int n_tiles);
+int dim_op_group_by_tile(const float* tile_idx_dev, int ld_tile, const float* kpts_dev, int ld_kpts, const float* desc_nd_dev, int ld_desc, int n, int D,
+                         const int32_t* row_of_tile_dev, int n_tiles, int cap, float* kt_dev, float* dt_dev, long long* it_dev, int32_t* nt_dev, void* workspace, void* stream);
+int dim_op_tile_match_keys(const long long* matches_dev, const int32_t* n_matches_dev, const long long* it_dev, const int32_t* pair_rows_dev, const int32_t* slot_dev,
+                           int n_pairs, int nk, int cap, unsigned long long* keys_dev, void* stream);
+size_t dim_op_unique_match_rows_workspace_bytes(long long n);
+int dim_op_unique_match_rows(const unsigned long long* keys_dev, long long n, int n_slots, int cap_m, int rows_are_i64, void* rows_dev, int32_t* cnt_dev,
+                             int32_t* n_full_dev, void* workspace, void* stream);
 /* Tile slicing of _extract_by_tile (extractors/extractor_base.py:279-328) on the device: image_dev [H][W][C] fp32 as the numpy array
  * arrived (0..255), origins (x, y) int32 per tile (negative / overhanging = the Tiler's zero padding) ->
  * out_dev [n_tiles][tile_h][tile_w][C], optionally / 255 (_frame2tensor). */

@@ -27,7 +27,7 @@ def test_hip_library_builds_and_exports_every_declared_symbol():
     for s in _declared_symbols():
         assert hasattr(lib, s), f"libdim_hip.so does not export {s}"
     lib.dim_abi_version.restype = ctypes.c_int
-    assert lib.dim_abi_version() == 1
+    assert lib.dim_abi_version() == 2
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -61,7 +61,7 @@ def test_product_library_rejects_the_research_keys_and_the_research_build_has_th
     lib.dim_last_error.restype = ctypes.c_char_p
     for key in (12, 13, 14, 15):
         assert lib.dim_tune_set(key, 1) != 0 and b"research" in lib.dim_last_error()
-    assert lib.dim_tune_set(16, 0) != 0 and lib.dim_tune_set(-1, 0) != 0
+    assert lib.dim_tune_set(17, 0) != 0 and lib.dim_tune_set(-1, 0) != 0
     assert lib.dim_tune_set(1, 2) == 0 and lib.dim_tune_set(11, 3) == 0
     assert not hasattr(lib, "dim_conv_wg_phase_read")
     text = (ROOT / "include" / "dim_hip.h").read_text()
