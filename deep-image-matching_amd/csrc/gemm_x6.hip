@@ -98,7 +98,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   static_assert(!ROLL || (((KV == 3 || KV == 4) && !PIPE) || (PIPE && KCH == 32 && !DB)) && (PROBE & ~1) == 0, "rolling fragment requests exist for the 64 x 512 blocks and (prototype) the pipelined 32-wide K loop");
   constexpr int ABUF = NPL * BM * RS;   // dwords of one staged activation tile
   constexpr int BN = 32 * NT * WN;
-  static_assert(KV == 0 || KV == 3 || KV == 4 || KV == 5 || (MODE == 2 && BN == 256 && (BM == 128 || BM == 256)), "the K|V image epilogue exists for the fp16x3 128 / 256 x 256 blocks");
+  static_assert(KV == 0 || KV == 3 || KV == 4 || KV == 5 || (MODE == 2 && ((BN == 256 && (BM == 128 || BM == 256)) || (BN == 128 && BM == 32))), "the K|V image epilogue exists for the fp16x3 128 / 256 x 256 blocks and the one-pair 32 x 128 block");
   static_assert(KV != 5 || (MODE == 2 && BM == 128 && NT == 3 && WN == 1), "the detector-head epilogue exists for the fp16x3 128 x 96 block (4 waves x 32 cells, all 65 channels per wave)");
   static_assert(KV != 4 || (MODE == 2 && BN == 512 && (BM == 64 || BM == 128) && WN == 4 && NT == 4), "the fused ffn exists for the fp16x3 64 / 128 x 512 blocks");
   static_assert(KV != 3 || (MODE == 2 && BN == 512 && BM == 64 && WN == 4), "the LayerNorm + GELU epilogue exists for the fp16x3 64 x 512 block");
@@ -652,10 +652,11 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       if (tile >= a.kv_tiles) continue;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int colw = wn * (32 * NT) + n * 32;          // first column of the 32-column tile inside the 256-column block (4 heads x 2 tiles)
+        const int nk0 = n0 & 255;                          // (128-column blocks: which half of the 256-column K / V range)
+        const int colw = nk0 + wn * (32 * NT) + n * 32;    // first column of the 32-column tile inside the 256-column range (4 heads x 2 tiles)
         const int head = colw >> 6, np = (colw >> 5) & 1;
         u32x4* const img = img_item + ((size_t)head * a.kv_tiles + tile) * KV_TILE_STRIDE;
-        const int cbase = n0 + colw;
+        const int cbase = (n0 - nk0) + colw;
         if (kblk) {
           // lane = key lx (+ 32-key tile m), register r = output dim cbase + 8 (r >> 2) + 4 half + (r & 3)
           const int key = m0 + wm * (32 * MT) + m * 32 + lx;
@@ -883,6 +884,22 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_stream_kernel(GemmArgs a) {
   gemm_x6_body<2, 64, 2, 0, 2, 0, false, 32, false, false, true, KS_T>(a, nullptr, (int)blockIdx.y);
 }
 #endif
+// one LightGlue pair per call (32 x 128 blocks, see launch_gemm_x6): the q|k|v projection writing the attention kernel's K | V tile images from its epilogue (KV above; two 128-column blocks per 256-column K / V range)
+constexpr int RS64 = 64 / 2 + 4;   // row stride in dwords of a staged 64-wide chunk (conflict-free like RS)
+template <int KCH>
+__global__ __launch_bounds__(256, 3) void gemm_x6_qkv_small_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 32 * (KCH / 2 + 4)];
+  const int by = (int)blockIdx.y, b256 = by >> 1;
+  if (b256 == a.kv_kblock) gemm_x6_body<2, 32, 1, 1, 4, 0, true, KCH>(a, Ap, by);
+  else if (b256 == a.kv_vblock) gemm_x6_body<2, 32, 1, 2, 4, 0, true, KCH>(a, Ap, by);
+  else gemm_x6_body<2, 32, 1, 0, 4, 0, true, KCH>(a, Ap, by);
+}
+// the plain 32 x 128 block with 64-wide K chunks: half the barrier pairs and staging round trips per MFMA of the 32-wide form (gemm_x6_kernel<2, 32, 1, 4>,
+// used when K is not a multiple of 64); bit-identical
+__global__ __launch_bounds__(256, 3) void gemm_x6_small32_kc64_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 32 * RS64];
+  gemm_x6_body<2, 32, 1, 0, 4, 0, true, 64>(a, Ap, (int)blockIdx.y);
+}
 // LightGlue's ffn.0 with LayerNorm + GELU in the epilogue: one workgroup owns 64 rows x all 512 columns
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 64 * RS];
@@ -1010,7 +1027,6 @@ __global__ __launch_bounds__(256, 1) void gemm_x6_qkv256_kernel(GemmArgs a) {
   else gemm_x6_body<2, 256, 2, 0, 4, 0, true>(a, Ap, by);
 }
 // ---- prototypes with 64-wide K chunks (dim_tune_set key 14 = 64; measured in round 4): the plain 128 x 256 block and the q|k|v kernel ----
-constexpr int RS64 = 64 / 2 + 4;
 __global__ __launch_bounds__(256, 2) void gemm_x6_wide_kc64_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 128 * RS64];
   gemm_x6_body<2, 128, 2, 0, 4, 0, true, 64>(a, Ap, (int)blockIdx.y);
@@ -1045,6 +1061,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_qkv_roll_kernel(GemmArgs a) {
   if (by == a.kv_kblock) gemm_x6_body<2, 128, 2, 1, 4, 0, true, 32, false, true>(a, Ap, by);
   else if (by == a.kv_vblock) gemm_x6_body<2, 128, 2, 2, 4, 0, true, 32, false, true>(a, Ap, by);
   else gemm_x6_body<2, 128, 2, 0, 4, 0, true, 32, false, true>(a, Ap, by);
+}
+// ---- round 6 probe of the one-pair 32 x 128 block (dim_tune_set key 14 = 76): the double-buffered activation tile ----
+__global__ __launch_bounds__(256, 3) void gemm_x6_small32_db_kernel(GemmArgs a) {
+  __shared__ unsigned Ap[2 * 2 * 32 * RS];
+  gemm_x6_body<2, 32, 1, 0, 4, 0, true, 32, true>(a, Ap, (int)blockIdx.y);
 }
 #endif   // DIM_RESEARCH
 // LightGlue's ffn.0 -> LayerNorm -> GELU -> ffn.3 (+ residual) in one kernel: 64 rows per workgroup, the hidden tensor stays on the CU
@@ -1111,7 +1132,13 @@ static bool wide_block(int M, int n_pad, int batch, int split_mode) {
   // dim_gemm_x6_wide(): 2 = forced (tests); 1 = when the launch still fills 2 workgroups per CU
   return split_mode == 2 && dim_gemm_x6_wide() && n_pad % 256 == 0 && (dim_gemm_x6_wide() == 2 || (long)cdiv(M, 128) * (n_pad / 256) * batch >= 512);
 }
-bool gemm_x6_fuses_kv(int M, int n_pad, int batch, int split_mode) { return !small_problem(M, n_pad, batch) && wide_block(M, n_pad, batch, split_mode); }
+// launches of at most two 64-row workgroups per CU (one LightGlue pair per call): the 32 x 128 block (see launch_gemm_x6)
+static bool small32(int M, int N, int batch, int split_mode) {
+  return split_mode == 2 && small_problem(M, N, batch) && (long)cdiv(M, 64) * cdiv(N, 128) * batch <= 512;
+}
+bool gemm_x6_fuses_kv(int M, int n_pad, int batch, int split_mode) {
+  return (!small_problem(M, n_pad, batch) && wide_block(M, n_pad, batch, split_mode)) || (n_pad % 256 == 0 && small32(M, n_pad, batch, split_mode));
+}
 
 int launch_gemm_x6_nt(const GemmArgs& a, int batch, int split_mode, hipStream_t s) {
   DIM_REQUIRE(a.bt && a.A0 && a.B && a.C && a.A1 == nullptr && a.bias == nullptr && a.R == nullptr && a.relu == 0, "gemm_x6_nt: plain A * B^T only");
@@ -1175,16 +1202,41 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     return 0;
   }
   const bool small = small_problem(a.M, a.N, batch);
-  DIM_REQUIRE(a.kv_img == nullptr || (!small && wide_block(a.M, a.n_pad, batch, a.split_mode)), "gemm_x6: K|V images need the 128 x 256 block (gemm_x6_fuses_kv)");
+  DIM_REQUIRE(a.kv_img == nullptr || gemm_x6_fuses_kv(a.M, a.n_pad, batch, a.split_mode), "gemm_x6: K|V images need the 128 x 256 or the 32 x 128 block (gemm_x6_fuses_kv)");
+  if (small && a.kv_img != nullptr) {
+    DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
+    DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == a.N / 256 - 1, "gemm_x6: the K and V blocks must be the last two");
+    if (a.K % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<64>), dim3(cdiv(a.M, 32), cdiv(a.N, BN), batch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<32>), dim3(cdiv(a.M, 32), cdiv(a.N, BN), batch), dim3(256), 0, s, a);
+    DIM_LAUNCH_CHECK();
+    return 0;
+  }
   if (small) {
     dim3 grid(cdiv(a.M, 64), cdiv(a.N, BN), batch);
 #ifdef DIM_RESEARCH   // the streaming K loop (14 = 63): bit-identical, measured SLOWER than the staged loop at every LightGlue shape (see STREAM above)
+    // round 6 probes of the small-problem block (same pieces, same per-accumulator term order: bit-identical): 71 = 64 x 128 with waves 1 x 4 (every weight
+    // fragment fetched by ONE wave, pipelined K loop), 74 = 64 x 256 with waves 1 x 4, 76 / 78 = the 32 x 128 block with a double-buffered tile / 32-wide chunks, 70 = round 5's block
+    if (a.split_mode == 2 && dim_gemm_kc() == 71) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64, 1, 4>), grid, dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && dim_gemm_kc() == 70) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);   // round 5's product block (waves 2 x 2)
+    else if (a.split_mode == 2 && dim_gemm_kc() == 74 && a.n_pad % 256 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64, 2, 4>), dim3(grid.x, cdiv(a.N, 256), grid.z), dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && dim_gemm_kc() == 78) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 32, 1, 4>), dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);   // the 32 x 128 block with 32-wide chunks
+    else if (a.split_mode == 2 && dim_gemm_kc() == 76) hipLaunchKernelGGL(gemm_x6_small32_db_kernel, dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);
+    else
     if (a.split_mode == 2 && dim_gemm_kc() == 63 && a.K == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<16>), grid, dim3(256), 0, s, a);
     else if (a.split_mode == 2 && dim_gemm_kc() == 63 && a.K == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<32>), grid, dim3(256), 0, s, a);
     else if (a.split_mode == 2 && dim_gemm_kc() == 63) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<0>), grid, dim3(256), 0, s, a);
     else
 #endif
-    if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);
+    // fp16x3, launches of at most two 64-row workgroups per CU (one LightGlue pair per call: 2 x 2048 rows): 32 x 128 blocks, waves 1 x 4 — every wave owns all
+    // 32 rows x 32 columns, so a weight fragment is fetched by exactly ONE wave (the 2 x 2 waves of the 64-row block fetch each twice through the CU's vector-memory
+    // path, the bound of these launches), twice the workgroups, the k-step-pipelined loop.  Bit-identical to the 64-row block (same pieces, same term order per
+    // accumulator).  Measured at 4096 rows (profiles/r06_small_gemm_variants.json): 256 -> 768 13.3 -> 10.8 us, 256 -> 512 10.0 -> 8.5, 512 -> 512 15.0 -> 12.9,
+    // 512 -> 256 + residual 13.7 -> 9.7.
+    // 64-wide K chunks where K allows (every linear of LightGlue): 256 -> 768 10.7, 256 -> 512 8.0, 512 -> 512 12.8, 512 -> 256 + residual 8.8 us.
+    if (a.split_mode == 2 && (long)grid.x * grid.y * grid.z <= 512 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0))
+      hipLaunchKernelGGL(gemm_x6_small32_kc64_kernel, dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && (long)grid.x * grid.y * grid.z <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 32, 1, 4>), dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);
+    else if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<1, 64>), grid, dim3(256), 0, s, a);
   } else if (wide_block(a.M, a.n_pad, batch, a.split_mode)) {
     dim3 grid(cdiv(a.M, 128), cdiv(a.N, 256), batch);

@@ -254,7 +254,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
   };
   // fp16x3 at batch sizes that run the 128 x 256 GEMM block: the q|k|v projections write the attention kernel's K | V tile
   // images themselves (rotary + pre-split in the epilogue; dim_tune_set key 8 = 0 keeps the separate kv_prep pass)
-  const bool fuse_kv = pmode == 2 && dim_fuse_kv() && gemm_x6_fuses_kv(N, 512, I, 2);
+  const bool fuse_kv = pmode == 2 && dim_fuse_kv() && gemm_x6_fuses_kv(N, 512, I, 2) && gemm_x6_fuses_kv(N, 768, I, 2);
   auto gemm_qkv = [&](const SplitWeights* Bx, const float* bias, int Nn, int kblock, bool rotary) -> int {
     GemmArgs g;
     g.A0 = st.desc; g.lda0 = 256; g.strideA0 = s256;
