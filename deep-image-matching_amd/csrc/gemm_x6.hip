@@ -87,7 +87,7 @@ __device__ __forceinline__ unsigned ft_now() {
 #ifndef DIM_STREAM_D
 #define DIM_STREAM_D 4
 #endif
-template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32, bool DB = false, bool ROLL = false, bool STREAM = false, int STREAM_KS = 0>
+template <int MODE, int BM, int NT, int KV, int WN, int PROBE = 0, bool PIPE = false, int KCH = 32, bool DB = false, bool ROLL = false, bool STREAM = false, int STREAM_KS = 0, bool BSET = false, int K_T = 0>
 __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, int by) {
   using S = SplitMma<MODE>;
   constexpr int WM = 4 / WN, MT = BM / (32 * WM);  // 32-row MFMA tiles per wave
@@ -95,6 +95,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   constexpr int KC = KCH, RS = KCH / 2 + 4, Q4_SHIFT = KCH == 32 ? 3 : 4, KSTEPS = KCH / 16;   // (shadow the file-level 32-wide constants)
   static_assert(KCH == 32 || (KCH == 64 && PIPE && PROBE == 0), "64-wide chunks exist for the pipelined K loop");
   static_assert(!DB || (PIPE && KCH == 32 && PROBE == 0), "the double-buffered tile exists for the pipelined 32-wide K loop");
+  static_assert(!BSET || (PIPE && KCH == 64 && !DB && !ROLL && !STREAM && PROBE == 0 && NT * (KCH / 16) <= 4), "chunk-level fragment sets exist for the pipelined 64-wide K loop of one-tile waves");
   static_assert(!ROLL || (((KV == 3 || KV == 4) && !PIPE) || (PIPE && KCH == 32 && !DB)) && (PROBE & ~1) == 0, "rolling fragment requests exist for the 64 x 512 blocks and (prototype) the pipelined 32-wide K loop");
   constexpr int ABUF = NPL * BM * RS;   // dwords of one staged activation tile
   constexpr int BN = 32 * NT * WN;
@@ -129,7 +130,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
 
   FT_DECL
   float4 ra[NLD];
-  auto load_chunk = [&](int k0) {
+  auto load_chunk_r = [&](float4 (&ra)[NLD], int k0) {
     const float* src; int ld, kk0;
     if (A1 == nullptr || k0 < a.ksplit) { src = A0; ld = a.lda0; kk0 = k0; }
     else { src = A1; ld = a.lda1; kk0 = k0 - a.ksplit; }
@@ -142,7 +143,8 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       ra[i] = *(const float4*)(src + (size_t)((PROBE & 1) ? ((m0 + row) & 2047) : min(m0 + row, rows - 1)) * ld + kk0 + q * 4);
     }
   };
-  auto store_chunk = [&](int abuf = 0) {
+  auto load_chunk = [&](int k0) { load_chunk_r(ra, k0); };
+  auto store_chunk_r = [&](const float4 (&ra)[NLD], int abuf) {
     unsigned* const Ab = Ap + abuf * ABUF;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -160,6 +162,7 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       for (int pl = 0; pl < NPL; ++pl) { d[pl * BM * RS] = p0[pl]; d[pl * BM * RS + 1] = p1[pl]; }
     }
   };
+  auto store_chunk = [&](int abuf = 0) { store_chunk_r(ra, abuf); };
 
   // one 16-wide k-step of the chunk staged in LDS against the weight fragments fbk[n][plane]
   auto mma_step = [&](int ks, const u32x4 (&fbk)[NT][NPL], int abuf = 0) {
@@ -285,6 +288,45 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
       mma_roll(1, fb1, min(kst + 3, KS - 1));
       __syncthreads();
       if (k0 + KC < a.K) store_chunk();
+    }
+  } else if (PIPE && BSET) {
+    // BSET (round 6; the one-pair 32 x 128 blocks): weight fragments AND activations requested a whole chunk period ahead of their use.  A launch of one LightGlue
+    // pair is bound by the latency of its L2 (first touch: MALL) requests times the bytes it keeps in flight — a wave of the step-pipelined loop above has ONE k-step
+    // of fragments (2 KB) and one chunk of activations outstanding, ~1/3 of what the CU's 64 B / clk path needs at ~800 clocks of latency (a 32 x 512 block that
+    // streams all of ffn.0's weights through one workgroup per CU runs at 25 B / clk: 26 us), and only 3 MFMAs between a fragment request and its use.  With one
+    // 32-column tile per wave a whole 64-wide chunk of fragments is 32 registers.  Iteration c: split + stage A(c) [requested in iteration c - 2], barrier, request
+    // A(c + 2) and then the fragment set of chunk c + 1, the MFMAs of chunk c [its set was requested in iteration c - 1; vector-memory requests retire in order, so
+    // the wait in front of them retires A(c + 1) as well and leaves exactly this iteration's requests in flight], barrier.  Two chunks per loop trip (the register
+    // sets swap roles; K must be a multiple of 128).  Same pieces, same per-accumulator term order: bit-identical.
+    // K_T (256, 512: every linear of LightGlue) unrolls the loop completely: in straight-line code the compiler sizes every wait for exactly the request it needs;
+    // at the header of a real loop it merges the counts of the entry and the back edge and waits for (nearly) everything in flight.  0: run-time K, that loop.
+    u32x4 fs0[KSTEPS][NT][NPL], fs1[KSTEPS][NT][NPL];
+    float4 rb[NLD];   // activations of the odd chunks (ra: the even ones)
+    const int Kt = K_T ? K_T : a.K;
+    __builtin_amdgcn_sched_barrier(0);   // (A(0) was requested above: keep it the oldest request)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) load_b(ks, fs0[ks]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_chunk_r(rb, min(KC, Kt - KC));
+    __builtin_amdgcn_sched_barrier(0);
+    auto chunk = [&](int k0, float4 (&ac)[NLD], const u32x4 (&cur)[KSTEPS][NT][NPL], u32x4 (&nxt)[KSTEPS][NT][NPL]) {
+      store_chunk_r(ac, 0);
+      __syncthreads();
+      load_chunk_r(ac, min(k0 + 2 * KC, Kt - KC));   // (the tail harmlessly re-reads the last chunk)
+      __builtin_amdgcn_sched_barrier(0);
+      const int kn = min(k0 + KC, Kt - KC);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) load_b((kn >> 4) + ks, nxt[ks]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) mma_step(ks, cur[ks]);
+      __syncthreads();
+    };
+    if constexpr (K_T != 0) {
+#pragma unroll
+      for (int k0 = 0; k0 < K_T; k0 += 2 * KC) { chunk(k0, ra, fs0, fs1); chunk(k0 + KC, rb, fs1, fs0); }
+    } else {
+      for (int k0 = 0; k0 < a.K; k0 += 2 * KC) { chunk(k0, ra, fs0, fs1); chunk(k0 + KC, rb, fs1, fs0); }
     }
   } else if (PIPE && DB) {
     u32x4 fb0[NT][NPL], fb1[NT][NPL];
@@ -886,19 +928,20 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_stream_kernel(GemmArgs a) {
 #endif
 // one LightGlue pair per call (32 x 128 blocks, see launch_gemm_x6): the q|k|v projection writing the attention kernel's K | V tile images from its epilogue (KV above; two 128-column blocks per 256-column K / V range)
 constexpr int RS64 = 64 / 2 + 4;   // row stride in dwords of a staged 64-wide chunk (conflict-free like RS)
-template <int KCH>
+template <int KCH, bool BSET, int K_T = 0>
 __global__ __launch_bounds__(256, 3) void gemm_x6_qkv_small_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 32 * (KCH / 2 + 4)];
   const int by = (int)blockIdx.y, b256 = by >> 1;
-  if (b256 == a.kv_kblock) gemm_x6_body<2, 32, 1, 1, 4, 0, true, KCH>(a, Ap, by);
-  else if (b256 == a.kv_vblock) gemm_x6_body<2, 32, 1, 2, 4, 0, true, KCH>(a, Ap, by);
-  else gemm_x6_body<2, 32, 1, 0, 4, 0, true, KCH>(a, Ap, by);
+  if (b256 == a.kv_kblock) gemm_x6_body<2, 32, 1, 1, 4, 0, true, KCH, false, false, false, 0, BSET, K_T>(a, Ap, by);
+  else if (b256 == a.kv_vblock) gemm_x6_body<2, 32, 1, 2, 4, 0, true, KCH, false, false, false, 0, BSET, K_T>(a, Ap, by);
+  else gemm_x6_body<2, 32, 1, 0, 4, 0, true, KCH, false, false, false, 0, BSET, K_T>(a, Ap, by);
 }
 // the plain 32 x 128 block with 64-wide K chunks: half the barrier pairs and staging round trips per MFMA of the 32-wide form (gemm_x6_kernel<2, 32, 1, 4>,
 // used when K is not a multiple of 64); bit-identical
+template <bool BSET, int K_T = 0>
 __global__ __launch_bounds__(256, 3) void gemm_x6_small32_kc64_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 32 * RS64];
-  gemm_x6_body<2, 32, 1, 0, 4, 0, true, 64>(a, Ap, (int)blockIdx.y);
+  gemm_x6_body<2, 32, 1, 0, 4, 0, true, 64, false, false, false, 0, BSET, K_T>(a, Ap, (int)blockIdx.y);
 }
 // LightGlue's ffn.0 with LayerNorm + GELU in the epilogue: one workgroup owns 64 rows x all 512 columns
 __global__ __launch_bounds__(256, 2) void gemm_x6_ffn_ln_kernel(GemmArgs a) {
@@ -1206,8 +1249,14 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   if (small && a.kv_img != nullptr) {
     DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
     DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == a.N / 256 - 1, "gemm_x6: the K and V blocks must be the last two");
-    if (a.K % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<64>), dim3(cdiv(a.M, 32), cdiv(a.N, BN), batch), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<32>), dim3(cdiv(a.M, 32), cdiv(a.N, BN), batch), dim3(256), 0, s, a);
+    const dim3 qg(cdiv(a.M, 32), cdiv(a.N, BN), batch);
+#ifdef DIM_RESEARCH
+    if (dim_gemm_kc() == 79 && a.K % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<64, false>), qg, dim3(256), 0, s, a);   // step-pipelined fragments (A/B)
+    else
+#endif
+    if (a.K == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<64, true, 256>), qg, dim3(256), 0, s, a);
+    else if (a.K % 128 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<64, true>), qg, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<32, false>), qg, dim3(256), 0, s, a);
     DIM_LAUNCH_CHECK();
     return 0;
   }
@@ -1219,6 +1268,7 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     if (a.split_mode == 2 && dim_gemm_kc() == 71) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64, 1, 4>), grid, dim3(256), 0, s, a);
     else if (a.split_mode == 2 && dim_gemm_kc() == 70) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);   // round 5's product block (waves 2 x 2)
     else if (a.split_mode == 2 && dim_gemm_kc() == 74 && a.n_pad % 256 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64, 2, 4>), dim3(grid.x, cdiv(a.N, 256), grid.z), dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && dim_gemm_kc() == 79 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_small32_kc64_kernel<false>), dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);   // 64-wide chunks, step-pipelined fragments
     else if (a.split_mode == 2 && dim_gemm_kc() == 78) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 32, 1, 4>), dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);   // the 32 x 128 block with 32-wide chunks
     else if (a.split_mode == 2 && dim_gemm_kc() == 76) hipLaunchKernelGGL(gemm_x6_small32_db_kernel, dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);
     else
@@ -1233,8 +1283,12 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     // accumulator).  Measured at 4096 rows (profiles/r06_small_gemm_variants.json): 256 -> 768 13.3 -> 10.8 us, 256 -> 512 10.0 -> 8.5, 512 -> 512 15.0 -> 12.9,
     // 512 -> 256 + residual 13.7 -> 9.7.
     // 64-wide K chunks where K allows (every linear of LightGlue): 256 -> 768 10.7, 256 -> 512 8.0, 512 -> 512 12.8, 512 -> 256 + residual 8.8 us.
-    if (a.split_mode == 2 && (long)grid.x * grid.y * grid.z <= 512 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0))
-      hipLaunchKernelGGL(gemm_x6_small32_kc64_kernel, dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);
+    if (a.split_mode == 2 && (long)grid.x * grid.y * grid.z <= 512 && a.K % 128 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) {
+      const dim3 g32(cdiv(a.M, 32), grid.y, grid.z);
+      if (a.K == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_small32_kc64_kernel<true, 256>), g32, dim3(256), 0, s, a);
+      else if (a.K == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_small32_kc64_kernel<true, 512>), g32, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_small32_kc64_kernel<true>), g32, dim3(256), 0, s, a);
+    }
     else if (a.split_mode == 2 && (long)grid.x * grid.y * grid.z <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 32, 1, 4>), dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);
     else if (a.split_mode == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<1, 64>), grid, dim3(256), 0, s, a);

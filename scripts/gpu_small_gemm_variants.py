@@ -31,7 +31,7 @@ for K, N, with_r in ((256, 768, False), (256, 512, False), (512, 512, False), (5
     h, npad = ctypes.c_void_p(), ctypes.c_int()
     assert lib.dim_x3_create(p(W), K, N, ctypes.byref(h), ctypes.byref(npad)) == 0
     outs, times = {}, {}
-    for name, kc in (("product_32x128_kc64", 0), ("64x128_1x4", 71), ("product_round5_64x128_2x2", 70), ("32x128_kc32", 78), ("32x128_dbuf", 76), ("64x256_1x4", 74), ("product_again", 0)):
+    for name, kc in (("product_32x128_chunk_ahead", 0), ("32x128_kc64_step_pipelined", 79), ("64x128_1x4", 71), ("product_round5_64x128_2x2", 70), ("32x128_kc32", 78), ("32x128_dbuf", 76), ("64x256_1x4", 74), ("product_again", 0)):
         assert lib.dim_tune_set(14, kc) == 0, lib.dim_last_error()
         C = torch.full((M, N), -3.0).cuda()
         run = lambda: capi.check(lib, lib.dim_op_gemm_x6_f32(p(A), K, h, npad.value, p(bias), p(R) if with_r else None, N, p(C), N, M, N, K, 0, stream))
@@ -40,7 +40,7 @@ for K, N, with_r in ((256, 768, False), (256, 512, False), (512, 512, False), (5
         times[name] = t_us(run)
     lib.dim_tune_set(14, 0)
     rec = {"K": K, "N": N, "residual": with_r, "us": times,
-           "bit_equal_to_product": {k: bool(torch.equal(outs["product_32x128_kc64"], v)) for k, v in outs.items() if k != "product_32x128_kc64"}}
+           "bit_equal_to_product": {k: bool(torch.equal(outs["product_32x128_chunk_ahead"], v)) for k, v in outs.items() if k != "product_32x128_chunk_ahead"}}
     res["shapes"].append(rec)
     lib.dim_x3_destroy(h)
 print(json.dumps(res))
