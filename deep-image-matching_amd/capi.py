@@ -45,6 +45,12 @@ def installed_device():
     return _INSTALLED_DEVICE
 
 
+class LgRawFeatures(ctypes.Structure):
+    """include/dim_hip.h: dim_lg_raw_features (one image's keypoints / descriptors as uploaded, for dim_lg_stage_features)."""
+    _fields_ = [("kpts_dev", ctypes.c_void_p), ("desc_dev", ctypes.c_void_p), ("n", ctypes.c_int), ("kpts_f16", ctypes.c_int),
+                ("desc_f16", ctypes.c_int), ("desc_is_dn", ctypes.c_int)]
+
+
 def check(lib, rc: int) -> None:
     if rc != 0:
         msg = lib.dim_last_error().decode(errors="replace")

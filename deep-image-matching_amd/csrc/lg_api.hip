@@ -24,6 +24,54 @@ struct LayerW {
 };
 }  // namespace
 
+namespace {
+// dim_lg_stage_features: the arrays of a pair exactly as features.h5 holds them -> the fp32 (N, D) feature table of dim_lg_match.  One workgroup per
+// (32 keypoints, image).  (D, N) descriptors (extractors/superpoint.py:121-127 stores them so) are read along N — 32 consecutive keypoints of one dim =
+// one 64- / 128-byte run — and turned through a 32 x 33 LDS tile; fp16 -> fp32 is exact; rows past the live count are zeroed like the host path did.
+struct StageArgs {
+  const void* kp[2]; const void* ds[2];
+  int n[2], kp_f16[2], ds_f16[2], ds_dn[2];
+  int cap, D;
+  float* kt; float* dt;
+};
+__device__ __forceinline__ float stage_ld(const void* p, size_t i, int f16) { return f16 ? (float)((const _Float16*)p)[i] : ((const float*)p)[i]; }
+__global__ __launch_bounds__(256) void lg_stage_kernel(StageArgs a) {
+  __shared__ float tile[32][33];
+  const int im = blockIdx.y, r0 = blockIdx.x * 32, t = threadIdx.x, n = a.n[im];
+  if (t < 64) {
+    const int row = r0 + (t >> 1);
+    if (row < a.cap) a.kt[((size_t)im * a.cap + row) * 2 + (t & 1)] = row < n ? stage_ld(a.kp[im], (size_t)row * 2 + (t & 1), a.kp_f16[im]) : 0.0f;
+  }
+  float* const out = a.dt + (size_t)im * a.cap * a.D;
+  const int f16 = a.ds_f16[im];
+  if (!a.ds_dn[im]) {   // (N, D): thread -> (row t >> 3, four consecutive dims)
+    const int row = r0 + (t >> 3);
+    if (row >= a.cap) return;
+    for (int d0 = (t & 7) * 4; d0 < a.D; d0 += 32) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < n) {
+        const size_t i = (size_t)row * a.D + d0;
+        v = make_float4(stage_ld(a.ds[im], i, f16), stage_ld(a.ds[im], i + 1, f16), stage_ld(a.ds[im], i + 2, f16), stage_ld(a.ds[im], i + 3, f16));
+      }
+      *(float4*)(out + (size_t)row * a.D + d0) = v;
+    }
+    return;
+  }
+  for (int d0 = 0; d0 < a.D; d0 += 32) {   // (D, N): read [dim t >> 3][keypoints 4 (t & 7) ..], write [keypoint t >> 3][dims 4 (t & 7) ..]
+    const int dd = t >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rr = (t & 7) * 4 + j;
+      tile[dd][rr] = (r0 + rr < n) ? stage_ld(a.ds[im], (size_t)(d0 + dd) * n + r0 + rr, f16) : 0.0f;
+    }
+    __syncthreads();
+    const int row = r0 + (t >> 3), c = (t & 7) * 4;
+    if (row < a.cap) *(float4*)(out + (size_t)row * a.D + d0 + c) = make_float4(tile[c][t >> 3], tile[c + 1][t >> 3], tile[c + 2][t >> 3], tile[c + 3][t >> 3]);
+    __syncthreads();
+  }
+}
+}  // namespace
+
 struct dim_lg {
   DimHandleBase base;   // first member: dim_handle_tune_set
   dim_lg_config cfg;
@@ -341,6 +389,25 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
 }
 
 int dim_lg_max_kpts(dim_lg* h) { return h ? h->nmax : -1; }
+
+int dim_lg_stage_features(const dim_lg_raw_features* img0, const dim_lg_raw_features* img1, int cap, int D, float* kpts_tab_dev, float* desc_tab_dev,
+                          void* stream) {
+  DIM_REQUIRE(img0 && img1 && kpts_tab_dev && desc_tab_dev, "dim_lg_stage_features: null argument");
+  DIM_REQUIRE(cap > 0 && D > 0 && D % 32 == 0, "dim_lg_stage_features: cap %d, D %d (a multiple of 32)", cap, D);
+  StageArgs a;
+  const dim_lg_raw_features* im[2] = {img0, img1};
+  for (int i = 0; i < 2; ++i) {
+    DIM_REQUIRE(im[i]->n >= 0 && im[i]->n <= cap, "dim_lg_stage_features: image %d has %d keypoints, table capacity %d", i, im[i]->n, cap);
+    DIM_REQUIRE(im[i]->n == 0 || (im[i]->kpts_dev && im[i]->desc_dev), "dim_lg_stage_features: image %d: null arrays", i);
+    DIM_REQUIRE(((size_t)im[i]->kpts_dev & 3) == 0 && ((size_t)im[i]->desc_dev & 15) == 0, "dim_lg_stage_features: image %d: keypoints must be 4-byte, descriptors 16-byte aligned", i);
+    a.kp[i] = im[i]->kpts_dev; a.ds[i] = im[i]->desc_dev; a.n[i] = im[i]->n;
+    a.kp_f16[i] = im[i]->kpts_f16 ? 1 : 0; a.ds_f16[i] = im[i]->desc_f16 ? 1 : 0; a.ds_dn[i] = im[i]->desc_is_dn ? 1 : 0;
+  }
+  a.cap = cap; a.D = D; a.kt = kpts_tab_dev; a.dt = desc_tab_dev;
+  hipLaunchKernelGGL(lg_stage_kernel, dim3(cdiv(cap, 32), 2), dim3(256), 0, (hipStream_t)stream, a);
+  DIM_LAUNCH_CHECK();
+  return 0;
+}
 
 int dim_lg_debug_desc(dim_lg* h, const float** desc, const int32_t** n_cur, const int32_t** ind) {
   DIM_REQUIRE(h, "dim_lg_debug_desc: null handle");

@@ -14,6 +14,7 @@ See INTEGRATION.md for the module files a maintainer adds to the reference tree.
 from __future__ import annotations
 
 import logging
+import ctypes
 import os
 from typing import Optional
 
@@ -443,54 +444,81 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
         return res["matches"][0].cpu().numpy()
 
     def _match_pairs_staged(self, f0: dict, f1: dict, dev) -> np.ndarray:
-        """The same call with ONE host-to-device and ONE device-to-host transfer (round 5).  LightGlueHIP.__call__ — the reference-shaped
-        entry the parity tests use — spends ~25 small operations around the match (two table fills, four pageable uploads and four slice copies, the
-        count / size tensors, two .item() read-backs, the .long() conversions, the result download): 0.5 ms of host time around 2.0 ms of kernels
-        at 2048 x 2048 keypoints, 12 % of the GPU time of the config-1 line in copy kernels (profiles/r05_config1_kernel_stats.csv).  Here both
-        images' keypoints, descriptors, sizes and counts are written into one page-locked buffer laid out as the library's feature table
-        ([2][cap][2] | [2][cap][D] | [2][2] | int32 [2]) and uploaded in one copy; the match count and the (S, 2) index table share one device
-        buffer and come back in one copy, enqueued behind the match so that the range guard's synchronisation covers it."""
+        """The same call with ONE host-to-device and ONE device-to-host transfer (round 5) of the arrays AS THE CALLER HOLDS THEM (round 6).
+        The reference's loop hands ``_match_pairs`` what features.h5 holds: float16 arrays, SuperPoint / ALIKED descriptors as (D, N)
+        (extractors/extractor_base.py:56-99, extractors/superpoint.py:121-127).  Converting them on the host — numpy's half -> float cast through a
+        transposed view — costs 1.2 - 1.6 ms per image, more than the whole match on the device; here the raw bytes of both images' keypoints and
+        descriptors go straight into one page-locked buffer (a memcpy), up in one copy, and ``dim_lg_stage_features`` builds the fp32 (N, D)
+        feature table on the device (transpose through LDS; fp16 -> fp32 is exact, so the table equals the host conversion's).  The match count
+        and the (S, 2) index table share one device buffer and come back in one copy, enqueued behind the match so that the range guard's
+        synchronisation covers it."""
         net = self._net
-        k0, k1 = np.asarray(f0["keypoints"], dtype=np.float32), np.asarray(f1["keypoints"], dtype=np.float32)
-        m, n, D = k0.shape[0], k1.shape[0], net.input_dim
-        cap = max(m, n, 1)
+        D = net.input_dim
+
+        def raw(f):
+            k, d = f["keypoints"], f["descriptors"]
+            if k.dtype not in (np.float16, np.float32):
+                k = k.astype(np.float32)
+            k = np.ascontiguousarray(k)
+            if d.dtype not in (np.float16, np.float32):
+                d = d.astype(np.float32)
+            dn = 0
+            if not d.flags.c_contiguous:
+                if d.T.flags.c_contiguous:    # featuresDict2Lightglue's transposed view of a (D, N) array: keep the array
+                    d, dn = d.T, 1
+                else:
+                    d = np.ascontiguousarray(d)
+            return k, d, dn
 
         def size_of(f, k):   # LGN:26-27: size inferred from the keypoint extent when the features carry none
             if "image_size" in f:
                 return np.asarray(f["image_size"], dtype=np.float32).reshape(2)
+            k = np.asarray(k, dtype=np.float32)
             return (1 + k.max(0) - k.min(0)).astype(np.float32) if k.size else np.ones(2, np.float32)
 
-        o_kt, o_dt, o_st = 0, 4 * cap, 4 * cap + 2 * cap * D
-        nfl = o_st + 4 + 2
+        (k0, d0, dn0), (k1, d1, dn1) = raw(f0), raw(f1)
+        m, n = k0.shape[0], k1.shape[0]
+        if (m and (d0.shape[0] if dn0 else d0.shape[1]) != D) or (n and (d1.shape[0] if dn1 else d1.shape[1]) != D):
+            raise ValueError(f"descriptor dimension {d0.shape} / {d1.shape} does not match the matcher's input_dim {D}")
+        cap = max(m, n, 1)
+        # raw staging: [sizes 4 f32 | counts 2 i32 | pad] then the four arrays at 256-byte boundaries
+        offs, cur = [], 256
+        for arr in (k0, d0, k1, d1):
+            offs.append(cur)
+            cur += (arr.nbytes + 255) & ~255
         st = self.__dict__.setdefault("_staging", _PinnedStaging())
-        pin = st.get("lg_in", nfl * 4)[: nfl * 4].view(torch.float32)
+        pin = st.get("lg_in", cur)[:cur]
         h = pin.numpy()
-        kt, dt = h[o_kt:o_dt].reshape(2, cap, 2), h[o_dt:o_st].reshape(2, cap, D)
-        for i, (k, f, cnt) in enumerate(((k0, f0, m), (k1, f1, n))):
-            kt[i, :cnt] = k
-            dt[i, :cnt] = f["descriptors"]            # ((D, N) inputs arrive as a transposed view: the copy un-transposes)
-            kt[i, cnt:] = 0.0
-            dt[i, cnt:] = 0.0
-        h[o_st:o_st + 2] = size_of(f0, k0)
-        h[o_st + 2:o_st + 4] = size_of(f1, k1)
-        h[o_st + 4:o_st + 6].view(np.int32)[:] = (m, n)
+        h[:16].view(np.float32)[0:2] = size_of(f0, k0)
+        h[:16].view(np.float32)[2:4] = size_of(f1, k1)
+        h[16:24].view(np.int32)[:] = (m, n)
+        for arr, o in zip((k0, d0, k1, d1), offs):
+            if arr.nbytes:
+                h[o:o + arr.nbytes] = arr.reshape(-1).view(np.uint8)
         lean = self.__dict__.get("_lean")
         NK = net.nk
-        if lean is None or lean["net"] is not net or lean["dev"].numel() < nfl:
+        tab_floats = 2 * cap * (2 + D)
+        if lean is None or lean["net"] is not net or lean["raw"].numel() < cur or lean["tab"].numel() < tab_floats:
             flat = torch.zeros(2 + NK * 2, dtype=torch.int64, device=dev)       # [n_matches (int32) | pad | matches NK x 2]
             out = {"matches": flat[2:].view(1, NK, 2), "scores": torch.zeros(1, NK, dtype=torch.float32, device=dev),
                    "n_matches": flat[:1].view(torch.int32)[:1], "matches01": torch.zeros(1, 2, NK, dtype=torch.int32, device=dev),
                    "mscores01": torch.zeros(1, 2, NK, dtype=torch.float32, device=dev), "stop": torch.zeros(1, dtype=torch.int32, device=dev),
                    "prune01": torch.zeros(1, 2, NK, dtype=torch.int32, device=dev)}
-            lean = {"net": net, "dev": torch.empty(max(nfl, 2 * NK * (2 + D) + 6), dtype=torch.float32, device=dev), "flat": flat, "out": out}
+            lean = {"net": net, "raw": torch.empty(max(cur, 256 + 4 * 2 * NK * (2 + D) + 1024), dtype=torch.uint8, device=dev),
+                    "tab": torch.empty(max(tab_floats, 2 * NK * (2 + D)), dtype=torch.float32, device=dev), "flat": flat, "out": out}
             self.__dict__["_lean"] = lean
-        d = lean["dev"]
+        rawd, tab = lean["raw"], lean["tab"]
         pout = st.get("lg_out", (2 + NK * 2) * 8)[: (2 + NK * 2) * 8].view(torch.int64)
+        base = rawd.data_ptr()
+        descr = [capi.LgRawFeatures(base + offs[0], base + offs[1], m, int(k0.dtype == np.float16), int(d0.dtype == np.float16), dn0),
+                 capi.LgRawFeatures(base + offs[2], base + offs[3], n, int(k1.dtype == np.float16), int(d1.dtype == np.float16), dn1)]
+        kt, dt = tab[: 4 * cap].view(2, cap, 2), tab[4 * cap: 4 * cap + 2 * cap * D].view(2, cap, D)
+        sizes, counts = rawd[:16].view(torch.float32).view(2, 2), rawd[16:24].view(torch.int32)
 
         def run():
-            d[:nfl].copy_(pin, non_blocking=True)
-            net.match_batch(d[o_kt:o_dt].view(2, cap, 2), d[o_dt:o_st].view(2, cap, D), d[o_st + 4:o_st + 6].view(torch.int32), d[o_st:o_st + 4].view(2, 2),
-                            n_pairs=1, out=lean["out"])
+            rawd[:cur].copy_(pin, non_blocking=True)
+            capi.check(net.lib, net.lib.dim_lg_stage_features(ctypes.byref(descr[0]), ctypes.byref(descr[1]), int(cap), int(D), capi.ptr(kt), capi.ptr(dt), net._stream()))
+            net.match_batch(kt, dt, counts, sizes, n_pairs=1, out=lean["out"])
             pout.copy_(lean["flat"], non_blocking=True)
 
         with net._ctx():

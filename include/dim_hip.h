@@ -248,6 +248,22 @@ void dim_lg_destroy(dim_lg* h);
 /* Row stride (>= max_kpts, multiple of 4) of the per-point output arrays below. */
 int dim_lg_max_kpts(dim_lg* h);
 
+/* The conversion half of featuresDict2Lightglue (matchers/lightglue.py:18-64: descriptors (D, N) -> (N, D), :38-43, and
+ * torch.as_tensor(v, dtype=torch.float32, device=device), :62) on the device, for ONE pair whose arrays were uploaded exactly as
+ * features.h5 holds them (save_features_h5 with as_half, extractors/extractor_base.py:56-99: float16; SuperPoint / ALIKED write their
+ * descriptors as (D, N), extractors/superpoint.py:121-127): fills rows [0, n) of slots 0 and 1 of a feature table
+ * kpts_tab_dev [2][cap][2], desc_tab_dev [2][cap][D] (fp32, the layout dim_lg_match reads) and zeroes rows [n, cap).  fp16 -> fp32 is exact,
+ * so the table equals what the host conversion produced.  Keypoints 4-byte, descriptors 16-byte aligned; D a multiple of 32. */
+typedef struct dim_lg_raw_features {
+  const void* kpts_dev;   /* (N, 2) row-major, float32 or float16 */
+  const void* desc_dev;   /* (N, D) or (D, N) row-major, float32 or float16 */
+  int n;                  /* keypoints (<= cap) */
+  int kpts_f16, desc_f16; /* 1: float16, 0: float32 */
+  int desc_is_dn;         /* 1: (D, N), 0: (N, D) */
+} dim_lg_raw_features;
+int dim_lg_stage_features(const dim_lg_raw_features* img0, const dim_lg_raw_features* img1, int cap, int D, float* kpts_tab_dev, float* desc_tab_dev,
+                          void* stream);
+
 /* Matches n_pairs pairs in one call.  Features come from a device feature table
  * (slot i = image i, as written by dim_sp_extract):
  *   kpts_tab_dev [n_img][cap][2], desc_tab_dev [n_img][cap][input_dim] (row-major (N,D):

@@ -257,3 +257,29 @@ def test_gemm_x6_nt_vs_fp64(emu_lib, M, N, K):
     scale = (A.double().abs() @ B.double().abs().t())
     assert ((C[:M, :N].double() - ref).abs() / scale).max().item() < 5e-7
     assert bool((C[M:] == -7.0).all()) and bool((C[:, N:] == -7.0).all())
+
+
+@pytest.mark.parametrize("kf16,df16,dn", [(0, 0, 0), (1, 1, 1), (0, 1, 0), (1, 0, 1)])
+def test_lg_stage_features_equals_the_host_conversion(emu_lib, kf16, df16, dn):
+    """dim_lg_stage_features: one pair's arrays as features.h5 holds them (float16 or float32, descriptors (N, D) or (D, N)) -> the fp32 (N, D)
+    feature table, bit for bit what featuresDict2Lightglue's host path produces (matchers/lightglue.py:38-43,62: transpose, torch.as_tensor(...,
+    float32)); rows past the live count are zero; ragged counts incl. 0 and a count that is not a multiple of the 32-row block."""
+    import importlib
+    import numpy as np
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    g = np.random.default_rng(7 + kf16 + 2 * df16 + 4 * dn)
+    D, cap = 128, 77
+    for n0, n1 in ((77, 45), (0, 33), (64, 0)):
+        arrs, descr, keep = [], [], []
+        for n in (n0, n1):
+            k = (g.random((n, 2)) * 1000).astype(np.float16 if kf16 else np.float32)
+            d = g.standard_normal((D, n) if dn else (n, D)).astype(np.float16 if df16 else np.float32)
+            kt, dt = torch.from_numpy(np.ascontiguousarray(k)), torch.from_numpy(np.ascontiguousarray(d))
+            keep += [kt, dt]
+            descr.append(capi.LgRawFeatures(kt.data_ptr(), dt.data_ptr(), n, kf16, df16, dn))
+            arrs.append((k.astype(np.float32), (d.T if dn else d).astype(np.float32)))
+        ktab, dtab = torch.full((2, cap, 2), -7.0), torch.full((2, cap, D), -7.0)
+        assert emu_lib.dim_lg_stage_features(ctypes.byref(descr[0]), ctypes.byref(descr[1]), cap, D, p(ktab), p(dtab), None) == 0, emu_lib.dim_last_error()
+        for i, n in enumerate((n0, n1)):
+            assert np.array_equal(ktab[i, :n].numpy(), arrs[i][0]) and np.array_equal(dtab[i, :n].numpy(), arrs[i][1])
+            assert not ktab[i, n:].any() and not dtab[i, n:].any()
