@@ -69,6 +69,10 @@ static int g_fold_out_proj = 1;
 int dim_fold_out_proj() { return tuned(4, g_fold_out_proj); }
 static int g_fuse_kv = 1;
 int dim_fuse_kv() { return tuned(8, g_fuse_kv); }
+static int g_follow_stop = 1;
+int dim_follow_stop_flags() { return tuned(18, g_follow_stop); }
+static int g_defer_assign = 1;
+int dim_defer_assignment() { return tuned(17, g_defer_assign); }
 static int g_fuse_ffn_ln = 3;
 int dim_fuse_ffn_ln() { return tuned(11, g_fuse_ffn_ln); }
 #ifdef DIM_RESEARCH   // research build (build.build_variant("research")): prototype / timing-probe selectors, see dim_kernels.h
@@ -284,6 +288,8 @@ int dim_tune_set(int key, int value) {
   if (key == 10) g_al_tile_rows = value;
   if (key == 11) g_fuse_ffn_ln = value;
   if (key == 16) g_fuse_sp_head = value;
+  if (key == 17) g_defer_assign = value;
+  if (key == 18) g_follow_stop = value;
 #ifdef DIM_RESEARCH
   if (key == 12) g_attn_probe = value;
   if (key == 13) g_gemm_probe = value;
@@ -293,15 +299,15 @@ int dim_tune_set(int key, int value) {
   DIM_REQUIRE(key < 12 || key > 15, "dim_tune_set: key %d selects a research prototype / timing probe that the product library does not contain "
               "(build.build_variant(\"research\", [\"-DDIM_RESEARCH\"]) -> libdim_hip_research.so)", key);
 #endif
-  DIM_REQUIRE(key >= 0 && key <= 16, "dim_tune_set: unknown key %d", key);
+  DIM_REQUIRE(key >= 0 && key <= 18, "dim_tune_set: unknown key %d", key);
   return 0;
 }
 
 int dim_handle_tune_set(void* handle, int key, int value) {
   DimHandleBase* b = (DimHandleBase*)handle;
   DIM_REQUIRE(b != nullptr && b->magic == DIM_HANDLE_MAGIC, "dim_handle_tune_set: not an extractor / matcher handle of this library");
-  DIM_REQUIRE(key == 1 || key == 3 || key == 4 || key == 5 || key == 8 || key == 9 || key == 10 || key == 11 || key == 16,
-              "dim_handle_tune_set: key %d has no per-handle form (arithmetic 1; fusion 3, 4, 5, 8, 9, 11, 16; ALIKED tile rows 10)", key);
+  DIM_REQUIRE(key == 1 || key == 3 || key == 4 || key == 5 || key == 8 || key == 9 || key == 10 || key == 11 || key == 16 || key == 17 || key == 18,
+              "dim_handle_tune_set: key %d has no per-handle form (arithmetic 1; fusion 3, 4, 5, 8, 9, 11, 16, 17, 18; ALIKED tile rows 10)", key);
   b->tune.v[key] = value < 0 ? -1 : value;
   return 0;
 }

@@ -326,7 +326,7 @@ void dim_sat_host_bump(int site);  // a range violation established on the host 
 // ---- per-handle overrides of the dim_tune_set choices (include/dim_hip.h: dim_handle_tune_set) ----
 // Every extractor / matcher handle starts with a DimHandleBase; the C-ABI entry points open a DimTuneScope on it, and the accessors
 // (dim_precision_mode(), dim_fuse_conv1a(), ...) return the handle's override while the scope is open on this thread, else the process default.
-constexpr int DIM_TUNE_KEYS = 17;
+constexpr int DIM_TUNE_KEYS = 19;
 constexpr unsigned DIM_HANDLE_MAGIC = 0x44494d48u;   // "DIMH"
 struct DimTune {
   int v[DIM_TUNE_KEYS];

@@ -26,6 +26,8 @@ struct SplitWeights {
   int n_pad = 0;  // GEMM operands: padded column count
   const float* inv_ch() const { return (const float*)(dev + scale_off); }
 };
+// per-layer weights of one linear (LightGlue's final_proj): dim_lg_match's deferred assignment lets every item pick the layer its pair stopped at
+struct GemmLayerTab { const unsigned short* Bx3; const float* inv_ch; const float* bias; };
 struct GemmArgs {
   const float* A0 = nullptr; const float* A1 = nullptr;
   int lda0 = 0, lda1 = 0, ksplit = 0;
@@ -43,6 +45,9 @@ struct GemmArgs {
   const int* rows = nullptr; int rows_mul = 1, rows_off = 0, rows_scale = 1;
   const int* cols = nullptr; int cols_mul = 1, cols_off = 0;
   const int* flag = nullptr; int flag_shift = 0, flag_eq = 0;
+  // flag_any: run for every item whose flag is > 0 (instead of == flag_eq); layer_tab (plain split-precision blocks only): such an item takes
+  // Bx3 / inv_ch / bias from layer_tab[flag - 1]
+  int flag_any = 0; const GemmLayerTab* layer_tab = nullptr;
   int relu = 0;  // epilogue activation: 0 none, 1 ReLU, 2 SELU
   // LightGlue q|k|v projections (fp16x3, 128 x 256 blocks only; gemm_x6_fuses_kv()): the 256-column blocks kv_kblock / kv_vblock
   // are not stored as fp32 but written pre-split, in the tile-image layout lg_attn_x6.hip's attention kernel stages from
@@ -132,6 +137,8 @@ static inline int dim_attn_probe() { return 0; }
 #endif
 int dim_fuse_ffn_ln();       // dim_tune_set key 11.  3 (default): LightGlue's whole feed-forward (ffn.0, LayerNorm, GELU, ffn.3, residual) is one kernel when the
                              // launch fills the GPU with 64-row blocks, 4 = always (tests); 1 / 2: only LayerNorm + GELU in ffn.0's epilogue; 0: separate kernels
+int dim_follow_stop_flags();   // 1 (default): dim_lg_match with adaptive depth on a handle for <= 2 pairs follows the stop flags on the host and stops enqueueing layers nobody needs (dim_tune_set key 18)
+int dim_defer_assignment();   // 1 (default): adaptive-depth LightGlue runs the assignment ONCE after the layer loop, every pair with its stop layer's weights (dim_tune_set key 17; 0 = gated launches after every layer)
 int dim_fuse_kv();           // 1 (default): LightGlue's K | V tile images written by the projection GEMM's epilogue (dim_tune_set key 8)
 int dim_nms_big_tiles();     // 1 (default): 64 x 64 NMS tiles on large score maps (dim_tune_set key 7; 2 = forced)
 void dim_nms_set_big_tiles(int v);

@@ -914,9 +914,19 @@ __device__ __forceinline__ void gemm_x6_body(const GemmArgs& a, unsigned* Ap, in
   if (MODE == 2) sat_report(a.sat, vmax);
 }
 
+// layer_tab (dim_kernels.h): the item's flag selects the layer whose weights it multiplies by; false = the item is not live
+__device__ __forceinline__ bool gemm_pick_layer(GemmArgs& a) {
+  if (a.layer_tab == nullptr) return true;
+  const int fl = a.flag[blockIdx.z >> a.flag_shift];
+  if (fl <= 0) return false;
+  const GemmLayerTab lt = a.layer_tab[fl - 1];
+  a.Bx3 = lt.Bx3; a.inv_ch = lt.inv_ch; a.bias = lt.bias; a.flag = nullptr;
+  return true;
+}
 template <int MODE, int BM, int NT = 2, int WN = 2>
 __global__ __launch_bounds__(256, ((BM / (32 * (4 / WN))) * NT >= 16 ? 1 : ((BM / (32 * (4 / WN))) * NT >= 8 ? 2 : 3))) void gemm_x6_kernel(GemmArgs a) {
   __shared__ unsigned Ap[SplitMma<MODE>::NPL * BM * RS];
+  if (!gemm_pick_layer(a)) return;
   gemm_x6_body<MODE, BM, NT, 0, WN, 0, (WN == 4)>(a, Ap, (int)blockIdx.y);   // the wide block runs the pipelined K loop
 }
 #ifdef DIM_RESEARCH
@@ -941,6 +951,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x6_qkv_small_kernel(GemmArgs a) {
 template <bool BSET, int K_T = 0>
 __global__ __launch_bounds__(256, 3) void gemm_x6_small32_kc64_kernel(GemmArgs a) {
   __shared__ unsigned Ap[2 * 32 * RS64];
+  if (!gemm_pick_layer(a)) return;
   gemm_x6_body<2, 32, 1, 0, 4, 0, true, 64, false, false, false, 0, BSET, K_T>(a, Ap, (int)blockIdx.y);
 }
 // LightGlue's ffn.0 with LayerNorm + GELU in the epilogue: one workgroup owns 64 rows x all 512 columns
@@ -981,7 +992,10 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : 2)) void gemm_x6_nt_kernel(Ge
   constexpr int NPL = S::NPL, BM = 128;
   __shared__ unsigned Ap[NPL * BM * RS], Bp[NPL * BM * RS];
   const int z = blockIdx.z;
-  if (a.flag && a.flag[z >> a.flag_shift] != a.flag_eq) return;
+  if (a.flag) {
+    const int fl = a.flag[z >> a.flag_shift];
+    if (a.flag_any ? fl <= 0 : fl != a.flag_eq) return;
+  }
   const int rows = a.rows ? a.rows[z * a.rows_mul + a.rows_off] * a.rows_scale : a.M;
   const int cols = a.cols ? a.cols[z * a.cols_mul + a.cols_off] : a.N;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BM;
@@ -1202,6 +1216,10 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
   DIM_REQUIRE(a.n_pad % BN == 0 && a.n_pad >= a.N, "gemm_x6: n_pad=%d must be a multiple of %d covering N=%d", a.n_pad, BN, a.N);
   DIM_REQUIRE(a.lda0 % 4 == 0 && (a.A1 == nullptr || a.lda1 % 4 == 0), "gemm_x6: leading dims must be multiples of 4");
   if (batch <= 0 || a.M <= 0 || a.N <= 0) return 0;
+  // research selectors (prototype blocks, timing probes): never for a launch with per-item layer weights — only the product blocks pick a layer
+  const int kc_sel = a.layer_tab ? 32 : dim_gemm_kc(), probe_sel = a.layer_tab ? 0 : dim_gemm_probe();
+  (void)kc_sel; (void)probe_sel;
+  DIM_REQUIRE(a.layer_tab == nullptr || (a.d2s_out == nullptr && a.ln_gamma == nullptr && a.B2x3 == nullptr), "gemm_x6: per-item layer weights exist for the plain blocks");
   if (a.d2s_out != nullptr) {
     DIM_REQUIRE(a.split_mode == 2 && a.N == 65 && a.n_pad >= 96 && a.bias && a.R == nullptr && a.relu == 0 && a.kv_img == nullptr && a.ln_gamma == nullptr && a.A1 == nullptr &&
                 batch == 1 && a.d2s_h > 0 && a.d2s_w > 0 && a.M % (a.d2s_h * a.d2s_w) == 0 && (a.d2s_w * 8) % 4 == 0,
@@ -1215,9 +1233,9 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
                 a.kv_img == nullptr && a.ldr == a.ldc && a.strideR == a.strideC,
                 "gemm_x6: the fused feed-forward needs the fp16x3 512 -> 256 shapes, a residual laid out like the output and both bias vectors");
 #ifdef DIM_RESEARCH
-    if (dim_gemm_kc() == 128) hipLaunchKernelGGL(gemm_x6_ffn_fused128_kernel, dim3(cdiv(a.M, 128), 1, batch), dim3(256), 0, s, a);
-    else if (dim_gemm_kc() == 35) hipLaunchKernelGGL(gemm_x6_ffn_fused_roll_probe_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
-    else if (dim_gemm_kc() == 36) hipLaunchKernelGGL(gemm_x6_ffn_fused_step_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    if (kc_sel == 128) hipLaunchKernelGGL(gemm_x6_ffn_fused128_kernel, dim3(cdiv(a.M, 128), 1, batch), dim3(256), 0, s, a);
+    else if (kc_sel == 35) hipLaunchKernelGGL(gemm_x6_ffn_fused_roll_probe_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
+    else if (kc_sel == 36) hipLaunchKernelGGL(gemm_x6_ffn_fused_step_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
     else
 #endif
     hipLaunchKernelGGL(gemm_x6_ffn_fused_kernel, dim3(cdiv(a.M, 64), 1, batch), dim3(256), 0, s, a);
@@ -1228,7 +1246,7 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     DIM_REQUIRE(a.split_mode == 2 && a.N == 512 && a.n_pad == 512 && a.ln_beta && a.bias && a.R == nullptr && a.relu == 0 && a.kv_img == nullptr,
                 "gemm_x6: the LayerNorm + GELU epilogue needs the fp16x3 512-column ffn.0 shape");
     const dim3 lg(cdiv(a.M, 64), 1, batch);
-    switch (dim_gemm_probe()) {
+    switch (probe_sel) {
 #ifdef DIM_RESEARCH
       case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<1>), lg, dim3(256), 0, s, a); break;
       case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_ffn_ln_probe_kernel<2>), lg, dim3(256), 0, s, a); break;
@@ -1244,6 +1262,7 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     DIM_LAUNCH_CHECK();
     return 0;
   }
+  DIM_REQUIRE(a.layer_tab == nullptr || (a.flag != nullptr && a.kv_img == nullptr), "gemm_x6: per-item layer weights exist for the plain blocks");
   const bool small = small_problem(a.M, a.N, batch);
   DIM_REQUIRE(a.kv_img == nullptr || gemm_x6_fuses_kv(a.M, a.n_pad, batch, a.split_mode), "gemm_x6: K|V images need the 128 x 256 or the 32 x 128 block (gemm_x6_fuses_kv)");
   if (small && a.kv_img != nullptr) {
@@ -1251,7 +1270,7 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
     DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == a.N / 256 - 1, "gemm_x6: the K and V blocks must be the last two");
     const dim3 qg(cdiv(a.M, 32), cdiv(a.N, BN), batch);
 #ifdef DIM_RESEARCH
-    if (dim_gemm_kc() == 79 && a.K % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<64, false>), qg, dim3(256), 0, s, a);   // step-pipelined fragments (A/B)
+    if (kc_sel == 79 && a.K % 64 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<64, false>), qg, dim3(256), 0, s, a);   // step-pipelined fragments (A/B)
     else
 #endif
     if (a.K == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_qkv_small_kernel<64, true, 256>), qg, dim3(256), 0, s, a);
@@ -1265,16 +1284,16 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
 #ifdef DIM_RESEARCH   // the streaming K loop (14 = 63): bit-identical, measured SLOWER than the staged loop at every LightGlue shape (see STREAM above)
     // round 6 probes of the small-problem block (same pieces, same per-accumulator term order: bit-identical): 71 = 64 x 128 with waves 1 x 4 (every weight
     // fragment fetched by ONE wave, pipelined K loop), 74 = 64 x 256 with waves 1 x 4, 76 / 78 = the 32 x 128 block with a double-buffered tile / 32-wide chunks, 70 = round 5's block
-    if (a.split_mode == 2 && dim_gemm_kc() == 71) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64, 1, 4>), grid, dim3(256), 0, s, a);
-    else if (a.split_mode == 2 && dim_gemm_kc() == 70) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);   // round 5's product block (waves 2 x 2)
-    else if (a.split_mode == 2 && dim_gemm_kc() == 74 && a.n_pad % 256 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64, 2, 4>), dim3(grid.x, cdiv(a.N, 256), grid.z), dim3(256), 0, s, a);
-    else if (a.split_mode == 2 && dim_gemm_kc() == 79 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_small32_kc64_kernel<false>), dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);   // 64-wide chunks, step-pipelined fragments
-    else if (a.split_mode == 2 && dim_gemm_kc() == 78) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 32, 1, 4>), dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);   // the 32 x 128 block with 32-wide chunks
-    else if (a.split_mode == 2 && dim_gemm_kc() == 76) hipLaunchKernelGGL(gemm_x6_small32_db_kernel, dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);
+    if (a.split_mode == 2 && kc_sel == 71) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64, 1, 4>), grid, dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && kc_sel == 70) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64>), grid, dim3(256), 0, s, a);   // round 5's product block (waves 2 x 2)
+    else if (a.split_mode == 2 && kc_sel == 74 && a.n_pad % 256 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 64, 2, 4>), dim3(grid.x, cdiv(a.N, 256), grid.z), dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && kc_sel == 79 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_small32_kc64_kernel<false>), dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);   // 64-wide chunks, step-pipelined fragments
+    else if (a.split_mode == 2 && kc_sel == 78) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 32, 1, 4>), dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);   // the 32 x 128 block with 32-wide chunks
+    else if (a.split_mode == 2 && kc_sel == 76) hipLaunchKernelGGL(gemm_x6_small32_db_kernel, dim3(cdiv(a.M, 32), grid.y, grid.z), dim3(256), 0, s, a);
     else
-    if (a.split_mode == 2 && dim_gemm_kc() == 63 && a.K == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<16>), grid, dim3(256), 0, s, a);
-    else if (a.split_mode == 2 && dim_gemm_kc() == 63 && a.K == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<32>), grid, dim3(256), 0, s, a);
-    else if (a.split_mode == 2 && dim_gemm_kc() == 63) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<0>), grid, dim3(256), 0, s, a);
+    if (a.split_mode == 2 && kc_sel == 63 && a.K == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<16>), grid, dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && kc_sel == 63 && a.K == 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<32>), grid, dim3(256), 0, s, a);
+    else if (a.split_mode == 2 && kc_sel == 63) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_stream_kernel<0>), grid, dim3(256), 0, s, a);
     else
 #endif
     // fp16x3, launches of at most two 64-row workgroups per CU (one LightGlue pair per call: 2 x 2048 rows): 32 x 128 blocks, waves 1 x 4 — every wave owns all
@@ -1298,14 +1317,14 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
       DIM_REQUIRE(a.bias && a.N % 256 == 0 && a.kv_tiles > 0 && a.R == nullptr && a.relu == 0, "gemm_x6: bad K|V image request");
       DIM_REQUIRE(a.kv_kblock >= 0 && a.kv_vblock == a.kv_kblock + 1 && a.kv_vblock == (int)grid.y - 1, "gemm_x6: the K and V blocks must be the last two");
 #ifdef DIM_RESEARCH
-      if (dim_gemm_kc() == 256) hipLaunchKernelGGL(gemm_x6_qkv256_kernel, dim3(cdiv(a.M, 256), grid.y, grid.z), dim3(256), 0, s, a);
-      else if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_qkv_roll_kernel, grid, dim3(256), 0, s, a);
-      else if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_qkv_db_kernel, grid, dim3(256), 0, s, a);
-      else if (dim_gemm_kc() == 64 && a.K % 64 == 0) hipLaunchKernelGGL(gemm_x6_qkv_kc64_kernel, grid, dim3(256), 0, s, a);
+      if (kc_sel == 256) hipLaunchKernelGGL(gemm_x6_qkv256_kernel, dim3(cdiv(a.M, 256), grid.y, grid.z), dim3(256), 0, s, a);
+      else if (kc_sel == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_qkv_roll_kernel, grid, dim3(256), 0, s, a);
+      else if (kc_sel == 33) hipLaunchKernelGGL(gemm_x6_qkv_db_kernel, grid, dim3(256), 0, s, a);
+      else if (kc_sel == 64 && a.K % 64 == 0) hipLaunchKernelGGL(gemm_x6_qkv_kc64_kernel, grid, dim3(256), 0, s, a);
       else
 #endif
       hipLaunchKernelGGL(gemm_x6_qkv_kernel, grid, dim3(256), 0, s, a);
-    } else switch (dim_gemm_probe()) {
+    } else switch (probe_sel) {
 #ifdef DIM_RESEARCH
       case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<1>), grid, dim3(256), 0, s, a); break;
       case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_probe_kernel<2>), grid, dim3(256), 0, s, a); break;
@@ -1325,10 +1344,10 @@ int launch_gemm_x6(const GemmArgs& a, int batch, hipStream_t s) {
 #endif
       default:
 #ifdef DIM_RESEARCH
-        if (dim_gemm_kc() == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 256, 2, 4>), dim3(cdiv(a.M, 256), grid.y, grid.z), dim3(256), 0, s, a);
-        else if (dim_gemm_kc() == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_wide_roll_kernel, grid, dim3(256), 0, s, a);
-        else if (dim_gemm_kc() == 33) hipLaunchKernelGGL(gemm_x6_wide_db_kernel, grid, dim3(256), 0, s, a);
-        else if (dim_gemm_kc() == 64 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(gemm_x6_wide_kc64_kernel, grid, dim3(256), 0, s, a);
+        if (kc_sel == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 256, 2, 4>), dim3(cdiv(a.M, 256), grid.y, grid.z), dim3(256), 0, s, a);
+        else if (kc_sel == 37 && a.K >= 64) hipLaunchKernelGGL(gemm_x6_wide_roll_kernel, grid, dim3(256), 0, s, a);
+        else if (kc_sel == 33) hipLaunchKernelGGL(gemm_x6_wide_db_kernel, grid, dim3(256), 0, s, a);
+        else if (kc_sel == 64 && a.K % 64 == 0 && (a.A1 == nullptr || a.ksplit % 64 == 0)) hipLaunchKernelGGL(gemm_x6_wide_kc64_kernel, grid, dim3(256), 0, s, a);
         else
 #endif
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_x6_kernel<2, 128, 2, 4>), grid, dim3(256), 0, s, a);

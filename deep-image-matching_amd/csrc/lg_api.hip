@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "../../include/dim_hip.h"
@@ -24,6 +25,7 @@ struct LayerW {
 };
 }  // namespace
 
+constexpr int FOLLOW_MAX_PAIRS = 2;   // handles created for at most this many pairs may follow the stop flags on the host
 namespace {
 // dim_lg_stage_features: the arrays of a pair exactly as features.h5 holds them -> the fp32 (N, D) feature table of dim_lg_match.  One workgroup per
 // (32 keypoints, image).  (D, N) descriptors (extractors/superpoint.py:121-127 stores them so) are read along N — 32 consecutive keypoints of one dim =
@@ -79,6 +81,12 @@ struct dim_lg {
   std::vector<LayerW> L;
   std::vector<float> thr;
   float *inproj_w, *inproj_b, *Wr;
+  // the deferred assignment of adaptive depth (dim_lg_match): per-layer tables the kernels index with a pair's stop layer
+  float *match_w_all = nullptr, *match_b_all = nullptr;   // [layers][256], [layers]
+  GemmLayerTab* proj_tab[3] = {nullptr, nullptr, nullptr};   // [mode][layers]: final_proj's split weights / inverse scales / bias
+  // adaptive depth at one or two pairs per call: the host follows the stop flags two layers behind the device (dim_lg_match)
+  int* done_host = nullptr;            // page-locked, device-mapped: [layers][max_pairs flags | sequence word] written by lg_decide_kernel
+  int call_seq = 0;
   LgState st;
   std::vector<void*> allocs;
 };
@@ -159,6 +167,7 @@ extern "C" {
 void dim_lg_destroy(dim_lg* h) {
   if (!h) return;
   for (void* p : h->allocs) hipFree(p);
+  if (h->done_host) hipHostFree(h->done_host);
   delete h;
 }
 
@@ -227,6 +236,29 @@ int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pai
     d.tok_w = d.tok_b = nullptr;
     if (s.token_w) { LG_TRY(upload(h, &d.tok_w, vec(s.token_w, 256))); LG_TRY(upload(h, &d.tok_b, vec(s.token_b, 1))); }
     DIM_REQUIRE(i == w->n_layers - 1 || s.token_w, "dim_lg_create: token_confidence.%d missing", i);
+  }
+  {
+    std::vector<float> mw((size_t)w->n_layers * 256), mb(w->n_layers);
+    for (int i = 0; i < w->n_layers; ++i) {
+      memcpy(&mw[(size_t)i * 256], w->layers[i].assign_match_w, 256 * sizeof(float));
+      mb[i] = w->layers[i].assign_match_b[0];
+    }
+    LG_TRY(upload(h, &h->match_w_all, mw)); LG_TRY(upload(h, &h->match_b_all, mb));
+    for (int mode = 1; mode <= 2; ++mode) {
+      std::vector<GemmLayerTab> tab(w->n_layers);
+      for (int i = 0; i < w->n_layers; ++i) tab[i] = GemmLayerTab{h->L[i].proj_x[mode].dev, h->L[i].proj_x[mode].inv_ch(), h->L[i].proj_b};
+      LG_TRY(dev_alloc(h, &h->proj_tab[mode], tab.size()));
+      if (hipMemcpy(h->proj_tab[mode], tab.data(), tab.size() * sizeof(GemmLayerTab), hipMemcpyHostToDevice) != hipSuccess) {
+        dim_set_error("weight upload failed"); dim_lg_destroy(h); return -1;
+      }
+    }
+  }
+  if (max_pairs <= FOLLOW_MAX_PAIRS) {
+    void* q = nullptr;
+    const size_t nb = (size_t)w->n_layers * (max_pairs + 1) * sizeof(int);
+    if (hipHostMalloc(&q, nb, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { dim_set_error("dim_lg_create: page-locked allocation failed"); dim_lg_destroy(h); return -1; }
+    memset(q, 0, nb);
+    h->done_host = (int*)q;
   }
   LgState& st = h->st;
   const size_t P = max_pairs, I = 2 * P, N = h->nmax;
@@ -321,8 +353,58 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     g.M = N; g.N = 256; g.K = h->input_dim; g.rows = st.n_cur; g.sat = sat(DIM_SAT_LG_INPUT);
     LG_RUN(launch_gemm(g, I, s));
   }
+  // ---- assignment (LGN:540-542).  tag = layer + 1: the pairs that stopped at that layer, with its weights (gated launches after every layer that may
+  // stop pairs).  tag = 0, the DEFERRED form of adaptive depth (round 6): a stopped pair's descriptors, counts and index tables are frozen — every later
+  // launch skips it — so ONE pass after the loop serves every pair, each item reading final_proj / matchability weights of its own stop layer from
+  // per-layer tables (GemmLayerTab, match_w_all).  Same arithmetic on the same operands: identical results; 6 launches per call instead of 6 per layer —
+  // at one pair per call (the plugin hooks, reference-default confidences) ~48 empty launches of ~3 us each.  Split modes only (dim_tune_set key 17).
+  const bool defer = early && x6 && dim_defer_assignment() != 0;
+  auto assignment = [&](int tag, const LayerW* w) -> int {
+    {
+      GemmArgs g;
+      g.A0 = st.desc; g.lda0 = 256; g.strideA0 = s256; g.C = st.md; g.ldc = 256; g.strideC = s256; g.ldr = 256; g.strideR = s256;
+      g.M = N; g.N = 256; g.K = 256; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = tag;
+      g.sat = sat(DIM_SAT_LG_DESC);   // guarded: the similarity splits it
+      if (tag == 0) { g.set_split(h->L[0].proj_x[pmode]); g.bias = h->L[0].proj_b; g.layer_tab = h->proj_tab[pmode]; }   // (shape fields from layer 0; pointers per item)
+      else { g.B = w->proj_w; g.ldb = 256; g.bias = w->proj_b; if (x6) g.set_split(w->proj_x[pmode]); }
+      if (x6) LG_RUN(launch_gemm_x6(g, I, s)); else LG_RUN(launch_gemm(g, I, s));
+    }
+    GemmArgs g;
+    g.A0 = st.md; g.lda0 = 256; g.strideA0 = 2 * s256; g.B = st.md + s256; g.ldb = 256; g.strideB = 2 * s256; g.bt = 1;
+    g.C = st.sim; g.ldc = N; g.strideC = (long long)N * N; g.M = N; g.N = N; g.K = 256;
+    g.rows = st.n_cur; g.rows_mul = 2; g.rows_off = 0; g.cols = st.n_cur; g.cols_mul = 2; g.cols_off = 1;
+    g.flag = st.done; g.flag_shift = 0; g.flag_eq = tag; g.flag_any = tag == 0 ? 1 : 0;
+    if (x6) LG_RUN(launch_gemm_x6_nt(g, n_pairs, pmode, s));   // split-precision on the 16-bit matrix cores like every other product
+    else LG_RUN(launch_gemm(g, n_pairs, s));
+    LG_RUN(launch_lg_assign_stats(st, tag, tag == 0 ? h->match_w_all : w->match_w, tag == 0 ? h->match_b_all : w->match_b, s));
+    LG_RUN(launch_lg_assign_argmax(st, tag, dense_scores_dev, s));
+    return 0;
+  };
+  // ---- one or two pairs per call (the plugin hooks) with adaptive depth: the HOST follows the stop flags two layers behind the device.  Every launch
+  // skips a stopped pair by itself, but a launch that finds nothing to do still costs ~3 us, and reference-default LightGlue stops most pairs of
+  // an exhaustive job after 3 - 5 of 9 layers: ~20 launches per skipped layer = more time than the layers that ran.  After layer i's decide the flags
+  // land in page-locked host memory (lg_decide_kernel writes them there itself, then the call's sequence number behind a system-scope fence); before
+  // layer i + 2 is enqueued the host spins on that word (the device is then working on layer i + 1, which is already in the stream: no bubble as
+  // long as a layer lasts longer than the hand-over) and leaves the loop when every pair has stopped.  Results cannot change: the skipped launches
+  // would all have returned at their flag test.  (A first version copied the flags with hipMemcpyAsync + an event per layer: the nine blit kernels
+  // cost a pair that runs all layers 0.04 ms, profiles/r06_b1_adaptive.json.)  dim_tune_set key 18 = 0: never follow — the call then enqueues
+  // everything without touching the host, as batched calls always do.
+  const bool follow = early && h->done_host != nullptr && n_pairs <= FOLLOW_MAX_PAIRS && dim_follow_stop_flags() != 0;
+  const int mstride = h->max_pairs + 1;
+  const int seq = follow ? (h->call_seq = (h->call_seq % 0x3fffffff) + 1) : 0;
   for (int i = 0; i < Lr; ++i) {
     const LayerW& w = h->L[i];
+    if (follow && i >= 2) {
+      const int* m = h->done_host + (size_t)(i - 2) * mstride;
+      bool seen = false;
+      for (long spin = 0; spin < 400000000L; ++spin) {   // (~1 s at worst: then the call simply goes on enqueueing)
+        if (__atomic_load_n(m + h->max_pairs, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+        if ((spin & 1023) == 1023) std::this_thread::yield();
+      }
+      bool all = seen;
+      for (int p = 0; p < n_pairs; ++p) all = all && m[p] != 0;
+      if (all) break;
+    }
     // ---- self block (LGN:146-159) ----
     if (fuse_kv) LG_RUN(gemm_qkv(w.qkv_x, w.qkv_b, 768, 1, true));
     else LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.qkv_w, w.qkv_x, 768, w.qkv_b, nullptr, st.qkv, 768, s768, 768, 256, 0, st.sat_qkv));
@@ -364,24 +446,13 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     const bool last = (i == Lr - 1);
     if (!last && (early || prune))
       LG_RUN(launch_lg_confidence(st, w.tok_w, w.tok_b, w.match_w, w.match_b, h->thr[i], early ? 1 : 0, s));
-    if (last || early) LG_RUN(launch_lg_decide(st, i, (float)h->cfg.depth_confidence, early ? 1 : 0, last ? 1 : 0, s));
-    if (last || early) {
-      // ---- assignment for the pairs that stopped at this layer (LGN:540-542) ----
-      const int tag = i + 1;
-      LG_RUN(gemm_items(st.desc, 256, s256, nullptr, 0, 0, 0, w.proj_w, w.proj_x, 256, w.proj_b, nullptr, st.md, 256, s256, 256, 256, tag, sat(DIM_SAT_LG_DESC)));   // guarded: the similarity splits it
-      GemmArgs g;
-      g.A0 = st.md; g.lda0 = 256; g.strideA0 = 2 * s256; g.B = st.md + s256; g.ldb = 256; g.strideB = 2 * s256; g.bt = 1;
-      g.C = st.sim; g.ldc = N; g.strideC = (long long)N * N; g.M = N; g.N = N; g.K = 256;
-      g.rows = st.n_cur; g.rows_mul = 2; g.rows_off = 0; g.cols = st.n_cur; g.cols_mul = 2; g.cols_off = 1;
-      g.flag = st.done; g.flag_shift = 0; g.flag_eq = tag;
-      if (x6) LG_RUN(launch_gemm_x6_nt(g, n_pairs, pmode, s));   // split-precision on the 16-bit matrix cores like every other product
-      else LG_RUN(launch_gemm(g, n_pairs, s));
-      LG_RUN(launch_lg_assign_stats(st, tag, w.match_w, w.match_b, s));
-      LG_RUN(launch_lg_assign_argmax(st, tag, dense_scores_dev, s));
-    }
+    if (last || early)
+      LG_RUN(launch_lg_decide(st, i, (float)h->cfg.depth_confidence, early ? 1 : 0, last ? 1 : 0, s, follow ? h->done_host + (size_t)i * mstride : nullptr, h->max_pairs, seq));
+    if ((last || early) && !defer) LG_RUN(assignment(i + 1, &w));   // the pairs that stopped at this layer (LGN:540-542)
     if (!last && prune)
       LG_RUN(launch_lg_prune(st, i, h->cfg.width_confidence, h->thr[i], early ? 1 : 0, h->cfg.pruning_min_kpts, s));
   }
+  if (defer) LG_RUN(assignment(0, nullptr));
   LG_RUN(launch_lg_finalize(st, Lr, prune ? 1 : 0, (float)h->cfg.filter_threshold, N, (long long*)matches_dev, mscores_dev,
                             n_matches_dev, matches01_dev, mscores01_dev, stop_dev, prune01_dev, s));
 #undef LG_RUN

@@ -46,7 +46,7 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
 int launch_lg_ln_gelu(const LgState& st, const float* gamma, const float* beta, hipStream_t s);
 int launch_lg_confidence(const LgState& st, const float* w_tok, const float* b_tok, const float* w_match,
                          const float* b_match, float thr, int use_token, hipStream_t s);
-int launch_lg_decide(const LgState& st, int layer, float depth_conf, int early, int last, hipStream_t s);
+int launch_lg_decide(const LgState& st, int layer, float depth_conf, int early, int last, hipStream_t s, int* mirror = nullptr, int seq_off = 0, int seq = 0);
 int launch_lg_prune(const LgState& st, int layer, double width_conf, float thr, int use_token, int pruning_min,
                     hipStream_t s);
 int launch_lg_assign_stats(const LgState& st, int tag, const float* w_match, const float* b_match, hipStream_t s);

@@ -163,19 +163,28 @@ __global__ __launch_bounds__(256) void lg_confidence_kernel(LgState st, const fl
 }
 
 // one thread per pair: early-stop decision (LGN:593-604) / last-layer close-out.
-__global__ void lg_decide_kernel(LgState st, int layer, float depth_conf, int early, int last) {
+// mirror (nullptr, or page-locked host memory mapped into the device's address space; n_pairs <= 64 = one wave): the flags as they stand after this layer,
+// then — behind a system-scope fence — the call's sequence number in mirror[seq_off]: the host (dim_lg_match, key 18) spins on that word two layers behind
+// the device and stops enqueueing layers once every pair has left.  Two 4-byte stores over the host link instead of a copy command + an event per layer.
+__global__ void lg_decide_kernel(LgState st, int layer, float depth_conf, int early, int last, int* mirror, int seq_off, int seq) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= st.n_pairs) return;
-  if (st.done[p] == 0) {
-    if (last) {
-      st.done[p] = layer + 1;
-    } else if (early) {
-      const float num = (float)(st.n_orig[2 * p] + st.n_orig[2 * p + 1]);
-      const float ratio = 1.0f - (float)st.cnt_lt[p] / num;
-      if (ratio > depth_conf) st.done[p] = layer + 1;
+  if (p < st.n_pairs) {
+    if (st.done[p] == 0) {
+      if (last) {
+        st.done[p] = layer + 1;
+      } else if (early) {
+        const float num = (float)(st.n_orig[2 * p] + st.n_orig[2 * p + 1]);
+        const float ratio = 1.0f - (float)st.cnt_lt[p] / num;
+        if (ratio > depth_conf) st.done[p] = layer + 1;
+      }
     }
+    st.cnt_lt[p] = 0;
+    if (mirror != nullptr) mirror[p] = st.done[p];
   }
-  st.cnt_lt[p] = 0;
+  if (mirror != nullptr && blockIdx.x == 0) {
+    __threadfence_system();
+    if (threadIdx.x == 0) __atomic_store_n(mirror + seq_off, seq, __ATOMIC_RELEASE);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -267,7 +276,9 @@ __global__ void lg_prune_commit_kernel(LgState st, int layer) {
 __global__ __launch_bounds__(256) void lg_row_stats_kernel(LgState st, int tag, const float* __restrict__ w_match,
                                                            const float* __restrict__ b_match) {
   const int item = blockIdx.y, p = item >> 1, side = item & 1;
-  if (st.done[p] != tag) return;
+  const int dn = st.done[p];
+  if (tag ? dn != tag : dn <= 0) return;   // tag 0: every stopped pair (its layer's weights: lg_api.hip, the deferred assignment)
+  if (tag == 0) { w_match += (size_t)(dn - 1) * 256; b_match += dn - 1; }   // [layers][256] / [layers] tables
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = st.n_cur[item];
   if (row >= n) return;
@@ -293,7 +304,8 @@ __global__ __launch_bounds__(256) void lg_row_stats_kernel(LgState st, int tag, 
 __global__ __launch_bounds__(1024) void lg_col_stats_kernel(LgState st, int tag) {
   __shared__ float red[16][64];
   const int p = blockIdx.y;
-  if (st.done[p] != tag) return;
+  const int dn = st.done[p];
+  if (tag ? dn != tag : dn <= 0) return;   // tag 0: every stopped pair (its layer's weights: lg_api.hip, the deferred assignment)
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + tx;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
@@ -328,7 +340,8 @@ __device__ __forceinline__ float lg_score(float sim, float rm, float rl, float c
 // row argmax (first maximal index, Tensor.max on CPU) — wave per row; optionally dumps the dense matrix.
 __global__ __launch_bounds__(256) void lg_row_argmax_kernel(LgState st, int tag, float* __restrict__ dense) {
   const int p = blockIdx.y;
-  if (st.done[p] != tag) return;
+  const int dn = st.done[p];
+  if (tag ? dn != tag : dn <= 0) return;   // tag 0: every stopped pair (its layer's weights: lg_api.hip, the deferred assignment)
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
   if (row >= nrow) return;
@@ -354,7 +367,8 @@ __global__ __launch_bounds__(1024) void lg_col_argmax_kernel(LgState st, int tag
   __shared__ float redv[16][64];
   __shared__ int redi[16][64];
   const int p = blockIdx.y;
-  if (st.done[p] != tag) return;
+  const int dn = st.done[p];
+  if (tag ? dn != tag : dn <= 0) return;   // tag 0: every stopped pair (its layer's weights: lg_api.hip, the deferred assignment)
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + tx;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
@@ -486,8 +500,9 @@ int launch_lg_confidence(const LgState& st, const float* w_tok, const float* b_t
   DIM_LAUNCH_CHECK();
   return 0;
 }
-int launch_lg_decide(const LgState& st, int layer, float depth_conf, int early, int last, hipStream_t s) {
-  hipLaunchKernelGGL(lg_decide_kernel, dim3(cdiv(st.n_pairs, 64)), dim3(64), 0, s, st, layer, depth_conf, early, last);
+int launch_lg_decide(const LgState& st, int layer, float depth_conf, int early, int last, hipStream_t s, int* mirror, int seq_off, int seq) {
+  DIM_REQUIRE(mirror == nullptr || st.n_pairs <= 64, "lg_decide: the host mirror exists for at most 64 pairs");
+  hipLaunchKernelGGL(lg_decide_kernel, dim3(cdiv(st.n_pairs, 64)), dim3(64), 0, s, st, layer, depth_conf, early, last, mirror, seq_off, seq);
   DIM_LAUNCH_CHECK();
   return 0;
 }
@@ -511,7 +526,9 @@ __device__ __forceinline__ float exp_le0_z(float d) { return d > -INFINITY ? exp
 __global__ __launch_bounds__(256) void lg_row_stats4_kernel(LgState st, int tag, const float* __restrict__ w_match,
                                                             const float* __restrict__ b_match) {
   const int item = blockIdx.y, p = item >> 1, side = item & 1;
-  if (st.done[p] != tag) return;
+  const int dn = st.done[p];
+  if (tag ? dn != tag : dn <= 0) return;   // tag 0: every stopped pair (its layer's weights: lg_api.hip, the deferred assignment)
+  if (tag == 0) { w_match += (size_t)(dn - 1) * 256; b_match += dn - 1; }   // [layers][256] / [layers] tables
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = st.n_cur[item];
   if (row >= n) return;
@@ -552,7 +569,8 @@ constexpr int COL_CW = 16, COL_RG = 1024 / COL_CW;
 __global__ __launch_bounds__(1024) void lg_col_stats4_kernel(LgState st, int tag) {
   __shared__ float4 redm[COL_RG][COL_CW], reds[COL_RG][COL_CW];
   const int p = blockIdx.y;
-  if (st.done[p] != tag) return;
+  const int dn = st.done[p];
+  if (tag ? dn != tag : dn <= 0) return;   // tag 0: every stopped pair (its layer's weights: lg_api.hip, the deferred assignment)
   const int tx = threadIdx.x % COL_CW, ty = threadIdx.x / COL_CW;
   const int col = blockIdx.x * (4 * COL_CW) + tx * 4;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
@@ -594,7 +612,8 @@ __global__ __launch_bounds__(1024) void lg_col_stats4_kernel(LgState st, int tag
 }
 __global__ __launch_bounds__(256) void lg_row_argmax4_kernel(LgState st, int tag, float* __restrict__ dense) {
   const int p = blockIdx.y;
-  if (st.done[p] != tag) return;
+  const int dn = st.done[p];
+  if (tag ? dn != tag : dn <= 0) return;   // tag 0: every stopped pair (its layer's weights: lg_api.hip, the deferred assignment)
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];
   if (row >= nrow) return;
@@ -631,7 +650,8 @@ __global__ __launch_bounds__(1024) void lg_col_argmax4_kernel(LgState st, int ta
   __shared__ float4 redv[COL_RG][COL_CW];
   __shared__ int redi[COL_RG][COL_CW][4];
   const int p = blockIdx.y;
-  if (st.done[p] != tag) return;
+  const int dn = st.done[p];
+  if (tag ? dn != tag : dn <= 0) return;   // tag 0: every stopped pair (its layer's weights: lg_api.hip, the deferred assignment)
   const int tx = threadIdx.x % COL_CW, ty = threadIdx.x / COL_CW;
   const int col = blockIdx.x * (4 * COL_CW) + tx * 4;
   const int nrow = st.n_cur[2 * p], ncol = st.n_cur[2 * p + 1];

@@ -49,6 +49,11 @@ int dim_device_synchronize(void);
  *   key 9  1 (default) ALIKED BatchNorm + SELU applied while the consumer stages its input, 0 = separate pass;
  *   key 16 1 (default) SuperPoint's detector tail (convPb 256 -> 65, softmax, depth-to-space) as one kernel in fp16x3, 0 = GEMM + softmax kernels
  *          (bit-identical score maps);
+ *   key 17 1 (default) adaptive-depth LightGlue (depth_confidence > 0) evaluates the assignment once, after the layer loop, for every pair with the
+ *          weights of the layer it stopped at; 0 = gated assignment launches after every layer (same results);
+ *   key 18 1 (default) dim_lg_match with adaptive depth on a handle created for at most two pairs (the per-call plugin hooks) reads the stop
+ *          flags back two layers behind the device (an event wait per layer) and does not enqueue the layers that no pair needs; 0 = the call
+ *          never touches the host, as calls on larger handles always do (same results);
  *   key 11 LightGlue's feed-forward: 3 (default) ffn.0 + LayerNorm + GELU + ffn.3 + residual as one kernel when the launch fills the GPU,
  *          4 = always, 1 / 2 = LayerNorm + GELU in ffn.0's epilogue only (when large / always), 0 = separate kernels;
  *   kernel-shape selection (same results; the defaults pick by problem size, the other values force a shape — used by the tests to reach

@@ -242,6 +242,8 @@ hipError_t hipMalloc(void** p, size_t n) {
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }

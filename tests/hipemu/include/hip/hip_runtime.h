@@ -99,6 +99,7 @@ static inline void __syncthreads() { hipemu::barrier(); }
 static inline void __builtin_amdgcn_s_barrier() { hipemu::barrier(); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
+static inline void __threadfence_system() {}
 
 template <typename T>
 static inline T hipemu_shfl_from(T v, int src_lane_for_me) {
@@ -344,6 +345,10 @@ static inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); re
 extern "C" {
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
+#define hipHostMallocMapped 0x2
+#define hipHostMallocCoherent 0x40000000
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
+hipError_t hipHostFree(void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 #define HIP_SYMBOL(x) (&(x))
 static inline hipError_t hipMemcpyFromSymbol(void* d, const void* sym, size_t n) { memcpy(d, sym, n); return hipSuccess; }

@@ -162,6 +162,67 @@ def test_batch_with_ragged_and_empty_images_on_the_projection_written_images(emu
         emu_lib.dim_tune_set(6, 1)
 
 
+def test_deferred_assignment_equals_the_gated_launches_after_every_layer(emu_lib):
+    """Adaptive depth: a pair that stops at layer i is skipped by every later launch, so its assignment can wait.  dim_tune_set(17, 1) (default) runs the
+    final projection / similarity / double softmax / arg-max ONCE after the layer loop, every item reading the weights of its own stop layer from per-layer
+    tables; (17, 0) launches them, gated on the stop layer, after every layer.  A ragged batch whose pairs stop at different layers (incl. the
+    no-keypoints exit and pruning): every output bit for bit equal, dense log-assignment included; and the stop layers really differ."""
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_lightglue_state_dict(5, 256, n_layers=4, gain=2.0)
+    sd = {k: v.clone() for k, v in sd.items()}
+    for i in range(3):   # token-confidence biases that make the layers differently sure of themselves: pairs leave at different depths
+        sd[f"token_confidence.{i}.token.0.bias"] = sd[f"token_confidence.{i}.token.0.bias"] + (-2.0, 1.5, 3.0)[i]
+    conf = {"n_layers": 4, "depth_confidence": 0.6, "width_confidence": 0.99, "filter_threshold": 0.0, "pruning_min_kpts": -1}
+    g = torch.Generator().manual_seed(4)
+    n_img, cap = 5, 90
+    counts = [90, 0, 41, 77, 64]
+    kt = torch.rand(n_img, cap, 2, generator=g) * 640
+    dt = torch.nn.functional.normalize(torch.randn(n_img, cap, 256, generator=g), dim=-1)
+    dt[4] = dt[3] + 0.05 * torch.randn(cap, 256, generator=g)     # a pair with real correspondences behaves differently from noise pairs
+    nt = torch.tensor(counts, dtype=torch.int32)
+    st = torch.tensor([[480.0, 640.0]] * n_img)
+    pairs = torch.tensor([[0, 2], [3, 4], [0, 1], [4, 3], [2, 3]], dtype=torch.int32)
+    outs = []
+    try:
+        for defer in (1, 0):
+            assert emu_lib.dim_tune_set(17, defer) == 0
+            net = lg_mod.LightGlueHIP(sd, conf, max_pairs=5, max_kpts=cap, device="cpu", lib=emu_lib)
+            outs.append(net.match_batch(kt, dt, nt, st, pair_idx=pairs, dense=True))
+    finally:
+        emu_lib.dim_tune_set(17, 1)
+    a, b = outs
+    for k in ("n_matches", "stop", "dense"):
+        assert torch.equal(a[k], b[k]), k
+    for p, (i0, i1) in enumerate(pairs.tolist()):   # (the tables are only defined up to the live counts)
+        S = int(a["n_matches"][p])
+        assert torch.equal(a["matches"][p, :S], b["matches"][p, :S]) and torch.equal(a["scores"][p, :S], b["scores"][p, :S])
+        for side, img in enumerate((i0, i1)):
+            n = counts[img]
+            for k in ("matches01", "mscores01", "prune01"):
+                assert torch.equal(a[k][p, side, :n], b[k][p, side, :n]), (k, p, side)
+    assert len(set(a["stop"].tolist())) >= 2, a["stop"]
+    assert int(a["n_matches"].sum()) > 0
+    # one pair per call (the plugin hooks): the host follows the stop flags two layers behind and stops enqueueing layers (dim_tune_set key 18) — every pair
+    # alone, followed and not followed: bit for bit the same, and the same matches as its row of the batch (whose launches take other block shapes:
+    # scores to fp32 rounding)
+    assert min(a["stop"].tolist()) <= 2, a["stop"]     # (a pair that leaves early enough for the loop to be cut short)
+    single = {}
+    try:
+        for follow in (1, 0):
+            assert emu_lib.dim_tune_set(18, follow) == 0
+            net1 = lg_mod.LightGlueHIP(sd, conf, max_pairs=1, max_kpts=cap, device="cpu", lib=emu_lib)
+            for p in range(len(pairs)):
+                o = net1.match_batch(kt, dt, nt, st, pair_idx=pairs[p:p + 1].contiguous(), dense=True)
+                S = int(a["n_matches"][p])
+                assert int(o["n_matches"][0]) == S and int(o["stop"][0]) == int(a["stop"][p])
+                assert torch.equal(o["matches"][0, :S], a["matches"][p, :S]) and (o["scores"][0, :S] - a["scores"][p, :S]).abs().max().item() < 1e-5 if S else True
+                single[(follow, p)] = (o["matches"][0, :S].clone(), o["scores"][0, :S].clone(), o["dense"][0].clone())
+    finally:
+        emu_lib.dim_tune_set(18, 1)
+    for p in range(len(pairs)):
+        assert all(torch.equal(x, y) for x, y in zip(single[(1, p)], single[(0, p)])), p
+
+
 def test_ffn_layernorm_gelu_epilogue_equals_the_separate_pass(emu_lib):
     """dim_tune_set(11, 2) forces the 64 x 512 ffn.0 block whose epilogue applies LayerNorm(512) + erf-GELU (the production
     path at large batches) at the golden sizes; (11, 0) keeps ffn.0 -> lg_ln_gelu_kernel.  Same statistics (two-pass mean /
