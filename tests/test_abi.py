@@ -61,7 +61,7 @@ def test_product_library_rejects_the_research_keys_and_the_research_build_has_th
     lib.dim_last_error.restype = ctypes.c_char_p
     for key in (12, 13, 14, 15):
         assert lib.dim_tune_set(key, 1) != 0 and b"research" in lib.dim_last_error()
-    assert lib.dim_tune_set(17, 0) != 0 and lib.dim_tune_set(-1, 0) != 0
+    assert lib.dim_tune_set(19, 0) != 0 and lib.dim_tune_set(-1, 0) != 0
     assert lib.dim_tune_set(1, 2) == 0 and lib.dim_tune_set(11, 3) == 0
     assert not hasattr(lib, "dim_conv_wg_phase_read")
     text = (ROOT / "include" / "dim_hip.h").read_text()
