@@ -657,7 +657,7 @@ def measure_hook_path(dev, lib, n_img: int = 6, n_pair: int = 6):
            "device_only_ms_per_image": e[0].elapsed_time(e[1]) / n_img, "device_only_ms_per_pair": e[1].elapsed_time(e[2]) / n_pair,
            "note": "batch-1 calls through plugins.SuperPointExtractor._extract / LightGlueMatcher._match_pairs (numpy in / out, one guard read-back per call) at the "
                    "headline sizes (1024 x 1024, 2048 x 2048 keypoints, 9 layers); device_only_* = the same batch-1 library calls on resident tensors (HIP events). "
-                   "The calls are kernel-bound, not launch-bound: the rocprofv3 kernel times of a call add up to its wall time (profiles/r05_hook_path_*)"}
+                   "The calls are kernel-bound, not launch-bound: the rocprofv3 kernel times of a call add up to its wall time (profiles/r06_hook_path_b1_kernel_stats.csv; round 6: 32 x 128 GEMM blocks, chunk-ahead requests, K | V images from the small projection — profiles/r06_b1_steps.json; adaptive pairs: profiles/r06_b1_adaptive.json)"}
     del ex, mt
     torch.cuda.empty_cache()
     return rec
