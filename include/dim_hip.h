@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIM_HIP_ABI_VERSION 2   /* 2 (round 6): handle structs carry a tune header, dim_tune_set key 16, keypoint slots up to 32768 */
+#define DIM_HIP_ABI_VERSION 2   /* 2 (round 6): handle structs carry a tune header, dim_tune_set keys 16 - 18, keypoint slots up to 32768, dim_lg_stage_features, the dim_op_* sort entries */
 
 const char* dim_last_error(void);
 int dim_abi_version(void);

@@ -201,3 +201,37 @@ def test_match_list_flip_rate_at_2048_within_the_measured_fp32_envelope(hip_lib)
     for th in (0.0, 0.1):
         assert len(flips[th]) <= 3 * basis["rate"] * total[th] + 1, (th, flips[th], basis)
     _record({"test": "lg_flip_rate_2048_first_8_pairs", "matches": total, "flips": flips, "basis": basis})
+
+
+def test_one_pair_adaptive_depth_deferred_assignment_and_followed_stop_flags_on_hardware(hip_lib):
+    """One pair per call with the reference's default confidences (the plugin hooks), pairs DESIGNED to stop after 3 / 5 / 7 / 9 layers
+    (workloads.adaptive_lightglue_workload): round 6 evaluates the assignment once after the layer loop (dim_tune_set key 17) and lets the host follow
+    the stop flags through mapped page-locked memory, two layers behind the device, to stop enqueueing layers (key 18) — real concurrency between the
+    host's spin and lg_decide_kernel's system-scope stores, which the emulator cannot show.  Every setting must give the same stop layer and bit for bit
+    the same matches, scores and dense log-assignment, repeatedly (the sequence number guards against a stale word of the previous call)."""
+    wl = importlib.import_module("deep-image-matching_amd.workloads")
+    stops = (3, 5, 7, 9)
+    sd, kp, de, cnt, sz, expect = wl.adaptive_lightglue_workload(len(stops), n_kpts=1024, stops=stops)
+    kp, de, cnt, sz = kp.cuda(), de.cuda(), cnt.cuda(), sz.cuda()
+    conf = {"depth_confidence": 0.95, "width_confidence": 0.99, "filter_threshold": 0.1}
+    ref = {}
+    try:
+        for k17, k18 in ((0, 0), (1, 0), (1, 1)):
+            assert hip_lib.dim_tune_set(17, k17) == 0 and hip_lib.dim_tune_set(18, k18) == 0
+            net = _lg().LightGlueHIP(sd, conf, max_pairs=1, max_kpts=1024)
+            for rep in range(3):
+                for p, s in enumerate(stops):
+                    pi = torch.tensor([[2 * p, 2 * p + 1]], dtype=torch.int32, device="cuda")
+                    o = net.match_batch(kp, de, cnt, sz, pair_idx=pi, dense=True)
+                    torch.cuda.synchronize()
+                    S = int(o["n_matches"][0])
+                    assert int(o["stop"][0]) == s == int(expect[p])
+                    got = (o["matches"][0, :S].cpu(), o["scores"][0, :S].cpu(), o["dense"][0].cpu())
+                    if p not in ref:
+                        ref[p] = got
+                        assert S > 100
+                    else:
+                        assert all(torch.equal(a, b) for a, b in zip(ref[p], got)), (k17, k18, rep, p)
+    finally:
+        hip_lib.dim_tune_set(17, 1)
+        hip_lib.dim_tune_set(18, 1)
