@@ -285,7 +285,11 @@ int dim_lg_stage_features(const dim_lg_raw_features* img0, const dim_lg_raw_feat
  *   stop_dev      [n_pairs]              — "stop" (LGN:570)
  *   prune01_dev   [n_pairs][2][NK] int32 — prune0 / prune1
  *   dense_scores_dev: NULL, or [n_pairs][NK+1][NK+1] receiving the inner MxN block of the
- *   log assignment matrix (parity tests only). */
+ *   log assignment matrix (parity tests only).
+ * The call only enqueues work on `stream` and never reads results back — with one exception: on a handle created for at most two pairs, with
+ * depth_confidence > 0 (adaptive depth), it waits (spinning on mapped page-locked memory, two layers behind the device) for the pairs' stop flags and
+ * stops enqueueing layers once every pair has stopped (dim_tune_set key 18 = 0 turns that off; results are identical either way).  A handle must not be
+ * used from two threads at once. */
 int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev, const int32_t* n_tab_dev,
                  const float* size_tab_dev, int cap, const int32_t* pair_idx_dev, int n_pairs, int64_t* matches_dev,
                  float* mscores_dev, int32_t* n_matches_dev, int32_t* matches01_dev, float* mscores01_dev,
