@@ -16,6 +16,9 @@ lg_mod = importlib.import_module("deep-image-matching_amd.lightglue_hip")
 GOLD = Path(__file__).parent / "golden"
 
 
+_REF_CACHE = {}
+
+
 def run_case(lib, case, device="cpu"):
     sd = gc.lg_weights(case)
     f0, f1 = gc.lg_inputs(case)
@@ -24,8 +27,10 @@ def run_case(lib, case, device="cpu"):
             "image1": {"keypoints": f1["kpts"][None], "descriptors": f1["desc"][None], "image_size": f1["size"][None]}}
     out = net(data, dense=True)
     out = {k: ([t.cpu() for t in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v)) for k, v in out.items()}
-    ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, case["conf"], taps=True)
-    return out, ref
+    key = repr(sorted(case.items(), key=lambda kv: kv[0]))
+    if key not in _REF_CACHE:   # (the oracle's output for a case does not depend on the library under test: several tests run the same case with other kernel selections)
+        _REF_CACHE[key] = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, case["conf"], taps=True)
+    return out, _REF_CACHE[key]
 
 
 @pytest.mark.parametrize("name", list(gc.LG_CASES))
