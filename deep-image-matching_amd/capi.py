@@ -115,7 +115,7 @@ def run_guarded(lib, stream, fn, what: str, policy: str = "fallback", logger=Non
     mode = get_arithmetic(lib) if arithmetic is None else (ARITHMETIC[arithmetic] if isinstance(arithmetic, str) else int(arithmetic))
     if mode != 2 or policy == "off":
         return fn()
-    saturation(lib, stream, reset=True)  # drop anything a previous unguarded call left behind
+    check(lib, lib.dim_saturation_reset(stream))  # drop anything a previous unguarded call left behind (one enqueued memset: no read-back, no synchronisation)
     out = fn()
     total, sites = saturation(lib, stream, reset=True)
     if total == 0:

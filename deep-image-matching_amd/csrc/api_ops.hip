@@ -150,6 +150,13 @@ int dim_saturation_read(unsigned* counts_host, unsigned long long* total, int re
   return 0;
 }
 
+int dim_saturation_reset(void* stream) {
+  unsigned* b = sat_block();
+  if (b) DIM_HIP(hipMemsetAsync(b, 0, DIM_SAT_SITES * sizeof(unsigned), (hipStream_t)stream));
+  for (int i = 0; i < DIM_SAT_SITES; ++i) g_sat_host[i] = 0;
+  return 0;
+}
+
 int dim_op_read_clocks(unsigned long long* out_dev, void* stream) {
   DIM_REQUIRE(out_dev, "dim_op_read_clocks: null argument");
   hipLaunchKernelGGL(read_clocks_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out_dev);

@@ -101,6 +101,9 @@ enum {
   DIM_SAT_SITES = 16
 };
 int dim_saturation_read(unsigned* counts_host, unsigned long long* total, int reset, void* stream);
+/* Zeroes the counters without reading them: one memset enqueued on `stream`, no synchronisation (what a guarded call does before it starts, to drop
+ * anything an earlier unguarded call left behind). */
+int dim_saturation_reset(void* stream);
 
 /* Shader-clock probe: writes {s_memtime (shader cycles), s_memrealtime (100 MHz)} to out_dev[2] on `stream`;
  * two probes around a region give its average shader clock = d(cycles) / d(realtime) * 100 MHz (bench.py). */
