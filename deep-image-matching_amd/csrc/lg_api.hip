@@ -389,7 +389,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
   // would all have returned at their flag test.  (A first version copied the flags with hipMemcpyAsync + an event per layer: the nine blit kernels
   // cost a pair that runs all layers 0.04 ms, profiles/r06_b1_adaptive.json.)  dim_tune_set key 18 = 0: never follow — the call then enqueues
   // everything without touching the host, as batched calls always do.
-  const bool follow = early && h->done_host != nullptr && n_pairs <= FOLLOW_MAX_PAIRS && dim_follow_stop_flags() != 0;
+  bool follow = early && h->done_host != nullptr && n_pairs <= FOLLOW_MAX_PAIRS && dim_follow_stop_flags() != 0;
   const int mstride = h->max_pairs + 1;
   const int seq = follow ? (h->call_seq = (h->call_seq % 0x3fffffff) + 1) : 0;
   for (int i = 0; i < Lr; ++i) {
@@ -404,6 +404,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
       bool all = seen;
       for (int p = 0; p < n_pairs; ++p) all = all && m[p] != 0;
       if (all) break;
+      if (!seen) follow = false;   // the device is not making progress while we wait (a stream held back by the caller?): enqueue the rest without looking
     }
     // ---- self block (LGN:146-159) ----
     if (fuse_kv) LG_RUN(gemm_qkv(w.qkv_x, w.qkv_b, 768, 1, true));
