@@ -256,9 +256,12 @@ int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pai
   if (max_pairs <= FOLLOW_MAX_PAIRS) {
     void* q = nullptr;
     const size_t nb = (size_t)w->n_layers * (max_pairs + 1) * sizeof(int);
-    if (hipHostMalloc(&q, nb, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { dim_set_error("dim_lg_create: page-locked allocation failed"); dim_lg_destroy(h); return -1; }
-    memset(q, 0, nb);
-    h->done_host = (int*)q;
+    if (hipHostMalloc(&q, nb, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {   // (without it the calls simply do not follow the stop flags)
+      memset(q, 0, nb);
+      h->done_host = (int*)q;
+    } else {
+      (void)hipGetLastError();
+    }
   }
   LgState& st = h->st;
   const size_t P = max_pairs, I = 2 * P, N = h->nmax;
