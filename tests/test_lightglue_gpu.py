@@ -235,3 +235,29 @@ def test_one_pair_adaptive_depth_deferred_assignment_and_followed_stop_flags_on_
     finally:
         hip_lib.dim_tune_set(17, 1)
         hip_lib.dim_tune_set(18, 1)
+
+
+@pytest.mark.parametrize("kf16,df16,dn", [(0, 0, 0), (1, 1, 1), (0, 1, 0), (1, 0, 1)])
+def test_lg_stage_features_on_hardware_equals_the_host_conversion(hip_lib, kf16, df16, dn):
+    """dim_lg_stage_features at the headline size (2048 / 1777 keypoints, D = 256, table capacity 2048): float16 / float32 arrays in (N, D) / (D, N) layout ->
+    the fp32 (N, D) feature table, bit for bit the host conversion (transpose + astype(float32)); rows past the live counts are zero."""
+    import ctypes
+    capi = importlib.import_module("deep-image-matching_amd.capi")
+    g = np.random.default_rng(11 + kf16 + 2 * df16 + 4 * dn)
+    D, cap, counts = 256, 2048, (2048, 1777)
+    dev, descr, want = [], [], []
+    for n in counts:
+        k = (g.random((n, 2)) * 1000).astype(np.float16 if kf16 else np.float32)
+        d = g.standard_normal((D, n) if dn else (n, D)).astype(np.float16 if df16 else np.float32)
+        kt, dt = torch.from_numpy(k).cuda(), torch.from_numpy(d).cuda()
+        dev += [kt, dt]
+        descr.append(capi.LgRawFeatures(kt.data_ptr(), dt.data_ptr(), n, kf16, df16, dn))
+        want.append((k.astype(np.float32), (d.T if dn else d).astype(np.float32)))
+    ktab = torch.full((2, cap, 2), -7.0, device="cuda")
+    dtab = torch.full((2, cap, D), -7.0, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(hip_lib, hip_lib.dim_lg_stage_features(ctypes.byref(descr[0]), ctypes.byref(descr[1]), cap, D, capi.ptr(ktab), capi.ptr(dtab), stream))
+    torch.cuda.synchronize()
+    for i, n in enumerate(counts):
+        assert np.array_equal(ktab[i, :n].cpu().numpy(), want[i][0]) and np.array_equal(dtab[i, :n].cpu().numpy(), want[i][1])
+        assert not ktab[i, n:].any() and not dtab[i, n:].any()
