@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -400,9 +401,13 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     if (follow && i >= 2) {
       const int* m = h->done_host + (size_t)(i - 2) * mstride;
       bool seen = false;
-      for (long spin = 0; spin < 400000000L; ++spin) {   // (~1 s at worst: then the call simply goes on enqueueing)
+      const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(500);   // (at worst: then the call simply goes on enqueueing)
+      for (long spin = 0;; ++spin) {
         if (__atomic_load_n(m + h->max_pairs, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
-        if ((spin & 1023) == 1023) std::this_thread::yield();
+        if ((spin & 1023) == 1023) {
+          if (std::chrono::steady_clock::now() > t_end) break;
+          std::this_thread::yield();
+        }
       }
       bool all = seen;
       for (int p = 0; p < n_pairs; ++p) all = all && m[p] != 0;
