@@ -575,7 +575,10 @@ class TiledPairPipeline:
             st[base[i]: base[i] + tmax] = torch.as_tensor(np_f32(f["image_size"]), device=dev)
         tp = [(s, base[int(pairs[p, 0])] + ta, base[int(pairs[p, 1])] + tb) for s, p in enumerate(mine) for ta, tb in sel[p]]
         B = max(1, min(self.tile_pair_batch, len(tp)))
-        net = self.mat._ensure_pairs(cap_t, B)
+        # the handle is sized for the CONFIGURED batch, not for this job's: a job with fewer tile pairs than the batch (a warm-up pass, a small first image pair)
+        # would otherwise leave a handle that the next longer job rebuilds — ~1 s of weight splitting, uploads and allocations inside its matching phase
+        # (found in round 6: bench.py --workload config5 --tile-pair-batch 32 ran at 8.7 instead of 12.6 image-pairs/s with identical kernel time)
+        net = self.mat._ensure_pairs(cap_t, max(1, self.tile_pair_batch))
         NK = net.nk
         pidx_all = torch.tensor([[r0, r1] for _, r0, r1 in tp], dtype=torch.int32, device=dev).contiguous()
         slot_all = torch.tensor([s for s, _, _ in tp], dtype=torch.int32, device=dev)

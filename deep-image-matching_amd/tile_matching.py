@@ -439,7 +439,7 @@ def match_tile_pairs_batched(net_for, features0: dict, features1: dict, tile_pai
         st[i] = np.asarray(f["image_size"], dtype=np.float32).reshape(2)
     dev = torch.device(device)
     kt_d, dt_d, nt_d, st_d = (torch.from_numpy(a).to(dev) for a in (kt, dt, nt, st))
-    net = net_for(cap, min(pair_batch, len(tile_pairs)))
+    net = net_for(cap, pair_batch)   # (always the full batch: a handle sized for a short first job would be rebuilt — ~1 s of weight splitting, uploads and allocations — by the next longer one)
     chunks = []
     for s in range(0, len(tile_pairs), pair_batch):
         chunk = tile_pairs[s:s + pair_batch]
@@ -549,7 +549,7 @@ def match_tile_pairs_batched_device(net_for, f0: dict, f1: dict, tile_pairs: Seq
     st = torch.zeros(T, 2, dtype=torch.float32, device=dev)
     st[: len(t0s)] = torch.as_tensor(np.asarray(f0["image_size"], dtype=np.float32).reshape(2), device=dev)
     st[len(t0s):] = torch.as_tensor(np.asarray(f1["image_size"], dtype=np.float32).reshape(2), device=dev)
-    net = net_for(cap, min(pair_batch, len(tile_pairs)))
+    net = net_for(cap, pair_batch)   # (always the full batch: a handle sized for a short first job would be rebuilt — ~1 s of weight splitting, uploads and allocations — by the next longer one)
     NK = net.nk
     keys = torch.empty(len(tile_pairs), NK, dtype=torch.int64, device=dev)
     zero_slot = torch.zeros(min(pair_batch, len(tile_pairs)), dtype=torch.int32, device=dev)
