@@ -395,7 +395,9 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
   // small batches leave most CUs idle and make every workgroup walk all key tiles alone: cut the key range
   const int wgs = cdiv(st.nmax, 128) * 4 * st.n_items;
   a.part = st.attn_part;
-  a.splits = (st.attn_part && st.n_items <= st.attn_part_items) ? (wgs <= 128 ? 4 : (wgs <= 256 ? 2 : 1)) : 1;
+  // ... into the fewest parts (1, 2, 4) that give the launch two workgroups per CU (512).  (Until round 6: 4 parts up to 128 workgroups, 2 up to 256, else 1 —
+  // one pair of 2304 keypoints ran 288 workgroups of 36 tiles, 1.1 per CU: 2.01 ms against 1.52 at 2048; three pairs of 2048 ran 384 of 64 tiles.)
+  a.splits = (st.attn_part && st.n_items <= st.attn_part_items) ? (wgs >= 512 ? 1 : (wgs >= 256 ? 2 : 4)) : 1;
   a.probe = cross ? dim_attn_probe() : 0;
   if (a.probe == 2) a.splits = 16;  // probe 2: every query block's key range in 16 parts -> the partial-record volume of a shared score tile, written AND merged
   if (dim_attn_probe() == 8 || dim_attn_probe() == 16) { a.probe = 0; if (a.splits > 1) a.splits = dim_attn_probe(); }   // research: a finer key split for small batches (results stay correct)

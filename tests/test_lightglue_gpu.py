@@ -261,3 +261,33 @@ def test_lg_stage_features_on_hardware_equals_the_host_conversion(hip_lib, kf16,
     for i, n in enumerate(counts):
         assert np.array_equal(ktab[i, :n].cpu().numpy(), want[i][0]) and np.array_equal(dtab[i, :n].cpu().numpy(), want[i][1])
         assert not ktab[i, n:].any() and not dtab[i, n:].any()
+
+
+def test_key_split_attention_in_the_in_between_shapes_vs_oracle(hip_lib):
+    """The key range of an attention launch is cut into the fewest parts (1, 2, 4) that give it two workgroups per CU (round 6: one pair of 2304 keypoints
+    now takes 4 parts of 18 tiles instead of 2 of 36, three pairs of 2048 take 2 instead of 1).  A ragged one-pair call in the first shape against the
+    oracle; a three-pair call in the second against the same pairs run alone (which the full-size test pins to the oracle), fixed work."""
+    weights = importlib.import_module("deep-image-matching_amd.weights")
+    sd = weights.synthetic_lightglue_state_dict(0, 256, gain=2.0)
+    conf = {"depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.0}
+    f0, f1 = _full_inputs(33, 2304, 2100)
+    net = _lg().LightGlueHIP(sd, conf, max_pairs=1, max_kpts=2304)
+    out = _cpu(net(_data(f0, f1), dense=True))
+    ref = lightglue_ref.lightglue_forward(f0["kpts"], f0["desc"], f0["size"], f1["kpts"], f1["desc"], f1["size"], sd, conf, taps=True)
+    compare_lightglue(out, ref, dense_ref=ref.get("log_assignment"), dense_out=out["dense"])
+    g = torch.Generator().manual_seed(6)
+    counts = [2048, 1900, 1777, 2048, 2001, 1500]
+    kt = torch.rand(6, 2048, 2, generator=g) * 1024
+    dt = torch.nn.functional.normalize(torch.randn(6, 2048, 256, generator=g), dim=-1)
+    nt, st = torch.tensor(counts, dtype=torch.int32), torch.tensor([[1024.0, 1024.0]] * 6)
+    big = _lg().LightGlueHIP(sd, conf, max_pairs=3, max_kpts=2048)
+    o = {k: v.cpu() for k, v in big.match_batch(kt.cuda(), dt.cuda(), nt.cuda(), st.cuda()).items()}
+    one = _lg().LightGlueHIP(sd, conf, max_pairs=1, max_kpts=2048)
+    for p in range(3):
+        a, b = 2 * p, 2 * p + 1
+        data = {"image0": {"keypoints": kt[a, :counts[a]][None], "descriptors": dt[a, :counts[a]][None], "image_size": st[a][None]},
+                "image1": {"keypoints": kt[b, :counts[b]][None], "descriptors": dt[b, :counts[b]][None], "image_size": st[b][None]}}
+        r = _cpu(one(data))
+        S = int(o["n_matches"][p])
+        assert int(o["stop"][p]) == r["stop"] and torch.equal(o["matches"][p, :S], r["matches"][0])
+        torch.testing.assert_close(o["scores"][p, :S], r["scores"][0], rtol=1e-3, atol=1e-9)
