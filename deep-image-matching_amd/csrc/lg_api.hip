@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -266,7 +267,7 @@ int dim_lg_create(const dim_lg_weights* w, const dim_lg_config* cfg, int max_pai
   }
   LgState& st = h->st;
   const size_t P = max_pairs, I = 2 * P, N = h->nmax;
-  st.n_pairs = max_pairs; st.n_items = 2 * max_pairs; st.nmax = h->nmax;
+  st.n_pairs = max_pairs; st.n_items = 2 * max_pairs; st.nmax = h->nmax; st.nsel = h->nmax;
   LG_TRY(dev_alloc(h, &st.desc, I * N * 256)); LG_TRY(dev_alloc(h, &st.enc, I * N * 64));
   LG_TRY(dev_alloc(h, &st.qkv, I * N * 768)); LG_TRY(dev_alloc(h, &st.ctx, I * N * 256));
   LG_TRY(dev_alloc(h, &st.msg, I * N * 256)); LG_TRY(dev_alloc(h, &st.hid, I * N * 512));
@@ -299,6 +300,12 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
   LgState st = h->st;
   st.n_pairs = n_pairs; st.n_items = 2 * n_pairs;
   const int N = st.nmax, I = st.n_items, Lr = h->n_layers;
+  // Nsel: no item can have more live rows than the feature table has rows per image (`cap`), whatever the handle's capacity N is — the plugins size their
+  // handles to the next power of two, so a 2100-keypoint pair runs on a 4096-row handle.  Launch shapes and kernel selections (the one-pair GEMM blocks, the
+  // key-split attention, K | V images from the projection, the fast assignment kernels) follow Nsel; strides and layouts follow N.  (Round 6, found by sweeping the
+  // keypoint count on power-of-two handles: 2100 keypoints on a 4096-row handle 2.24 ms, on a handle of its own size ~1.6.)
+  const int Nsel = std::min(N, (cap + 3) & ~3);
+  st.nsel = Nsel;
   const long long s256 = (long long)N * 256, s512 = (long long)N * 512, s768 = (long long)N * 768;
   const bool early = h->cfg.depth_confidence > 0, prune = h->cfg.width_confidence > 0;  // LGN:480-481
 #define LG_RUN(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
@@ -311,7 +318,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
                         h->input_dim == 256 ? 1 : 0, sat(DIM_SAT_LG_INPUT), s));
   const bool fold = x6 && dim_fold_out_proj();  // split modes: out_proj folded into ffn.0 (one GEMM less per block)
   // fp16x3 at batch sizes that fill the GPU with 64-row blocks: LayerNorm + GELU run in ffn.0's epilogue (dim_tune_set key 11)
-  const bool fuse_ln = pmode == 2 && dim_fuse_ffn_ln() && (dim_fuse_ffn_ln() == 2 || (long)((N + 63) / 64) * I >= 512);   // 2 = forced (tests)
+  const bool fuse_ln = pmode == 2 && dim_fuse_ffn_ln() && (dim_fuse_ffn_ln() == 2 || (long)((Nsel + 63) / 64) * I >= 512);   // 2 = forced (tests)
   auto gemm_items = [&](const float* A, int lda, long long sA, const float* A1, int lda1, long long sA1, int ksplit,
                         const float* B, const SplitWeights* Bx, int ldb, const float* bias, const float* R, float* C, int ldc,
                         long long sC, int Nn, int K, int flag_eq, unsigned* sat_ctr = nullptr, const float* ln_g = nullptr,
@@ -320,30 +327,30 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     g.ln_gamma = ln_g; g.ln_beta = ln_b;
     g.A0 = A; g.lda0 = lda; g.strideA0 = sA; g.A1 = A1; g.lda1 = lda1; g.strideA1 = sA1; g.ksplit = ksplit;
     g.B = B; g.ldb = ldb; g.bias = bias; g.R = R; g.ldr = ldc; g.strideR = sC; g.C = C; g.ldc = ldc; g.strideC = sC;
-    g.M = N; g.N = Nn; g.K = K; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = flag_eq;
+    g.M = Nsel; g.N = Nn; g.K = K; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = flag_eq;
     g.sat = sat_ctr;
     if (x6) { g.set_split(Bx[pmode]); return launch_gemm_x6(g, I, s); }
     return launch_gemm(g, I, s);
   };
   // ... and ffn.3 + the residual in the same kernel (dim_tune_set key 11 = 3 / 4 = forced): the hidden tensor is never stored
-  const bool fuse_ffn = fold && pmode == 2 && (dim_fuse_ffn_ln() == 4 || (dim_fuse_ffn_ln() == 3 && (long)((N + 63) / 64) * I >= 512));
+  const bool fuse_ffn = fold && pmode == 2 && (dim_fuse_ffn_ln() == 4 || (dim_fuse_ffn_ln() == 3 && (long)((Nsel + 63) / 64) * I >= 512));
   auto ffn_fused = [&](const SplitWeights* w0, const float* b0, const float* lg, const float* lb, const SplitWeights* w3, const float* b3) -> int {
     GemmArgs g;
     g.A0 = st.desc; g.lda0 = 256; g.strideA0 = s256; g.A1 = st.ctx; g.lda1 = 256; g.strideA1 = s256; g.ksplit = 256;
     g.bias = b0; g.ln_gamma = lg; g.ln_beta = lb; g.set_split(w0[2]); g.set_split2(w3[2]); g.bias2 = b3;
     g.R = st.desc; g.ldr = 256; g.strideR = s256; g.C = st.desc; g.ldc = 256; g.strideC = s256;
-    g.M = N; g.N = 512; g.K = 512; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = 0;
+    g.M = Nsel; g.N = 512; g.K = 512; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = 0;
     g.sat = st.sat_ffn; g.sat2 = sat(DIM_SAT_LG_DESC);
     return launch_gemm_x6(g, I, s);
   };
   // fp16x3 at batch sizes that run the 128 x 256 GEMM block: the q|k|v projections write the attention kernel's K | V tile
   // images themselves (rotary + pre-split in the epilogue; dim_tune_set key 8 = 0 keeps the separate kv_prep pass)
-  const bool fuse_kv = pmode == 2 && dim_fuse_kv() && gemm_x6_fuses_kv(N, 512, I, 2) && gemm_x6_fuses_kv(N, 768, I, 2);
+  const bool fuse_kv = pmode == 2 && dim_fuse_kv() && gemm_x6_fuses_kv(Nsel, 512, I, 2) && gemm_x6_fuses_kv(Nsel, 768, I, 2);
   auto gemm_qkv = [&](const SplitWeights* Bx, const float* bias, int Nn, int kblock, bool rotary) -> int {
     GemmArgs g;
     g.A0 = st.desc; g.lda0 = 256; g.strideA0 = s256;
     g.bias = bias; g.C = st.qkv; g.ldc = 768; g.strideC = s768;
-    g.M = N; g.N = Nn; g.K = 256; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = 0;
+    g.M = Nsel; g.N = Nn; g.K = 256; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = 0;
     g.sat = st.sat_qkv;
     g.kv_img = st.kv_img; g.kv_tiles = (N + 31) / 32; g.kv_kblock = kblock; g.kv_vblock = kblock + 1; g.kv_nmax = N;
     g.kv_enc = rotary ? st.enc : nullptr;
@@ -354,7 +361,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     GemmArgs g;
     g.A0 = desc_tab_dev; g.lda0 = h->input_dim; g.strideA0 = (long long)cap * h->input_dim; g.a_idx = pair_idx_dev;
     g.B = h->inproj_w; g.ldb = 256; g.bias = h->inproj_b; g.C = st.desc; g.ldc = 256; g.strideC = s256;
-    g.M = N; g.N = 256; g.K = h->input_dim; g.rows = st.n_cur; g.sat = sat(DIM_SAT_LG_INPUT);
+    g.M = Nsel; g.N = 256; g.K = h->input_dim; g.rows = st.n_cur; g.sat = sat(DIM_SAT_LG_INPUT);
     LG_RUN(launch_gemm(g, I, s));
   }
   // ---- assignment (LGN:540-542).  tag = layer + 1: the pairs that stopped at that layer, with its weights (gated launches after every layer that may
@@ -367,7 +374,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     {
       GemmArgs g;
       g.A0 = st.desc; g.lda0 = 256; g.strideA0 = s256; g.C = st.md; g.ldc = 256; g.strideC = s256; g.ldr = 256; g.strideR = s256;
-      g.M = N; g.N = 256; g.K = 256; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = tag;
+      g.M = Nsel; g.N = 256; g.K = 256; g.rows = st.n_cur; g.flag = st.done; g.flag_shift = 1; g.flag_eq = tag;
       g.sat = sat(DIM_SAT_LG_DESC);   // guarded: the similarity splits it
       if (tag == 0) { g.set_split(h->L[0].proj_x[pmode]); g.bias = h->L[0].proj_b; g.layer_tab = h->proj_tab[pmode]; }   // (shape fields from layer 0; pointers per item)
       else { g.B = w->proj_w; g.ldb = 256; g.bias = w->proj_b; if (x6) g.set_split(w->proj_x[pmode]); }
@@ -375,7 +382,7 @@ int dim_lg_match(dim_lg* h, const float* kpts_tab_dev, const float* desc_tab_dev
     }
     GemmArgs g;
     g.A0 = st.md; g.lda0 = 256; g.strideA0 = 2 * s256; g.B = st.md + s256; g.ldb = 256; g.strideB = 2 * s256; g.bt = 1;
-    g.C = st.sim; g.ldc = N; g.strideC = (long long)N * N; g.M = N; g.N = N; g.K = 256;
+    g.C = st.sim; g.ldc = N; g.strideC = (long long)N * N; g.M = Nsel; g.N = Nsel; g.K = 256;
     g.rows = st.n_cur; g.rows_mul = 2; g.rows_off = 0; g.cols = st.n_cur; g.cols_mul = 2; g.cols_off = 1;
     g.flag = st.done; g.flag_shift = 0; g.flag_eq = tag; g.flag_any = tag == 0 ? 1 : 0;
     if (x6) LG_RUN(launch_gemm_x6_nt(g, n_pairs, pmode, s));   // split-precision on the 16-bit matrix cores like every other product

@@ -393,7 +393,8 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
   a.q_img = (kv_ready && cross) ? 1 : 0;
   a.enc = st.enc; a.kv_img = (u32x4*)st.kv_img; a.nmax = st.nmax; a.tiles = cdiv(st.nmax, 32);
   // small batches leave most CUs idle and make every workgroup walk all key tiles alone: cut the key range
-  const int wgs = cdiv(st.nmax, 128) * 4 * st.n_items;
+  const int nsel = st.nsel > 0 ? st.nsel : st.nmax;   // rows that can be live in this call: the query blocks / merge rows beyond them would only exit
+  const int wgs = cdiv(nsel, 128) * 4 * st.n_items;
   a.part = st.attn_part;
   // ... into the fewest parts (1, 2, 4) that give the launch two workgroups per CU (512).  (Until round 6: 4 parts up to 128 workgroups, 2 up to 256, else 1 —
   // one pair of 2304 keypoints ran 288 workgroups of 36 tiles, 1.1 per CU: 2.01 ms against 1.52 at 2048; three pairs of 2048 ran 384 of 64 tiles.)
@@ -404,7 +405,7 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
   const bool two_ahead = dim_attn_probe() == 22;   // research, 22: the key-split launches with TWO tiles of prefetch distance (prototype; results identical, measured slower)
   if (two_ahead) a.probe = 0;
   (void)two_ahead;
-  a.qblocks = cdiv(st.nmax, 128) * a.splits;
+  a.qblocks = cdiv(nsel, 128) * a.splits;
   a.groups = 4 * st.n_items;
   dim3 grid((unsigned)(cdiv(a.groups, 8) * 8 * a.qblocks));  // whole rounds of 8 groups, one per XCD (surplus workgroups exit)
   if (dim_precision_mode() == 2) {
@@ -423,7 +424,7 @@ int launch_lg_attention_x6(const LgState& st, int cross, hipStream_t s, int kv_r
   }
   if (a.splits > 1) {
     const float out_scale = dim_precision_mode() == 2 ? DIM_F16_ACT_SCALE : 1.0f;
-    const dim3 cg(cdiv(st.nmax, 16), 4, st.n_items);
+    const dim3 cg(cdiv(nsel, 16), 4, st.n_items);
     if (a.splits == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_combine_kernel<4>), cg, dim3(256), 0, s, a, out_scale);
     else if (a.splits == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_combine_kernel<2>), cg, dim3(256), 0, s, a, out_scale);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_combine_kernel<0>), cg, dim3(256), 0, s, a, out_scale);

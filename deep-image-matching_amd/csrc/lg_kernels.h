@@ -33,6 +33,7 @@ struct LgState {  // device pointers owned by the handle
   float* tdesc; float* tenc; int* tind;  // compaction scratch
   void* kv_img;   // [items][4][ceil(nmax/32)][1536 x 16 B] pre-split K|V tile images (split-precision attention)
   unsigned* sat_qkv = nullptr; unsigned* sat_ffn = nullptr;  // fp16x3 range-guard counters (dim_common.h), set per call
+  int nsel = 0;   // upper bound of the live rows of any item in THIS call (<= nmax; dim_lg_match: the feature table's rows per image): launch shapes follow it, strides follow nmax
   float* attn_part; int attn_part_items;  // scratch of the key-split attention used for small batches ([items][4][nmax][4][68])
 };
 

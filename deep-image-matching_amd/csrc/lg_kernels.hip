@@ -22,13 +22,13 @@ __global__ __launch_bounds__(256) void lg_init_kernel(LgState st, const float* _
                                                       int cap, int in_dim, const float* __restrict__ Wr, int copy_desc, unsigned* sat) {
   const int item = blockIdx.y;
   const int img = pair_idx ? pair_idx[item] : item;
-  const int n = min(n_tab[img], st.nmax);
+  const int n = min(min(n_tab[img], st.nmax), cap);   // (a table of `cap` rows per image cannot hold more)
   const int j = threadIdx.x & 31, pt = blockIdx.x * 8 + (threadIdx.x >> 5);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st.n_cur[item] = n; st.n_new[item] = n; st.n_orig[item] = n;
     if ((item & 1) == 0) {
       const int img1 = pair_idx ? pair_idx[item + 1] : item + 1;
-      const int n1 = min(n_tab[img1], st.nmax);
+      const int n1 = min(min(n_tab[img1], st.nmax), cap);
       st.done[item >> 1] = (n == 0 || n1 == 0) ? -1 : 0;  // LGN:491-492 at i = 0 -> stop = 1
       st.cnt_lt[item >> 1] = 0;
     }
@@ -521,8 +521,9 @@ int launch_lg_prune(const LgState& st, int layer, double width_conf, float thr, 
 // above walk a row twice in 4-byte steps, one dependent load per iteration: 0.38 ms per pass and 50 pairs, 2.2 TB/s).  A row lives in
 // 8 float4 registers per lane; a column group of 4 columns per thread keeps online (max, sum) pairs.  exp(x) for x <= 0 is the
 // 6-instruction exp_le0 (dim_common.h, ~1.5 ulp). ----
-constexpr int ROW_CH = 8;   // float4 chunks per lane: 64 lanes x 4 x 8 = 2048 columns
+constexpr int ROW_CH_MAX = 16;   // float4 chunks per lane: 64 lanes x 4 x 16 = 4096 columns (8 for rows of up to 2048)
 __device__ __forceinline__ float exp_le0_z(float d) { return d > -INFINITY ? exp_le0(d) : 0.0f; }   // exp(d), d <= 0, with exp(-inf) = 0 (exp_le0 itself returns NaN there)
+template <int ROW_CH>   // float4 chunks per lane: 8 = rows of up to 2048 live columns, 16 = up to 4096 (round 6: a 2100-keypoint pair fell to the generic kernels)
 __global__ __launch_bounds__(256) void lg_row_stats4_kernel(LgState st, int tag, const float* __restrict__ w_match,
                                                             const float* __restrict__ b_match) {
   const int item = blockIdx.y, p = item >> 1, side = item & 1;
@@ -610,6 +611,7 @@ __global__ __launch_bounds__(1024) void lg_col_stats4_kernel(LgState st, int tag
     }
   }
 }
+template <int ROW_CH>
 __global__ __launch_bounds__(256) void lg_row_argmax4_kernel(LgState st, int tag, float* __restrict__ dense) {
   const int p = blockIdx.y;
   const int dn = st.done[p];
@@ -693,11 +695,14 @@ __global__ __launch_bounds__(1024) void lg_col_argmax4_kernel(LgState st, int ta
     st.best[c + e] = b; st.arg[c + e] = ix;
   }
 }
-static bool assign_fast_shape(const LgState& st) { return (st.nmax & 3) == 0 && st.nmax <= 256 * ROW_CH; }
+// (the fast kernels hold a row's live columns in registers: what must fit is the live count's bound nsel, the row stride nmax only has to be a multiple of 4)
+static bool assign_fast_shape(const LgState& st) { return (st.nmax & 3) == 0 && (st.nsel > 0 ? st.nsel : st.nmax) <= 256 * ROW_CH_MAX; }
+static bool assign_rows_2048(const LgState& st) { return (st.nsel > 0 ? st.nsel : st.nmax) <= 2048; }
 
 int launch_lg_assign_stats(const LgState& st, int tag, const float* w_match, const float* b_match, hipStream_t s) {
   if (assign_fast_shape(st)) {
-    hipLaunchKernelGGL(lg_row_stats4_kernel, dim3(cdiv(st.nmax, 4), st.n_items), dim3(256), 0, s, st, tag, w_match, b_match);
+    if (assign_rows_2048(st)) hipLaunchKernelGGL(HIP_KERNEL_NAME(lg_row_stats4_kernel<8>), dim3(cdiv(st.nmax, 4), st.n_items), dim3(256), 0, s, st, tag, w_match, b_match);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(lg_row_stats4_kernel<16>), dim3(cdiv(st.nmax, 4), st.n_items), dim3(256), 0, s, st, tag, w_match, b_match);
     hipLaunchKernelGGL(lg_col_stats4_kernel, dim3(cdiv(st.nmax, 4 * COL_CW), st.n_pairs), dim3(1024), 0, s, st, tag);
     DIM_LAUNCH_CHECK();
     return 0;
@@ -709,7 +714,8 @@ int launch_lg_assign_stats(const LgState& st, int tag, const float* w_match, con
 }
 int launch_lg_assign_argmax(const LgState& st, int tag, float* dense_scores, hipStream_t s) {
   if (assign_fast_shape(st)) {
-    hipLaunchKernelGGL(lg_row_argmax4_kernel, dim3(cdiv(st.nmax, 4), st.n_pairs), dim3(256), 0, s, st, tag, dense_scores);
+    if (assign_rows_2048(st)) hipLaunchKernelGGL(HIP_KERNEL_NAME(lg_row_argmax4_kernel<8>), dim3(cdiv(st.nmax, 4), st.n_pairs), dim3(256), 0, s, st, tag, dense_scores);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(lg_row_argmax4_kernel<16>), dim3(cdiv(st.nmax, 4), st.n_pairs), dim3(256), 0, s, st, tag, dense_scores);
     hipLaunchKernelGGL(lg_col_argmax4_kernel, dim3(cdiv(st.nmax, 4 * COL_CW), st.n_pairs), dim3(1024), 0, s, st, tag);
     DIM_LAUNCH_CHECK();
     return 0;
