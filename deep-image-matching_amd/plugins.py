@@ -404,8 +404,12 @@ class LightGlueMatcher(BatchedTileMatchingMixin, _MatcherBase):
 
     def _ensure(self, n: int):
         if self._net is None or n > self._net_n:
-            self._net_n = max(256, 1 << (max(n, 1) - 1).bit_length())
             dev = self._device if isinstance(self._device, (str, torch.device)) else "cuda"
+            # a handle is rebuilt when a pair has more keypoints than it holds (~0.5 - 1 s: weight splitting, uploads, allocations).  Since round 6 an oversized
+            # handle costs nothing measurable (launch shapes follow the pair, not the handle: 2048 keypoints on a 4096 / 8192-row handle 1.464 / 1.485 vs 1.461 ms,
+            # scripts/gpu_lg_capacity_cost.py) and a 4096-row handle is ~0.2 GB, so on a GPU the first one already holds 4096 keypoints per image
+            floor = 4096 if str(getattr(dev, "type", dev)).startswith("cuda") else 256
+            self._net_n = max(floor, 1 << (max(n, 1) - 1).bit_length())
             self._net = LightGlueHIP(self._sd, self._conf, max_pairs=1, max_kpts=self._net_n, device=dev, lib=self._lib,
                                      on_saturation=self._on_sat, arithmetic=self._arith)
 
