@@ -143,12 +143,18 @@ void fold_out_proj(const std::vector<float>& wout, const std::vector<float>& bou
     for (int j = 0; j < 256; ++j) sb += (double)bout[j] * w1[(size_t)(256 + j) * 512 + o];
     bf[o] = (float)sb;
   }
-  for (int i = 0; i < 256; ++i)
-    for (int o = 0; o < 512; ++o) {
-      double sw = 0.0;
-      for (int j = 0; j < 256; ++j) sw += (double)wout[(size_t)i * 256 + j] * w1[(size_t)(256 + j) * 512 + o];
-      wf[(size_t)(256 + i) * 512 + o] = (float)sw;
+  // (row i of Wout * W1b: j outermost so that the inner loop walks W1b's rows contiguously — per (i, o) the products are added in the same order j = 0 .. 255 as
+  // the dot-product form, so the folded weights are bit-identical; 33.5 M strided multiply-adds per block made a 9-layer handle take 1.2 s to create)
+  std::vector<double> acc(512);
+  for (int i = 0; i < 256; ++i) {
+    std::fill(acc.begin(), acc.end(), 0.0);
+    for (int j = 0; j < 256; ++j) {
+      const double a = (double)wout[(size_t)i * 256 + j];
+      const float* row = &w1[(size_t)(256 + j) * 512];
+      for (int o = 0; o < 512; ++o) acc[o] += a * row[o];
     }
+    for (int o = 0; o < 512; ++o) wf[(size_t)(256 + i) * 512 + o] = (float)acc[o];
+  }
 }
 // nn.Linear weight [out][in] -> GEMM operand [in][out] (optionally scaled)
 std::vector<float> transpose(const float* w, int out_f, int in_f, float scale = 1.0f) {
